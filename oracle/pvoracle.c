@@ -1,0 +1,536 @@
+/*
+ * pvoracle.c -- CPU ORACLE for the PyPeVoc phase-vocoder hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is a plain-C, float64, single-threaded
+ * restatement of the reference algorithm.  It exists to CHECK the HIP path and
+ * to be timed as the "port" CPU baseline.  Nothing under pypevoc_amd/ links,
+ * loads or calls it; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may.
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function here
+ * against tests/golden/G*.npz, which tests/golden/make_golden.py produced by
+ * importing the reference itself (goiosunsw/PyPeVoc @ v1).
+ *
+ * Reference lines restated (PV.py = pypevoc/PVAnalysis.py, PF.py = pypevoc/PeakFinder.py):
+ *   pvo_setup / pvo_analyze : PV.py:72-131 (constants), 150-158 (windowed FFT),
+ *                             160-211 (calc_pv_frame), 133-148 (dphase2freq),
+ *                             213-264 (run_pv frame loop and packing)
+ *   pvo_peakfinder          : PF.py:35-74 (ctor thresholds), 155-194 (findpos),
+ *                             113-136 (filter_by_salience)
+ *   pvo_track               : PV.py:299-322 (toSinSum), 871-957 (SinSum.add_frame),
+ *                             62-68 (dpitch2st), 819-830, 984-994
+ *   pvo_synth               : PV.py:684-756 (RegPartial.synth), 1053-1070 (SinSum.synth,
+ *                             with the integer edge length Python 2 produced)
+ * The FFT itself is numpy's pocketfft in the reference (PV.py:157); any correct
+ * FFT agrees to ~1e-15 relative, here a radix-2 real FFT (naive DFT when nfft is
+ * not a power of two).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: numpy's scalar loops do
+ * not fuse multiply-add, so neither does the oracle).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PVO_PI 3.141592653589793238462643383279502884
+static const double pi2 = 2.0 * PVO_PI; /* PV.py:45 */
+
+/* ------------------------------------------------------------------ FFT -- */
+
+typedef struct {
+    int n;        /* transform length */
+    int pow2;     /* 1 if n is a power of two (>= 4) */
+    int m;        /* n/2 */
+    double *twr, *twi; /* e^{-2 pi i k / n}, k < n */
+    int *rev;     /* bit reversal for length m */
+    double *zr, *zi;
+} pvo_fft;
+
+static void fft_free(pvo_fft *p) {
+    free(p->twr); free(p->twi); free(p->rev); free(p->zr); free(p->zi);
+    memset(p, 0, sizeof(*p));
+}
+
+static int fft_init(pvo_fft *p, int n) {
+    memset(p, 0, sizeof(*p));
+    p->n = n; p->m = n / 2;
+    p->pow2 = (n >= 4) && ((n & (n - 1)) == 0);
+    p->twr = (double *)malloc(sizeof(double) * n);
+    p->twi = (double *)malloc(sizeof(double) * n);
+    p->zr = (double *)malloc(sizeof(double) * n);
+    p->zi = (double *)malloc(sizeof(double) * n);
+    p->rev = (int *)malloc(sizeof(int) * (p->m > 0 ? p->m : 1));
+    if (!p->twr || !p->twi || !p->zr || !p->zi || !p->rev) { fft_free(p); return -1; }
+    for (int k = 0; k < n; k++) {
+        p->twr[k] = cos(pi2 * k / n);
+        p->twi[k] = -sin(pi2 * k / n);
+    }
+    if (p->pow2) {
+        int bits = 0;
+        while ((1 << bits) < p->m) bits++;
+        for (int i = 0; i < p->m; i++) {
+            int r = 0;
+            for (int b = 0; b < bits; b++) if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+            p->rev[i] = r;
+        }
+    }
+    return 0;
+}
+
+/* Half spectrum X[0..n/2) of the real sequence xw[0..n).  outr/outi have n/2 entries. */
+static void fft_real_half(pvo_fft *p, const double *xw, double *outr, double *outi) {
+    const int n = p->n, m = p->m;
+    if (!p->pow2) { /* naive DFT with exactly reduced twiddle index */
+        for (int k = 0; k < m; k++) {
+            double sr = 0.0, si = 0.0;
+            for (int j = 0; j < n; j++) {
+                int q = (int)(((int64_t)j * k) % n);
+                sr += xw[j] * p->twr[q];
+                si += xw[j] * p->twi[q];
+            }
+            outr[k] = sr; outi[k] = si;
+        }
+        return;
+    }
+    /* pack z[j] = x[2j] + i x[2j+1], complex FFT of length m (twiddle stride 2) */
+    double *zr = p->zr, *zi = p->zi;
+    for (int j = 0; j < m; j++) { int r = p->rev[j]; zr[r] = xw[2 * j]; zi[r] = xw[2 * j + 1]; }
+    for (int len = 2; len <= m; len <<= 1) {
+        int half = len >> 1, step = n / len; /* e^{-2 pi i q / len} = tw[q * n / len] */
+        for (int s = 0; s < m; s += len) {
+            for (int q = 0; q < half; q++) {
+                double wr = p->twr[q * step], wi = p->twi[q * step];
+                int a = s + q, b = a + half;
+                double tr = zr[b] * wr - zi[b] * wi, ti = zr[b] * wi + zi[b] * wr;
+                zr[b] = zr[a] - tr; zi[b] = zi[a] - ti;
+                zr[a] += tr; zi[a] += ti;
+            }
+        }
+    }
+    /* untangle: X[k] = E[k] + e^{-2 pi i k/n} O[k] */
+    for (int k = 0; k < m; k++) {
+        int kk = (m - k) % m;
+        double ar = zr[k], ai = zi[k], br = zr[kk], bi = -zi[kk];
+        double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);
+        double dr = 0.5 * (ar - br), di = 0.5 * (ai - bi);
+        double orr = di, oi = -dr;
+        double wr = p->twr[k], wi = p->twi[k];
+        outr[k] = er + (orr * wr - oi * wi);
+        outi[k] = ei + (orr * wi + oi * wr);
+    }
+}
+
+/* --------------------------------------------------------- PeakFinder ---- */
+
+/* PF.py:35-74 + 155-194 + 113-136.  y[n]; npeaks<=0 means "not npeaks" (-> n).
+ * thr_kind: 0 = minamp None (-> min(y)), 1 = minrattomax given, 2 = minval given.
+ * Writes the findpos() positions ascending into idx[0..count) and, after
+ * filter_by_salience(rad) (skipped when rad < 0), keep[0..count).
+ * scratch: n doubles.  Returns count. */
+static int peakfinder_core(const double *y, int n, int npeaks, int thr_kind, double thr_val,
+                           int rad, int *idx, int *keep, double *scratch) {
+    if (npeaks <= 0) npeaks = n;                 /* PF.py:64-67 */
+    double maxy = y[0], miny = y[0];
+    for (int i = 1; i < n; i++) { if (y[i] > maxy) maxy = y[i]; if (y[i] < miny) miny = y[i]; }
+    double minamp = 0.0; int have = 0;
+    if (thr_kind == 1) { minamp = maxy * thr_val; have = 1; }   /* PF.py:60 */
+    else if (thr_kind == 2) { minamp = thr_val; have = 1; }     /* PF.py:58 */
+    if (!have || minamp == 0.0) minamp = miny;                  /* PF.py:69-70 "if not self.minamp" */
+    int count = 0;
+    if (n >= 3) {
+        int nm = n - 2;
+        double *pk = scratch;                     /* pkmskamp, PF.py:166-167 */
+        for (int i = 0; i < nm; i++) {
+            int ismax = (y[i] < y[i + 1]) && (y[i + 1] >= y[i + 2]);
+            pk[i] = ismax ? (y[i + 1] - miny) : 0.0 * (y[i + 1] - miny);
+        }
+        double th = minamp - miny;                /* PF.py:174 */
+        double m; int b;
+        /* PF.py:172-187: argmax = first index of the maximum */
+        m = pk[0]; b = 0;
+        for (int i = 1; i < nm; i++) if (pk[i] > m) { m = pk[i]; b = i; }
+        int nsel = 1;
+        if (m > th) { idx[count++] = b + 1; pk[b] = th - 1; }
+        while (m > th && nsel < npeaks) {
+            m = pk[0]; b = 0;
+            for (int i = 1; i < nm; i++) if (pk[i] > m) { m = pk[i]; b = i; }
+            if (m > th) { idx[count++] = b + 1; pk[b] = th - 1; nsel++; }
+        }
+        /* PF.py:189 np.sort(pos) */
+        for (int i = 1; i < count; i++) {
+            int v = idx[i], j = i - 1;
+            while (j >= 0 && idx[j] > v) { idx[j + 1] = idx[j]; j--; }
+            idx[j + 1] = v;
+        }
+    }
+    for (int i = 0; i < count; i++) keep[i] = 1;  /* PF.py:191 */
+    if (rad >= 0) {                               /* PF.py:113-136, sal = 0 */
+        for (int i = 0; i < count; i++) {
+            int p = idx[i];
+            double v = y[p];
+            int wmin = p - rad > 1 ? p - rad : 1;
+            int wmax = p + rad < n ? p + rad : n;
+            for (int j = wmin; j <= wmax && j < n; j++) if (y[j] > v) { keep[i] = 0; break; }
+        }
+    }
+    return count;
+}
+
+int pvo_peakfinder(const double *y, int n, int npeaks, int thr_kind, double thr_val, int rad,
+                   int *idx, int *keep) {
+    double *scratch = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+    if (!scratch) return -1;
+    int c = peakfinder_core(y, n, npeaks, thr_kind, thr_val, rad, idx, keep, scratch);
+    free(scratch);
+    return c;
+}
+
+/* ------------------------------------------------------------ analysis --- */
+
+int64_t pvo_nframes(int64_t nsamp, int nfft, int hop) {
+    /* PV.py:223-249: pos = 0, hop, 2 hop, ... while pos < nsamp - nfft */
+    int64_t maxpos = nsamp - nfft;
+    if (maxpos <= 0 || hop <= 0) return 0;
+    return (maxpos + hop - 1) / hop;
+}
+
+/* numpy complex128 division a / b (Smith's method, incl. the zero-denominator branch). */
+static void npy_cdiv(double ar, double ai, double br, double bi, double *qr, double *qi) {
+    double abr = fabs(br), abi = fabs(bi);
+    if (abr >= abi) {
+        if (abr == 0.0 && abi == 0.0) { *qr = ar / abr; *qi = ai / abr; return; }
+        double rat = bi / br, scl = 1.0 / (br + bi * rat);
+        *qr = (ar + ai * rat) * scl; *qi = (ai - ar * rat) * scl;
+    } else {
+        double rat = br / bi, scl = 1.0 / (bi + br * rat);
+        *qr = (ar * rat + ai) * scl; *qi = (ai * rat - ar) * scl;
+    }
+}
+
+/* Full run_pv.  x: float64[nsamp]; win: float64[nfft] (= wind(nfft), PV.py:97).
+ * Outputs caller-allocated: f, mag, ph, realph, binno: F*npks (C order, zero padded);
+ * t, totalmag: F.  The previous half spectrum starts from zeros (PV.py:121).
+ * Returns the number of frames written or <0. */
+int64_t pvo_analyze(const double *x, int64_t nsamp, double sr, int nfft, int hop, int npks,
+                    double pkthresh, const double *win,
+                    double *f, double *mag, double *ph, double *realph, double *binno,
+                    double *t, double *totalmag) {
+    if (nfft < 4 || hop <= 0 || npks <= 0) return -1;
+    const int nfft2 = nfft / 2;                         /* PV.py:88 */
+    const int64_t F = pvo_nframes(nsamp, nfft, hop);
+    /* PV.py:98-118 */
+    double wsum2 = 0.0;
+    for (int i = 0; i < nfft; i++) wsum2 = wsum2 + win[i] * win[i];
+    const double wfact = sqrt(wsum2 * nfft) / 2.0;
+    const double fstep = sr / (double)nfft;
+    const double dt = (double)hop / sr;
+    double *fbin = (double *)malloc(sizeof(double) * nfft2);
+    double *wfbin = (double *)malloc(sizeof(double) * nfft2);
+    double *xw = (double *)malloc(sizeof(double) * nfft);
+    double *fr_ = (double *)malloc(sizeof(double) * nfft2), *fi_ = (double *)malloc(sizeof(double) * nfft2);
+    double *or_ = (double *)calloc(nfft2, sizeof(double)), *oi_ = (double *)calloc(nfft2, sizeof(double));
+    double *famp = (double *)malloc(sizeof(double) * nfft2);
+    double *scratch = (double *)malloc(sizeof(double) * nfft2);
+    int *idx = (int *)malloc(sizeof(int) * (npks > nfft2 ? npks : nfft2));
+    int *keep = (int *)malloc(sizeof(int) * (npks > nfft2 ? npks : nfft2));
+    pvo_fft plan;
+    if (!fbin || !wfbin || !xw || !fr_ || !fi_ || !or_ || !oi_ || !famp || !scratch || !idx || !keep ||
+        fft_init(&plan, nfft) != 0)
+        return -2;
+    for (int k = 0; k < nfft2; k++) {
+        fbin[k] = (double)k * fstep;                    /* PV.py:114 */
+        double dthetabin = pi2 * fbin[k] * dt;          /* PV.py:116 */
+        wfbin[k] = nearbyint(dthetabin / pi2) * pi2;    /* PV.py:118, np.round = half-even */
+    }
+    const double scl = 1.0 / wfact;                     /* complex / real scalar in numpy = * (1/w) */
+    for (int64_t fr = 0; fr < F; fr++) {
+        const int64_t pos = fr * (int64_t)hop;
+        for (int i = 0; i < nfft; i++) xw[i] = x[pos + i] * win[i];   /* PV.py:155-156 */
+        fft_real_half(&plan, xw, fr_, fi_);
+        for (int k = 0; k < nfft2; k++) { fr_[k] *= scl; fi_[k] *= scl; famp[k] = hypot(fr_[k], fi_[k]); }
+        /* PV.py:175-178 */
+        int cnt = peakfinder_core(famp, nfft2, npks, 1, pkthresh, 5, idx, keep, scratch);
+        double *of = f + fr * npks, *om = mag + fr * npks, *op = ph + fr * npks,
+               *orp = realph + fr * npks, *ob = binno + fr * npks;
+        for (int j = 0; j < npks; j++) of[j] = om[j] = op[j] = orp[j] = ob[j] = 0.0;
+        int nout = 0;
+        for (int i = 0; i < cnt; i++) {
+            if (!keep[i]) continue;
+            int nbin = idx[i];
+            double thisph = atan2(fi_[nbin], fr_[nbin]);           /* PV.py:188 */
+            double qr, qi;
+            npy_cdiv(fr_[nbin], fi_[nbin], or_[nbin], oi_[nbin], &qr, &qi);   /* PV.py:171 */
+            double dph = atan2(qi, qr);                            /* PV.py:190 */
+            /* PV.py:140-147; a NaN dph makes all three candidates NaN, argmin then returns
+             * index 0 and `freq > 0` (PV.py:193) is False */
+            if (isnan(dph)) continue;
+            double best = 0.0, bestdf = 0.0, bestabs = 0.0;
+            for (int m = -1; m <= 1; m++) {
+                double dphw = dph + wfbin[nbin] + pi2 * (double)m;
+                double freq = dphw / dt / pi2;
+                double df = fbin[nbin] - freq;
+                double a = fabs(df);
+                if (m == -1 || a < bestabs) { best = freq; bestdf = df; bestabs = a; }  /* first minimum */
+            }
+            if (best > 0.0) {                                       /* PV.py:193 */
+                int imin = nbin - 1 > 1 ? nbin - 1 : 1;             /* PV.py:197-199, wd = 1 */
+                int imax = nbin + 1 < nfft2 ? nbin + 1 : nfft2;
+                double s = 0.0;
+                for (int j = imin; j <= imax && j < nfft2; j++) s = s + famp[j] * famp[j];
+                ob[nout] = (double)nbin;
+                of[nout] = best;
+                om[nout] = sqrt(s);
+                op[nout] = thisph;
+                orp[nout] = thisph + PVO_PI * bestdf / fstep;       /* PV.py:207 */
+                nout++;
+            }
+        }
+        memcpy(or_, fr_, sizeof(double) * nfft2);                   /* PV.py:209 */
+        memcpy(oi_, fi_, sizeof(double) * nfft2);
+        double tm = 0.0;
+        for (int k = 0; k < nfft2; k++) tm += famp[k] * famp[k];
+        totalmag[fr] = sqrt(tm);                                    /* PV.py:210 */
+        t[fr] = ((double)pos + nfft / 2.0) / sr;                    /* PV.py:247 */
+    }
+    fft_free(&plan);
+    free(fbin); free(wfbin); free(xw); free(fr_); free(fi_); free(or_); free(oi_);
+    free(famp); free(scratch); free(idx); free(keep);
+    return F;
+}
+
+/* Windowed, normalised half spectrum of frame `fr` (PV.py:150-158, 169): for checking the
+ * device STFT stage in isolation.  outr/outi: nfft/2. */
+int pvo_stft_frame(const double *x, int64_t pos, int nfft, const double *win, double *outr, double *outi) {
+    pvo_fft plan;
+    if (fft_init(&plan, nfft) != 0) return -1;
+    double *xw = (double *)malloc(sizeof(double) * nfft);
+    double wsum2 = 0.0;
+    for (int i = 0; i < nfft; i++) wsum2 = wsum2 + win[i] * win[i];
+    const double scl = 1.0 / (sqrt(wsum2 * nfft) / 2.0);
+    for (int i = 0; i < nfft; i++) xw[i] = x[pos + i] * win[i];
+    fft_real_half(&plan, xw, outr, outi);
+    for (int k = 0; k < nfft / 2; k++) { outr[k] *= scl; outi[k] *= scl; }
+    free(xw); fft_free(&plan);
+    return 0;
+}
+
+/* ------------------------------------------------------------- tracker --- */
+
+typedef struct { double mag; int key; } magkey;
+
+/* descending (mag, key): Python sorted(zip(pmag, pidx), reverse=True), PV.py:893 */
+static int cmp_desc(const void *a, const void *b) {
+    const magkey *p = (const magkey *)a, *q = (const magkey *)b;
+    if (p->mag > q->mag) return -1;
+    if (p->mag < q->mag) return 1;
+    return (p->key > q->key) ? -1 : (p->key < q->key);
+}
+
+/* toSinSum (PV.py:299-322) = add_frame for every frame (PV.py:871-957), maxpitchjmp as given
+ * (the reference always runs with 0.5: toSinSum does not forward its argument).
+ * f, mag: F*K.  Outputs: partial_id[F*K] (-1 = slot not in any partial),
+ * part_start[cap], part_len[cap], cap >= F*K.  Returns the number of partials. */
+int64_t pvo_track(const double *f, const double *mag, int64_t F, int K, double maxpitchjmp,
+                  int32_t *partial_id, int32_t *part_start, int32_t *part_len) {
+    int64_t P = 0;
+    magkey *cur = (magkey *)malloc(sizeof(magkey) * K);
+    magkey *prev = (magkey *)malloc(sizeof(magkey) * K);   /* key = partial index */
+    double *prevf = (double *)malloc(sizeof(double) * K);
+    int *prevslot = (int *)malloc(sizeof(int) * K);
+    char *unused = (char *)malloc(K);
+    int nprev = 0;  /* partials whose end == fr-1 (PV.py:887, 984-994) */
+    for (int64_t fr = 0; fr < F; fr++) {
+        const double *ff = f + fr * K, *mm = mag + fr * K;
+        int32_t *pid = partial_id + fr * K;
+        /* PV.py:874-876: argsort(mag)[::-1], keep f>0 & mag>0.  Ties: reversed stable order. */
+        int nc = 0;
+        for (int s = 0; s < K; s++) { pid[s] = -1; if (ff[s] > 0 && mm[s] > 0) { cur[nc].mag = mm[s]; cur[nc].key = s; nc++; } }
+        qsort(cur, nc, sizeof(magkey), cmp_desc);
+        /* previous partials sorted descending by (mag at fr-1, partial index), PV.py:891-900 */
+        qsort(prev, nprev, sizeof(magkey), cmp_desc);
+        for (int i = 0; i < nprev; i++) {
+            /* frequency of that partial at fr-1: find it through the id table of frame fr-1 */
+            const int32_t *ppid = partial_id + (fr - 1) * K;
+            int slot = -1;
+            for (int s = 0; s < K; s++) if (ppid[s] == prev[i].key) { slot = s; break; }
+            prevslot[i] = slot;
+            prevf[i] = f[(fr - 1) * K + slot];
+            unused[i] = 1;
+        }
+        for (int c = 0; c < nc; c++) {
+            int s = cur[c].key;
+            double fc = ff[s];
+            int target = -1;
+            /* PV.py:905-928: nearest (first minimum) among the unused previous partials */
+            int nearest = -1; double best = 0.0;
+            for (int i = 0; i < nprev; i++) {
+                if (!unused[i]) continue;
+                double st = fabs(17.312 * (fc / prevf[i] - 1.0));   /* dpitch2st, PV.py:62-68 */
+                if (nearest < 0 || st < best) { nearest = i; best = st; }
+            }
+            if (nearest >= 0 && best < maxpitchjmp) { target = prev[nearest].key; unused[nearest] = 0; }
+            if (target < 0) {                                       /* add_empty_partial, PV.py:819-830 */
+                target = (int)P;
+                part_start[P] = (int32_t)fr; part_len[P] = 0; P++;
+            }
+            pid[s] = target;
+            part_len[target] += 1;                                  /* append_point, PV.py:949 */
+        }
+        /* the partials that end at fr are exactly those that received a point at fr */
+        nprev = 0;
+        for (int c = 0; c < nc; c++) { int s = cur[c].key; prev[nprev].mag = mm[s]; prev[nprev].key = pid[s]; nprev++; }
+    }
+    free(cur); free(prev); free(prevf); free(prevslot); free(unused);
+    return P;
+}
+
+/* ----------------------------------------------------------- resynthesis - */
+
+/* np.interp(x, xp, fp) for increasing xp (numpy compiled_interp semantics) */
+static double np_interp(double x, const double *xp, const double *fp, int n) {
+    if (n == 1) return fp[0];
+    if (x > xp[n - 1]) return fp[n - 1];
+    if (x < xp[0]) return fp[0];
+    int lo = 0, hi = n - 1;            /* find j with xp[j] <= x < xp[j+1] */
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (x >= xp[mid]) lo = mid; else hi = mid; }
+    int j = (x >= xp[n - 1]) ? n - 1 : lo;
+    if (j == n - 1) return fp[j];
+    if (xp[j] == x) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    return slope * (x - xp[j]) + fp[j];
+}
+
+/* RegPartial.synth (PV.py:684-756).  pf/pm/pr: the partial's f, mag, realph (nfr points).
+ * overlap = hop_analysis/nfft, fstep = sr/nfft (PV.py:824-825).  sig must hold
+ * hop*nfr + 2*edgsam samples; returns edgsam through *edg. */
+static int regpartial_synth(const double *pf, const double *pm, const double *pr, int nfr,
+                            double overlap, double fstep, double sr, int hop, double edge,
+                            double *sig, int *edg) {
+    const double dfr = 1. / overlap / 2.;                       /* PV.py:687 */
+    const int64_t nnew = (int64_t)ceil((double)hop * (nfr + dfr)); /* len(np.arange(hop*(nfr+dfr))) */
+    double *fsig = (double *)malloc(sizeof(double) * nnew);
+    double *msig = (double *)malloc(sizeof(double) * nnew);
+    double *xpf = (double *)malloc(sizeof(double) * nfr), *xpm = (double *)malloc(sizeof(double) * nfr);
+    double *phv = (double *)malloc(sizeof(double) * (hop > 0 ? hop : 1));
+    const int edgsam = (int)(dfr * hop * edge);                 /* PV.py:740 */
+    if (!fsig || !msig || !xpf || !xpm || !phv) return -1;
+    for (int j = 0; j < nfr; j++) {
+        xpf[j] = hop * (dfr + .5 + (double)j);                  /* PV.py:701 */
+        xpm[j] = hop * (dfr + (double)j);                       /* PV.py:702 */
+    }
+    for (int64_t n = 0; n < nnew; n++) {
+        fsig[n] = np_interp((double)n, xpf, pf, nfr);
+        msig[n] = np_interp((double)n, xpm, pm, nfr);
+    }
+    double *body = sig + edgsam;
+    double phcornext = 0.0, lastph = 0.0;
+    for (int ii = 0; ii < nfr; ii++) {                          /* PV.py:703 */
+        /* PV.py:705-708: ph = [0, 2 pi cumsum(fsig[hop ii : hop(ii+1)-1] / sr)] */
+        double acc = 0.0;
+        phv[0] = 0.0;
+        for (int m = 1; m < hop; m++) { acc = acc + fsig[(int64_t)hop * ii + m - 1] / sr; phv[m] = pi2 * acc; }
+        double phcor = PVO_PI * (fsig[(int64_t)hop * (ii + 1)] - fsig[(int64_t)hop * ii]) / fstep / 2.;   /* :715 */
+        if (ii < nfr - 1)
+            phcornext = PVO_PI * (fsig[(int64_t)hop * (ii + 2)] - fsig[(int64_t)hop * (ii + 1)]) / fstep / 2.; /* :717 */
+        double ph0 = pr[ii] + phcor;                            /* :721 */
+        for (int m = 0; m < hop; m++) phv[m] += ph0;
+        if (ii < nfr - 1) {                                     /* :724-729 */
+            double phend = phv[hop - 1] + pi2 * fsig[(int64_t)hop * (ii + 1)] / sr;
+            double arg = pr[ii + 1] + phcornext - phend + PVO_PI;
+            double md = fmod(arg, pi2);                         /* np.mod: result has the divisor's sign */
+            if (md != 0.0 && md < 0.0) md += pi2;
+            double dph = md - PVO_PI;
+            double step = dph / (double)hop;                    /* np.linspace(0, dph, hop+1)[:-1] */
+            for (int m = 0; m < hop; m++) phv[m] += (double)m * step + 0.0;
+        }
+        for (int m = 0; m < hop; m++) body[(int64_t)hop * ii + m] = msig[(int64_t)hop * ii + m] * cos(phv[m]);  /* :734-736 */
+        lastph = phv[hop - 1];
+    }
+    /* attack, PV.py:742-745 */
+    {
+        double acc = 0.0;
+        double *cs = (double *)malloc(sizeof(double) * (edgsam > 0 ? edgsam : 1));
+        double c = pf[0] * 1.0 / sr;
+        for (int k = 0; k < edgsam; k++) { acc = acc + c; cs[k] = acc; }
+        for (int j = 0; j < edgsam; j++) {
+            double a = msig[0] * (1 - cos(PVO_PI * (double)j / (double)edgsam)) / 2.;
+            double phb = pr[0] - pi2 * cs[edgsam - 1 - j];
+            sig[j] = a * cos(phb);
+        }
+        /* release, PV.py:748-751 */
+        acc = 0.0;
+        c = pf[nfr - 1] * 1.0 / sr;
+        double mend = msig[(int64_t)hop * nfr];
+        for (int j = 0; j < edgsam; j++) {
+            acc = acc + c;
+            double a = mend * (1 + cos(PVO_PI * (double)j / (double)edgsam)) / 2.;
+            sig[edgsam + (int64_t)hop * nfr + j] = a * cos(lastph + pi2 * acc);
+        }
+        free(cs);
+    }
+    *edg = edgsam;
+    free(fsig); free(msig); free(xpf); free(xpm); free(phv);
+    return 0;
+}
+
+/* SinSum.synth output length (PV.py:1055-1059, 1070 with integer edgsamp). */
+int64_t pvo_synth_len(const int32_t *part_start, const int32_t *part_len, int64_t P,
+                      int nfft, int hop_analysis, int hop_synth, double edge) {
+    if (P <= 0) return -1;   /* max() of an empty list raises in the reference */
+    int64_t maxend = 0;
+    for (int64_t p = 0; p < P; p++) { int64_t e = (int64_t)part_start[p] + part_len[p] - 1; if (e > maxend) maxend = e; }
+    double dfr = (double)nfft / (double)hop_analysis / 2.;
+    int64_t edgsamp = (int64_t)(edge * hop_synth * dfr);
+    return (maxend + 2) * hop_synth + 2 * edgsamp - edgsamp;
+}
+
+/* SinSum.synth (PV.py:1053-1070).  f, mag, realph: F*K analysis arrays; partial_id: F*K
+ * from pvo_track; part_start/part_len: P.  w: pvo_synth_len() samples. */
+int pvo_synth(const double *f, const double *mag, const double *realph, const int32_t *partial_id,
+              int64_t F, int K, const int32_t *part_start, const int32_t *part_len, int64_t P,
+              double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+              double *w, int64_t wlen) {
+    const int hop = hop_synth;
+    double dfr = (double)nfft / (double)hop_analysis / 2.;          /* PV.py:1055 */
+    int64_t edgsamp = (int64_t)(edge * hop * dfr);                  /* PV.py:1056 (int, see header) */
+    int64_t need = pvo_synth_len(part_start, part_len, P, nfft, hop_analysis, hop_synth, edge);
+    if (need < 0 || wlen != need) return -1;
+    int64_t fulllen = need + edgsamp;
+    double *full = (double *)calloc(fulllen, sizeof(double));
+    if (!full) return -2;
+    const double overlap = hop_analysis / (double)nfft;             /* PV.py:824 */
+    const double fstep = sr / (double)nfft;                         /* PV.py:825 */
+    int maxlen = 0;
+    for (int64_t p = 0; p < P; p++) if (part_len[p] > maxlen) maxlen = part_len[p];
+    double *pf = (double *)malloc(sizeof(double) * (maxlen + 1)), *pm = (double *)malloc(sizeof(double) * (maxlen + 1)),
+           *pr = (double *)malloc(sizeof(double) * (maxlen + 1));
+    const double dfrp = 1. / overlap / 2.;
+    int64_t siglen_max = (int64_t)hop * maxlen + 2 * ((int64_t)(dfrp * hop * edge) + 1);
+    double *sig = (double *)malloc(sizeof(double) * (siglen_max + 1));
+    if (!pf || !pm || !pr || !sig) return -2;
+    for (int64_t p = 0; p < P; p++) {                                /* PV.py:1060-1069 */
+        int nfr = part_len[p];
+        if (nfr < minframes || nfr < 1) continue;
+        for (int j = 0; j < nfr; j++) {
+            int64_t fr = (int64_t)part_start[p] + j;
+            int slot = -1;
+            for (int s = 0; s < K; s++) if (partial_id[fr * K + s] == (int32_t)p) { slot = s; break; }
+            if (slot < 0) { free(full); return -3; }
+            pf[j] = f[fr * K + slot]; pm[j] = mag[fr * K + slot]; pr[j] = realph[fr * K + slot];
+        }
+        int edgsam = 0;
+        if (regpartial_synth(pf, pm, pr, nfr, overlap, fstep, sr, hop, edge, sig, &edgsam) != 0) { free(full); return -2; }
+        int64_t spl_st = (int64_t)((double)part_start[p] * hop - edgsam);   /* PV.py:756 int(...) */
+        spl_st += edgsamp;                                           /* PV.py:1066 */
+        int64_t len = (int64_t)hop * nfr + 2 * (int64_t)edgsam;
+        if (spl_st >= 0) {
+            if (spl_st + len > fulllen) { free(full); return -4; }   /* numpy would raise */
+            for (int64_t i = 0; i < len; i++) full[spl_st + i] += sig[i];
+        }
+    }
+    memcpy(w, full + edgsamp, sizeof(double) * need);               /* PV.py:1070 */
+    free(full); free(pf); free(pm); free(pr); free(sig);
+    (void)F;
+    return 0;
+}

@@ -1,0 +1,169 @@
+"""ctypes front end of the CPU oracle (oracle/pvoracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker / reported baseline.  The product package (pypevoc_amd)
+never imports this module.  Parity of the oracle itself is pinned against the reference's
+own outputs in tests/test_oracle_golden.py (fixtures: tests/golden/make_golden.py).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpvoracle.so")
+    src = os.path.join(_HERE, "pvoracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpvoracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libpvoracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        L.pvo_nframes.restype = ctypes.c_int64
+        L.pvo_nframes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+        L.pvo_analyze.restype = ctypes.c_int64
+        L.pvo_analyze.argtypes = [_dp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_double, _dp] + [_dp] * 7
+        L.pvo_stft_frame.restype = ctypes.c_int
+        L.pvo_stft_frame.argtypes = [_dp, ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp]
+        L.pvo_peakfinder.restype = ctypes.c_int
+        L.pvo_peakfinder.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                     ctypes.c_int, _ip, _ip]
+        L.pvo_track.restype = ctypes.c_int64
+        L.pvo_track.argtypes = [_dp, _dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                _i32p, _i32p, _i32p]
+        L.pvo_synth_len.restype = ctypes.c_int64
+        L.pvo_synth_len.argtypes = [_i32p, _i32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_double]
+        L.pvo_synth.restype = ctypes.c_int
+        L.pvo_synth.argtypes = [_dp, _dp, _dp, _i32p, ctypes.c_int64, ctypes.c_int, _i32p, _i32p,
+                                ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp, ctypes.c_int64]
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def nframes(nsamp, nfft, hop):
+    return int(lib().pvo_nframes(int(nsamp), int(nfft), int(hop)))
+
+
+def analyze(x, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, win=None):
+    """run_pv on float64 data.  Returns dict(f, mag, ph, realph, binno, t, totalmag)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if hop is None:
+        hop = int(nfft / 2)
+    hop = int(hop)
+    win = np.hanning(nfft) if win is None else win
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    F = nframes(len(x), nfft, hop)
+    out = {k: np.zeros((F, npks)) for k in ("f", "mag", "ph", "realph", "binno")}
+    out["t"] = np.zeros(F)
+    out["totalmag"] = np.zeros(F)
+    r = lib().pvo_analyze(_d(x), len(x), float(sr), int(nfft), hop, int(npks), float(pkthresh), _d(win),
+                          _d(out["f"]), _d(out["mag"]), _d(out["ph"]), _d(out["realph"]),
+                          _d(out["binno"]), _d(out["t"]), _d(out["totalmag"]))
+    if r != F:
+        raise RuntimeError("pvo_analyze failed: %d" % r)
+    return out
+
+
+def stft_frame(x, pos, nfft, win=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    win = np.hanning(nfft) if win is None else win
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    re = np.zeros(nfft // 2)
+    im = np.zeros(nfft // 2)
+    if lib().pvo_stft_frame(_d(x), int(pos), int(nfft), _d(win), _d(re), _d(im)) != 0:
+        raise RuntimeError("pvo_stft_frame failed")
+    return re + 1j * im
+
+
+def peakfinder(y, npeaks=None, minrattomax=None, minval=None, rad=5):
+    """PeakFinder(y, npeaks=, minrattomax=, minval=) then filter_by_salience(rad) (rad=None: no
+    filter).  Returns (positions after findpos, keep mask)."""
+    y = np.ascontiguousarray(np.squeeze(y), dtype=np.float64)
+    n = len(y)
+    kind, val = 0, 0.0
+    if minrattomax is not None:
+        kind, val = 1, float(minrattomax)
+    elif minval is not None:
+        kind, val = 2, float(minval)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    keep = np.zeros(max(n, 1), dtype=np.int32)
+    c = lib().pvo_peakfinder(_d(y), n, int(npeaks) if npeaks else 0, kind, val,
+                             -1 if rad is None else int(rad),
+                             idx.ctypes.data_as(_ip), keep.ctypes.data_as(_ip))
+    if c < 0:
+        raise RuntimeError("pvo_peakfinder failed")
+    return idx[:c].copy(), keep[:c].astype(bool)
+
+
+def track(f, mag, maxpitchjmp=0.5):
+    """toSinSum: returns (partial_id[F,K], part_start[P], part_len[P])."""
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    mag = np.ascontiguousarray(mag, dtype=np.float64)
+    F, K = f.shape
+    pid = np.full((F, K), -1, dtype=np.int32)
+    st = np.zeros(max(F * K, 1), dtype=np.int32)
+    ln = np.zeros(max(F * K, 1), dtype=np.int32)
+    P = lib().pvo_track(_d(f), _d(mag), F, K, float(maxpitchjmp), _i32(pid), _i32(st), _i32(ln))
+    return pid, st[:P].copy(), ln[:P].copy()
+
+
+def part_slots(pid, st, ln):
+    """CSR slot list in the layout of the golden fixtures (part_slot)."""
+    F, K = pid.shape
+    slots = []
+    for p in range(len(st)):
+        for j in range(ln[p]):
+            s = np.flatnonzero(pid[st[p] + j] == p)
+            assert len(s) == 1
+            slots.append(s[0])
+    return np.array(slots, dtype=np.int16)
+
+
+def synth(f, mag, realph, pid, st, ln, sr, nfft, hop_analysis, hop_synth=None, edge=1.0, minframes=3):
+    """SinSum.synth(sr, hop_synth, edge, minframes)."""
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    mag = np.ascontiguousarray(mag, dtype=np.float64)
+    realph = np.ascontiguousarray(realph, dtype=np.float64)
+    pid = np.ascontiguousarray(pid, dtype=np.int32)
+    st = np.ascontiguousarray(st, dtype=np.int32)
+    ln = np.ascontiguousarray(ln, dtype=np.int32)
+    F, K = f.shape
+    if hop_synth is None:
+        hop_synth = hop_analysis
+    hop_synth = int(hop_synth)
+    n = lib().pvo_synth_len(_i32(st), _i32(ln), len(st), int(nfft), int(hop_analysis), hop_synth, float(edge))
+    if n < 0:
+        raise ValueError("max() arg is an empty sequence")
+    w = np.zeros(n)
+    r = lib().pvo_synth(_d(f), _d(mag), _d(realph), _i32(pid), F, K, _i32(st), _i32(ln), len(st),
+                        float(sr), int(nfft), int(hop_analysis), hop_synth, float(edge), int(minframes),
+                        _d(w), n)
+    if r != 0:
+        raise RuntimeError("pvo_synth failed: %d" % r)
+    return w

@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/pvoracle.c) against the reference's own outputs.
+
+The golden vectors were produced by importing goiosunsw/PyPeVoc itself
+(tests/golden/make_golden.py).  Tolerances are float64 round-off only: the oracle restates
+the same arithmetic; the FFT (pocketfft in the reference) is the only different routine.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import GOLDEN, golden_names, load_golden
+
+ANALYSIS = golden_names()
+TRACKED = [n for n in ANALYSIS if not n.startswith("G9_")]
+
+
+def _same_peaks(g, o):
+    assert np.array_equal(g["binno"], o["binno"])
+    assert np.array_equal(g["f"] > 0, o["f"] > 0)
+
+
+@pytest.mark.parametrize("name", ANALYSIS)
+def test_analysis_matches_reference(oracle, name):
+    g = load_golden(name)
+    o = oracle.analyze(g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"])
+    assert o["f"].shape == g["f"].shape == (g["nframes"], g["npks"])
+    _same_peaks(g, o)
+    # stated float64 tolerances: |df| <= 1e-9 Hz, rel mag 1e-12 (+ a floor for
+    # peaks at the 1e-5 threshold of the spectrum), phases 1e-10 rad away from the x/0 frames
+    np.testing.assert_allclose(o["f"], g["f"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(o["mag"], g["mag"], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(o["ph"], g["ph"], rtol=0, atol=2e-9)
+    np.testing.assert_allclose(o["realph"], g["realph"], rtol=0, atol=2e-9)
+    np.testing.assert_allclose(o["t"], g["t"], rtol=0, atol=0)
+    np.testing.assert_allclose(o["totalmag"], g["totalmag"], rtol=1e-12, atol=1e-18)
+
+
+@pytest.mark.parametrize("name", TRACKED)
+def test_tracker_matches_reference(oracle, name):
+    g = load_golden(name)
+    # run the tracker on the REFERENCE's analysis arrays: isolates toSinSum
+    pid, st, ln = oracle.track(g["f"], g["mag"])
+    assert np.array_equal(st, g["part_start"])
+    assert np.array_equal(ln, g["part_len"])
+    assert np.array_equal(oracle.part_slots(pid, st, ln), g["part_slot"])
+
+
+@pytest.mark.parametrize("name", TRACKED)
+def test_synth_matches_reference(oracle, name):
+    g = load_golden(name)
+    hops = [int(k[5:]) for k in g if k.startswith("w_hop")]
+    if not hops:
+        pytest.skip("no waveform in this fixture")
+    pid, st, ln = oracle.track(g["f"], g["mag"])
+    for h in hops:
+        w = oracle.synth(g["f"], g["mag"], g["realph"], pid, st, ln, g["sr"], g["nfft"], g["hop"], h)
+        ref = g["w_hop%d" % h]
+        assert w.shape == ref.shape
+        tol = 1e-10 if ref.dtype == np.float64 else 2e-7   # G7 waveform is stored as float32
+        np.testing.assert_allclose(w, ref, rtol=0, atol=tol * max(1.0, np.abs(ref).max()))
+
+
+def test_g1_known_answer(oracle):
+    """The by-eye known answer of the reference's tests/test_pypevoc.py."""
+    g = load_golden("G1_two_sines")
+    o = oracle.analyze(g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"])
+    pid, st, ln = oracle.track(o["f"], o["mag"])
+    rows = []
+    for p in range(len(st)):
+        fr = np.arange(st[p], st[p] + ln[p])
+        sl = [np.flatnonzero(pid[i] == p)[0] for i in fr]
+        rows.append((int(st[p]), int(ln[p]), o["f"][fr, sl].mean(), o["mag"][fr, sl].mean()))
+    exp = [(0, 1, 419.897461, 0.099773), (0, 85, 1199.688926, 0.049980), (1, 84, 400.000007, 0.099773)]
+    assert len(rows) == 3
+    for r, e in zip(rows, exp):
+        assert r[0] == e[0] and r[1] == e[1]
+        assert abs(r[2] - e[2]) < 1e-6 and abs(r[3] - e[3]) < 1e-6
+
+
+def test_peakfinder_matches_reference(oracle):
+    g = np.load(os.path.join(GOLDEN, "G8_peakfinder.npz"))
+    ys = g["ys"].astype(np.float64)
+    for k in (1, 3, 8, 100):
+        for thr in (0.005, 0.2):
+            tag = "k%d_t%s" % (k, str(thr).replace(".", "p"))
+            for i, y in enumerate(ys):
+                pos, keep = oracle.peakfinder(y, npeaks=k, minrattomax=thr, rad=5)
+                n = int(g["cnt_" + tag][i])
+                assert len(pos) == n
+                assert np.array_equal(pos, g["pos_" + tag][i, :n])
+                assert np.array_equal(keep, g["keep_" + tag][i, :n].astype(bool))
+    # tests/test_peak_finder.py:16-20
+    pos, keep = oracle.peakfinder(g["ramp"], rad=None)
+    assert np.array_equal(pos[keep], g["ramp_pos"]) and list(pos) == [9]
+
+
+def test_nframes_formula(oracle):
+    # PV.py:224-225 frame count, checked against the reference's frame counts in the fixtures
+    for name in ANALYSIS:
+        g = load_golden(name)
+        assert oracle.nframes(len(g["x"]), g["nfft"], g["hop"]) == g["nframes"]
+    assert oracle.nframes(1024, 1024, 512) == 0
+    assert oracle.nframes(1025, 1024, 512) == 1
+    assert oracle.nframes(100, 1024, 512) == 0
