@@ -1,0 +1,175 @@
+/*
+ * pvx.h -- C ABI of libpvx_hip.so, the MI355X (gfx950) implementation of the PyPeVoc
+ * phase-vocoder hot path:  PV.run_pv() -> PV.toSinSum() -> SinSum.synth().
+ *
+ * The reference (goiosunsw/PyPeVoc, pure Python) has no FFI of its own; the boundary is its
+ * Python class API.  Each entry point below replaces the body of the reference method cited
+ * beside it (PV.py = pypevoc/PVAnalysis.py, PF.py = pypevoc/PeakFinder.py) and is what a
+ * ctypes binding inside those methods would call -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-allocated and caller-owned;
+ *   - "host" entry points take host pointers, copy in/out and return after the device has
+ *     finished; "_dev" entry points take device pointers (HBM-resident data) and a
+ *     hipStream_t passed as void*, and only enqueue work on that stream;
+ *   - return value 0 (or a non-negative count) on success, a negative pvx_status on error;
+ *     pvx_last_error() returns a thread-local message for the last failure;
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with
+ *     PVX_ERR_NO_DEVICE.
+ *   - array layouts are the reference's: (F, K) float64 C-order, zero padded, valid peaks
+ *     left-packed in ascending-bin order (PV.py:226-245, 256-264).
+ */
+#ifndef PVX_H
+#define PVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVX_VERSION 100
+
+typedef enum {
+    PVX_OK = 0,
+    PVX_ERR_NO_DEVICE = -1,   /* no HIP device / runtime failure at init */
+    PVX_ERR_INVALID = -2,     /* bad argument */
+    PVX_ERR_HIP = -3,         /* a HIP or rocFFT call failed */
+    PVX_ERR_ALLOC = -4,       /* device or host allocation failed */
+    PVX_ERR_UNSUPPORTED = -5, /* valid request outside what the kernels handle */
+    PVX_ERR_SIZE = -6         /* caller buffer too small / wrong length */
+} pvx_status;
+
+/* sample types accepted for the input signal x (PV.py:84 copies whatever the caller passed) */
+typedef enum { PVX_F32 = 0, PVX_F64 = 1, PVX_I16 = 2 } pvx_dtype;
+
+/* ---- library ------------------------------------------------------------------------- */
+
+/* Select and initialise the HIP device (idempotent per device).  device < 0: current device. */
+int pvx_init(int device);
+const char* pvx_last_error(void);
+int pvx_version(void);
+/* Name of the device the library is bound to ("" before pvx_init). */
+const char* pvx_device_name(void);
+
+/* Number of frames run_pv produces: pos = 0, hop, ... while pos < nsamp - nfft (PV.py:223-249). */
+int64_t pvx_nframes(int64_t nsamp, int nfft, int hop);
+
+/* ---- analysis: PV.__init__ constants + PV.run_pv (PV.py:72-131, 150-264) ------------- */
+
+typedef struct pvx_plan pvx_plan; /* opaque: constants, window, rocFFT plan, device workspace */
+
+/*
+ * Create an analysis plan.  Replaces the constant set-up of PV.__init__ (PV.py:97-121) and owns
+ * everything calc_fft_frame/calc_pv_frame need on the device.
+ *   win        nfft window samples = wind(nfft) (PV.py:97); NULL = symmetric Hann (np.hanning)
+ *   precision  32: float32 frames/spectra (per-peak arithmetic and outputs stay float64)
+ *              64: float64 end to end
+ *   max_rows   upper bound on frames processed per internal launch (0 = default); bounds the
+ *              device workspace: about max_rows * nfft * 3 * sizeof(real) bytes
+ */
+int pvx_plan_create(pvx_plan** plan, double sr, int nfft, int hop, int npks, double pkthresh,
+                    const double* win, int precision, int64_t max_rows);
+int pvx_plan_destroy(pvx_plan* plan);
+/* bytes of device workspace the plan holds */
+int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
+/* 0 = rocFFT per-frame FFT (three kernels per chunk), 1 = fused in-LDS FFT kernel where supported */
+int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
+/*
+ * Stage timing for bench.py's roofline line.  While enabled, hipEvents recorded on the launch
+ * stream bracket every stage of every chunk.  pvx_plan_get_timing synchronises with those events
+ * and returns, accumulated since the last call: ms[0] framing kernel, ms[1] rocFFT, ms[2]
+ * phase/peak kernel, ms[3] reserved (fused kernel); launches[i] = stage launches counted.
+ */
+int pvx_plan_set_timing(pvx_plan* plan, int enable);
+int pvx_plan_get_timing(pvx_plan* plan, double* ms /*[4]*/, int64_t* launches /*[4]*/);
+
+/*
+ * run_pv on `nsig` equal-length signals resident in HBM (nsig = 1: the reference's single
+ * signal).  Signal b starts at x + b * sig_stride samples and has nsamp samples.
+ *   d_f, d_mag, d_ph, d_realph, d_binno : device float64 [nsig, F, npks]
+ *   d_t, d_totalmag                     : device float64 [nsig, F]       (either may be NULL)
+ *   d_prev0 : optional device float64 [nfft/2][2] (re, im) -- the spectrum `oldfft` holds before
+ *             the first frame (PV.py:121, 209); NULL = zeros.  Used by the streaming
+ *             calc_pv_frame mirror; only valid with nsig == 1.
+ *   stream  : hipStream_t as void* (NULL = default stream).  Asynchronous.
+ * Returns F (frames per signal) or a negative status.
+ */
+int64_t pvx_analyze_dev(pvx_plan* plan, const void* d_x, int x_dtype, int64_t nsamp,
+                        int64_t nsig, int64_t sig_stride,
+                        double* d_f, double* d_mag, double* d_ph, double* d_realph, double* d_binno,
+                        double* d_t, double* d_totalmag, const double* d_prev0, void* stream);
+
+/* Same with host buffers (copies x in, results out, synchronous).  prev0 may be NULL.
+ * If last_spec is not NULL it receives the half spectrum of the last frame, float64 [nfft/2][2]
+ * (the value PV.oldfft holds after run_pv, PV.py:209). */
+int64_t pvx_analyze(pvx_plan* plan, const void* x, int x_dtype, int64_t nsamp,
+                    int64_t nsig, int64_t sig_stride,
+                    double* f, double* mag, double* ph, double* realph, double* binno,
+                    double* t, double* totalmag, const double* prev0, double* last_spec);
+
+/* calc_fft_frame (PV.py:150-158): windowed, 1/wfact-normalised spectra of `nfr` frames starting
+ * at sample positions pos[0..nfr); spec: host float64 [nfr][nfft/2+1][2] (bins 0..nfft/2; the
+ * remaining bins of the reference's length-nfft result are the conjugate mirror). */
+int pvx_stft_frames(pvx_plan* plan, const void* x, int x_dtype, int64_t nsamp,
+                    const int64_t* pos, int64_t nfr, double* spec);
+
+/* ---- PeakFinder (PF.py:35-74, 155-194, 113-136) -------------------------------------- */
+
+/*
+ * PeakFinder(y, npeaks=, minrattomax=, minval=) followed by filter_by_salience(rad) on `nrows`
+ * independent rows y[r][0..n) (host float64).
+ *   npeaks    <= 0: "not npeaks" -> n (PF.py:64-67)
+ *   thr_kind  0: no threshold given (minamp = min(y)); 1: minrattomax = thr_val; 2: minval = thr_val
+ *   rad       salience radius; < 0 skips filter_by_salience
+ *   pos       int32 [nrows][cap]: findpos() positions, ascending (PF.py:189)
+ *   keep      int8  [nrows][cap]: _keep after filter_by_salience
+ *   count     int32 [nrows]
+ *   cap       row capacity of pos/keep (>= min(npeaks, n) to hold everything)
+ */
+int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks, int thr_kind, double thr_val,
+                   int rad, int32_t* pos, int8_t* keep, int32_t* count, int cap);
+
+/* ---- tracker: PV.toSinSum / SinSum.add_frame (PV.py:299-322, 871-957) ---------------- */
+
+/*
+ * Builds the partial table from the analysis arrays of one signal.
+ *   f, mag            host float64 [F, K]
+ *   maxpitchjmp       semitone threshold (the reference always uses 0.5: PV.py:320-321)
+ *   partial_id        int32 [F, K]: partial index of every peak slot, -1 if the slot is empty
+ *   part_start/len    int32 [cap]: first frame and number of points of each partial, in the
+ *                     reference's creation order (PV.py:819-830)
+ *   cap               capacity of part_start/part_len (F*K always suffices)
+ * Returns the number of partials or a negative status.
+ */
+int64_t pvx_track(const double* f, const double* mag, int64_t F, int K, double maxpitchjmp,
+                  int32_t* partial_id, int32_t* part_start, int32_t* part_len, int64_t cap);
+int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t F, int K, double maxpitchjmp,
+                      int32_t* d_partial_id, int32_t* d_part_start, int32_t* d_part_len, int64_t cap,
+                      void* stream);
+
+/* ---- resynthesis: SinSum.synth / RegPartial.synth (PV.py:1053-1070, 684-756) ---------- */
+
+/* Output length of SinSum.synth: (max(end)+2)*hop_synth + int(edge*hop_synth*nfft/hop_analysis/2). */
+int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge);
+
+/*
+ * SinSum.synth(sr, hop_synth, edge, minframes, phase_preserve=True).
+ *   f, mag, realph    host float64 [F, K] analysis arrays
+ *   partial_id        int32 [F, K] from pvx_track;  part_start/part_len: int32 [P]
+ *   w                 host float64 [wlen], wlen = pvx_synth_len(max(end), ...)
+ */
+int pvx_synth(const double* f, const double* mag, const double* realph, const int32_t* partial_id,
+              int64_t F, int K, const int32_t* part_start, const int32_t* part_len, int64_t P,
+              double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+              double* w, int64_t wlen);
+int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph,
+                  const int32_t* d_partial_id, int64_t F, int K,
+                  const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
+                  double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                  double* d_w, int64_t wlen, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVX_H */

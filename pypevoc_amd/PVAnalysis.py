@@ -1,0 +1,618 @@
+"""Drop-in mirror of pypevoc.PVAnalysis for the hot path PV.run_pv -> PV.toSinSum -> SinSum.synth.
+
+Same class names, constructor arguments, attributes and array layouts as the reference
+(goiosunsw/PyPeVoc, pypevoc/PVAnalysis.py); the bodies of the hot methods are calls into
+libpvx_hip.so (HIP kernels for MI355X, C ABI in include/pvx.h).  There is no numpy fallback for
+those bodies: without the library / a GPU they raise.
+
+What is host Python here is only what the reference also does once per object (constants of
+PV.__init__, PVAnalysis.py:84-121) and the list-like views over device results.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+pi2 = 2.0 * np.pi                      # PVAnalysis.py:45
+
+
+def dpitch2st_exact(f1, f2):
+    """PVAnalysis.py:55-59."""
+    return 12 * np.log2(float(f2) / f1)
+
+
+def dpitch2st(f1, f2):
+    """PVAnalysis.py:62-68: approximate semitone interval used by the tracker."""
+    return 17.312 * (float(f2) / f1 - 1.0)
+
+
+class _Plan(object):
+    """Owner of a pvx_plan handle."""
+
+    def __init__(self, sr, nfft, hop, npks, pkthresh, win, precision, max_rows=0):
+        lib = _lib.load()
+        _lib.init()
+        h = ctypes.c_void_p()
+        win = np.ascontiguousarray(win, dtype=np.float64)
+        _lib.check(lib.pvx_plan_create(ctypes.byref(h), float(sr), int(nfft), int(hop), int(npks),
+                                       float(pkthresh), _lib.dptr(win), int(precision), int(max_rows)),
+                   "pvx_plan_create")
+        self.handle = h
+        self._lib = lib
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.pvx_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PV(object):
+    def __init__(self, x, sr, nfft=1024, hop=None, npks=20,
+                 pkthresh=0.005, wind=np.hanning, progress=True, precision=32):
+        '''
+        Phase vocoder object (PVAnalysis.py:72-131).
+        Arguments:
+            * sr   = Sampling rate
+            * nfft = Number of points in FFT analysis window
+            * hop  = Number of points between FFT windows
+            * npks = Maximum number of peaks at each frame
+            * pkthresh = Threshold of peak amplitude relative of maximum
+        Extra (not in the reference):
+            * precision = 32: float32 frames/spectra on the device (outputs float64, tolerances in
+                          DESIGN.md); 64: float64 end to end
+        '''
+        self.x = np.array(x)                                   # PVAnalysis.py:84
+        self.nsamp = len(self.x)
+        self.sr = sr
+        self.nfft = nfft
+        self.nfft2 = int(nfft / 2)
+        if hop is None:
+            self.hop = int(self.nfft / 2)
+        else:
+            self.hop = hop
+        self.peakthresh = pkthresh
+        self.npeaks = npks
+        self.nframes = 0
+        self.precision = precision
+
+        self.win = wind(nfft)
+        self.wsum = sum(self.win)
+        self.wsum2 = sum(self.win ** 2)
+        self.wfact = np.sqrt(self.wsum2 * self.nfft) / 2.0     # PVAnalysis.py:102
+        self.fstep = float(self.sr) / float(self.nfft)
+        self.dt = float(self.hop) / float(self.sr)
+        self.fbin = np.arange(float(nfft)) * self.fstep
+        dthetabin = pi2 * self.fbin * self.dt
+        self.wfbin = np.round(dthetabin / pi2) * pi2           # PVAnalysis.py:118
+        self.oldfft = np.zeros(self.nfft2)                     # PVAnalysis.py:121
+
+        self.t = []
+        self.f = []
+        self.ph = []
+        self.mag = []
+        # PVAnalysis.py:128-131 builds a console progress bar that prints once per frame; the whole
+        # analysis is a handful of kernel launches here, so `progress` only gates one final line.
+        self.progress = bool(progress)
+        self._plan = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _get_plan(self, rows=None):
+        if self._plan is None:
+            if int(self.hop) != self.hop:
+                raise TypeError("hop must be an integer number of samples")
+            want = 0
+            if rows is not None:
+                want = max(2, int(rows))
+            self._plan = _Plan(self.sr, self.nfft, int(self.hop), self.npeaks, self.peakthresh,
+                               self.win, self.precision, max_rows=want)
+        return self._plan
+
+    def _signal(self):
+        if self.x.ndim != 1:
+            raise ValueError("PV expects a 1-D signal")
+        return _lib.as_signal(self.x)
+
+    # ------------------------------------------------------------------ reference API
+    def dphase2freq(self, dph, nbin):
+        '''
+        "Instantaneous frequency" for the phase difference dph between two consecutive frames
+        (PVAnalysis.py:133-148).  Scalar helper for streaming users; run_pv evaluates the same
+        three candidates per peak on the device.
+        '''
+        dphw = dph + self.wfbin[nbin] + pi2 * np.arange(-1, 2)
+        freq = dphw / self.dt / pi2
+        df = self.fbin[nbin] - freq
+        ii = np.argmin(abs(df))
+        return freq[ii], df[ii]
+
+    def calc_fft_frame(self, pos):
+        '''Windowed, normalised FFT of the frame at pos (PVAnalysis.py:150-158), length nfft.'''
+        lib = _lib.load()
+        x, dt = self._signal()
+        nb = self.nfft // 2 + 1
+        spec = np.zeros((1, nb, 2))
+        posa = np.array([int(pos)], dtype=np.int64)
+        _lib.check(lib.pvx_stft_frames(self._get_plan().handle, x.ctypes.data_as(ctypes.c_void_p), dt,
+                                       len(x), posa.ctypes.data_as(_lib.c_int64_p), 1, _lib.dptr(spec)),
+                   "pvx_stft_frames")
+        half = spec[0, :, 0] + 1j * spec[0, :, 1]
+        full = np.zeros(self.nfft, dtype=complex)
+        full[:nb] = half
+        # conjugate mirror of a real signal's spectrum
+        full[nb:] = np.conj(half[1:self.nfft - nb + 1][::-1])
+        return full
+
+    def calc_pv_frame(self, pos):
+        '''
+        Peaks and frequencies of the frame at pos, based on the previous frame kept in
+        self.oldfft (PVAnalysis.py:160-211).  Returns f, mag, ph, realph, binno, totalmag.
+        '''
+        lib = _lib.load()
+        x, dt = self._signal()
+        pos = int(pos)
+        seg = x[pos:pos + self.nfft]
+        if len(seg) < self.nfft:
+            raise ValueError("operands could not be broadcast together: frame at %d leaves the signal" % pos)
+        seg = np.concatenate([seg, np.zeros(1, dtype=seg.dtype)])   # one frame: nsamp = nfft + 1
+        K = self.npeaks
+        out = [np.zeros((1, K)) for _ in range(5)]
+        t = np.zeros(1)
+        tm = np.zeros(1)
+        old = np.asarray(self.oldfft, dtype=complex)
+        prev0 = np.ascontiguousarray(np.stack([old.real, old.imag], axis=1), dtype=np.float64)
+        last = np.zeros((self.nfft2, 2))
+        F = lib.pvx_analyze(self._get_plan().handle, seg.ctypes.data_as(ctypes.c_void_p), dt, len(seg), 1, len(seg),
+                            *[_lib.dptr(a) for a in out], _lib.dptr(t), _lib.dptr(tm), _lib.dptr(prev0),
+                            _lib.dptr(last))
+        _lib.check(F, "pvx_analyze")
+        f, mag, ph, realph, binno = [a[0] for a in out]
+        n = int(np.count_nonzero(f > 0))
+        self.oldfft = last[:, 0] + 1j * last[:, 1]              # PVAnalysis.py:209
+        return (list(f[:n]), list(mag[:n]), list(ph[:n]), list(realph[:n]),
+                [int(b) for b in binno[:n]], float(tm[0]))
+
+    def run_pv(self):
+        '''The analysis loop (PVAnalysis.py:213-264) as one call into the HIP library.'''
+        lib = _lib.load()
+        x, dt = self._signal()
+        K = self.npeaks
+        F = int(lib.pvx_nframes(self.nsamp, self.nfft, int(self.hop)))
+        if F == 0:
+            # the reference ends with empty arrays (np.array([]))
+            self.f = np.array([]); self.mag = np.array([]); self.ph = np.array([])
+            self.realph = np.array([]); self.binno = np.array([]); self.t = np.array([])
+            self.nframes = 0
+            self.totalmag = []
+            return
+        f = np.empty((F, K)); mag = np.empty((F, K)); ph = np.empty((F, K))
+        realph = np.empty((F, K)); binno = np.empty((F, K))
+        t = np.empty(F); tm = np.empty(F)
+        last = np.zeros((self.nfft2, 2))
+        old = np.asarray(self.oldfft)
+        prev0 = None
+        if np.any(old != 0):                                     # run_pv after manual calc_pv_frame calls
+            oc = old.astype(complex)
+            prev0 = np.ascontiguousarray(np.stack([oc.real, oc.imag], axis=1), dtype=np.float64)
+        plan = self._get_plan(rows=F + 1)
+        r = lib.pvx_analyze(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), 1, len(x),
+                            _lib.dptr(f), _lib.dptr(mag), _lib.dptr(ph), _lib.dptr(realph), _lib.dptr(binno),
+                            _lib.dptr(t), _lib.dptr(tm),
+                            _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
+        _lib.check(r, "pvx_analyze")
+        self.f = f
+        self.mag = mag
+        self.ph = ph
+        self.realph = realph
+        self.binno = binno
+        self.t = t
+        self.nframes = F
+        self.totalmag = list(tm)                                 # PVAnalysis.py:264 (a Python list)
+        self.oldfft = last[:, 0] + 1j * last[:, 1]
+        if self.progress:
+            print("\r %d / %d (100%%)" % (self.nsamp, self.nsamp))
+
+    def toSinSum(self, maxpitchjmp=0.5):
+        '''
+        Convert to Sine sum (PVAnalysis.py:299-322).
+        NB: as in the reference, `maxpitchjmp` is accepted but NOT forwarded (PVAnalysis.py:320-321
+        call add_frame without it), so tracks are always built with the 0.5-semitone default.
+        '''
+        ss = SinSum(self.sr, nfft=self.nfft, hop=self.hop)
+        if self.nframes > 0:
+            ss._from_analysis(self.f, self.mag, self.ph, self.realph)
+        return ss
+
+    def get_time_vector(self):
+        return self.t
+
+    def get_sample_vector(self):
+        return (self.t * self.sr).astype('int')
+
+    def calc_f0(self, fmin=50, fmax=10000, thr=0.1):
+        """
+        Lowest-frequency strong peak per frame (PVAnalysis.py:371-391), vectorised over frames on
+        the (F, K) result arrays.
+        """
+        ff = np.asarray(self.f)
+        mm = np.asarray(self.mag)
+        fm = np.zeros(ff.shape[0])
+        im = np.zeros(ff.shape[0], dtype='i')
+        if ff.size:
+            maxmag = mm.max(axis=1, keepdims=True)
+            ok = (ff > fmin) & (ff < fmax) & (mm > maxmag * thr)
+            cand = np.where(ok, ff, np.inf)
+            isel = np.argmin(cand, axis=1)
+            has = ok.any(axis=1)
+            rows = np.arange(ff.shape[0])
+            fm[has] = ff[rows[has], isel[has]]
+            im[has] = isel[has]
+        self.fundamental_idx = im
+        return fm
+
+    @property
+    def fundamental_frequency(self):
+        try:
+            return self.f[np.arange(self.f.shape[0]), self.fundamental_idx]
+        except AttributeError:
+            return self.calc_f0()
+
+    @property
+    def fundamental_magnitude(self):
+        try:
+            return self.mag[np.arange(self.f.shape[0]), self.fundamental_idx]
+        except AttributeError:
+            self.calc_f0()
+            return self.mag[np.arange(self.f.shape[0]), self.fundamental_idx]
+
+    @property
+    def partial_sum_magnitude(self):
+        return np.sqrt(np.sum(self.mag ** 2, axis=1))
+
+    @property
+    def partial_magnitude_ratio(self):
+        return self.partial_sum_magnitude / self.totalmag
+
+
+class RegPartial(object):
+    def __init__(self, istart, pdict=None, overlap=0.5, fstep=None):
+        '''
+        A quasi-sinusoidal partial with homogeneous sampling (PVAnalysis.py:585-614).
+        '''
+        self.start_idx = istart
+        self.overlap = overlap
+        self.fstep = fstep
+        if pdict is None:
+            self.f = []
+            self.mag = []
+            self.ph = []
+            self.realph = []
+        else:
+            self.f = pdict['f']
+            self.mag = pdict['mag']
+            self.ph = pdict['ph']
+            try:
+                self.realph = pdict['realph']
+            except KeyError:
+                self.realph = pdict['ph']
+
+    def append_point(self, f, mag, ph, realph=None):
+        '''Add a single point to the end of partial (PVAnalysis.py:616-626).'''
+        self.f.append(f)
+        self.mag.append(mag)
+        self.ph.append(ph)
+        if realph is None:
+            self.realph.append(ph)
+        else:
+            self.realph.append(realph)
+
+    def get_freq_at_frame(self, fr):
+        relidx = fr - self.start_idx
+        if relidx >= 0:
+            return self.f[relidx]
+        else:
+            return np.nan
+
+    def get_mag_at_frame(self, fr):
+        relidx = fr - self.start_idx
+        if relidx >= 0:
+            return self.mag[relidx]
+        else:
+            return np.nan
+
+    def synth(self, sr, hop, intermediate=False, edge=.5):
+        '''
+        Phase-preserving resynthesis of this partial (PVAnalysis.py:684-756) on the device.
+        Returns (signal, first sample index).  fstep=None (no frequency-slope phase correction) is
+        not implemented by the kernel; SinSum always sets it (PVAnalysis.py:824-825).
+        '''
+        if intermediate:
+            raise NameError("name 'phsig' is not defined")      # what the reference raises (PVAnalysis.py:754)
+        if self.fstep is None:
+            raise NotImplementedError("RegPartial.synth without fstep is outside the device path")
+        hop = int(hop)
+        nfr = len(self.f)
+        dfr = 1. / self.overlap / 2.
+        edgsam = int(dfr * hop * edge)
+        # derive (nfft, hop_analysis) with hop_a/nfft == overlap and sr/nfft == fstep
+        nfft = int(round(sr / float(self.fstep)))
+        hop_a = int(round(self.overlap * nfft))
+        if abs(hop_a / float(nfft) - self.overlap) > 1e-15 or abs(sr / float(nfft) - self.fstep) > 1e-9 * self.fstep:
+            raise NotImplementedError("overlap/fstep do not correspond to integer nfft and hop")
+        pad = (edgsam + hop - 1) // hop + 1                     # frames of head room so the attack is not clipped
+        F = pad + nfr
+        f = np.zeros((F, 1)); mag = np.zeros((F, 1)); rp = np.zeros((F, 1))
+        pid = np.full((F, 1), -1, dtype=np.int32)
+        f[pad:, 0] = self.f; mag[pad:, 0] = self.mag; rp[pad:, 0] = self.realph
+        pid[pad:, 0] = 0
+        st = np.array([pad], dtype=np.int32)
+        ln = np.array([nfr], dtype=np.int32)
+        w = _device_synth(f, mag, rp, pid, st, ln, sr, nfft, hop_a, hop, edge, 1)
+        a = pad * hop - edgsam
+        return w[a:a + hop * nfr + 2 * edgsam].copy(), int((self.start_idx) * hop - edgsam)
+
+
+def _device_synth(f, mag, realph, pid, st, ln, sr, nfft, hop_a, hop_s, edge, minframes):
+    lib = _lib.load()
+    _lib.init()
+    F, K = f.shape
+    maxend = int((st.astype(np.int64) + ln - 1).max())
+    n = lib.pvx_synth_len(maxend, int(nfft), int(hop_a), int(hop_s), float(edge))
+    _lib.check(n, "pvx_synth_len")
+    w = np.zeros(n)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    mag = np.ascontiguousarray(mag, dtype=np.float64)
+    realph = np.ascontiguousarray(realph, dtype=np.float64)
+    pid = np.ascontiguousarray(pid, dtype=np.int32)
+    st = np.ascontiguousarray(st, dtype=np.int32)
+    ln = np.ascontiguousarray(ln, dtype=np.int32)
+    i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    _lib.check(lib.pvx_synth(_lib.dptr(f), _lib.dptr(mag), _lib.dptr(realph), i32(pid), F, K, i32(st), i32(ln),
+                             len(st), float(sr), int(nfft), int(hop_a), int(hop_s), float(edge), int(minframes),
+                             _lib.dptr(w), n), "pvx_synth")
+    return w
+
+
+class _PartialList(list):
+    """The `partial` list of a SinSum; remembers whether user code changed it."""
+    pass
+
+
+class SinSum(object):
+    def __init__(self, sr, nfft=1024, hop=512):
+        '''
+        Sine sum object (PVAnalysis.py:797-817): a sound decomposed in a sum of quasi-sine waves.
+        '''
+        self._partial = []
+        self._st = []
+        self._end = []
+        self.nfft = nfft
+        self.hop = hop
+        self.sr = sr
+        # device-side table (set by PV.toSinSum): analysis arrays + partial ids
+        self._tab = None
+        self._materialised = True
+
+    # ---- table built by the tracker kernels ------------------------------------------------
+    def _from_analysis(self, f, mag, ph, realph, maxpitchjmp=0.5):
+        lib = _lib.load()
+        _lib.init()
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        mag = np.ascontiguousarray(mag, dtype=np.float64)
+        F, K = f.shape
+        pid = np.empty((F, K), dtype=np.int32)
+        cap = F * K
+        st = np.empty(cap, dtype=np.int32)
+        ln = np.empty(cap, dtype=np.int32)
+        i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        P = lib.pvx_track(_lib.dptr(f), _lib.dptr(mag), F, K, float(maxpitchjmp), i32(pid), i32(st), i32(ln), cap)
+        _lib.check(P, "pvx_track")
+        self._tab = dict(f=f, mag=mag, ph=np.ascontiguousarray(ph, dtype=np.float64),
+                         realph=np.ascontiguousarray(realph, dtype=np.float64),
+                         pid=pid, st=st[:P].copy(), ln=ln[:P].copy())
+        self._materialised = False
+
+    def _materialise(self):
+        """Build the reference's Python objects (RegPartial lists, st, end) from the table."""
+        if self._materialised:
+            return
+        tab = self._tab
+        pid, st, ln = tab['pid'], tab['st'], tab['ln']
+        P = len(st)
+        F, K = pid.shape
+        # CSR gather: order the valid nodes by (partial, frame)
+        flat = pid.ravel()
+        nodes = np.flatnonzero(flat >= 0)
+        order = nodes[np.argsort(flat[nodes], kind='stable')]   # within a partial: ascending frame
+        off = np.concatenate([[0], np.cumsum(ln.astype(np.int64))])
+        vals = {k: tab[k].ravel()[order] for k in ('f', 'mag', 'ph', 'realph')}
+        overlap = self.hop / float(self.nfft)                    # PVAnalysis.py:824
+        fstep = self.sr / float(self.nfft)
+        parts = []
+        for p in range(P):
+            a, b = off[p], off[p + 1]
+            parts.append(RegPartial(int(st[p]), pdict=dict(f=vals['f'][a:b].tolist(), mag=vals['mag'][a:b].tolist(),
+                                                            ph=vals['ph'][a:b].tolist(),
+                                                            realph=vals['realph'][a:b].tolist()),
+                                    overlap=overlap, fstep=fstep))
+        self._partial = parts
+        self._st = [int(v) for v in st]
+        self._end = [int(v) for v in (st.astype(np.int64) + ln - 1)]
+        self._materialised = True
+
+    @property
+    def partial(self):
+        self._materialise()
+        self._tab_dirty = True      # the caller may mutate the objects; synth then re-packs them
+        return self._partial
+
+    @partial.setter
+    def partial(self, v):
+        self._materialise()
+        self._partial = v
+        self._tab_dirty = True
+
+    @property
+    def st(self):
+        self._materialise()
+        return self._st
+
+    @st.setter
+    def st(self, v):
+        self._materialise()
+        self._st = v
+
+    @property
+    def end(self):
+        self._materialise()
+        return self._end
+
+    @end.setter
+    def end(self, v):
+        self._materialise()
+        self._end = v
+
+    _tab_dirty = False
+
+    # ---- reference API ----------------------------------------------------------------------
+    def add_empty_partial(self, idx):
+        '''Append an empty partial at frame idx (PVAnalysis.py:819-830).'''
+        self._materialise()
+        newpart = RegPartial(idx, overlap=self.hop / float(self.nfft), fstep=self.sr / float(self.nfft))
+        self._partial.append(newpart)
+        self._st.append(idx)
+        self._end.append(idx)
+        self._tab_dirty = True
+        return newpart
+
+    def get_partials_idx_ending_at_frame(self, fr):
+        '''Index of the partials ending at fr (PVAnalysis.py:984-994).'''
+        self._materialise()
+        st = np.asarray(self._st)
+        end = np.asarray(self._end)
+        return np.flatnonzero((fr >= st) & (fr == end)) if len(st) else np.array([])
+
+    def get_partials_idx_at_frame(self, fr):
+        self._materialise()
+        st = np.asarray(self._st)
+        end = np.asarray(self._end)
+        return np.flatnonzero((fr >= st) & (fr <= end)) if len(st) else np.array([])
+
+    def get_partials_at_frame(self, fr):
+        return [self._partial[i] for i in self.get_partials_idx_at_frame(fr)]
+
+    def add_frame(self, fr, f, mag, ph, realph=None, maxpitchjmp=0.5):
+        '''
+        Add the peaks of frame fr to the matching partials or start new ones (PVAnalysis.py:871-957).
+        The matching itself runs in the tracker kernels on a two-row table: row 0 = the partials
+        that end at fr-1 (in partial-index order), row 1 = the new peaks.
+        '''
+        lib = _lib.load()
+        _lib.init()
+        self._materialise()
+        f = np.asarray(f, dtype=np.float64)
+        mag = np.asarray(mag, dtype=np.float64)
+        ph = np.asarray(ph, dtype=np.float64)
+        rp = ph if realph is None else np.asarray(realph, dtype=np.float64)
+        pidx = [int(i) for i in self.get_partials_idx_ending_at_frame(fr - 1)]
+        K = max(len(f), len(pidx), 1)
+        tf = np.zeros((2, K)); tm = np.zeros((2, K))
+        for j, i in enumerate(pidx):
+            tf[0, j] = self._partial[i].get_freq_at_frame(fr - 1)
+            tm[0, j] = self._partial[i].get_mag_at_frame(fr - 1)
+        tf[1, :len(f)] = f
+        tm[1, :len(mag)] = mag
+        pid = np.empty((2, K), dtype=np.int32)
+        st = np.empty(2 * K, dtype=np.int32)
+        ln = np.empty(2 * K, dtype=np.int32)
+        i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        P = lib.pvx_track(_lib.dptr(tf), _lib.dptr(tm), 2, K, float(maxpitchjmp), i32(pid), i32(st), i32(ln), 2 * K)
+        _lib.check(P, "pvx_track")
+        # process the new peaks in the reference's order: extended partials keep their object,
+        # new ones are created in creation order (= ascending new id)
+        valid = [s for s in range(len(f)) if pid[1, s] >= 0]
+        news = sorted([s for s in valid if st[pid[1, s]] == 1], key=lambda s: pid[1, s])
+        for s in valid:
+            q = pid[1, s]
+            if st[q] == 0:                                       # continues the partial in row-0 slot
+                j = int(np.flatnonzero(pid[0] == q)[0])
+                idx = pidx[j]
+                self._partial[idx].append_point(f[s], mag[s], ph[s], realph=rp[s])
+                self._end[idx] = fr
+        for s in news:
+            part = self.add_empty_partial(fr)
+            part.append_point(f[s], mag[s], ph[s], realph=rp[s])
+            self._end[-1] = fr
+        self._tab_dirty = True
+
+    def _pack_partials(self):
+        """(F, K) arrays + ids from the Python partial objects (after user edits)."""
+        parts = self._partial
+        if not parts:
+            raise ValueError("max() arg is an empty sequence")
+        st = np.array([p.start_idx for p in parts], dtype=np.int64)
+        ln = np.array([len(p.f) for p in parts], dtype=np.int64)
+        F = int(max(max(self._end), (st + ln - 1).max())) + 1
+        occ = np.zeros(F, dtype=np.int64)
+        for s, l in zip(st, ln):
+            occ[s:s + l] += 1
+        K = max(int(occ.max()), 1)
+        f = np.zeros((F, K)); mag = np.zeros((F, K)); rp = np.zeros((F, K))
+        pid = np.full((F, K), -1, dtype=np.int32)
+        fill = np.zeros(F, dtype=np.int64)
+        for i, p in enumerate(parts):
+            for j in range(len(p.f)):
+                fr = p.start_idx + j
+                s = fill[fr]; fill[fr] += 1
+                f[fr, s] = p.f[j]; mag[fr, s] = p.mag[j]; rp[fr, s] = p.realph[j]
+                pid[fr, s] = i
+        return f, mag, rp, pid, st.astype(np.int32), ln.astype(np.int32)
+
+    def synth(self, sr, hop, edge=1.0, minframes=3, phase_preserve=True):
+        '''
+        Overlap-add resynthesis (PVAnalysis.py:1053-1070) on the device.  `hop` may differ from the
+        analysis hop (time stretch); callers pass floats like `mypv.hop/1` (examples/WavResynth.py:36),
+        which is truncated to int as Python 2 did.
+        '''
+        if not phase_preserve:
+            # RegPartial.synth_no_phase (PVAnalysis.py:653-682) fails on current numpy
+            # (np.ones(float)); mirror that instead of inventing behaviour.
+            raise TypeError("'float' object cannot be interpreted as an integer")
+        hop = int(hop)
+        if self._tab is not None and not self._tab_dirty:
+            tab = self._tab
+            if len(tab['st']) == 0:
+                raise ValueError("max() arg is an empty sequence")
+            return _device_synth(tab['f'], tab['mag'], tab['realph'], tab['pid'], tab['st'], tab['ln'],
+                                 sr, self.nfft, int(self.hop), hop, edge, minframes)
+        self._materialise()
+        f, mag, rp, pid, st, ln = self._pack_partials()
+        return _device_synth(f, mag, rp, pid, st, ln, sr, self.nfft, int(self.hop), hop, edge, minframes)
+
+    def get_avfreq(self):
+        return np.array([np.mean(xx.f) for xx in self.partial])
+
+    def get_avmag(self):
+        return np.array([np.mean(xx.mag) for xx in self.partial])
+
+    def get_nframes(self):
+        return max(self.end)
+
+    def get_summary(self, minlen=10):
+        psum = np.array([(ii, len(xx.f), np.mean(xx.f), np.mean(xx.mag))
+                         for ii, xx in enumerate(self.partial) if len(xx.f) > minlen],
+                        dtype=[('idx', 'i4'), ('n', 'i4'), ('f', 'f4'), ('mag', 'f4')])
+        psum.sort(order='mag')
+        return psum
+
+    # table access without building Python objects (large analyses)
+    def partial_table(self):
+        """(partial_id[F,K], part_start[P], part_len[P]) as produced by the tracker kernels."""
+        if self._tab is None or self._tab_dirty:
+            self._materialise()
+            _, _, _, pid, st, ln = self._pack_partials()
+            return pid, st, ln
+        return self._tab['pid'], self._tab['st'], self._tab['ln']

@@ -1,0 +1,128 @@
+"""ctypes binding of libpvx_hip.so (C ABI: include/pvx.h).
+
+The library is the product: there is no Python/numpy fallback.  Importing this module only loads
+the shared object; the first call that needs the device raises PvxError if no MI355X is usable.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvx_hip.so")
+
+PVX_F32, PVX_F64, PVX_I16 = 0, 1, 2
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_int8_p = ctypes.POINTER(ctypes.c_int8)
+
+# name -> (restype, argtypes); every symbol include/pvx.h declares
+SIGNATURES = {
+    "pvx_init": (ctypes.c_int, [ctypes.c_int]),
+    "pvx_last_error": (ctypes.c_char_p, []),
+    "pvx_version": (ctypes.c_int, []),
+    "pvx_device_name": (ctypes.c_char_p, []),
+    "pvx_nframes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "pvx_plan_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
+                                       ctypes.c_int, ctypes.c_int64]),
+    "pvx_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pvx_plan_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
+    "pvx_plan_set_fft_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pvx_plan_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pvx_plan_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int64_p]),
+    "pvx_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 8 +
+                        [ctypes.c_void_p]),
+    "pvx_analyze": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_int64] + [c_double_p] * 7 +
+                    [c_double_p, c_double_p]),
+    "pvx_stft_frames": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                       c_int64_p, ctypes.c_int64, c_double_p]),
+    "pvx_peakfinder": (ctypes.c_int, [c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_double, ctypes.c_int, c_int32_p, c_int8_p, c_int32_p,
+                                      ctypes.c_int]),
+    "pvx_track": (ctypes.c_int64, [c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                   c_int32_p, c_int32_p, c_int32_p, ctypes.c_int64]),
+    "pvx_track_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_void_p]),
+    "pvx_synth_len": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double]),
+    "pvx_synth": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.c_int64, ctypes.c_int,
+                                 c_int32_p, c_int32_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p,
+                                 ctypes.c_int64]),
+    "pvx_synth_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
+                                                             ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                             ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                                             ctypes.c_int64, ctypes.c_void_p]),
+}
+
+
+class PvxError(RuntimeError):
+    """A libpvx_hip call failed (message from pvx_last_error())."""
+
+
+_LIB = None
+
+
+def load():
+    """Load libpvx_hip.so and bind every entry point.  Fails loudly if the library is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pypevoc_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pypevoc_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what="pvx call"):
+    if rc < 0:
+        msg = load().pvx_last_error()
+        raise PvxError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else ""))
+    return rc
+
+
+_INIT_DEVICE = None
+
+
+def init(device=None):
+    """Bind the library to a HIP device (default: the current one).  Raises PvxError without a GPU."""
+    global _INIT_DEVICE
+    lib = load()
+    dev = -1 if device is None else int(device)
+    if _INIT_DEVICE is not None and (device is None or _INIT_DEVICE == dev):
+        return _INIT_DEVICE
+    check(lib.pvx_init(dev), "pvx_init")
+    _INIT_DEVICE = dev if dev >= 0 else 0
+    return _INIT_DEVICE
+
+
+def device_name():
+    return load().pvx_device_name().decode()
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_signal(x):
+    """Signal buffer in one of the three sample types the kernels read directly."""
+    x = np.asarray(x)
+    if x.dtype == np.float32:
+        return np.ascontiguousarray(x), PVX_F32
+    if x.dtype == np.int16:
+        return np.ascontiguousarray(x), PVX_I16
+    return np.ascontiguousarray(x, dtype=np.float64), PVX_F64

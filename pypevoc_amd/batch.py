@@ -1,0 +1,103 @@
+"""Batch and multi-GPU front end: the analysis of many independent signals.
+
+The reference analyses one signal per PV object in a Python loop (pypevoc/PVAnalysis.py:213-264).
+Independent signals are the natural unit to shard: PVBatch runs run_pv on B equal-length signals in
+one device call (pvx_analyze / pvx_analyze_dev with nsig = B), and `shard_range` / `gather_results`
+spread a batch over the ranks of a torch.distributed job (one process per GPU, RCCL over xGMI for
+the single result gather -- there is no other exchange on this path).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .PVAnalysis import _Plan
+
+FIELDS = ("f", "mag", "ph", "realph", "binno")
+
+
+def shard_range(nitems, rank, world):
+    """Contiguous block partition of `nitems` signals over `world` ranks (first ranks take the
+    remainder).  Returns (start, stop)."""
+    q, r = divmod(int(nitems), int(world))
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+class PVBatch(object):
+    """run_pv for a batch of equal-length signals `x[B, nsamp]` with shared parameters.
+
+    Results: f, mag, ph, realph, binno with shape (B, F, npks); t (F,); totalmag (B, F)."""
+
+    def __init__(self, x, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, wind=np.hanning,
+                 precision=32):
+        x = np.asarray(x)
+        if x.ndim != 2:
+            raise ValueError("PVBatch expects x[B, nsamp]")
+        self.x, self.x_dtype = _lib.as_signal(x)
+        self.nsig, self.nsamp = self.x.shape
+        self.sr = sr
+        self.nfft = nfft
+        self.nfft2 = int(nfft / 2)
+        self.hop = int(self.nfft / 2) if hop is None else int(hop)
+        self.npeaks = npks
+        self.peakthresh = pkthresh
+        self.win = wind(nfft)
+        self.precision = precision
+        self.nframes = 0
+        self._plan = None
+
+    def run_pv(self):
+        lib = _lib.load()
+        B, K = self.nsig, self.npeaks
+        F = int(lib.pvx_nframes(self.nsamp, self.nfft, self.hop))
+        self.nframes = F
+        shape = (B, F, K)
+        out = {k: np.zeros(shape) for k in FIELDS}
+        t = np.zeros((B, F))
+        tm = np.zeros((B, F))
+        if F > 0 and B > 0:
+            if self._plan is None:
+                self._plan = _Plan(self.sr, self.nfft, self.hop, K, self.peakthresh, self.win, self.precision,
+                                   max_rows=B * (F + 1))
+            r = lib.pvx_analyze(self._plan.handle, self.x.ctypes.data_as(ctypes.c_void_p), self.x_dtype,
+                                self.nsamp, B, self.nsamp, *[_lib.dptr(out[k]) for k in FIELDS],
+                                _lib.dptr(t), _lib.dptr(tm), None, None)
+            _lib.check(r, "pvx_analyze")
+        for k in FIELDS:
+            setattr(self, k, out[k])
+        self.t = t[0] if B > 0 else np.zeros(F)
+        self.totalmag = tm
+        return self
+
+
+def gather_results(local, nitems, group=None, dst=0):
+    """Gather per-rank result blocks to rank `dst` with ONE collective per call.
+
+    `local` is a torch tensor [n_local, ...] (device tensor under the nccl/RCCL backend, CPU tensor
+    under gloo) holding this rank's shard in `shard_range` order.  Shards may differ by one item, so
+    every rank pads to the largest shard; rank `dst` returns the [nitems, ...] concatenation, the
+    others None.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(nitems, r, world)[1] - shard_range(nitems, r, world)[0] for r in range(world)]
+    nmax = max(sizes) if sizes else 0
+    if local.shape[0] != sizes[rank]:
+        raise ValueError("rank %d holds %d items, expected %d" % (rank, local.shape[0], sizes[rank]))
+    pad = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    pad = pad.contiguous()
+    if world == 1:
+        return pad[: sizes[0]]
+    if rank == dst:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, gather_list=bufs, dst=dst, group=group)
+        return torch.cat([b[: sizes[r]] for r, b in enumerate(bufs)], dim=0)
+    dist.gather(pad, gather_list=None, dst=dst, group=group)
+    return None

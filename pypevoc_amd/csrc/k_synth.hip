@@ -1,0 +1,250 @@
+// k_synth.hip -- overlap-add resynthesis.  Replaces SinSum.synth (pypevoc/PVAnalysis.py:1053-1070)
+// and RegPartial.synth (PVAnalysis.py:684-756) for every partial at once.
+//
+// The reference synthesises partial after partial and adds each one into the output
+// (PVAnalysis.py:1060-1069).  Every hop-long body segment of a partial depends only on a few
+// neighbouring points of that partial, and partial body segment ii lands exactly on output samples
+// [(start+ii)*h, (start+ii+1)*h).  So the sum is restated as a GATHER: one workgroup owns one output
+// segment of h samples and adds up
+//   - the body segments of the (<= K) peaks of analysis frame `seg`,
+//   - the raised-cosine attacks of partials that start within the next ceil(E/h) frames,
+//   - the releases of partials that ended within the previous ceil(E/h) frames,
+// in LDS accumulators, then stores the segment once (coalesced).  No atomics; the order of the
+// additions is fixed (frame, then slot), so the output is reproducible run to run.
+//
+// Bound: f64 VALU (two interpolations, a block prefix sum and one cos per partial sample);
+// HBM traffic is 8*h bytes written per segment plus a few hundred bytes of table reads.
+// All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
+#include <math.h>
+
+#include "pvx_internal.h"
+
+namespace {
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double kPi2 = 2.0 * kPi;
+constexpr int NT = 256;
+constexpr int WMAX = 40;   // window of partial points kept in LDS (needs ceil(dfr + .5) + 6 <= WMAX)
+
+struct Win {               // a window of one partial's points, j in [j0, j0 + n)
+    double f[WMAX], m[WMAX], r[WMAX];
+    int j0, n;
+};
+
+// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); fp through the window
+__device__ inline double interp_w(double x, double h, double off, int nfr, const double* fp, int j0) {
+    if (nfr == 1) return fp[0 - j0];
+    const double xlast = h * (off + (double)(nfr - 1));
+    const double xfirst = h * (off + 0.0);
+    if (x > xlast) return fp[nfr - 1 - j0];
+    if (x < xfirst) return fp[0 - j0];
+    int j = (int)floor(x / h - off);
+    if (j < 0) j = 0;
+    if (j > nfr - 1) j = nfr - 1;
+    // settle on xp[j] <= x < xp[j+1] with the same xp values numpy compares against
+    while (j > 0 && x < h * (off + (double)j)) j--;
+    while (j < nfr - 1 && x >= h * (off + (double)(j + 1))) j++;
+    if (j == nfr - 1) return fp[j - j0];
+    const double xj = h * (off + (double)j);
+    if (xj == x) return fp[j - j0];
+    const double xj1 = h * (off + (double)(j + 1));
+    const double slope = (fp[j + 1 - j0] - fp[j - j0]) / (xj1 - xj);
+    return slope * (x - xj) + fp[j - j0];
+}
+
+// block-wide inclusive prefix sum of one double per thread (NT = 256 threads); returns the
+// inclusive value, *total = sum over the block.  Uses sc[4].
+__device__ inline double block_scan(double v, double* sc, double* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();
+    if (lane == 63) sc[wid] = inc;
+    __syncthreads();
+    double off = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        if (w < wid) off += sc[w];
+        tot += sc[w];
+    }
+    *total = tot;
+    return inc + off;
+}
+
+__global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* acc = (double*)smem;                       // [h] output accumulators
+    __shared__ Win win;
+    __shared__ double sc[NT / 64];
+    __shared__ int wslot[WMAX];
+
+    const int h = p.hop_s, K = p.K, tid = threadIdx.x;
+    const int64_t seg = blockIdx.x;                    // output samples [seg*h, seg*h + h)
+    const double dh = (double)h;
+    const double overlap = p.hop_a / (double)p.nfft;   // PVAnalysis.py:824
+    const double fstep = p.sr / (double)p.nfft;        // PVAnalysis.py:825
+    const double dfr = 1. / overlap / 2.;              // PVAnalysis.py:687
+    const int edgsam = (int)(dfr * h * p.edge);        // PVAnalysis.py:740
+    const double dfr_s = (double)p.nfft / (double)p.hop_a / 2.;      // PVAnalysis.py:1055
+    const int64_t edgsamp = (int64_t)(p.edge * h * dfr_s);           // PVAnalysis.py:1056 (integer, Python 2)
+    const int EF = edgsam > 0 ? (edgsam + h - 1) / h : 0;            // frames an edge can reach
+    const int WB = (int)ceil(dfr + 0.5) + 2;                         // points needed behind the node
+
+    for (int m = tid; m < h; m += NT) acc[m] = 0.0;
+
+    // contributions: kind 0 = body of a peak of frame seg; 1 = attack of a partial starting at
+    // frame seg+1 .. seg+EF; 2 = release of a partial whose last frame is seg-EF .. seg-1
+    const int64_t fr_lo = seg - EF, fr_hi = seg + EF;
+    for (int64_t fr = fr_lo; fr <= fr_hi; ++fr) {
+        if (fr < 0 || fr >= p.F) continue;
+        const int kind = (fr == seg) ? 0 : (fr > seg ? 1 : 2);
+        for (int s = 0; s < K; ++s) {
+            const int pid = p.partial_id[fr * K + s];
+            if (pid < 0) continue;
+            const int st = p.part_start[pid], nfr = p.part_len[pid];
+            if (nfr < p.minframes || nfr < 1) continue;                   // PVAnalysis.py:1061
+            if ((int64_t)st * h - edgsam + edgsamp < 0) continue;         // PVAnalysis.py:1067
+            const int ii = (int)(fr - st);                                // index of this point in its partial
+            if (kind == 1 && ii != 0) continue;
+            if (kind == 2 && ii != nfr - 1) continue;
+            // kind 0 additionally serves nothing else; a 1-point partial can be body + attack + release
+
+            // ---- gather the window of partial points into LDS
+            __syncthreads();
+            const int j0 = (ii - WB > 0) ? ii - WB : 0;
+            int j1 = ii + 3;
+            if (j1 > nfr - 1) j1 = nfr - 1;
+            const int wn = j1 - j0 + 1;                                   // <= WB + 4 <= WMAX (checked on the host)
+            for (int q = tid; q < wn * K; q += NT) {
+                const int d = q / K, s2 = q - d * K;
+                const int64_t f2 = (int64_t)st + j0 + d;
+                if (p.partial_id[f2 * K + s2] == pid) wslot[d] = s2;
+            }
+            __syncthreads();
+            if (tid < wn) {
+                const int64_t node = ((int64_t)st + j0 + tid) * K + wslot[tid];
+                win.f[tid] = p.f[node];
+                win.m[tid] = p.mag[node];
+                win.r[tid] = p.realph[node];
+            }
+            if (tid == 0) { win.j0 = j0; win.n = wn; }
+            __syncthreads();
+            const double* pf = win.f;
+            const double* pm = win.m;
+            const double* pr = win.r;
+            const double offf = dfr + .5, offm = dfr;                     // PVAnalysis.py:701-702
+
+            if (kind == 1) {
+                // ---- attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam
+                const int64_t o0 = (int64_t)st * h - edgsam;
+                const double m0 = interp_w(0.0, dh, offm, nfr, pm, j0);   // msig[0]
+                const double c = pf[0 - j0] * 1.0 / p.sr;
+                for (int m = tid; m < h; m += NT) {
+                    const int64_t j = seg * (int64_t)h + m - o0;
+                    if (j >= 0 && j < edgsam) {
+                        const double a = m0 * (1 - cos(kPi * (double)j / (double)edgsam)) / 2.;
+                        // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
+                        const double phb = pr[0 - j0] - kPi2 * ((double)(edgsam - j) * c);
+                        acc[m] += a * cos(phb);
+                    }
+                }
+                continue;
+            }
+
+            // ---- body segment ii (kind 0) or the final phase of the last segment (kind 2)
+            // PVAnalysis.py:705-708: ph[m] = 2 pi * sum_{q<m} fsig[h*ii + q] / sr, m = 0..h-1
+            const double nbase = dh * (double)ii;
+            double carry = 0.0, myph[1];
+            // phase corrections, PVAnalysis.py:711-718
+            const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
+            const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
+            const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
+            const double ph0 = pr[ii - j0] + phcor;                       // PVAnalysis.py:721
+            double lastph = 0.0;       // ph[h-1] + ph0 (before the discontinuity ramp)
+            // first sweep: prefix sums; keep each thread's values for up to one chunk at a time.
+            // Because the ramp needs ph[h-1] (phend) before any sample can be finalised, run the scan
+            // twice: sweep A computes the total, sweep B produces the samples.
+            {
+                double tot_all = 0.0;
+                for (int c0 = 0; c0 < h; c0 += NT) {
+                    const int m = c0 + tid;
+                    double term = 0.0;
+                    if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                    double tot;
+                    (void)block_scan(term, sc, &tot);
+                    tot_all += tot;
+                }
+                lastph = kPi2 * tot_all + ph0;
+            }
+            if (kind == 2) {
+                // ---- release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam
+                const int64_t o0 = ((int64_t)st + nfr) * h;
+                const double mend = interp_w(dh * (double)nfr, dh, offm, nfr, pm, j0);   // msig[hop*(ii+1)]
+                const double c = pf[nfr - 1 - j0] * 1.0 / p.sr;
+                for (int m = tid; m < h; m += NT) {
+                    const int64_t j = seg * (int64_t)h + m - o0;
+                    if (j >= 0 && j < edgsam) {
+                        const double a = mend * (1 + cos(kPi * (double)j / (double)edgsam)) / 2.;
+                        acc[m] += a * cos(lastph + kPi2 * ((double)(j + 1) * c));
+                    }
+                }
+                continue;
+            }
+            // kind 0: discontinuity ramp towards the next point, PVAnalysis.py:724-729
+            double step = 0.0;
+            if (ii < nfr - 1) {
+                const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf, j0);
+                const double phcornext = kPi * (fs2 - fs1) / fstep / 2.;
+                const double phend = lastph + kPi2 * fs1 / p.sr;
+                const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
+                double md = fmod(arg, kPi2);                              // np.mod: sign of the divisor
+                if (md != 0.0 && md < 0.0) md += kPi2;
+                const double dph = md - kPi;
+                step = dph / dh;                                          // np.linspace(0, dph, h+1)[:-1]
+            }
+            for (int c0 = 0; c0 < h; c0 += NT) {
+                const int m = c0 + tid;
+                double term = 0.0;
+                if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                double tot;
+                const double inc = block_scan(term, sc, &tot);
+                if (m < h) {
+                    myph[0] = kPi2 * (carry + inc) + ph0 + ((double)m * step + 0.0);
+                    const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
+                    acc[m] += ms * cos(myph[0]);                          // PVAnalysis.py:734-736
+                }
+                carry += tot;
+            }
+        }
+    }
+    __syncthreads();
+    for (int m = tid; m < h; m += NT) {
+        const int64_t o = seg * (int64_t)h + m;
+        if (o < p.wlen) p.w[o] = acc[m];
+    }
+}
+
+}  // namespace
+
+int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
+    if (p.wlen <= 0) return PVX_OK;
+    const int h = p.hop_s;
+    const double dfr = 1. / (p.hop_a / (double)p.nfft) / 2.;
+    if ((int)ceil(dfr + 0.5) + 6 > WMAX) {
+        pvx_set_error("nfft/hop = %g is too large for the resynthesis window (dfr=%g)", (double)p.nfft / p.hop_a, dfr);
+        return PVX_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)h * sizeof(double);
+    if (lds > 128 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
+    const int64_t nseg = (p.wlen + h - 1) / h;
+    if (nseg > 0x7fffffffLL) { pvx_set_error("too many output segments"); return PVX_ERR_INVALID; }
+    if (lds > 48 * 1024)
+        PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_synth_ola, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_synth_ola, dim3((unsigned)nseg), dim3(NT), lds, s, p);
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}

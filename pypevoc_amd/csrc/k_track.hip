@@ -1,0 +1,208 @@
+// k_track.hip -- sinusoidal track building.  Replaces PV.toSinSum (pypevoc/PVAnalysis.py:299-322)
+// = SinSum.add_frame for every frame (PVAnalysis.py:871-957) with add_empty_partial (819-830),
+// get_partials_idx_ending_at_frame (984-994), RegPartial.append_point (616-626), dpitch2st (62-68).
+//
+// The reference is a sequential loop over frames whose only carried state is "which partials
+// ended at frame fr-1" -- and that set is exactly the set of valid peaks (f > 0 and mag > 0) of
+// frame fr-1.  So the greedy assignment of frame fr depends on rows fr-1 and fr only and all
+// frames are linked in parallel:
+//   k_track_links  one wave64 per frame: greedy nearest-in-semitones assignment, new peaks in
+//                  descending magnitude against previous peaks in descending magnitude
+//   k_scan_counts  exclusive scan of "partials created per frame" -> creation-order numbering
+//   k_root_*       pointer jumping along the links: every peak learns the first point of its partial
+//   k_assign_ids   partial_id / part_start / part_len
+// Tiny, latency-bound integer work (<= K^2 compares per frame); no roofline claim.
+//
+// Exact-tie rule (measure-zero on real data): equal magnitudes are ordered higher slot first
+// (np.argsort(mag)[::-1] with a stable sort, PVAnalysis.py:874-875); the reference's secondary key
+// for previous partials is the partial index (PVAnalysis.py:893), here the slot index.
+#include <math.h>
+
+#include "pvx_internal.h"
+
+namespace {
+
+__device__ inline void wave_sync_t() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// arg-min with first-index ties (np.argmin, PVAnalysis.py:920)
+__device__ inline void wave_argmin(double& v, int& i) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        double u = __shfl_xor(v, o);
+        int j = __shfl_xor(i, o);
+        if (u < v || (u == v && j < i)) { v = u; i = j; }
+    }
+}
+
+// LDS per wave: cm[K] cf[K] pm[K] pf[K] doubles | corder[K] porder[K] used[K] ints
+__global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = p.K;
+    const int kp = (K + 1) & ~1;
+    const size_t per_wave = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 3;
+    unsigned char* base = smem + per_wave * wid;
+    double* cm = (double*)base;
+    double* cf = cm + kp;
+    double* pm = cf + kp;
+    double* pf = pm + kp;
+    int* corder = (int*)(pf + kp);   // corder[r] = slot of the r-th new peak (descending mag)
+    int* porder = corder + kp;       // porder[r] = slot (in frame fr-1) of the r-th previous peak
+    int* used = porder + kp;
+    const int64_t fr = (int64_t)blockIdx.x * nw + wid;
+    if (fr >= p.F) return;
+    const double* fc = p.f + fr * K;
+    const double* mc = p.mag + fr * K;
+    int32_t* link = p.link + fr * K;
+    int32_t* nrk = p.newrank + fr * K;
+    for (int s = lane; s < K; s += 64) {
+        cf[s] = fc[s]; cm[s] = mc[s];
+        if (fr > 0) { pf[s] = p.f[(fr - 1) * K + s]; pm[s] = p.mag[(fr - 1) * K + s]; }
+        else { pf[s] = 0.0; pm[s] = 0.0; }
+        link[s] = -2;
+        nrk[s] = -1;
+    }
+    wave_sync_t();
+    // descending-magnitude ranks of the valid entries (PVAnalysis.py:874-876, 891-893)
+    int nc = 0, np = 0;
+    for (int s0 = 0; s0 < K; s0 += 64) {
+        const int s = s0 + lane;
+        bool vc = false, vp = false;
+        if (s < K) {
+            vc = cf[s] > 0.0 && cm[s] > 0.0;
+            vp = pf[s] > 0.0 && pm[s] > 0.0;
+            if (vc) {
+                int r = 0;
+                for (int j = 0; j < K; j++)
+                    if (cf[j] > 0.0 && cm[j] > 0.0 && (cm[j] > cm[s] || (cm[j] == cm[s] && j > s))) r++;
+                corder[r] = s;
+            }
+            if (vp) {
+                int r = 0;
+                for (int j = 0; j < K; j++)
+                    if (pf[j] > 0.0 && pm[j] > 0.0 && (pm[j] > pm[s] || (pm[j] == pm[s] && j > s))) r++;
+                porder[r] = s;
+                used[r] = 0;
+            }
+        }
+        nc += __popcll(__ballot(vc));
+        np += __popcll(__ballot(vp));
+    }
+    wave_sync_t();
+    int nnew = 0;
+    for (int c = 0; c < nc; c++) {                                   // PVAnalysis.py:903
+        const int s = corder[c];
+        const double fcur = cf[s];
+        double best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < np; i += 64) {
+            if (!used[i]) {
+                double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));  // dpitch2st, PVAnalysis.py:62-68, 914
+                if (st < best) { best = st; bi = i; }
+            }
+        }
+        wave_argmin(best, bi);
+        const bool hit = (bi != 0x7fffffff) && (best < p.maxjmp);    // PVAnalysis.py:923
+        if (lane == 0) {
+            if (hit) { link[s] = porder[bi]; used[bi] = 1; }
+            else { link[s] = -1; nrk[s] = nnew; }                    // add_empty_partial
+        }
+        if (!hit) nnew++;
+        wave_sync_t();
+    }
+    if (lane == 0) p.newcount[fr] = nnew;
+}
+
+// exclusive scan of newcount[F] -> newbase[F+1] (single workgroup, 1024 threads, chunked)
+__global__ __launch_bounds__(1024) void k_scan_counts(TrackParams p) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < p.F; base += 1024) {
+        const int64_t i = base + tid;
+        long long v = (i < p.F) ? (long long)p.newcount[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            long long u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wid; w++) woff += wsum[w];
+        const long long carry = carry_s;
+        if (i < p.F) p.newbase[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) { p.newbase[p.F] = carry_s; *p.npartials = carry_s; }
+}
+
+__global__ __launch_bounds__(256) void k_root_init(TrackParams p) {
+    const int64_t n = p.F * (int64_t)p.K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = p.link[i];
+    int32_t r;
+    if (l == -2) r = -1;
+    else if (l == -1) r = (int32_t)i;
+    else r = (int32_t)(i - (i % p.K) - p.K + l);                     // (fr-1)*K + slot
+    p.root[i] = r;
+}
+
+// one pointer-jumping round: root <- root[root]; in place is safe (any value read is an ancestor)
+__global__ __launch_bounds__(256) void k_root_jump(TrackParams p) {
+    const int64_t n = p.F * (int64_t)p.K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = p.root[i];
+    if (r < 0 || r == (int32_t)i) return;
+    const int32_t rr = __hip_atomic_load(&p.root[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rr != r) __hip_atomic_store(&p.root[i], rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
+    const int64_t n = p.F * (int64_t)p.K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = p.root[i];
+    if (r < 0) { p.partial_id[i] = -1; return; }
+    const int64_t rfr = r / p.K;
+    const int64_t pid = p.newbase[rfr] + p.newrank[r];               // creation order, PVAnalysis.py:826
+    p.partial_id[i] = (int32_t)pid;
+    if (pid < p.cap) {
+        if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
+        atomicAdd(&p.part_len[pid], 1);                              // append_point
+    }
+}
+
+}  // namespace
+
+int pvx_launch_track(const TrackParams& p, hipStream_t s) {
+    if (p.F <= 0) return PVX_OK;
+    const int64_t n = p.F * (int64_t)p.K;
+    if (n >= 0x7fffffffLL) { pvx_set_error("F*K = %lld does not fit the 32-bit node index", (long long)n); return PVX_ERR_UNSUPPORTED; }
+    const int kp = (p.K + 1) & ~1;
+    int waves = 4;
+    size_t per_wave = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 3;
+    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    if (per_wave * waves > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
+    PVX_HIP_CHECK(hipMemsetAsync(p.part_len, 0, sizeof(int32_t) * (size_t)p.cap, s));
+    hipLaunchKernelGGL(k_track_links, dim3((unsigned)((p.F + waves - 1) / waves)), dim3(64 * waves), per_wave * waves, s, p);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_root_init, dim3(nb), dim3(256), 0, s, p);
+    int rounds = 1;
+    while ((1LL << rounds) < p.F) rounds++;
+    for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_root_jump, dim3(nb), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_assign_ids, dim3(nb), dim3(256), 0, s, p);
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}

@@ -1,0 +1,592 @@
+// pvx_api.hip -- host side of the C ABI declared in include/pvx.h: device selection, analysis
+// plans (constants of PV.__init__, pypevoc/PVAnalysis.py:72-131; rocFFT plan; device workspace),
+// chunked launch sequence of run_pv (PV.py:213-264) and the host-buffer convenience wrappers.
+//
+// There is deliberately no CPU path in this library: every entry point needs a HIP device.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pvx_internal.h"
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void pvx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* pvx_last_error(void) { return g_err; }
+extern "C" int pvx_version(void) { return PVX_VERSION; }
+
+// ---- device ---------------------------------------------------------------------------------
+static std::mutex g_mu;
+static int g_device = -1;
+static bool g_fft_setup = false;
+static char g_devname[256] = "";
+
+extern "C" int pvx_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        pvx_set_error("no HIP device available (%s); libpvx_hip has no CPU fallback",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return PVX_ERR_NO_DEVICE;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) { pvx_set_error("device %d out of range (%d devices)", device, n); return PVX_ERR_INVALID; }
+    PVX_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PVX_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    snprintf(g_devname, sizeof(g_devname), "%s (%s)", prop.name, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pvx_set_error("device %d is %s; libpvx_hip carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return PVX_ERR_NO_DEVICE;
+    }
+    if (!g_fft_setup) {
+        PVX_FFT_CHECK(rocfft_setup());
+        g_fft_setup = true;
+    }
+    g_device = device;
+    return PVX_OK;
+}
+
+extern "C" const char* pvx_device_name(void) { return g_devname; }
+
+int pvx_require_device() {
+    if (g_device >= 0) {
+        // the calling thread may be new: bind it
+        if (hipSetDevice(g_device) != hipSuccess) { pvx_set_error("hipSetDevice(%d) failed", g_device); return PVX_ERR_NO_DEVICE; }
+        return PVX_OK;
+    }
+    return pvx_init(-1);
+}
+
+extern "C" int64_t pvx_nframes(int64_t nsamp, int nfft, int hop) {
+    // PV.py:223-249: pos = 0, hop, 2 hop, ... while pos < nsamp - nfft (strict)
+    const int64_t maxpos = nsamp - nfft;
+    if (maxpos <= 0 || hop <= 0 || nfft <= 0) return 0;
+    return (maxpos + hop - 1) / hop;
+}
+
+// ---- plan -----------------------------------------------------------------------------------
+struct pvx_plan {
+    double sr = 0, pkthresh = 0, wfact = 0, fstep = 0, dt = 0;
+    int nfft = 0, hop = 0, npks = 0, N2 = 0, precision = 32, fft_mode = 0;
+    int64_t max_rows = 0;     // rows per launch (without the halo row)
+    int64_t ldi = 0, ldo = 0; // workspace row pitches (elements / complex elements)
+    std::vector<double> win;  // caller's window
+    void* d_win = nullptr;    // window / wfact in the working precision
+    double* d_wfbin = nullptr;
+    void* d_frames = nullptr; // [max_rows+1][ldi]
+    void* d_spec = nullptr;   // [max_rows+1][ldo] complex
+    void* d_work = nullptr;
+    size_t work_bytes = 0;
+    int64_t ws_bytes = 0;
+    rocfft_plan fft = nullptr;
+    rocfft_execution_info info = nullptr;
+    int frames_per_wave = 4;
+    // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+static size_t real_size(int precision) { return precision == 32 ? 4 : 8; }
+
+static void plan_free(pvx_plan* p) {
+    if (!p) return;
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    if (p->info) rocfft_execution_info_destroy(p->info);
+    if (p->fft) rocfft_plan_destroy(p->fft);
+    if (p->d_win) (void)hipFree(p->d_win);
+    if (p->d_wfbin) (void)hipFree(p->d_wfbin);
+    if (p->d_frames) (void)hipFree(p->d_frames);
+    if (p->d_spec) (void)hipFree(p->d_spec);
+    if (p->d_work) (void)hipFree(p->d_work);
+    delete p;
+}
+
+extern "C" int pvx_plan_destroy(pvx_plan* plan) {
+    plan_free(plan);
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_plan_workspace_bytes(const pvx_plan* plan) { return plan ? plan->ws_bytes : 0; }
+
+extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
+    if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    if (mode != 0) { pvx_set_error("fft mode %d is not available in this build", mode); return PVX_ERR_UNSUPPORTED; }
+    plan->fft_mode = mode;
+    return PVX_OK;
+}
+
+extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int npks, double pkthresh,
+                               const double* win, int precision, int64_t max_rows) {
+    if (!out) { pvx_set_error("null plan pointer"); return PVX_ERR_INVALID; }
+    *out = nullptr;
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (nfft < 4 || hop <= 0 || npks <= 0 || !(sr > 0) || (precision != 32 && precision != 64)) {
+        pvx_set_error("invalid analysis parameters (sr=%g nfft=%d hop=%d npks=%d precision=%d)", sr, nfft, hop, npks, precision);
+        return PVX_ERR_INVALID;
+    }
+    pvx_plan* p = new pvx_plan();
+    p->sr = sr; p->nfft = nfft; p->hop = hop; p->npks = npks; p->pkthresh = pkthresh;
+    p->precision = precision;
+    p->N2 = nfft / 2;                                   // PV.py:88
+    p->win.resize(nfft);
+    if (win) {
+        memcpy(p->win.data(), win, sizeof(double) * nfft);
+    } else {                                            // np.hanning(nfft)
+        for (int i = 0; i < nfft; i++) {
+            const double n = (double)(1 - nfft + 2 * i);
+            p->win[i] = 0.5 + 0.5 * cos(3.141592653589793238462643383279502884 * n / (double)(nfft - 1));
+        }
+    }
+    double wsum2 = 0.0;                                 // PV.py:99 (Python sum: left to right)
+    for (int i = 0; i < nfft; i++) wsum2 = wsum2 + p->win[i] * p->win[i];
+    p->wfact = sqrt(wsum2 * nfft) / 2.0;                // PV.py:102
+    p->fstep = sr / (double)nfft;                       // PV.py:105
+    p->dt = (double)hop / sr;                           // PV.py:108
+    if (!(p->wfact > 0)) { pvx_set_error("window has no energy"); plan_free(p); return PVX_ERR_INVALID; }
+
+    const size_t rs = real_size(precision);
+    // Launch size: the frame + spectrum workspace of one launch (~96 MiB by default) stays inside
+    // the 256 MiB Infinity Cache, so rocFFT and the peak kernel read what the previous kernel just
+    // wrote from on-die memory.  `max_rows` from the caller is a "rows needed" hint and only ever
+    // shrinks the workspace; PVX_MAX_ROWS (environment) overrides the cap for tuning.
+    int64_t cap_rows = (int64_t)(96.0 * 1024 * 1024 / ((double)nfft * rs * 2.0));
+    if (cap_rows < 256) cap_rows = 256;
+    if (cap_rows > 65536) cap_rows = 65536;
+    if (const char* e = getenv("PVX_MAX_ROWS")) {
+        const long long v = atoll(e);
+        if (v >= 2) cap_rows = (int64_t)v;
+    }
+    if (max_rows <= 0 || max_rows > cap_rows) max_rows = cap_rows;
+    if (max_rows < 2) max_rows = 2;
+    p->max_rows = max_rows;
+    p->ldi = (nfft + 3) & ~3;
+    p->ldo = ((nfft / 2 + 1) + 1) & ~1;                 // rocFFT writes nfft/2+1 bins; keep rows 16-byte aligned
+
+    // device constants
+    {
+        std::vector<double> wf(p->N2 > 0 ? p->N2 : 1);
+        const double pi2 = 2.0 * 3.141592653589793238462643383279502884;
+        for (int k = 0; k < p->N2; k++) {
+            const double fbin = (double)k * p->fstep;                   // PV.py:114
+            const double dthetabin = pi2 * fbin * p->dt;                // PV.py:116
+            wf[k] = nearbyint(dthetabin / pi2) * pi2;                   // PV.py:118 (np.round: half to even)
+        }
+        if (hipMalloc(&p->d_wfbin, sizeof(double) * wf.size()) != hipSuccess) { pvx_set_error("hipMalloc(wfbin) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        if (hipMemcpy(p->d_wfbin, wf.data(), sizeof(double) * wf.size(), hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(wfbin) failed"); plan_free(p); return PVX_ERR_HIP; }
+        // window with 1/wfact folded in (fft(x*win)/wfact, PV.py:156-157)
+        if (hipMalloc(&p->d_win, rs * nfft) != hipSuccess) { pvx_set_error("hipMalloc(win) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        hipError_t e;
+        if (precision == 32) {
+            std::vector<float> w(nfft);
+            for (int i = 0; i < nfft; i++) w[i] = (float)(p->win[i] / p->wfact);
+            e = hipMemcpy(p->d_win, w.data(), rs * nfft, hipMemcpyHostToDevice);
+        } else {
+            std::vector<double> w(nfft);
+            for (int i = 0; i < nfft; i++) w[i] = p->win[i] / p->wfact;
+            e = hipMemcpy(p->d_win, w.data(), rs * nfft, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) { pvx_set_error("hipMemcpy(win) failed"); plan_free(p); return PVX_ERR_HIP; }
+    }
+
+    const int64_t ws_rows = max_rows + 1;
+    const size_t fbytes = (size_t)ws_rows * p->ldi * rs, sbytes = (size_t)ws_rows * p->ldo * 2 * rs;
+    if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(&p->d_spec, sbytes) != hipSuccess) {
+        pvx_set_error("hipMalloc of %.1f MiB analysis workspace failed", (fbytes + sbytes) / 1048576.0);
+        plan_free(p);
+        return PVX_ERR_ALLOC;
+    }
+    // rocFFT: batched 1-D real -> hermitian, one transform per workspace row (PV.py:157)
+    rocfft_plan_description desc = nullptr;
+    rocfft_status st = rocfft_plan_description_create(&desc);
+    if (st == rocfft_status_success) {
+        size_t istride = 1, ostride = 1;
+        st = rocfft_plan_description_set_data_layout(desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                     nullptr, nullptr, 1, &istride, (size_t)p->ldi, 1, &ostride, (size_t)p->ldo);
+    }
+    if (st == rocfft_status_success) {
+        size_t len = (size_t)nfft;
+        st = rocfft_plan_create(&p->fft, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                precision == 32 ? rocfft_precision_single : rocfft_precision_double, 1, &len,
+                                (size_t)ws_rows, desc);
+    }
+    if (desc) rocfft_plan_description_destroy(desc);
+    if (st != rocfft_status_success) { pvx_set_error("rocfft_plan_create(nfft=%d, batch=%lld) failed: %d", nfft, (long long)ws_rows, (int)st); plan_free(p); return PVX_ERR_HIP; }
+    st = rocfft_plan_get_work_buffer_size(p->fft, &p->work_bytes);
+    if (st == rocfft_status_success) st = rocfft_execution_info_create(&p->info);
+    if (st != rocfft_status_success) { pvx_set_error("rocfft work buffer query failed: %d", (int)st); plan_free(p); return PVX_ERR_HIP; }
+    if (p->work_bytes) {
+        if (hipMalloc(&p->d_work, p->work_bytes) != hipSuccess) { pvx_set_error("hipMalloc(rocfft work, %zu) failed", p->work_bytes); plan_free(p); return PVX_ERR_ALLOC; }
+        st = rocfft_execution_info_set_work_buffer(p->info, p->d_work, p->work_bytes);
+        if (st != rocfft_status_success) { pvx_set_error("rocfft set_work_buffer failed: %d", (int)st); plan_free(p); return PVX_ERR_HIP; }
+    }
+    p->ws_bytes = (int64_t)(fbytes + sbytes + p->work_bytes);
+    *out = p;
+    return PVX_OK;
+}
+
+extern "C" int pvx_plan_set_timing(pvx_plan* plan, int enable) {
+    if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    plan->timing = enable != 0;
+    plan->ev_used = 0;
+    return PVX_OK;
+}
+
+static int plan_event(pvx_plan* p, hipStream_t s) {
+    if (!p->timing) return PVX_OK;
+    if (p->ev_used == p->ev_pool.size()) {
+        hipEvent_t e;
+        PVX_HIP_CHECK(hipEventCreate(&e));
+        p->ev_pool.push_back(e);
+    }
+    PVX_HIP_CHECK(hipEventRecord(p->ev_pool[p->ev_used++], s));
+    return PVX_OK;
+}
+
+extern "C" int pvx_plan_get_timing(pvx_plan* plan, double* ms, int64_t* launches) {
+    if (!plan || !ms || !launches) { pvx_set_error("null argument"); return PVX_ERR_INVALID; }
+    for (int i = 0; i < 4; i++) { ms[i] = 0.0; launches[i] = 0; }
+    const size_t quads = plan->ev_used / 4;
+    for (size_t q = 0; q < quads; q++) {
+        PVX_HIP_CHECK(hipEventSynchronize(plan->ev_pool[4 * q + 3]));
+        for (int st = 0; st < 3; st++) {
+            float t = 0.f;
+            PVX_HIP_CHECK(hipEventElapsedTime(&t, plan->ev_pool[4 * q + st], plan->ev_pool[4 * q + st + 1]));
+            ms[st] += (double)t;
+            launches[st] += 1;
+        }
+    }
+    plan->ev_used = 0;
+    return PVX_OK;
+}
+
+// ---- run_pv ---------------------------------------------------------------------------------
+static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                        int64_t F, double* d_f, double* d_mag, double* d_ph, double* d_realph, double* d_binno,
+                        double* d_t, double* d_totalmag, const double* d_prev0, hipStream_t s) {
+    const int64_t total_rows = nsig * (F + 1);
+    PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
+    for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
+        const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
+        FrameParams fp;
+        fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = sig_stride; fp.F = F; fp.R0 = R0;
+        fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
+        fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
+        int rc = plan_event(p, s);
+        if (rc != PVX_OK) return rc;
+        rc = pvx_launch_frames(fp, x_dtype, p->precision, s);
+        if (rc != PVX_OK) return rc;
+        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+        void* in[1] = {p->d_frames};
+        void* out[1] = {p->d_spec};
+        PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+        PeaksParams pp;
+        pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
+        pp.nfft = p->nfft; pp.hop = p->hop; pp.N2 = p->N2; pp.K = p->npks; pp.rad = 5;   // PV.py:177
+        pp.thr = p->pkthresh; pp.sr = p->sr; pp.fstep = p->fstep; pp.dt = p->dt;
+        pp.wfbin = p->d_wfbin; pp.prev0 = d_prev0;
+        pp.f = d_f; pp.mag = d_mag; pp.ph = d_ph; pp.realph = d_realph; pp.binno = d_binno;
+        pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
+        rc = pvx_launch_phase_peaks(pp, p->precision, s);
+        if (rc != PVX_OK) return rc;
+        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+    }
+    return PVX_OK;
+}
+
+static int check_analyze_args(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                              const void* prev0) {
+    if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    if (!x && nsamp > 0) { pvx_set_error("null signal"); return PVX_ERR_INVALID; }
+    if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID; }
+    if (nsamp < 0 || nsig < 1) { pvx_set_error("bad nsamp/nsig"); return PVX_ERR_INVALID; }
+    if (nsig > 1 && sig_stride < nsamp) { pvx_set_error("sig_stride %lld < nsamp %lld", (long long)sig_stride, (long long)nsamp); return PVX_ERR_INVALID; }
+    if (prev0 && nsig != 1) { pvx_set_error("prev0 is only valid with nsig == 1"); return PVX_ERR_INVALID; }
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_analyze_dev(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig,
+                                   int64_t sig_stride, double* d_f, double* d_mag, double* d_ph, double* d_realph,
+                                   double* d_binno, double* d_t, double* d_totalmag, const double* d_prev0,
+                                   void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    rc = check_analyze_args(p, d_x, x_dtype, nsamp, nsig, sig_stride, d_prev0);
+    if (rc != PVX_OK) return rc;
+    const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if (F == 0) return 0;
+    if (!d_f || !d_mag || !d_ph || !d_realph || !d_binno) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    rc = analyze_rows(p, d_x, x_dtype, nsamp, nsig, sig_stride, F, d_f, d_mag, d_ph, d_realph, d_binno, d_t,
+                      d_totalmag, d_prev0, (hipStream_t)stream);
+    return rc == PVX_OK ? F : rc;
+}
+
+static size_t dtype_size(int x_dtype) { return x_dtype == PVX_F32 ? 4 : (x_dtype == PVX_F64 ? 8 : 2); }
+
+namespace {
+struct DevBuf {   // RAII for the host-buffer wrappers
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { pvx_set_error("hipMalloc(%zu) failed", bytes); p = nullptr; return PVX_ERR_ALLOC; }
+        return PVX_OK;
+    }
+};
+}  // namespace
+
+extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                               double* f, double* mag, double* ph, double* realph, double* binno, double* t,
+                               double* totalmag, const double* prev0, double* last_spec) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    rc = check_analyze_args(p, x, x_dtype, nsamp, nsig, sig_stride, prev0);
+    if (rc != PVX_OK) return rc;
+    const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if (F == 0) return 0;
+    if (!f || !mag || !ph || !realph || !binno) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    if (nsig == 1) sig_stride = nsamp;
+    const size_t xbytes = (size_t)((nsig - 1) * sig_stride + nsamp) * dtype_size(x_dtype);
+    const size_t fk = (size_t)nsig * F * p->npks * sizeof(double), f1 = (size_t)nsig * F * sizeof(double);
+    DevBuf dx, dout, dprev;
+    if ((rc = dx.alloc(xbytes)) != PVX_OK) return rc;
+    if ((rc = dout.alloc(5 * fk + 2 * f1)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dx.p, x, xbytes, hipMemcpyHostToDevice));
+    if (prev0) {
+        if ((rc = dprev.alloc(sizeof(double) * 2 * p->N2)) != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipMemcpy(dprev.p, prev0, sizeof(double) * 2 * p->N2, hipMemcpyHostToDevice));
+    }
+    char* o = (char*)dout.p;
+    double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_realph = (double*)(o + 3 * fk),
+           *d_binno = (double*)(o + 4 * fk), *d_t = (double*)(o + 5 * fk), *d_tm = (double*)(o + 5 * fk + f1);
+    rc = analyze_rows(p, dx.p, x_dtype, nsamp, nsig, sig_stride, F, d_f, d_mag, d_ph, d_realph, d_binno, d_t, d_tm,
+                      (const double*)dprev.p, nullptr);
+    if (rc != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(mag, d_mag, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(ph, d_ph, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(realph, d_realph, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(binno, d_binno, fk, hipMemcpyDeviceToHost));
+    if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
+    if (totalmag) PVX_HIP_CHECK(hipMemcpy(totalmag, d_tm, f1, hipMemcpyDeviceToHost));
+    if (last_spec) {
+        // the last chunk's last row is still in the spectrum workspace
+        const int64_t total_rows = nsig * (F + 1);
+        const int64_t lastR0 = ((total_rows - 1) / p->max_rows) * p->max_rows;
+        const int64_t wsrow = (total_rows - 1) - lastR0 + 1;
+        const size_t rs = real_size(p->precision);
+        std::vector<unsigned char> tmp((size_t)p->N2 * 2 * rs);
+        PVX_HIP_CHECK(hipMemcpy(tmp.data(), (char*)p->d_spec + (size_t)wsrow * p->ldo * 2 * rs, tmp.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 2 * p->N2; i++)
+            last_spec[i] = p->precision == 32 ? (double)((float*)tmp.data())[i] : ((double*)tmp.data())[i];
+    }
+    return F;
+}
+
+extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const int64_t* pos, int64_t nfr,
+                               double* spec) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (!p || !x || !pos || !spec || nfr < 0) { pvx_set_error("bad argument"); return PVX_ERR_INVALID; }
+    if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID; }
+    const size_t es = dtype_size(x_dtype), rs = real_size(p->precision);
+    for (int64_t i = 0; i < nfr; i++)
+        if (pos[i] < 0 || pos[i] + p->nfft > nsamp) { pvx_set_error("frame %lld at %lld leaves the signal", (long long)i, (long long)pos[i]); return PVX_ERR_INVALID; }
+    // Each requested frame is framed as its own 1-frame "signal" (stride = its position), so the
+    // regular framing kernel can be used: signal b = samples [pos[b], pos[b]+nfft+1).
+    DevBuf dx;
+    if ((rc = dx.alloc((size_t)(p->nfft + 1) * es)) != PVX_OK) return rc;
+    const int nb = p->nfft / 2 + 1;
+    std::vector<unsigned char> row((size_t)nb * 2 * rs);
+    PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, nullptr));
+    for (int64_t i = 0; i < nfr; i++) {
+        // copy nfft samples (+1 so that nframes(nfft+1) == 1)
+        PVX_HIP_CHECK(hipMemset(dx.p, 0, (size_t)(p->nfft + 1) * es));
+        PVX_HIP_CHECK(hipMemcpy(dx.p, (const char*)x + (size_t)pos[i] * es, (size_t)p->nfft * es, hipMemcpyHostToDevice));
+        FrameParams fp;
+        fp.x = dx.p; fp.nsamp = p->nfft + 1; fp.sig_stride = p->nfft + 1; fp.F = 1; fp.R0 = 0; fp.ws_rows = 3;
+        fp.total_rows = 2; fp.nfft = p->nfft; fp.hop = p->hop; fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
+        if (p->max_rows < 2) { pvx_set_error("plan workspace too small"); return PVX_ERR_SIZE; }
+        rc = pvx_launch_frames(fp, x_dtype, p->precision, nullptr);
+        if (rc != PVX_OK) return rc;
+        void* in[1] = {p->d_frames};
+        void* out[1] = {p->d_spec};
+        PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+        // global row 1 (frame 0) sits in workspace row 2
+        PVX_HIP_CHECK(hipMemcpy(row.data(), (char*)p->d_spec + (size_t)2 * p->ldo * 2 * rs, row.size(), hipMemcpyDeviceToHost));
+        double* o = spec + (size_t)i * nb * 2;
+        for (int k = 0; k < 2 * nb; k++)
+            o[k] = p->precision == 32 ? (double)((float*)row.data())[k] : ((double*)row.data())[k];
+    }
+    return PVX_OK;
+}
+
+// ---- PeakFinder -----------------------------------------------------------------------------
+extern "C" int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks, int thr_kind, double thr_val, int rad,
+                              int32_t* pos, int8_t* keep, int32_t* count, int cap) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (!y || !pos || !keep || !count || nrows < 0 || n < 1 || cap < 1 || thr_kind < 0 || thr_kind > 2) {
+        pvx_set_error("bad PeakFinder argument");
+        return PVX_ERR_INVALID;
+    }
+    if (nrows == 0) return PVX_OK;
+    DevBuf dy, dpos, dkeep, dcount;
+    const size_t yb = (size_t)nrows * n * sizeof(double);
+    if ((rc = dy.alloc(yb)) != PVX_OK || (rc = dpos.alloc((size_t)nrows * cap * 4)) != PVX_OK ||
+        (rc = dkeep.alloc((size_t)nrows * cap)) != PVX_OK || (rc = dcount.alloc((size_t)nrows * 4)) != PVX_OK)
+        return rc;
+    PVX_HIP_CHECK(hipMemcpy(dy.p, y, yb, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemset(dpos.p, 0xff, (size_t)nrows * cap * 4));
+    PVX_HIP_CHECK(hipMemset(dkeep.p, 0, (size_t)nrows * cap));
+    PeakRowsParams pp;
+    pp.y = (const double*)dy.p; pp.nrows = nrows; pp.n = n; pp.npeaks = npeaks; pp.thr_kind = thr_kind;
+    pp.thr_val = thr_val; pp.rad = rad; pp.cap = cap;
+    pp.pos = (int32_t*)dpos.p; pp.keep = (int8_t*)dkeep.p; pp.count = (int32_t*)dcount.p;
+    rc = pvx_launch_peak_rows(pp, nullptr);
+    if (rc != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    PVX_HIP_CHECK(hipMemcpy(pos, dpos.p, (size_t)nrows * cap * 4, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(keep, dkeep.p, (size_t)nrows * cap, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(count, dcount.p, (size_t)nrows * 4, hipMemcpyDeviceToHost));
+    return PVX_OK;
+}
+
+// ---- tracker: PV.toSinSum (PV.py:299-322) ---------------------------------------------------
+extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t F, int K, double maxpitchjmp,
+                                 int32_t* d_partial_id, int32_t* d_part_start, int32_t* d_part_len, int64_t cap,
+                                 void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (F < 0 || K <= 0 || cap < 0) { pvx_set_error("bad tracker argument"); return PVX_ERR_INVALID; }
+    if (F == 0) return 0;
+    if (!d_f || !d_mag || !d_partial_id || !d_part_start || !d_part_len) { pvx_set_error("null tracker array"); return PVX_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)F * K;
+    DevBuf ws;
+    // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials int64
+    const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
+    size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
+    const size_t off_np = off_base + ((size_t)F + 1) * 8, total = off_np + 8;
+    if ((rc = ws.alloc(total)) != PVX_OK) return rc;
+    char* w = (char*)ws.p;
+    TrackParams tp;
+    tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
+    tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
+    tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
+    tp.root2 = nullptr; tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
+    tp.npartials = (int64_t*)(w + off_np);
+    rc = pvx_launch_track(tp, s);
+    if (rc != PVX_OK) return rc;
+    int64_t P = 0;
+    PVX_HIP_CHECK(hipMemcpyAsync(&P, tp.npartials, 8, hipMemcpyDeviceToHost, s));
+    PVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (P > cap) { pvx_set_error("%lld partials exceed the table capacity %lld", (long long)P, (long long)cap); return PVX_ERR_SIZE; }
+    return P;
+}
+
+extern "C" int64_t pvx_track(const double* f, const double* mag, int64_t F, int K, double maxpitchjmp,
+                             int32_t* partial_id, int32_t* part_start, int32_t* part_len, int64_t cap) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (F < 0 || K <= 0 || cap < 0) { pvx_set_error("bad tracker argument"); return PVX_ERR_INVALID; }
+    if (F == 0) return 0;
+    if (!f || !mag || !partial_id || !part_start || !part_len) { pvx_set_error("null tracker array"); return PVX_ERR_INVALID; }
+    const size_t n = (size_t)F * K;
+    const int64_t dcap = (int64_t)n;           // always sufficient on the device side
+    DevBuf df, dm, dpid, dst, dln;
+    if ((rc = df.alloc(n * 8)) != PVX_OK || (rc = dm.alloc(n * 8)) != PVX_OK || (rc = dpid.alloc(n * 4)) != PVX_OK ||
+        (rc = dst.alloc(n * 4)) != PVX_OK || (rc = dln.alloc(n * 4)) != PVX_OK)
+        return rc;
+    PVX_HIP_CHECK(hipMemcpy(df.p, f, n * 8, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dm.p, mag, n * 8, hipMemcpyHostToDevice));
+    const int64_t P = pvx_track_dev((const double*)df.p, (const double*)dm.p, F, K, maxpitchjmp, (int32_t*)dpid.p,
+                                    (int32_t*)dst.p, (int32_t*)dln.p, dcap, nullptr);
+    if (P < 0) return P;
+    if (P > cap) { pvx_set_error("%lld partials exceed the caller's capacity %lld", (long long)P, (long long)cap); return PVX_ERR_SIZE; }
+    PVX_HIP_CHECK(hipMemcpy(partial_id, dpid.p, n * 4, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(part_start, dst.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(part_len, dln.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    return P;
+}
+
+// ---- resynthesis: SinSum.synth (PV.py:1053-1070) -------------------------------------------
+extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge) {
+    if (nfft <= 0 || hop_analysis <= 0 || hop_synth <= 0 || max_end_frame < 0) return PVX_ERR_INVALID;
+    const double dfr = (double)nfft / (double)hop_analysis / 2.;      // PV.py:1055
+    const int64_t edgsamp = (int64_t)(edge * hop_synth * dfr);        // PV.py:1056, integer as under Python 2
+    return (max_end_frame + 2) * (int64_t)hop_synth + 2 * edgsamp - edgsamp;   // len(w[edgsamp:]), PV.py:1059, 1070
+}
+
+extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
+                             int64_t F, int K, const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
+                             double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                             double* d_w, int64_t wlen, void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (F <= 0 || K <= 0 || P <= 0 || nfft <= 0 || hop_analysis <= 0 || hop_synth <= 0 || !(sr > 0) || wlen <= 0 || !(edge >= 0)) {
+        pvx_set_error("bad resynthesis argument");
+        return PVX_ERR_INVALID;
+    }
+    if (!d_f || !d_mag || !d_realph || !d_partial_id || !d_part_start || !d_part_len || !d_w) { pvx_set_error("null resynthesis array"); return PVX_ERR_INVALID; }
+    SynthParams sp;
+    sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
+    sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
+    sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
+    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr;
+    return pvx_launch_synth(sp, (hipStream_t)stream);
+}
+
+extern "C" int pvx_synth(const double* f, const double* mag, const double* realph, const int32_t* partial_id, int64_t F,
+                         int K, const int32_t* part_start, const int32_t* part_len, int64_t P, double sr, int nfft,
+                         int hop_analysis, int hop_synth, double edge, int minframes, double* w, int64_t wlen) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (F <= 0 || K <= 0 || P <= 0 || !f || !mag || !realph || !partial_id || !part_start || !part_len || !w) {
+        pvx_set_error("bad resynthesis argument");
+        return PVX_ERR_INVALID;
+    }
+    int64_t maxend = 0;                                               // max(self.end), PV.py:1059
+    for (int64_t i = 0; i < P; i++) { const int64_t e = (int64_t)part_start[i] + part_len[i] - 1; if (e > maxend) maxend = e; }
+    const int64_t need = pvx_synth_len(maxend, nfft, hop_analysis, hop_synth, edge);
+    if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
+    const size_t n = (size_t)F * K;
+    DevBuf df, dm, dr, dpid, dst, dln, dw;
+    if ((rc = df.alloc(n * 8)) != PVX_OK || (rc = dm.alloc(n * 8)) != PVX_OK || (rc = dr.alloc(n * 8)) != PVX_OK ||
+        (rc = dpid.alloc(n * 4)) != PVX_OK || (rc = dst.alloc((size_t)P * 4)) != PVX_OK ||
+        (rc = dln.alloc((size_t)P * 4)) != PVX_OK || (rc = dw.alloc((size_t)wlen * 8)) != PVX_OK)
+        return rc;
+    PVX_HIP_CHECK(hipMemcpy(df.p, f, n * 8, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dm.p, mag, n * 8, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dr.p, realph, n * 8, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dpid.p, partial_id, n * 4, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dst.p, part_start, (size_t)P * 4, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dln.p, part_len, (size_t)P * 4, hipMemcpyHostToDevice));
+    rc = pvx_synth_dev((const double*)df.p, (const double*)dm.p, (const double*)dr.p, (const int32_t*)dpid.p, F, K,
+                       (const int32_t*)dst.p, (const int32_t*)dln.p, P, sr, nfft, hop_analysis, hop_synth, edge, minframes,
+                       (double*)dw.p, wlen, nullptr);
+    if (rc != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    PVX_HIP_CHECK(hipMemcpy(w, dw.p, (size_t)wlen * 8, hipMemcpyDeviceToHost));
+    return PVX_OK;
+}

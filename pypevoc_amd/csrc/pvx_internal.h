@@ -1,0 +1,117 @@
+// pvx_internal.h -- shared declarations of libpvx_hip (gfx950 only; no host fallback).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+#include <stdint.h>
+
+#include "pvx.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void pvx_set_error(const char* fmt, ...);
+
+#define PVX_HIP_CHECK(call)                                                                     \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            pvx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,     \
+                          __LINE__);                                                            \
+            return PVX_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define PVX_FFT_CHECK(call)                                                                     \
+    do {                                                                                        \
+        rocfft_status s__ = (call);                                                             \
+        if (s__ != rocfft_status_success) {                                                     \
+            pvx_set_error("%s failed: rocfft_status %d (%s:%d)", #call, (int)s__, __FILE__,     \
+                          __LINE__);                                                            \
+            return PVX_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+int pvx_require_device();  // PVX_OK or PVX_ERR_NO_DEVICE (sets the message)
+
+// ---- row space ------------------------------------------------------------------------------
+// The analysis works on a global "row space": every signal owns F+1 consecutive rows, row 0 of a
+// signal being an all-zero frame (the reference's initial oldfft = zeros, PV.py:121) and row q > 0
+// being frame q-1.  A launch covers global rows [R0, R0+nrows); workspace row j holds global row
+// R0-1+j, so every processed row finds its predecessor in workspace row j-1.
+
+struct FrameParams {
+    const void* x;        // input samples (InT)
+    int64_t nsamp;        // samples per signal
+    int64_t sig_stride;   // samples between signal starts
+    int64_t F;            // frames per signal
+    int64_t R0;           // first global row of this launch (workspace row 1)
+    int64_t ws_rows;      // workspace rows to write (= nrows + 1)
+    int64_t total_rows;   // nsig * (F + 1)
+    int nfft, hop;
+    const void* win;      // window * (1/wfact), T[nfft]
+    void* frames;         // T [ws_rows][ldi]
+    int64_t ldi;          // elements per workspace row
+};
+
+struct PeaksParams {
+    const void* spec;     // complex<T> [ws_rows][ldo]
+    int64_t ldo;          // complex elements per row
+    int64_t F, R0, nrows;
+    int nfft, hop, N2, K, rad;
+    double thr;           // pkthresh (PF minrattomax)
+    double sr, fstep, dt;
+    const double* wfbin;  // [N2] 2*pi*round_half_even(k*fstep*dt)  (PV.py:116-118)
+    const double* prev0;  // optional [N2][2] spectrum preceding frame 0 of signal 0
+    double *f, *mag, *ph, *realph, *binno, *t, *totalmag;
+    int frames_per_wave;
+};
+
+struct PeakRowsParams {   // standalone PeakFinder
+    const double* y;      // [nrows][n]
+    int64_t nrows;
+    int n, npeaks, thr_kind, rad, cap;
+    double thr_val;
+    int32_t* pos;         // [nrows][cap]
+    int8_t* keep;         // [nrows][cap]
+    int32_t* count;       // [nrows]
+};
+
+// launchers (defined in the .hip files)
+int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);
+int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
+int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
+size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
+
+struct TrackParams {
+    const double* f;      // [F][K]
+    const double* mag;
+    int64_t F;
+    int K;
+    double maxjmp;
+    int32_t* partial_id;  // [F][K]
+    int32_t* part_start;  // [cap]
+    int32_t* part_len;    // [cap]
+    int64_t cap;
+    // workspace
+    int32_t* link;        // [F][K]  slot in frame-1, -1 = starts a partial, -2 = empty slot
+    int32_t* newrank;     // [F][K]  rank among the new partials of its frame (creation order)
+    int32_t* newcount;    // [F]     partials created at each frame
+    int64_t* newbase;     // [F+1]   exclusive scan of newcount
+    int32_t* root;        // [F][K]  flattened index of the first point of the slot's partial
+    int32_t* root2;       // ping-pong
+    int64_t* npartials;   // [1]
+};
+int pvx_launch_track(const TrackParams& p, hipStream_t s);
+
+struct SynthParams {
+    const double *f, *mag, *realph;   // [F][K]
+    const int32_t* partial_id;        // [F][K]
+    const int32_t *part_start, *part_len;
+    int64_t F, P;
+    int K;
+    double sr, edge;
+    int nfft, hop_a, hop_s, minframes;
+    double* w;
+    int64_t wlen;
+    int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
+};
+int pvx_launch_synth(const SynthParams& p, hipStream_t s);

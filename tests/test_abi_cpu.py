@@ -1,0 +1,93 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/pvx.h declares, host
+logic that needs no device, and the loud failure without a GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from .conftest import ROOT, golden_names, load_golden
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pvx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pvx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pypevoc_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libpvx_hip.so lacks %s declared in include/pvx.h" % n
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_nframes_and_synth_len_host_logic():
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    for name in golden_names():
+        g = load_golden(name)
+        assert lib.pvx_nframes(len(g["x"]), g["nfft"], g["hop"]) == g["nframes"]
+        for k in g:
+            if k.startswith("w_hop"):
+                h = int(k[5:])
+                maxend = int((g["part_start"].astype(np.int64) + g["part_len"] - 1).max())
+                assert lib.pvx_synth_len(maxend, g["nfft"], g["hop"], h, 1.0) == len(g[k])
+    assert lib.pvx_nframes(1024, 1024, 512) == 0
+    assert lib.pvx_nframes(1025, 1024, 512) == 1
+    # frame counts of the BASELINE configs
+    assert lib.pvx_nframes(26460000, 2048, 512) == 51676
+    assert lib.pvx_nframes(1440000, 2048, 512) == 2809
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import pypevoc_amd
+    p = pypevoc_amd.PV(np.zeros(4096), 44100, nfft=1024, hop=512, npks=4, progress=False)
+    with pytest.raises(pypevoc_amd.PvxError) as e:
+        p.run_pv()
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(pypevoc_amd.PvxError):
+        pypevoc_amd.PeakFinder(np.arange(10.0))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pypevoc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "pvoracle" not in txt and "oracle/" not in txt and "import oracle" not in txt, fn
+
+
+def test_pv_constructor_constants_match_reference_formulas():
+    """PV.__init__ (PVAnalysis.py:84-121) is host arithmetic; check the values the kernels consume."""
+    import pypevoc_amd
+    p = pypevoc_amd.PV(np.zeros(5000), 44100, nfft=2048, npks=3, progress=False)
+    assert p.hop == 1024 and p.nfft2 == 1024 and p.nsamp == 5000
+    win = np.hanning(2048)
+    assert np.array_equal(p.win, win)
+    assert p.wfact == np.sqrt(sum(win ** 2) * 2048) / 2.0
+    assert p.fstep == 44100.0 / 2048 and p.dt == 1024 / 44100.0
+    # round-half-even wrap table for hop = nfft/2: 0,0,1,2,2,2,3,4
+    assert list((p.wfbin[:8] / (2 * np.pi)).round().astype(int)) == [0, 0, 1, 2, 2, 2, 3, 4]
+    assert p.oldfft.shape == (1024,) and not p.oldfft.any()
+
+
+def test_shard_range_partitions():
+    from pypevoc_amd.batch import shard_range
+    for n in (0, 1, 7, 8, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the N>1 path: signals are sharded over ranks, each rank produces its
+shard's result block (here: the oracle stands in for the device as the block producer -- the test
+exercises the partition + single gather, not the kernels), rank 0 gathers with one collective and
+must hold exactly the unsharded result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _signals(nsig, n=6000, sr=8000.0):
+    t = np.arange(n) / sr
+    return np.stack([0.3 * np.sin(2 * np.pi * (200.0 + 37.0 * b) * t) +
+                     0.1 * np.sin(2 * np.pi * (900.0 + 11.0 * b) * t) for b in range(nsig)])
+
+
+def _worker(rank, world, port, nsig, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pvoracle
+        from pypevoc_amd.batch import gather_results, shard_range
+        x = _signals(nsig)
+        a, b = shard_range(nsig, rank, world)
+        blocks = []
+        for i in range(a, b):
+            o = pvoracle.analyze(x[i], 8000.0, 512, 128, 4)
+            blocks.append(np.stack([o[k] for k in ("f", "mag", "ph", "realph", "binno")]))
+        F = pvoracle.nframes(x.shape[1], 512, 128)
+        local = torch.from_numpy(np.stack(blocks)) if blocks else torch.zeros((0, 5, F, 4), dtype=torch.float64)
+        full = gather_results(local, nsig, dst=0)
+        if rank == 0:
+            np.save(os.path.join(outdir, "gathered.npy"), full.numpy())
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nsig", [5, 4])
+def test_sharded_analysis_gather_world2(tmp_path, nsig):
+    from oracle import pvoracle
+    pvoracle.build()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, nsig, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "gathered.npy"))
+    x = _signals(nsig)
+    exp = []
+    for i in range(nsig):
+        o = pvoracle.analyze(x[i], 8000.0, 512, 128, 4)
+        exp.append(np.stack([o[k] for k in ("f", "mag", "ph", "realph", "binno")]))
+    exp = np.stack(exp)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
