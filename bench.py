@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- STFT frames/s of the phase-vocoder analysis stage (PV.run_pv) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): STFT frames/sec at 44.1 kHz, nfft=2048, hop=512, npks=8.
+A "step" is one full run_pv pass over the workload, with the signal(s) already resident in HBM:
+  N = 1 : BASELINE config 2 -- one 10-minute 44.1 kHz mono signal (26 460 000 samples, F = 51 676).
+  N > 1 : weak scaling -- one such signal per GPU (independent signals are the unit the path
+          shards on), plus the single result gather to rank 0 over RCCL/xGMI inside the step.
+value = frames processed by all ranks / wall time of the K timed steps (max over ranks).
+
+Also printed on the same JSON line:
+  roofline     -- the dominant kernel of the stage: algorithmic bytes per launch / its mean launch
+                  duration measured with HIP events recorded on the launch stream (libpvx_hip's
+                  stage timing), against the 8 TB/s HBM3E peak.
+  stage        -- the whole STFT+phase stage priced at SURVEY.md 8(d)'s 35 168 B/frame.
+  cpu_baseline -- the oracle (C port of the reference algorithm, single thread) timed on this host
+                  on the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR, NFFT, HOP, NPKS, SECONDS = 44100, 2048, 512, 8, 600
+HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def c2_signal(seconds=SECONDS, sr=SR, seed=1234, f0=220.0):
+    """SURVEY.md 8(d) C2 / G4 generator: 8 harmonics, 1 % / 5 Hz vibrato, amplitudes 0.3/h, noise."""
+    n = int(sr * seconds)
+    t = np.arange(n, dtype=np.float64) / sr
+    ph = 2 * np.pi * f0 * (t - 0.01 / (2 * np.pi * 5.0) * np.cos(2 * np.pi * 5.0 * t))
+    x = np.zeros(n)
+    for h in range(1, 9):
+        x += 0.3 / h * np.sin(h * ph)
+    x += 0.001 * np.random.default_rng(seed).standard_normal(n)
+    return x.astype(np.float32)
+
+
+def alg_bytes(nfft=NFFT, hop=HOP, npks=NPKS, s=4, c=8):
+    """Algorithmic bytes per frame: per kernel and for the stage."""
+    out = npks * 5 * 8 + 16
+    return dict(frames=hop * s + nfft * s,
+                fft=nfft * s + (nfft // 2 + 1) * c,
+                peaks=(nfft // 2 + 1) * c + out,
+                stage=hop * s + 2 * nfft * s + 2 * (nfft // 2 + 1) * c + out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seconds", type=int, default=SECONDS, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    _lib.init(local_rank)
+
+    # ---- workload, resident in HBM before the timed region
+    x_host = c2_signal(args.seconds, seed=1234 + rank, f0=220.0 * 2 ** (rank / 8.0))
+    x = torch.from_numpy(x_host).to(dev)
+    nsamp = x.numel()
+    F = int(lib.pvx_nframes(nsamp, NFFT, HOP))
+    K = NPKS
+    packed = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev)   # one block -> one gather
+    base = packed.data_ptr()
+    ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
+    gathered = [torch.empty_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    plan = ctypes.c_void_p()
+    win = np.hanning(NFFT)
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(SR), NFFT, HOP, K, 0.005, _lib.dptr(win),
+                                   args.precision, 0), "pvx_plan_create")
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp, *ptrs, None,
+                                ctypes.c_void_p(stream.cuda_stream))
+        _lib.check(r, "pvx_analyze_dev")
+        if world > 1:
+            dist.gather(packed, gather_list=gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # ---- timed region: exactly K steps, HIP events of the per-stage breakdown recorded live
+    _lib.check(lib.pvx_plan_set_timing(plan, 1), "pvx_plan_set_timing")
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    ms = (ctypes.c_double * 4)()
+    nl = (ctypes.c_int64 * 4)()
+    _lib.check(lib.pvx_plan_get_timing(plan, ms, nl), "pvx_plan_get_timing")
+    _lib.check(lib.pvx_plan_set_timing(plan, 0), "pvx_plan_set_timing")
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ab = alg_bytes()
+        frames_total = F * world * args.steps
+        value = frames_total / elapsed
+        names = ["k_frames", "rocfft_r2c", "k_phase_peaks"]
+        keys = ["frames", "fft", "peaks"]
+        per = []
+        for i in range(3):
+            if nl[i]:
+                dur = ms[i] * 1e-3 / nl[i]                       # mean launch duration [s]
+                frames_per_launch = F * args.steps / float(nl[i])  # zero rows excluded
+                ach = ab[keys[i]] * frames_per_launch / dur
+                per.append(dict(kernel=names[i], ms_per_launch=dur * 1e3, launches=int(nl[i]),
+                                alg_bytes_per_frame=ab[keys[i]], achieved_GBps=ach / 1e9))
+        dom = max(per, key=lambda d: d["ms_per_launch"] * d["launches"]) if per else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if dom and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        roofline = None
+        if dom:
+            roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["achieved_GBps"], 1),
+                            peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(dom["achieved_GBps"] * 1e9 / HBM_PEAK, 4),
+                            traffic=traffic, ms_per_launch=round(dom["ms_per_launch"], 4),
+                            alg_bytes_per_launch=int(dom["alg_bytes_per_frame"] * F * args.steps / dom["launches"]))
+        stage_s = sum(ms[i] for i in range(3)) * 1e-3 / args.steps
+        stage = dict(alg_bytes_per_frame=ab["stage"], ms_per_step_kernels=round(stage_s * 1e3, 4),
+                     achieved_GBps=round(ab["stage"] * F / stage_s / 1e9, 1) if stage_s > 0 else None,
+                     frac_of_8TBps=round(ab["stage"] * F / stage_s / HBM_PEAK, 4) if stage_s > 0 else None,
+                     kernels=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in per],
+                     step_ms_hip_events=round(ev_ms / args.steps, 4))
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import pvoracle
+            pvoracle.build()
+            xs = x_host.astype(np.float64)
+            t1 = time.perf_counter()
+            o = pvoracle.analyze(xs, SR, NFFT, HOP, NPKS)
+            dtc = time.perf_counter() - t1
+            cpu = dict(value=round(len(o["t"]) / dtc, 1), unit="frames/s", cores=1, kind="port",
+                       sample="the full N=1 workload once (%d frames, %.1f s of CPU time), oracle/pvoracle.c single thread, "
+                              "host has %d cores" % (len(o["t"]), dtc, os.cpu_count() or 0))
+        line = {
+            "metric": "STFT frames/sec (44.1 kHz, nfft=2048, hop=512)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: one %d-s 44.1 kHz mono signal per GPU, nfft=2048, hop=512, npks=8, "
+                                   "analysis only (PV.run_pv), F=%d frames/signal%s" %
+                                   (args.seconds, F, "; results gathered to rank 0 over RCCL" if world > 1 else ""),
+                       "nfft": NFFT, "hop": HOP, "npks": NPKS, "sr": SR, "frames_per_gpu": F,
+                       "parallelism": "signals sharded 1/GPU" if world > 1 else "single GPU"},
+            "roofline": roofline, "stage": stage, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+    lib.pvx_plan_destroy(plan)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
