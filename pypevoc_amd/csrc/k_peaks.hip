@@ -8,14 +8,21 @@
 //    is discarded -- PV.py:176 -- so it has no counterpart here)
 //
 // Roofline: HBM.  One wave64 per frame: the half spectrum (nfft/2 complex) is streamed once with
-// 16-byte-per-lane loads, magnitudes go to LDS, everything else (min/max/energy wave reductions,
-// local-maximum scores, top-K by repeated wave arg-max, salience test) runs out of LDS/registers.
-// Only the <= K selected bins are re-read (current and previous row; L2 hits, the wave that owns
-// frame fr-1 is the same wave or its neighbour).  Algorithmic bytes/frame = (nfft/2)*sizeof(complex)
-// read + (5K+2)*8 written.
+// 16-byte-per-lane loads and only |X| is kept, in LDS.  Everything else runs out of LDS/registers:
+//   - min / max / energy: DPP row reductions + 4 readlanes (no LDS crossbar traffic);
+//   - candidates = interior local maxima above the threshold, compacted into an LDS list with
+//     ballot + mbcnt (list order = ascending bin, so no sort is ever needed);
+//   - top-npeaks of the candidates: nothing to do when there are <= npeaks of them (the common
+//     case), otherwise an exact radix select on the float bits driven by ballots/popcounts only;
+//   - salience test: 2*rad+1 LDS reads per selected peak.
+// The per-peak phase-vocoder arithmetic is batched: a wave first selects the peaks of G frames, then
+// all 64 lanes work on (frame, peak) pairs at once, re-reading only the <= K selected bins of the
+// current and previous rows (L2 hits).  Algorithmic bytes/frame = (nfft/2)*sizeof(complex) read +
+// (5K+2)*8 written.
 //
-// The per-peak arithmetic (atan2, frequency candidates, energy, realph) is float64 in both
-// precisions: it is <= K values per frame and it is what the reference's float64 outputs hold.
+// precision=32: angles are computed in float32 (the float32 FFT already limits them to ~1e-7 rad)
+// and assembled into float64 outputs around the exactly known bin centre; precision=64: the
+// reference's operation order in float64 throughout.
 #include <float.h>
 #include <math.h>
 
@@ -32,97 +39,172 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T> __device__ inline T neg_inf();
-template <> __device__ inline float neg_inf<float>() { return -INFINITY; }
-template <> __device__ inline double neg_inf<double>() { return -(double)INFINITY; }
-
-template <typename T> __device__ inline T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { T u = __shfl_xor(v, o); v = u > v ? u : v; }
-    return v;
+__device__ inline int lane_prefix(unsigned long long bal) {   // set bits of bal below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
-template <typename T> __device__ inline T wave_min(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { T u = __shfl_xor(v, o); v = u < v ? u : v; }
-    return v;
+
+// ---- DPP reductions: 4 in-row steps (quad xor 1, xor 2, half mirror, mirror), then one readlane
+// per row of 16.  Result is wave-uniform.
+template <int CTRL> __device__ inline float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ inline double dpp_d(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline float rl_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline double rl_d(double v, int l) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+#define PVX_ROW_REDUCE(v, OP, DPP)            \
+    v = OP(v, DPP<0xB1>(v));                  \
+    v = OP(v, DPP<0x4E>(v));                  \
+    v = OP(v, DPP<0x141>(v));                 \
+    v = OP(v, DPP<0x140>(v));
+__device__ inline float wave_max(float v) {
+    PVX_ROW_REDUCE(v, fmaxf, dpp_f)
+    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ inline float wave_min(float v) {
+    PVX_ROW_REDUCE(v, fminf, dpp_f)
+    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ inline double dmax(double a, double b) { return a > b ? a : b; }
+__device__ inline double dmin(double a, double b) { return a < b ? a : b; }
+__device__ inline double dadd(double a, double b) { return a + b; }
+__device__ inline double wave_max(double v) {
+    PVX_ROW_REDUCE(v, dmax, dpp_d)
+    return dmax(dmax(rl_d(v, 0), rl_d(v, 16)), dmax(rl_d(v, 32), rl_d(v, 48)));
+}
+__device__ inline double wave_min(double v) {
+    PVX_ROW_REDUCE(v, dmin, dpp_d)
+    return dmin(dmin(rl_d(v, 0), rl_d(v, 16)), dmin(rl_d(v, 32), rl_d(v, 48)));
 }
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-// arg-max with "first index wins" ties (np.argmax, PF.py:173/183)
-template <typename T> __device__ inline void wave_argmax(T& v, int& i) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        T u = __shfl_xor(v, o);
-        int j = __shfl_xor(i, o);
-        if (u > v || (u == v && j < i)) { v = u; i = j; }
-    }
+    PVX_ROW_REDUCE(v, dadd, dpp_d)
+    return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
 
+template <typename T> struct Key;
+template <> struct Key<float> {
+    using type = unsigned int;
+    static constexpr int TOP = 30;   // scores are >= 0: the sign bit is never set
+    static __device__ inline type of(float v) { return __float_as_uint(v); }
+};
+template <> struct Key<double> {
+    using type = unsigned long long;
+    static constexpr int TOP = 62;
+    static __device__ inline type of(double v) { return (unsigned long long)__double_as_longlong(v); }
+};
+
 // ---------------------------------------------------------------------------------------------
-// PeakFinder core on one row held in LDS.
-//   y[n]      : the row (T)
-//   score[n]  : scratch (T)
-//   sel[cap], srt[cap] : int scratch, cap >= min(npeaks, n)
-// Returns (wave-uniform) the number of positions; srt[0..count) = positions ascending (PF.py:189).
-// miny/maxy must be the wave-reduced extremes of y.
+// PeakFinder core on one row held in LDS (PF.py:155-194 semantics, restated without the K-round
+// arg-max loop).  pkmskamp (PF.py:166-167) is y-miny at interior local maxima and 0 elsewhere; the
+// reference repeatedly takes the arg-max (first index on ties) while it exceeds th = minamp-miny and
+// fewer than npeaks have been taken, then sorts the positions.  Equivalent statement used here:
+//   candidates  = local maxima with score > th                    (score > 0 always for a maximum)
+//   selected    = the npeaks best candidates by (score desc, index asc), all of them if fewer;
+//   if th < 0 the zeros of pkmskamp qualify too: after ALL maxima, non-maximum interior bins are
+//   taken in ascending index order until npeaks are selected.
+// Output: out[0..count) ascending bin indices (wave-uniform count).
+//   y[n] row; cs[cap]/ci[cap] candidate scratch, cap >= n/2 + 1.
 template <typename T>
-__device__ inline int peak_select(const T* y, T* score, int* sel, int* srt, int n, int npeaks,
-                                  double minamp_in, bool have_minamp, T miny, int lane) {
+__device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
+                                  bool have_minamp, T miny, int lane) {
     if (n < 3) return 0;
     // PF.py:69-70: "if not self.minamp: self.minamp = np.min(self.y)"
-    double minamp = (have_minamp && minamp_in != 0.0) ? minamp_in : (double)miny;
-    const double th = minamp - (double)miny;                       // PF.py:174
-    const T NEG = neg_inf<T>();
-    // PF.py:166-167: interior local maxima, score = y - miny, 0 elsewhere
-    T bv = NEG;
-    int bi = 0x7fffffff;
-    for (int k = lane; k < n; k += 64) {
-        T s = NEG;
+    const double minamp = (have_minamp && minamp_in != 0.0) ? minamp_in : (double)miny;
+    const double th = minamp - (double)miny;                        // PF.py:174
+    // ---- candidates, compacted in ascending bin order
+    int C = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool cand = false;
+        T s = (T)0;
         if (k >= 1 && k <= n - 2) {
-            T a = y[k - 1], b = y[k], c = y[k + 1];
-            s = (a < b && b >= c) ? (T)(b - miny) : (T)0;
+            const T a = y[k - 1], b = y[k], c = y[k + 1];
+            s = (T)(b - miny);
+            cand = (a < b) && (b >= c) && ((double)s > th);
         }
-        score[k] = s;
-        if (s > bv) { bv = s; bi = k; }
+        const unsigned long long bal = __ballot(cand);
+        if (cand) { const int pos = C + lane_prefix(bal); cs[pos] = s; ci[pos] = k; }
+        C += __popcll(bal);
     }
-    int nsel = 0;
-    while (nsel < npeaks) {                                        // PF.py:177-187
-        T v = bv;
-        int i = bi;
-        wave_argmax(v, i);
-        if (!((double)v > th)) break;
-        if (lane == 0) sel[nsel] = i;
-        nsel++;
-        if ((i & 63) == lane) {                                    // owner retires it and rescans its bins
-            score[i] = NEG;                                        // pkmskamp[b] = th - 1
-            bv = NEG;
-            bi = 0x7fffffff;
-            for (int k = lane; k < n; k += 64) {
-                T s = score[k];
-                if (s > bv) { bv = s; bi = k; }
+    wave_sync();
+    if (C <= npeaks) {
+        if (th < 0.0 && C < npeaks) {
+            // zeros of pkmskamp are above the (negative) threshold: all maxima, then the first
+            // non-maximum interior bins, emitted together in ascending bin order
+            const int need = npeaks - C;
+            int zc = 0, cnt = 0;
+            for (int k0 = 0; k0 < n && cnt < npeaks; k0 += 64) {
+                const int k = k0 + lane;
+                bool ismax = false, isz = false;
+                if (k >= 1 && k <= n - 2) {
+                    const T a = y[k - 1], b = y[k], c = y[k + 1];
+                    ismax = (a < b) && (b >= c);
+                    isz = !ismax;
+                }
+                const unsigned long long bz = __ballot(isz);
+                const bool take = ismax || (isz && (zc + lane_prefix(bz)) < need);
+                const unsigned long long bt = __ballot(take);
+                if (take) out[cnt + lane_prefix(bt)] = k;
+                zc += __popcll(bz);
+                cnt += __popcll(bt);
             }
+            wave_sync();
+            return cnt;
         }
+        for (int c = lane; c < C; c += 64) out[c] = ci[c];
+        wave_sync();
+        return C;
+    }
+    // ---- C > npeaks: exact radix select of the npeaks-th largest score (bits of a non-negative
+    // float order like unsigned integers).  Ballot + popcount only.
+    using K = Key<T>;
+    using KT = typename K::type;
+    const KT k0r = (lane < C) ? K::of(cs[lane]) : (KT)0;            // first two per lane live in registers
+    const KT k1r = (lane + 64 < C) ? K::of(cs[lane + 64]) : (KT)0;
+    KT prefix = 0;
+    for (int bit = K::TOP; bit >= 0; --bit) {
+        const KT trial = prefix | ((KT)1 << bit);
+        int cnt = __popcll(__ballot(k0r >= trial)) + __popcll(__ballot(k1r >= trial));
+        for (int c = lane + 128; c - lane < C; c += 64) {           // wave-uniform trip count
+            const bool p = (c < C) && (K::of(cs[c]) >= trial);
+            cnt += __popcll(__ballot(p));
+        }
+        if (cnt >= npeaks) prefix = trial;
+    }
+    // prefix = key of the npeaks-th best; strictly greater ones all go, ties in index order
+    int ngt = __popcll(__ballot(k0r > prefix)) + __popcll(__ballot(k1r > prefix));
+    for (int c = lane + 128; c - lane < C; c += 64) ngt += __popcll(__ballot((c < C) && (K::of(cs[c]) > prefix)));
+    const int need = npeaks - ngt;
+    int tc = 0, cnt = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const KT key = (c < C) ? K::of(cs[c]) : (KT)0;
+        const bool tie = (c < C) && (key == prefix);
+        const unsigned long long bt = __ballot(tie);
+        const bool take = (c < C) && ((key > prefix) || (tie && (tc + lane_prefix(bt)) < need));
+        const unsigned long long bk = __ballot(take);
+        if (take) out[cnt + lane_prefix(bk)] = ci[c];
+        tc += __popcll(bt);
+        cnt += __popcll(bk);
     }
     wave_sync();
-    // np.sort(pos): rank by counting (positions are distinct)
-    for (int e = lane; e < nsel; e += 64) {
-        int mine = sel[e], r = 0;
-        for (int j = 0; j < nsel; j++) r += (sel[j] < mine) ? 1 : 0;
-        srt[r] = mine;
-    }
-    wave_sync();
-    return nsel;
+    return cnt;
 }
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
 // [max(p-rad,1), min(p+rad,n)] (clipped to the array) exceeds y[p]
 template <typename T> __device__ inline bool salient(const T* y, int n, int p, int rad) {
     if (rad < 0) return true;
-    T v = y[p];
-    int lo = p - rad > 1 ? p - rad : 1;
+    const T v = y[p];
+    const int lo = p - rad > 1 ? p - rad : 1;
     int hi = p + rad < n ? p + rad : n;
     if (hi > n - 1) hi = n - 1;
     bool keep = true;
@@ -135,6 +217,20 @@ template <typename T> struct Vec16;   // 16-byte global access
 template <> struct Vec16<float> { using type = float4; static constexpr int CPV = 2; };
 template <> struct Vec16<double> { using type = double2; static constexpr int CPV = 1; };
 
+constexpr int GMAX = 8;               // frames a wave batches before the per-peak pass
+
+// LDS per wave (bytes), shared with the host-side sizing below
+__host__ __device__ inline size_t peaks_lds_per_wave(int N2, int K, size_t ts) {
+    const size_t n2pad = (size_t)((N2 + 3) & ~3);
+    const size_t cap = n2pad / 2 + 4;
+    const size_t kpad = (size_t)((K + 3) & ~3);
+    // y[n2pad] T | cs[cap] T | ci[cap] int | sel[kpad] int | lst[GMAX][kpad] int | cnt[GMAX] int | tot[GMAX] double
+    size_t b = n2pad * ts + cap * ts + cap * 4 + kpad * 4 + (size_t)GMAX * kpad * 4 + GMAX * 4;
+    b = (b + 7) & ~(size_t)7;
+    b += GMAX * 8;
+    return (b + 15) & ~(size_t)15;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,59 +239,62 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     const int nwaves = blockDim.x >> 6;
     const int N2 = p.N2, K = p.K;
     const int n2pad = (N2 + 3) & ~3;
+    const int cap = n2pad / 2 + 4;
     const int kpad = (K + 3) & ~3;
-    // per-wave LDS carve: y[n2pad] T | score[n2pad] T | sel[kpad] int | srt[kpad] int
-    const size_t per_wave = (size_t)n2pad * sizeof(T) * 2 + (size_t)kpad * sizeof(int) * 2;
-    unsigned char* base = smem + per_wave * wid;
+    unsigned char* base = smem + peaks_lds_per_wave(N2, K, sizeof(T)) * wid;
     T* y = (T*)base;
-    T* score = y + n2pad;
-    int* sel = (int*)(score + n2pad);
-    int* srt = sel + kpad;
+    T* cs = y + n2pad;
+    int* ci = (int*)(cs + cap);
+    int* sel = ci + cap;
+    int* lst = sel + kpad;                       // [GMAX][kpad]
+    int* cntv = lst + GMAX * kpad;               // [GMAX]
+    double* totv = (double*)(((uintptr_t)(cntv + GMAX) + 7) & ~(uintptr_t)7);   // [GMAX]
 
-    const int64_t wave_global = (int64_t)blockIdx.x * nwaves + wid;
-    for (int it = 0; it < p.frames_per_wave; ++it) {
-        const int64_t rel = wave_global * p.frames_per_wave + it;   // row within the launch
-        if (rel >= p.nrows) break;                                  // wave-uniform
-        const int64_t g = p.R0 + rel;
-        const int64_t b = g / (p.F + 1);
-        const int64_t q = g - b * (p.F + 1);
-        if (q == 0) continue;                                       // zero row of a signal
-        const int64_t fr = q - 1;
-        const int64_t orow = b * p.F + fr;                          // output row
+    const int G = p.frames_per_wave < GMAX ? p.frames_per_wave : GMAX;
+    const int64_t rel0 = ((int64_t)blockIdx.x * nwaves + wid) * G;           // first row of this wave
+    if (rel0 >= p.nrows) return;
+    const int ng = (p.nrows - rel0 < G) ? (int)(p.nrows - rel0) : G;
+
+    // ================= phase A: per frame, stream |X| into LDS and select the peak bins
+    for (int g = 0; g < ng; ++g) {
+        const int64_t rel = rel0 + g;
+        const int64_t gr = p.R0 + rel;
+        const int64_t q = gr % (p.F + 1);
+        if (q == 0) {                                                // zero row of a signal: no output
+            if (lane == 0) cntv[g] = -1;
+            continue;
+        }
         const T* cur = (const T*)p.spec + (size_t)(rel + 1) * p.ldo * 2;
-        const T* prv = (const T*)p.spec + (size_t)rel * p.ldo * 2;
-        const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
-
-        wave_sync();   // previous iteration's readers are done with y/score/sel/srt
-        // ---- pass 1: stream the row, |X| -> LDS, extremes and energy (PV.py:173, 210; PF.py:60,164)
-        T lmax = neg_inf<T>(), lmin = -neg_inf<T>();
+        wave_sync();                                                 // y / cs / ci / sel free again
+        // ---- stream the row: |X| -> LDS, extremes and energy (PV.py:173, 210; PF.py:60, 164)
+        T lmax = (T)-INFINITY, lmin = (T)INFINITY;
         double lsum = 0.0;
         {
             using V = typename Vec16<T>::type;
             constexpr int CPV = Vec16<T>::CPV;
             const int nvec = N2 / CPV;
             const V* cv = (const V*)cur;
-#pragma unroll 4
+#pragma unroll 8
             for (int i = lane; i < nvec; i += 64) {
-                V v = cv[i];
+                const V v = cv[i];
                 if constexpr (CPV == 2) {
-                    T m0 = sqrtf(v.x * v.x + v.y * v.y);
-                    T m1 = sqrtf(v.z * v.z + v.w * v.w);
+                    const float e0 = v.x * v.x + v.y * v.y, e1 = v.z * v.z + v.w * v.w;
+                    const float m0 = sqrtf(e0), m1 = sqrtf(e1);
                     *(float2*)(y + 2 * i) = make_float2(m0, m1);
                     lmax = fmaxf(lmax, fmaxf(m0, m1));
                     lmin = fminf(lmin, fminf(m0, m1));
-                    lsum += (double)m0 * (double)m0 + (double)m1 * (double)m1;
+                    lsum += (double)e0 + (double)e1;
                 } else {
-                    T m0 = hypot(v.x, v.y);                         // np.abs of complex128
+                    const T m0 = hypot(v.x, v.y);                    // np.abs of complex128
                     y[i] = m0;
                     lmax = m0 > lmax ? m0 : lmax;
                     lmin = m0 < lmin ? m0 : lmin;
                     lsum += m0 * m0;
                 }
             }
-            for (int k = nvec * CPV + lane; k < N2; k += 64) {      // odd tail (CPV == 2, N2 odd)
-                T re = cur[2 * k], im = cur[2 * k + 1];
-                T m0 = (T)sqrt((double)re * re + (double)im * im);
+            for (int k = nvec * CPV + lane; k < N2; k += 64) {       // odd tail (CPV == 2, N2 odd)
+                const T re = cur[2 * k], im = cur[2 * k + 1];
+                const T m0 = (T)sqrt((double)re * re + (double)im * im);
                 y[k] = m0;
                 lmax = m0 > lmax ? m0 : lmax;
                 lmin = m0 < lmin ? m0 : lmin;
@@ -206,91 +305,142 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
         const T miny = wave_min(lmin);
         const double tot = wave_sum(lsum);
         wave_sync();
+        // ---- PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
+        const double minamp = (double)maxy * p.thr;                  // PF.py:60
+        const int nsel = peak_select<T>(y, cs, ci, sel, N2, K, minamp, true, miny, lane);
+        int nk = 0;
+        for (int e0 = 0; e0 < nsel; e0 += 64) {
+            const int e = e0 + lane;
+            int pb = 0;
+            bool keep = false;
+            if (e < nsel) { pb = sel[e]; keep = salient<T>(y, N2, pb, p.rad); }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) lst[g * kpad + nk + lane_prefix(bal)] = pb;
+            nk += __popcll(bal);
+        }
+        if (lane == 0) { cntv[g] = nk; totv[g] = tot; }
+    }
+    wave_sync();
 
-        // ---- peak picking (PV.py:175-178)
-        const double minamp = (double)maxy * p.thr;                 // PF.py:60
-        const int nsel = peak_select<T>(y, score, sel, srt, N2, K, minamp, true, miny, lane);
-
-        // ---- per-peak phase vocoder arithmetic, ascending bin order (PV.py:187-207)
+    // ================= phase B: per-peak phase vocoder arithmetic on (frame, peak) pairs
+    // lanes_per_frame LPF = smallest power of two >= K (at most 64); 64/LPF frames per pass
+    int LPF = 1;
+    while (LPF < K && LPF < 64) LPF <<= 1;
+    const int fpp = 64 / LPF;
+    const int gl = lane / LPF, e0 = lane - gl * LPF;
+    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
+    for (int gb = 0; gb < ng; gb += fpp) {
+        const int g = gb + gl;
+        const bool gvalid = g < ng;
+        const int cnt = gvalid ? cntv[g] : -1;
+        const int64_t rel = rel0 + (gvalid ? g : 0);
+        const int64_t gr = p.R0 + rel;
+        const int64_t b = gr / (p.F + 1);
+        const int64_t fr = gr - b * (p.F + 1) - 1;
+        const int64_t orow = b * p.F + fr;
+        const T* cur = (const T*)p.spec + (size_t)(rel + 1) * p.ldo * 2;
+        const T* prv = (const T*)p.spec + (size_t)rel * p.ldo * 2;
+        const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
         double* of = p.f + orow * K;
         double* om = p.mag + orow * K;
         double* op = p.ph + orow * K;
         double* orp = p.realph + orow * K;
         double* ob = p.binno + orow * K;
         int nout = 0;
-        for (int basei = 0; basei < nsel; basei += 64) {
-            const int e = basei + lane;
-            bool valid = e < nsel;
+        // all lanes run the same number of passes (ballots inside): wave-uniform bound
+        for (int eb = 0; eb < K; eb += LPF) {
+            const int e = eb + e0;
+            bool valid = (cnt >= 0) && (e < cnt);
             int nbin = 0;
             double freq = 0.0, dfb = 0.0, thisph = 0.0, mg = 0.0;
             if (valid) {
-                nbin = srt[e];
-                valid = salient<T>(y, N2, nbin, p.rad);
-            }
-            if (valid) {
-                const double re = (double)cur[2 * nbin], im = (double)cur[2 * nbin + 1];
-                double pr, pi;
-                if (use_prev0) { pr = p.prev0[2 * nbin]; pi = p.prev0[2 * nbin + 1]; }
-                else { pr = (double)prv[2 * nbin]; pi = (double)prv[2 * nbin + 1]; }
-                thisph = atan2(im, re);                              // PV.py:188
-                double dph;
-                if (pr == 0.0 && pi == 0.0) {
-                    // numpy: (a+bj)/(0+0j) = (a/0) + (b/0)j -> +-inf +-inf j, NaN when a or b is 0;
-                    // angle() then is +-pi/4, +-3pi/4 by quadrant (PV.py:171, 190; frame 0 and any
-                    // frame that follows an all-zero one)
-                    if (re == 0.0 || im == 0.0 || re != re || im != im) dph = NAN;
-                    else dph = (re > 0.0) ? (im > 0.0 ? kPi / 4 : -kPi / 4) : (im > 0.0 ? 3 * kPi / 4 : -3 * kPi / 4);
+                nbin = lst[g * kpad + e];
+                const T re = cur[2 * nbin], im = cur[2 * nbin + 1];
+                T pr, pi;
+                if (use_prev0) { pr = (T)p.prev0[2 * nbin]; pi = (T)p.prev0[2 * nbin + 1]; }
+                else { pr = prv[2 * nbin]; pi = prv[2 * nbin + 1]; }
+                // PV.py:197-199: 3-bin energy, bin 0 excluded
+                const int imin = nbin - 1 > 1 ? nbin - 1 : 1;
+                int imax = nbin + 1 < N2 ? nbin + 1 : N2;
+                if (imax > N2 - 1) imax = N2 - 1;
+                bool nanph = false;
+                if constexpr (sizeof(T) == 4) {
+                    // ---- float32 angles, float64 assembly around the bin centre
+                    const float tph = atan2f(im, re);                    // PV.py:188
+                    float dph;
+                    if (pr == 0.f && pi == 0.f) {
+                        // numpy: (a+bj)/(0+0j) = (a/0) + (b/0)j -> +-inf +-inf j, NaN when a or b is 0;
+                        // angle() is then +-pi/4, +-3pi/4 by quadrant (PV.py:171, 190: frame 0 and
+                        // any frame that follows an all-zero one)
+                        nanph = (re == 0.f || im == 0.f || re != re || im != im);
+                        const float q4 = (float)(kPi / 4);
+                        dph = (re > 0.f) ? (im > 0.f ? q4 : -q4) : (im > 0.f ? 3.f * q4 : -3.f * q4);
+                    } else {
+                        dph = atan2f(im * pr - re * pi, re * pr + im * pi);   // angle(fx * conj(old))
+                        nanph = dph != dph;
+                    }
+                    // PV.py:140-147 in closed form: with c = nbin*hop/nfft (cycles the bin centre
+                    // advances per hop) and w = wfbin/2pi, candidate m has df*dt = c - w - dph/2pi - m;
+                    // c - w is exact in float64, |c - w| <= 1/2
+                    const double cw = (double)nbin * (double)p.hop / (double)p.nfft - p.wfbin[nbin] / kPi2;
+                    const float u = (float)cw - dph * (float)(1.0 / kPi2);
+                    float best = u + 1.f, ab = fabsf(best);               // m = -1
+                    if (fabsf(u) < ab) { best = u; ab = fabsf(u); }       // m = 0   (first minimum wins)
+                    if (fabsf(u - 1.f) < ab) { best = u - 1.f; }          // m = +1
+                    dfb = (double)best / p.dt;                            // df = fbin - freq
+                    freq = (double)nbin * p.fstep - dfb;
+                    thisph = (double)tph;
+                    float s = 0.f;
+                    for (int j = imin; j <= imax; j++) { const float a = cur[2 * j], c = cur[2 * j + 1]; s += a * a + c * c; }
+                    mg = (double)sqrtf(s);
                 } else {
-                    // angle(fx/old) = angle(fx * conj(old))
-                    dph = atan2(im * pr - re * pi, re * pr + im * pi);
-                }
-                if (dph != dph) {
-                    valid = false;                                   // NaN: `freq > 0` is False (PV.py:193)
-                } else {
-                    // PV.py:140-147: three unwrapping candidates, the one nearest the bin centre
-                    const double fb = (double)nbin * p.fstep;        // PV.py:114
+                    const double dre = re, dim = im, dpr = pr, dpi = pi;
+                    thisph = atan2(dim, dre);                             // PV.py:188
+                    double dph;
+                    if (dpr == 0.0 && dpi == 0.0) {
+                        nanph = (dre == 0.0 || dim == 0.0 || dre != dre || dim != dim);
+                        dph = (dre > 0.0) ? (dim > 0.0 ? kPi / 4 : -kPi / 4) : (dim > 0.0 ? 3 * kPi / 4 : -3 * kPi / 4);
+                    } else {
+                        dph = atan2(dim * dpr - dre * dpi, dre * dpr + dim * dpi);
+                        nanph = dph != dph;
+                    }
+                    // PV.py:140-147 literally: three unwrapping candidates, nearest the bin centre
+                    const double fb = (double)nbin * p.fstep;             // PV.py:114
                     const double w0 = dph + p.wfbin[nbin];
                     double bestabs = 0.0;
 #pragma unroll
                     for (int m = -1; m <= 1; m++) {
-                        double dphw = w0 + kPi2 * (double)m;
-                        double fq = dphw / p.dt / kPi2;
-                        double df = fb - fq;
-                        double a = fabs(df);
+                        const double dphw = w0 + kPi2 * (double)m;
+                        const double fq = dphw / p.dt / kPi2;
+                        const double df = fb - fq;
+                        const double a = fabs(df);
                         if (m == -1 || a < bestabs) { freq = fq; dfb = df; bestabs = a; }
                     }
-                    valid = freq > 0.0;                              // PV.py:193
-                }
-                if (valid) {
-                    // PV.py:197-199: 3-bin energy, bin 0 excluded
-                    const int imin = nbin - 1 > 1 ? nbin - 1 : 1;
-                    int imax = nbin + 1 < N2 ? nbin + 1 : N2;
-                    if (imax > N2 - 1) imax = N2 - 1;
                     double s = 0.0;
-                    for (int j = imin; j <= imax; j++) {
-                        double a = (double)cur[2 * j], c = (double)cur[2 * j + 1];
-                        s = s + (a * a + c * c);
-                    }
+                    for (int j = imin; j <= imax; j++) { const double a = cur[2 * j], c = cur[2 * j + 1]; s = s + (a * a + c * c); }
                     mg = sqrt(s);
                 }
+                valid = !nanph && (freq > 0.0);                           // PV.py:193 (NaN fails the test)
             }
-            const unsigned long long bal = __ballot(valid);
+            const unsigned long long bal = __ballot(valid) & gmask;
             if (valid) {
                 const int o = nout + __popcll(bal & ((1ull << lane) - 1ull));
                 ob[o] = (double)nbin;
                 of[o] = freq;
                 om[o] = mg;
                 op[o] = thisph;
-                orp[o] = thisph + kPi * dfb / p.fstep;               // PV.py:207
+                orp[o] = thisph + kPi * dfb / p.fstep;                    // PV.py:207
             }
             nout += __popcll(bal);
         }
-        for (int j = nout + lane; j < K; j += 64) {                  // zero padding, PV.py:226-239
-            ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
-        }
-        if (lane == 0) {
-            if (p.totalmag) p.totalmag[orow] = sqrt(tot);            // PV.py:210
-            if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + p.nfft / 2.0) / p.sr;   // PV.py:247
+        if (cnt >= 0) {
+            for (int j = nout + e0; j < K; j += LPF) {                    // zero padding, PV.py:226-239
+                ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
+            }
+            if (e0 == 0) {
+                if (p.totalmag) p.totalmag[orow] = sqrt(totv[g]);                                   // PV.py:210
+                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + p.nfft / 2.0) / p.sr;         // PV.py:247
+            }
         }
     }
 }
@@ -298,6 +448,11 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
 // ---------------------------------------------------------------------------------------------
 // Standalone PeakFinder on rows of float64 (the drop-in for `PeakFinder(y, ...)` +
 // filter_by_salience): one wave per row.
+__host__ __device__ inline size_t rows_lds_per_wave(int n, int npk) {
+    const size_t npad = (size_t)((n + 3) & ~3), cap = npad / 2 + 4, kpad = (size_t)((npk + 3) & ~3);
+    return (npad * 8 + cap * 8 + cap * 4 + kpad * 4 + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(256) void k_peak_rows(PeakRowsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -306,19 +461,18 @@ __global__ __launch_bounds__(256) void k_peak_rows(PeakRowsParams p) {
     const int n = p.n;
     const int npk = (p.npeaks <= 0 || p.npeaks > n) ? n : p.npeaks;    // PF.py:64-67 (at most n-2 exist)
     const int npad = (n + 3) & ~3;
-    const int kpad = (npk + 3) & ~3;
-    const size_t per_wave = (size_t)npad * sizeof(double) * 2 + (size_t)kpad * sizeof(int) * 2;
-    unsigned char* base = smem + per_wave * wid;
+    const int cap = npad / 2 + 4;
+    unsigned char* base = smem + rows_lds_per_wave(n, npk) * wid;
     double* y = (double*)base;
-    double* score = y + npad;
-    int* sel = (int*)(score + npad);
-    int* srt = sel + kpad;
+    double* cs = y + npad;
+    int* ci = (int*)(cs + cap);
+    int* sel = ci + cap;
     const int64_t row = (int64_t)blockIdx.x * nwaves + wid;
     if (row >= p.nrows) return;
     const double* src = p.y + row * (int64_t)n;
     double lmax = -(double)INFINITY, lmin = (double)INFINITY;
     for (int k = lane; k < n; k += 64) {
-        double v = src[k];
+        const double v = src[k];
         y[k] = v;
         lmax = v > lmax ? v : lmax;
         lmin = v < lmin ? v : lmin;
@@ -329,11 +483,11 @@ __global__ __launch_bounds__(256) void k_peak_rows(PeakRowsParams p) {
     bool have = false;
     if (p.thr_kind == 1) { minamp = maxy * p.thr_val; have = true; }   // PF.py:60
     else if (p.thr_kind == 2) { minamp = p.thr_val; have = true; }     // PF.py:58
-    const int nsel = peak_select<double>(y, score, sel, srt, n, npk, minamp, have, miny, lane);
+    const int nsel = peak_select<double>(y, cs, ci, sel, n, npk, minamp, have, miny, lane);
     int32_t* pos = p.pos + row * (int64_t)p.cap;
     int8_t* keep = p.keep + row * (int64_t)p.cap;
     for (int e = lane; e < nsel && e < p.cap; e += 64) {
-        int q = srt[e];
+        const int q = sel[e];
         pos[e] = q;
         keep[e] = salient<double>(y, n, q, p.rad) ? 1 : 0;
     }
@@ -343,15 +497,16 @@ __global__ __launch_bounds__(256) void k_peak_rows(PeakRowsParams p) {
 }  // namespace
 
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves) {
-    const size_t ts = precision == 32 ? 4 : 8;
-    const size_t n2pad = (size_t)((N2 + 3) & ~3), kpad = (size_t)((K + 3) & ~3);
-    return (n2pad * ts * 2 + kpad * sizeof(int) * 2) * (size_t)waves;
+    return peaks_lds_per_wave(N2, K, precision == 32 ? 4 : 8) * (size_t)waves;
 }
 
 static constexpr size_t kMaxLds = 160 * 1024;
 
-int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s) {
-    if (p.nrows <= 0) return PVX_OK;
+int pvx_launch_phase_peaks(const PeaksParams& pin, int precision, hipStream_t s) {
+    if (pin.nrows <= 0) return PVX_OK;
+    PeaksParams p = pin;
+    if (p.frames_per_wave < 1) p.frames_per_wave = 1;
+    if (p.frames_per_wave > GMAX) p.frames_per_wave = GMAX;
     int waves = 4;
     while (waves > 1 && pvx_phase_peaks_lds_bytes(p.N2, p.K, precision, waves) > kMaxLds / 2) waves >>= 1;
     const size_t lds = pvx_phase_peaks_lds_bytes(p.N2, p.K, precision, waves);
@@ -381,9 +536,8 @@ int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s) {
     const int n = p.n;
     const int npk = (p.npeaks <= 0 || p.npeaks > n) ? n : p.npeaks;
     int waves = 4;
-    auto bytes = [&](int w) { return pvx_phase_peaks_lds_bytes(n, npk, 64, w); };
-    while (waves > 1 && bytes(waves) > kMaxLds / 2) waves >>= 1;
-    const size_t lds = bytes(waves);
+    while (waves > 1 && rows_lds_per_wave(n, npk) * waves > kMaxLds / 2) waves >>= 1;
+    const size_t lds = rows_lds_per_wave(n, npk) * waves;
     if (lds > kMaxLds) {
         pvx_set_error("PeakFinder row of %d samples does not fit in LDS (%zu bytes)", n, lds);
         return PVX_ERR_UNSUPPORTED;

@@ -175,6 +175,10 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         const long long v = atoll(e);
         if (v >= 2) cap_rows = (int64_t)v;
     }
+    if (const char* e = getenv("PVX_FPW")) {
+        const int v = atoi(e);
+        if (v >= 1) p->frames_per_wave = v;
+    }
     if (max_rows <= 0 || max_rows > cap_rows) max_rows = cap_rows;
     if (max_rows < 2) max_rows = 2;
     p->max_rows = max_rows;
