@@ -73,13 +73,20 @@ int pvx_plan_create(pvx_plan** plan, double sr, int nfft, int hop, int npks, dou
 int pvx_plan_destroy(pvx_plan* plan);
 /* bytes of device workspace the plan holds */
 int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
-/* 0 = rocFFT per-frame FFT (three kernels per chunk), 1 = fused in-LDS FFT kernel where supported */
+/*
+ * FFT mode of the analysis stage:
+ *   0  framing kernel -> rocFFT batched real FFT -> phase/peak kernel (any nfft, both precisions)
+ *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
+ *      intermediate arrays in HBM (nfft = 2048, precision = 32)
+ * A new plan uses 1 where it is supported, else 0 (environment PVX_FFT_MODE=0 forces 0).
+ */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
+int pvx_plan_get_fft_mode(const pvx_plan* plan);
 /*
  * Stage timing for bench.py's roofline line.  While enabled, hipEvents recorded on the launch
  * stream bracket every stage of every chunk.  pvx_plan_get_timing synchronises with those events
  * and returns, accumulated since the last call: ms[0] framing kernel, ms[1] rocFFT, ms[2]
- * phase/peak kernel, ms[3] reserved (fused kernel); launches[i] = stage launches counted.
+ * phase/peak kernel, ms[3] fused kernel (fft mode 1); launches[i] = stage launches counted.
  */
 int pvx_plan_set_timing(pvx_plan* plan, int enable);
 int pvx_plan_get_timing(pvx_plan* plan, double* ms /*[4]*/, int64_t* launches /*[4]*/);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "pvx_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "pvx_plan_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
     "pvx_plan_set_fft_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pvx_plan_get_fft_mode": (ctypes.c_int, [ctypes.c_void_p]),
     "pvx_plan_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pvx_plan_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int64_p]),
     "pvx_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,

@@ -97,11 +97,16 @@ struct pvx_plan {
     int64_t ws_bytes = 0;
     rocfft_plan fft = nullptr;
     rocfft_execution_info info = nullptr;
+    bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
+    void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
+    float* d_specrow = nullptr;  // 1024 complex: spectrum of one requested row (fused mode)
+    int64_t fused_blocks = 0;    // PVX_FUSED_BLOCKS override
     int frames_per_wave = 4;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    std::vector<std::pair<int, size_t>> ev_spans;   // (stage, index of the start event; end = next event)
 };
 
 static size_t real_size(int precision) { return precision == 32 ? 4 : 8; }
@@ -116,6 +121,8 @@ static void plan_free(pvx_plan* p) {
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_spec) (void)hipFree(p->d_spec);
     if (p->d_work) (void)hipFree(p->d_work);
+    if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+    if (p->d_specrow) (void)hipFree(p->d_specrow);
     delete p;
 }
 
@@ -128,10 +135,16 @@ extern "C" int64_t pvx_plan_workspace_bytes(const pvx_plan* plan) { return plan 
 
 extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
-    if (mode != 0) { pvx_set_error("fft mode %d is not available in this build", mode); return PVX_ERR_UNSUPPORTED; }
+    if (mode != 0 && mode != 1) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
+    if (mode == 1 && !pvx_fused_supported(plan->nfft, plan->precision, plan->npks)) {
+        pvx_set_error("the fused kernel handles nfft=2048 at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
+        return PVX_ERR_UNSUPPORTED;
+    }
     plan->fft_mode = mode;
     return PVX_OK;
 }
+
+extern "C" int pvx_plan_get_fft_mode(const pvx_plan* plan) { return plan ? plan->fft_mode : PVX_ERR_INVALID; }
 
 extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int npks, double pkthresh,
                                const double* win, int precision, int64_t max_rows) {
@@ -211,12 +224,32 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (e != hipSuccess) { pvx_set_error("hipMemcpy(win) failed"); plan_free(p); return PVX_ERR_HIP; }
     }
 
+    // fused kernel tables
+    if (pvx_fused_supported(nfft, precision, npks)) {
+        std::vector<float> tw(2 * 2048);
+        const double pi = 3.141592653589793238462643383279502884;
+        for (int j = 0; j < 2048; j++) { tw[2 * j] = (float)cos(2.0 * pi * j / 2048.0); tw[2 * j + 1] = (float)(-sin(2.0 * pi * j / 2048.0)); }
+        if (hipMalloc(&p->d_twiddle, tw.size() * 4) != hipSuccess || hipMalloc((void**)&p->d_specrow, 2048 * 4) != hipSuccess) { pvx_set_error("hipMalloc(fused tables) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
+        p->fft_mode = 1;
+        if (const char* e = getenv("PVX_FFT_MODE")) { if (atoi(e) == 0) p->fft_mode = 0; }
+        if (const char* e = getenv("PVX_FUSED_BLOCKS")) { const long long v = atoll(e); if (v > 0) p->fused_blocks = v; }
+    }
+    *out = p;
+    return PVX_OK;
+}
+
+// frames + spectrum workspace and the rocFFT plan (fft mode 0, calc_fft_frame): created on first use
+static int ensure_rocfft(pvx_plan* p) {
+    if (p->rocfft_ready) return PVX_OK;
+    const int nfft = p->nfft, precision = p->precision;
+    const size_t rs = real_size(precision);
+    const int64_t max_rows = p->max_rows;
     const int64_t ws_rows = max_rows + 1;
     const size_t fbytes = (size_t)ws_rows * p->ldi * rs, sbytes = (size_t)ws_rows * p->ldo * 2 * rs;
     if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(&p->d_spec, sbytes) != hipSuccess) {
         pvx_set_error("hipMalloc of %.1f MiB analysis workspace failed", (fbytes + sbytes) / 1048576.0);
-        plan_free(p);
-        return PVX_ERR_ALLOC;
+                return PVX_ERR_ALLOC;
     }
     // rocFFT: batched 1-D real -> hermitian, one transform per workspace row (PV.py:157)
     rocfft_plan_description desc = nullptr;
@@ -233,17 +266,17 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
                                 (size_t)ws_rows, desc);
     }
     if (desc) rocfft_plan_description_destroy(desc);
-    if (st != rocfft_status_success) { pvx_set_error("rocfft_plan_create(nfft=%d, batch=%lld) failed: %d", nfft, (long long)ws_rows, (int)st); plan_free(p); return PVX_ERR_HIP; }
+    if (st != rocfft_status_success) { pvx_set_error("rocfft_plan_create(nfft=%d, batch=%lld) failed: %d", nfft, (long long)ws_rows, (int)st); return PVX_ERR_HIP; }
     st = rocfft_plan_get_work_buffer_size(p->fft, &p->work_bytes);
     if (st == rocfft_status_success) st = rocfft_execution_info_create(&p->info);
-    if (st != rocfft_status_success) { pvx_set_error("rocfft work buffer query failed: %d", (int)st); plan_free(p); return PVX_ERR_HIP; }
+    if (st != rocfft_status_success) { pvx_set_error("rocfft work buffer query failed: %d", (int)st); return PVX_ERR_HIP; }
     if (p->work_bytes) {
-        if (hipMalloc(&p->d_work, p->work_bytes) != hipSuccess) { pvx_set_error("hipMalloc(rocfft work, %zu) failed", p->work_bytes); plan_free(p); return PVX_ERR_ALLOC; }
+        if (hipMalloc(&p->d_work, p->work_bytes) != hipSuccess) { pvx_set_error("hipMalloc(rocfft work, %zu) failed", p->work_bytes); return PVX_ERR_ALLOC; }
         st = rocfft_execution_info_set_work_buffer(p->info, p->d_work, p->work_bytes);
-        if (st != rocfft_status_success) { pvx_set_error("rocfft set_work_buffer failed: %d", (int)st); plan_free(p); return PVX_ERR_HIP; }
+        if (st != rocfft_status_success) { pvx_set_error("rocfft set_work_buffer failed: %d", (int)st); return PVX_ERR_HIP; }
     }
     p->ws_bytes = (int64_t)(fbytes + sbytes + p->work_bytes);
-    *out = p;
+    p->rocfft_ready = true;
     return PVX_OK;
 }
 
@@ -251,16 +284,20 @@ extern "C" int pvx_plan_set_timing(pvx_plan* plan, int enable) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     plan->timing = enable != 0;
     plan->ev_used = 0;
+    plan->ev_spans.clear();
     return PVX_OK;
 }
 
-static int plan_event(pvx_plan* p, hipStream_t s) {
+// stage >= 0: the event starts a span of that stage (which ends at the next recorded event);
+// stage < 0: the event only ends the previous span
+static int plan_event(pvx_plan* p, hipStream_t s, int stage) {
     if (!p->timing) return PVX_OK;
     if (p->ev_used == p->ev_pool.size()) {
         hipEvent_t e;
         PVX_HIP_CHECK(hipEventCreate(&e));
         p->ev_pool.push_back(e);
     }
+    if (stage >= 0) p->ev_spans.push_back(std::make_pair(stage, p->ev_used));
     PVX_HIP_CHECK(hipEventRecord(p->ev_pool[p->ev_used++], s));
     return PVX_OK;
 }
@@ -268,25 +305,42 @@ static int plan_event(pvx_plan* p, hipStream_t s) {
 extern "C" int pvx_plan_get_timing(pvx_plan* plan, double* ms, int64_t* launches) {
     if (!plan || !ms || !launches) { pvx_set_error("null argument"); return PVX_ERR_INVALID; }
     for (int i = 0; i < 4; i++) { ms[i] = 0.0; launches[i] = 0; }
-    const size_t quads = plan->ev_used / 4;
-    for (size_t q = 0; q < quads; q++) {
-        PVX_HIP_CHECK(hipEventSynchronize(plan->ev_pool[4 * q + 3]));
-        for (int st = 0; st < 3; st++) {
-            float t = 0.f;
-            PVX_HIP_CHECK(hipEventElapsedTime(&t, plan->ev_pool[4 * q + st], plan->ev_pool[4 * q + st + 1]));
-            ms[st] += (double)t;
-            launches[st] += 1;
-        }
+    if (plan->ev_used) PVX_HIP_CHECK(hipEventSynchronize(plan->ev_pool[plan->ev_used - 1]));
+    for (const auto& sp : plan->ev_spans) {
+        if (sp.second + 1 >= plan->ev_used || sp.first > 3) continue;
+        float t = 0.f;
+        PVX_HIP_CHECK(hipEventElapsedTime(&t, plan->ev_pool[sp.second], plan->ev_pool[sp.second + 1]));
+        ms[sp.first] += (double)t;
+        launches[sp.first] += 1;
     }
     plan->ev_used = 0;
+    plan->ev_spans.clear();
     return PVX_OK;
 }
 
 // ---- run_pv ---------------------------------------------------------------------------------
 static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                         int64_t F, double* d_f, double* d_mag, double* d_ph, double* d_realph, double* d_binno,
-                        double* d_t, double* d_totalmag, const double* d_prev0, hipStream_t s) {
+                        double* d_t, double* d_totalmag, const double* d_prev0, hipStream_t s,
+                        int64_t spec_row = -1) {
     const int64_t total_rows = nsig * (F + 1);
+    int rc;
+    if (p->fft_mode == 1) {
+        // one launch: window + FFT + peaks per wave, no intermediate arrays (k_fused.hip)
+        FusedParams fp;
+        fp.x = d_x; fp.sig_stride = sig_stride; fp.F = F; fp.total_rows = total_rows;
+        fp.hop = p->hop; fp.K = p->npks; fp.rad = 5;                                     // PV.py:177
+        fp.thr = p->pkthresh; fp.sr = p->sr; fp.fstep = p->fstep; fp.dt = p->dt;
+        fp.wfbin = p->d_wfbin; fp.prev0 = d_prev0;
+        fp.f = d_f; fp.mag = d_mag; fp.ph = d_ph; fp.realph = d_realph; fp.binno = d_binno;
+        fp.t = d_t; fp.totalmag = d_totalmag; fp.win = p->d_win; fp.twiddle = p->d_twiddle;
+        fp.spec_out = spec_row >= 0 ? p->d_specrow : nullptr; fp.spec_row = spec_row;
+        fp.blocks_override = p->fused_blocks;
+        if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
+        if ((rc = pvx_launch_fused(fp, x_dtype, s)) != PVX_OK) return rc;
+        return plan_event(p, s, -1);
+    }
+    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
     PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
     for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
         const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
@@ -294,15 +348,13 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = sig_stride; fp.F = F; fp.R0 = R0;
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
         fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
-        int rc = plan_event(p, s);
-        if (rc != PVX_OK) return rc;
-        rc = pvx_launch_frames(fp, x_dtype, p->precision, s);
-        if (rc != PVX_OK) return rc;
-        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+        if ((rc = plan_event(p, s, 0)) != PVX_OK) return rc;
+        if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
+        if ((rc = plan_event(p, s, 1)) != PVX_OK) return rc;
         void* in[1] = {p->d_frames};
         void* out[1] = {p->d_spec};
         PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
-        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+        if ((rc = plan_event(p, s, 2)) != PVX_OK) return rc;
         PeaksParams pp;
         pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
         pp.nfft = p->nfft; pp.hop = p->hop; pp.N2 = p->N2; pp.K = p->npks; pp.rad = 5;   // PV.py:177
@@ -310,9 +362,8 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         pp.wfbin = p->d_wfbin; pp.prev0 = d_prev0;
         pp.f = d_f; pp.mag = d_mag; pp.ph = d_ph; pp.realph = d_realph; pp.binno = d_binno;
         pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
-        rc = pvx_launch_phase_peaks(pp, p->precision, s);
-        if (rc != PVX_OK) return rc;
-        if ((rc = plan_event(p, s)) != PVX_OK) return rc;
+        if ((rc = pvx_launch_phase_peaks(pp, p->precision, s)) != PVX_OK) return rc;
+        if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
     }
     return PVX_OK;
 }
@@ -381,8 +432,9 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
     char* o = (char*)dout.p;
     double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_realph = (double*)(o + 3 * fk),
            *d_binno = (double*)(o + 4 * fk), *d_t = (double*)(o + 5 * fk), *d_tm = (double*)(o + 5 * fk + f1);
+    const int64_t all_rows = nsig * (F + 1);
     rc = analyze_rows(p, dx.p, x_dtype, nsamp, nsig, sig_stride, F, d_f, d_mag, d_ph, d_realph, d_binno, d_t, d_tm,
-                      (const double*)dprev.p, nullptr);
+                      (const double*)dprev.p, nullptr, last_spec ? all_rows - 1 : -1);
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
     PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
@@ -392,7 +444,11 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
     PVX_HIP_CHECK(hipMemcpy(binno, d_binno, fk, hipMemcpyDeviceToHost));
     if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
     if (totalmag) PVX_HIP_CHECK(hipMemcpy(totalmag, d_tm, f1, hipMemcpyDeviceToHost));
-    if (last_spec) {
+    if (last_spec && p->fft_mode == 1) {
+        std::vector<float> tmp(2 * (size_t)p->N2);
+        PVX_HIP_CHECK(hipMemcpy(tmp.data(), p->d_specrow, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = (double)tmp[i];
+    } else if (last_spec) {
         // the last chunk's last row is still in the spectrum workspace
         const int64_t total_rows = nsig * (F + 1);
         const int64_t lastR0 = ((total_rows - 1) / p->max_rows) * p->max_rows;
@@ -412,6 +468,7 @@ extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t 
     if (rc != PVX_OK) return rc;
     if (!p || !x || !pos || !spec || nfr < 0) { pvx_set_error("bad argument"); return PVX_ERR_INVALID; }
     if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID; }
+    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
     const size_t es = dtype_size(x_dtype), rs = real_size(p->precision);
     for (int64_t i = 0; i < nfr; i++)
         if (pos[i] < 0 || pos[i] + p->nfft > nsamp) { pvx_set_error("frame %lld at %lld leaves the signal", (long long)i, (long long)pos[i]); return PVX_ERR_INVALID; }

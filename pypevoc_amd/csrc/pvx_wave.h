@@ -1,0 +1,272 @@
+// pvx_wave.h -- wave64-level building blocks shared by the analysis kernels (k_peaks.hip,
+// k_fused.hip): LDS hand-off inside one wave, ballot prefix, DPP reductions, the PeakFinder core
+// (pypevoc/PeakFinder.py:155-194, 113-136) and the per-peak phase-vocoder arithmetic
+// (pypevoc/PVAnalysis.py:133-148, 187-207).
+#pragma once
+
+#include <float.h>
+#include <math.h>
+
+#include "pvx_internal.h"
+
+namespace pvxw {
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double kPi2 = 2.0 * kPi;   // PV.py:45
+
+__device__ inline void wave_sync() {
+    // LDS hand-off between lanes of ONE wave: order the accesses, no cross-wave barrier.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline int lane_prefix(unsigned long long bal) {   // set bits of bal below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
+// ---- DPP reductions: 4 in-row steps (quad xor 1, xor 2, half mirror, mirror), then one readlane
+// per row of 16.  Result is wave-uniform.
+template <int CTRL> __device__ inline float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ inline double dpp_d(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline float rl_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline double rl_d(double v, int l) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+#define PVX_ROW_REDUCE(v, OP, DPP)            \
+    v = OP(v, DPP<0xB1>(v));                  \
+    v = OP(v, DPP<0x4E>(v));                  \
+    v = OP(v, DPP<0x141>(v));                 \
+    v = OP(v, DPP<0x140>(v));
+__device__ inline float wave_max(float v) {
+    PVX_ROW_REDUCE(v, fmaxf, dpp_f)
+    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ inline float wave_min(float v) {
+    PVX_ROW_REDUCE(v, fminf, dpp_f)
+    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ inline double dmax(double a, double b) { return a > b ? a : b; }
+__device__ inline double dmin(double a, double b) { return a < b ? a : b; }
+__device__ inline double dadd(double a, double b) { return a + b; }
+__device__ inline double wave_max(double v) {
+    PVX_ROW_REDUCE(v, dmax, dpp_d)
+    return dmax(dmax(rl_d(v, 0), rl_d(v, 16)), dmax(rl_d(v, 32), rl_d(v, 48)));
+}
+__device__ inline double wave_min(double v) {
+    PVX_ROW_REDUCE(v, dmin, dpp_d)
+    return dmin(dmin(rl_d(v, 0), rl_d(v, 16)), dmin(rl_d(v, 32), rl_d(v, 48)));
+}
+__device__ inline double wave_sum(double v) {
+    PVX_ROW_REDUCE(v, dadd, dpp_d)
+    return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
+}
+
+template <typename T> struct Key;
+template <> struct Key<float> {
+    using type = unsigned int;
+    static constexpr int TOP = 30;   // scores are >= 0: the sign bit is never set
+    static __device__ inline type of(float v) { return __float_as_uint(v); }
+};
+template <> struct Key<double> {
+    using type = unsigned long long;
+    static constexpr int TOP = 62;
+    static __device__ inline type of(double v) { return (unsigned long long)__double_as_longlong(v); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// PeakFinder core on one row held in LDS (PF.py:155-194 semantics, restated without the K-round
+// arg-max loop).  pkmskamp (PF.py:166-167) is y-miny at interior local maxima and 0 elsewhere; the
+// reference repeatedly takes the arg-max (first index on ties) while it exceeds th = minamp-miny and
+// fewer than npeaks have been taken, then sorts the positions.  Equivalent statement used here:
+//   candidates  = local maxima with score > th                    (score > 0 always for a maximum)
+//   selected    = the npeaks best candidates by (score desc, index asc), all of them if fewer;
+//   if th < 0 the zeros of pkmskamp qualify too: after ALL maxima, non-maximum interior bins are
+//   taken in ascending index order until npeaks are selected.
+// Output: out[0..count) ascending bin indices (wave-uniform count).
+//   y[n] row; cs[cap]/ci[cap] candidate scratch, cap >= n/2 + 1.
+template <typename T>
+__device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
+                                  bool have_minamp, T miny, int lane) {
+    if (n < 3) return 0;
+    // PF.py:69-70: "if not self.minamp: self.minamp = np.min(self.y)"
+    const double minamp = (have_minamp && minamp_in != 0.0) ? minamp_in : (double)miny;
+    const double th = minamp - (double)miny;                        // PF.py:174
+    // ---- candidates, compacted in ascending bin order
+    int C = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool cand = false;
+        T s = (T)0;
+        if (k >= 1 && k <= n - 2) {
+            const T a = y[k - 1], b = y[k], c = y[k + 1];
+            s = (T)(b - miny);
+            cand = (a < b) && (b >= c) && ((double)s > th);
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (cand) { const int pos = C + lane_prefix(bal); cs[pos] = s; ci[pos] = k; }
+        C += __popcll(bal);
+    }
+    wave_sync();
+    if (C <= npeaks) {
+        if (th < 0.0 && C < npeaks) {
+            // zeros of pkmskamp are above the (negative) threshold: all maxima, then the first
+            // non-maximum interior bins, emitted together in ascending bin order
+            const int need = npeaks - C;
+            int zc = 0, cnt = 0;
+            for (int k0 = 0; k0 < n && cnt < npeaks; k0 += 64) {
+                const int k = k0 + lane;
+                bool ismax = false, isz = false;
+                if (k >= 1 && k <= n - 2) {
+                    const T a = y[k - 1], b = y[k], c = y[k + 1];
+                    ismax = (a < b) && (b >= c);
+                    isz = !ismax;
+                }
+                const unsigned long long bz = __ballot(isz);
+                const bool take = ismax || (isz && (zc + lane_prefix(bz)) < need);
+                const unsigned long long bt = __ballot(take);
+                if (take) out[cnt + lane_prefix(bt)] = k;
+                zc += __popcll(bz);
+                cnt += __popcll(bt);
+            }
+            wave_sync();
+            return cnt;
+        }
+        for (int c = lane; c < C; c += 64) out[c] = ci[c];
+        wave_sync();
+        return C;
+    }
+    // ---- C > npeaks: exact radix select of the npeaks-th largest score (bits of a non-negative
+    // float order like unsigned integers).  Ballot + popcount only.
+    using K = Key<T>;
+    using KT = typename K::type;
+    const KT k0r = (lane < C) ? K::of(cs[lane]) : (KT)0;            // first two per lane live in registers
+    const KT k1r = (lane + 64 < C) ? K::of(cs[lane + 64]) : (KT)0;
+    KT prefix = 0;
+    for (int bit = K::TOP; bit >= 0; --bit) {
+        const KT trial = prefix | ((KT)1 << bit);
+        int cnt = __popcll(__ballot(k0r >= trial)) + __popcll(__ballot(k1r >= trial));
+        for (int c = lane + 128; c - lane < C; c += 64) {           // wave-uniform trip count
+            const bool p = (c < C) && (K::of(cs[c]) >= trial);
+            cnt += __popcll(__ballot(p));
+        }
+        if (cnt >= npeaks) prefix = trial;
+    }
+    // prefix = key of the npeaks-th best; strictly greater ones all go, ties in index order
+    int ngt = __popcll(__ballot(k0r > prefix)) + __popcll(__ballot(k1r > prefix));
+    for (int c = lane + 128; c - lane < C; c += 64) ngt += __popcll(__ballot((c < C) && (K::of(cs[c]) > prefix)));
+    const int need = npeaks - ngt;
+    int tc = 0, cnt = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const KT key = (c < C) ? K::of(cs[c]) : (KT)0;
+        const bool tie = (c < C) && (key == prefix);
+        const unsigned long long bt = __ballot(tie);
+        const bool take = (c < C) && ((key > prefix) || (tie && (tc + lane_prefix(bt)) < need));
+        const unsigned long long bk = __ballot(take);
+        if (take) out[cnt + lane_prefix(bk)] = ci[c];
+        tc += __popcll(bt);
+        cnt += __popcll(bk);
+    }
+    wave_sync();
+    return cnt;
+}
+
+// filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
+// [max(p-rad,1), min(p+rad,n)] (clipped to the array) exceeds y[p]
+template <typename T> __device__ inline bool salient(const T* y, int n, int p, int rad) {
+    if (rad < 0) return true;
+    const T v = y[p];
+    const int lo = p - rad > 1 ? p - rad : 1;
+    int hi = p + rad < n ? p + rad : n;
+    if (hi > n - 1) hi = n - 1;
+    bool keep = true;
+    for (int j = lo; j <= hi; j++) keep = keep && !(y[j] > v);
+    return keep;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-peak phase-vocoder arithmetic (PV.py:187-207 with dphase2freq, PV.py:133-148).
+// Inputs: bin, current (re, im), previous (pr, pi), s3 = 3-bin energy sum (PV.py:197-199).
+// precision 32: float32 angles, float64 assembly around the exactly known bin centre;
+// precision 64: the reference's operation order in float64.
+struct PeakConst {
+    double fstep, dt;
+    int nfft, hop;
+    const double* wfbin;
+};
+
+struct PeakOut {
+    double freq, dfb, thisph, mag;
+    bool valid;
+};
+
+template <typename T>
+__device__ inline PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T s3, const PeakConst& c) {
+    PeakOut o;
+    bool nanph = false;
+    if constexpr (sizeof(T) == 4) {
+        const float tph = atan2f(im, re);                            // PV.py:188
+        float dph;
+        if (pr == 0.f && pi == 0.f) {
+            // numpy: (a+bj)/(0+0j) = (a/0) + (b/0)j -> +-inf +-inf j, NaN when a or b is 0; angle()
+            // is then +-pi/4, +-3pi/4 by quadrant (PV.py:171, 190: frame 0 and any frame that
+            // follows an all-zero one)
+            nanph = (re == 0.f || im == 0.f || re != re || im != im);
+            const float q4 = (float)(kPi / 4);
+            dph = (re > 0.f) ? (im > 0.f ? q4 : -q4) : (im > 0.f ? 3.f * q4 : -3.f * q4);
+        } else {
+            dph = atan2f(im * pr - re * pi, re * pr + im * pi);      // angle(fx * conj(old))
+            nanph = dph != dph;
+        }
+        // PV.py:140-147 in closed form: with cyc = nbin*hop/nfft (cycles the bin centre advances per
+        // hop) and w = wfbin/2pi, candidate m has df*dt = cyc - w - dph/2pi - m; cyc - w is exact in
+        // float64 and |cyc - w| <= 1/2
+        const double cw = (double)nbin * (double)c.hop / (double)c.nfft - c.wfbin[nbin] / kPi2;
+        const float u = (float)cw - dph * (float)(1.0 / kPi2);
+        float best = u + 1.f, ab = fabsf(best);                      // m = -1
+        if (fabsf(u) < ab) { best = u; ab = fabsf(u); }              // m = 0   (first minimum wins)
+        if (fabsf(u - 1.f) < ab) { best = u - 1.f; }                 // m = +1
+        o.dfb = (double)best / c.dt;                                 // df = fbin - freq
+        o.freq = (double)nbin * c.fstep - o.dfb;
+        o.thisph = (double)tph;
+        o.mag = (double)sqrtf(s3);
+    } else {
+        const double dre = re, dim = im, dpr = pr, dpi = pi;
+        o.thisph = atan2(dim, dre);                                  // PV.py:188
+        double dph;
+        if (dpr == 0.0 && dpi == 0.0) {
+            nanph = (dre == 0.0 || dim == 0.0 || dre != dre || dim != dim);
+            dph = (dre > 0.0) ? (dim > 0.0 ? kPi / 4 : -kPi / 4) : (dim > 0.0 ? 3 * kPi / 4 : -3 * kPi / 4);
+        } else {
+            dph = atan2(dim * dpr - dre * dpi, dre * dpr + dim * dpi);
+            nanph = dph != dph;
+        }
+        // PV.py:140-147 literally: three unwrapping candidates, the one nearest the bin centre
+        const double fb = (double)nbin * c.fstep;                    // PV.py:114
+        const double w0 = dph + c.wfbin[nbin];
+        double bestabs = 0.0;
+        o.freq = 0.0; o.dfb = 0.0;
+#pragma unroll
+        for (int m = -1; m <= 1; m++) {
+            const double dphw = w0 + kPi2 * (double)m;
+            const double fq = dphw / c.dt / kPi2;
+            const double df = fb - fq;
+            const double a = fabs(df);
+            if (m == -1 || a < bestabs) { o.freq = fq; o.dfb = df; bestabs = a; }
+        }
+        o.mag = sqrt((double)s3);
+    }
+    o.valid = !nanph && (o.freq > 0.0);                              // PV.py:193 (NaN fails the test)
+    return o;
+}
+
+}  // namespace pvxw

@@ -42,12 +42,11 @@ def main():
             plan = ctypes.c_void_p()
             _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(bench.SR), bench.NFFT, bench.HOP, K, 0.005,
                                            _lib.dptr(win), 32, 0), "plan")
-            if mode:
-                rc = lib.pvx_plan_set_fft_mode(plan, mode)
-                if rc < 0:
-                    print("mode %d unavailable" % mode)
-                    lib.pvx_plan_destroy(plan)
-                    continue
+            rc = lib.pvx_plan_set_fft_mode(plan, mode)
+            if rc < 0:
+                print("mode %d unavailable" % mode)
+                lib.pvx_plan_destroy(plan)
+                continue
 
             def step():
                 _lib.check(lib.pvx_analyze_dev(plan, x.data_ptr(), 0, nsamp, 1, nsamp, *ptrs, None,
@@ -59,6 +58,7 @@ def main():
             if ref is None:
                 ref = out
             same = bool(torch.equal(out, ref))
+            maxdiff = float((out - ref).abs().max())
             lib.pvx_plan_set_timing(plan, 1)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             n = 20
@@ -79,8 +79,8 @@ def main():
             t = e0.elapsed_time(e1) / n
             t2 = e2.elapsed_time(e3) / n
             print("round %d rows=%6d fpw=%d mode=%d: %.4f ms/step (%.4f without stage events) = %.1f Mframes/s | "
-                  "frames %.4f fft %.4f peaks %.4f fused %.4f ms/step | same_as_first=%s" %
-                  (rnd, r, fpw, mode, t, t2, F / t2 / 1e3, ms[0] / n, ms[1] / n, ms[2] / n, ms[3] / n, same))
+                  "frames %.4f fft %.4f peaks %.4f fused %.4f ms/step | same_as_first=%s maxdiff=%.3g" %
+                  (rnd, r, fpw, mode, t, t2, F / t2 / 1e3, ms[0] / n, ms[1] / n, ms[2] / n, ms[3] / n, same, maxdiff))
             sys.stdout.flush()
             lib.pvx_plan_destroy(plan)
 
