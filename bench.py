@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default (fused where supported), 0: rocFFT path, 1: fused")
     ap.add_argument("--seconds", type=int, default=SECONDS, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -102,6 +103,8 @@ def main():
     win = np.hanning(NFFT)
     _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(SR), NFFT, HOP, K, 0.005, _lib.dptr(win),
                                    args.precision, 0), "pvx_plan_create")
+    if args.fft_mode >= 0:
+        _lib.check(lib.pvx_plan_set_fft_mode(plan, args.fft_mode), "pvx_plan_set_fft_mode")
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -119,8 +122,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # ---- timed region: exactly K steps, HIP events of the per-stage breakdown recorded live
-    _lib.check(lib.pvx_plan_set_timing(plan, 1), "pvx_plan_set_timing")
+    # ---- timed region: exactly K steps
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     fence()
@@ -132,10 +134,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
+    # ---- the same K steps once more with libpvx_hip's stage events on the launch stream: per-kernel
+    # launch durations for the roofline line (kept out of the timed region: the extra event records
+    # cost a few percent)
+    _lib.check(lib.pvx_plan_set_timing(plan, 1), "pvx_plan_set_timing")
+    for _ in range(args.steps):
+        step()
+    fence()
     ms = (ctypes.c_double * 4)()
     nl = (ctypes.c_int64 * 4)()
     _lib.check(lib.pvx_plan_get_timing(plan, ms, nl), "pvx_plan_get_timing")
     _lib.check(lib.pvx_plan_set_timing(plan, 0), "pvx_plan_set_timing")
+    fft_mode = int(lib.pvx_plan_get_fft_mode(plan))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -145,16 +155,18 @@ def main():
         ab = alg_bytes()
         frames_total = F * world * args.steps
         value = frames_total / elapsed
-        names = ["k_frames", "rocfft_r2c", "k_phase_peaks"]
-        keys = ["frames", "fft", "peaks"]
+        names = ["k_frames", "rocfft_r2c", "k_phase_peaks", "k_fused_pv2048"]
+        # algorithmic bytes per frame of each kernel.  The fused kernel is priced at the
+        # stage figure of SURVEY.md 8(d): it does the work of the whole STFT+phase stage.
+        abk = [ab["frames"], ab["fft"], ab["peaks"], ab["stage"]]
         per = []
-        for i in range(3):
+        for i in range(4):
             if nl[i]:
-                dur = ms[i] * 1e-3 / nl[i]                       # mean launch duration [s]
+                dur = ms[i] * 1e-3 / nl[i]                         # mean launch duration [s]
                 frames_per_launch = F * args.steps / float(nl[i])  # zero rows excluded
-                ach = ab[keys[i]] * frames_per_launch / dur
+                ach = abk[i] * frames_per_launch / dur
                 per.append(dict(kernel=names[i], ms_per_launch=dur * 1e3, launches=int(nl[i]),
-                                alg_bytes_per_frame=ab[keys[i]], achieved_GBps=ach / 1e9))
+                                alg_bytes_per_frame=abk[i], achieved_GBps=ach / 1e9))
         dom = max(per, key=lambda d: d["ms_per_launch"] * d["launches"]) if per else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -168,9 +180,11 @@ def main():
             roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["achieved_GBps"], 1),
                             peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(dom["achieved_GBps"] * 1e9 / HBM_PEAK, 4),
                             traffic=traffic, ms_per_launch=round(dom["ms_per_launch"], 4),
-                            alg_bytes_per_launch=int(dom["alg_bytes_per_frame"] * F * args.steps / dom["launches"]))
-        stage_s = sum(ms[i] for i in range(3)) * 1e-3 / args.steps
-        stage = dict(alg_bytes_per_frame=ab["stage"], ms_per_step_kernels=round(stage_s * 1e3, 4),
+                            alg_bytes_per_launch=int(dom["alg_bytes_per_frame"] * F * args.steps / dom["launches"]),
+                            note="algorithmic bytes = SURVEY.md 8(d) contract figure for the STFT+phase stage; "
+                                 "`traffic` = HBM bytes per launch from rocprofv3 PMC (profiles/)")
+        stage_s = sum(ms[i] for i in range(4)) * 1e-3 / args.steps
+        stage = dict(fft_mode=fft_mode, alg_bytes_per_frame=ab["stage"], ms_per_step_kernels=round(stage_s * 1e3, 4),
                      achieved_GBps=round(ab["stage"] * F / stage_s / 1e9, 1) if stage_s > 0 else None,
                      frac_of_8TBps=round(ab["stage"] * F / stage_s / HBM_PEAK, 4) if stage_s > 0 else None,
                      kernels=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in per],
