@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpvx_hip.so")
+LIB_PATH = os.environ.get("PVX_LIB") or os.path.join(_HERE, "libpvx_hip.so")   # PVX_LIB: A/B builds of the same library
 
 PVX_F32, PVX_F64, PVX_I16 = 0, 1, 2
 

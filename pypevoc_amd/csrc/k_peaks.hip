@@ -37,7 +37,7 @@ template <> struct Vec16<double> { using type = double2; static constexpr int CP
 constexpr int GMAX = 8;               // frames a wave batches before the per-peak pass
 
 // LDS per wave (bytes), shared with the host-side sizing below
-__host__ __device__ inline size_t peaks_lds_per_wave(int N2, int K, size_t ts) {
+__host__ __device__ __forceinline__ size_t peaks_lds_per_wave(int N2, int K, size_t ts) {
     const size_t n2pad = (size_t)((N2 + 3) & ~3);
     const size_t cap = n2pad / 2 + 4;
     const size_t kpad = (size_t)((K + 3) & ~3);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
 // ---------------------------------------------------------------------------------------------
 // Standalone PeakFinder on rows of float64 (the drop-in for `PeakFinder(y, ...)` +
 // filter_by_salience): one wave per row.
-__host__ __device__ inline size_t rows_lds_per_wave(int n, int npk) {
+__host__ __device__ __forceinline__ size_t rows_lds_per_wave(int n, int npk) {
     const size_t npad = (size_t)((n + 3) & ~3), cap = npad / 2 + 4, kpad = (size_t)((npk + 3) & ~3);
     return (npad * 8 + cap * 8 + cap * 4 + kpad * 4 + 15) & ~(size_t)15;
 }

@@ -14,29 +14,32 @@ namespace pvxw {
 constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kPi2 = 2.0 * kPi;   // PV.py:45
 
-__device__ inline void wave_sync() {
-    // LDS hand-off between lanes of ONE wave: order the accesses, no cross-wave barrier.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+__device__ __forceinline__ void wave_sync() {
+    // LDS hand-off between lanes of ONE wave.  LDS operations of a wave execute in order; what is
+    // needed is (a) that the compiler does not move LDS accesses across this point and (b) that the
+    // LDS queue has drained.  Deliberately NOT a workgroup fence: that would also wait for every
+    // outstanding global load/store (vmcnt(0)) and serialise the prefetch of the next frame.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ inline int lane_prefix(unsigned long long bal) {   // set bits of bal below this lane
+__device__ __forceinline__ int lane_prefix(unsigned long long bal) {   // set bits of bal below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
 
 // ---- DPP reductions: 4 in-row steps (quad xor 1, xor 2, half mirror, mirror), then one readlane
 // per row of 16.  Result is wave-uniform.
-template <int CTRL> __device__ inline float dpp_f(float v) {
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-template <int CTRL> __device__ inline double dpp_d(double v) {
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
     long long b = __builtin_bit_cast(long long, v);
     int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
     int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ inline float rl_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ inline double rl_d(double v, int l) {
+__device__ __forceinline__ float rl_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double rl_d(double v, int l) {
     long long b = __builtin_bit_cast(long long, v);
     int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
@@ -46,26 +49,26 @@ __device__ inline double rl_d(double v, int l) {
     v = OP(v, DPP<0x4E>(v));                  \
     v = OP(v, DPP<0x141>(v));                 \
     v = OP(v, DPP<0x140>(v));
-__device__ inline float wave_max(float v) {
+__device__ __forceinline__ float wave_max(float v) {
     PVX_ROW_REDUCE(v, fmaxf, dpp_f)
     return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
 }
-__device__ inline float wave_min(float v) {
+__device__ __forceinline__ float wave_min(float v) {
     PVX_ROW_REDUCE(v, fminf, dpp_f)
     return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
 }
-__device__ inline double dmax(double a, double b) { return a > b ? a : b; }
-__device__ inline double dmin(double a, double b) { return a < b ? a : b; }
-__device__ inline double dadd(double a, double b) { return a + b; }
-__device__ inline double wave_max(double v) {
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double wave_max(double v) {
     PVX_ROW_REDUCE(v, dmax, dpp_d)
     return dmax(dmax(rl_d(v, 0), rl_d(v, 16)), dmax(rl_d(v, 32), rl_d(v, 48)));
 }
-__device__ inline double wave_min(double v) {
+__device__ __forceinline__ double wave_min(double v) {
     PVX_ROW_REDUCE(v, dmin, dpp_d)
     return dmin(dmin(rl_d(v, 0), rl_d(v, 16)), dmin(rl_d(v, 32), rl_d(v, 48)));
 }
-__device__ inline double wave_sum(double v) {
+__device__ __forceinline__ double wave_sum(double v) {
     PVX_ROW_REDUCE(v, dadd, dpp_d)
     return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
@@ -74,12 +77,12 @@ template <typename T> struct Key;
 template <> struct Key<float> {
     using type = unsigned int;
     static constexpr int TOP = 30;   // scores are >= 0: the sign bit is never set
-    static __device__ inline type of(float v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ type of(float v) { return __float_as_uint(v); }
 };
 template <> struct Key<double> {
     using type = unsigned long long;
     static constexpr int TOP = 62;
-    static __device__ inline type of(double v) { return (unsigned long long)__double_as_longlong(v); }
+    static __device__ __forceinline__ type of(double v) { return (unsigned long long)__double_as_longlong(v); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -93,8 +96,11 @@ template <> struct Key<double> {
 //   taken in ascending index order until npeaks are selected.
 // Output: out[0..count) ascending bin indices (wave-uniform count).
 //   y[n] row; cs[cap]/ci[cap] candidate scratch, cap >= n/2 + 1.
-template <typename T>
-__device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
+//   NS > 0: n == NS is known at compile time (fused kernel): the scan is unrolled and split into a
+//   read phase (all LDS loads in flight at once) and a compaction phase, one LDS round trip instead
+//   of one per 64 bins.
+template <typename T, int NS = 0>
+__device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
                                   bool have_minamp, T miny, int lane) {
     if (n < 3) return 0;
     // PF.py:69-70: "if not self.minamp: self.minamp = np.min(self.y)"
@@ -102,18 +108,50 @@ __device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, i
     const double th = minamp - (double)miny;                        // PF.py:174
     // ---- candidates, compacted in ascending bin order
     int C = 0;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        const int k = k0 + lane;
-        bool cand = false;
-        T s = (T)0;
-        if (k >= 1 && k <= n - 2) {
-            const T a = y[k - 1], b = y[k], c = y[k + 1];
-            s = (T)(b - miny);
-            cand = (a < b) && (b >= c) && ((double)s > th);
+    if constexpr (NS > 0) {
+        constexpr int NIT = (NS + 63) / 64;
+        T sv[NIT];
+        unsigned long long bals[NIT];
+        // read phase: unconditional (index-clamped) loads so that all of them are in flight together
+        T ya[NIT], yb[NIT], yc[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int k = i * 64 + lane;
+            const int kc = k < NS ? k : NS - 1;
+            ya[i] = y[kc > 0 ? kc - 1 : 0];
+            yb[i] = y[kc];
+            yc[i] = y[kc < NS - 1 ? kc + 1 : NS - 1];
         }
-        const unsigned long long bal = __ballot(cand);
-        if (cand) { const int pos = C + lane_prefix(bal); cs[pos] = s; ci[pos] = k; }
-        C += __popcll(bal);
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int k = i * 64 + lane;
+            const T s = (T)(yb[i] - miny);
+            const bool cand = ((int)(k >= 1) & (int)(k <= NS - 2) & (int)(ya[i] < yb[i]) & (int)(yb[i] >= yc[i]) & (int)((double)s > th)) != 0;
+            sv[i] = s;
+            bals[i] = __ballot(cand);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const unsigned long long bal = bals[i];
+            if (bal != 0ull) {                                       // wave-uniform
+                if ((bal >> lane) & 1ull) { const int pos = C + lane_prefix(bal); cs[pos] = sv[i]; ci[pos] = i * 64 + lane; }
+                C += __popcll(bal);
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            bool cand = false;
+            T s = (T)0;
+            if (k >= 1 && k <= n - 2) {
+                const T a = y[k - 1], b = y[k], c = y[k + 1];
+                s = (T)(b - miny);
+                cand = (a < b) && (b >= c) && ((double)s > th);
+            }
+            const unsigned long long bal = __ballot(cand);
+            if (cand) { const int pos = C + lane_prefix(bal); cs[pos] = s; ci[pos] = k; }
+            C += __popcll(bal);
+        }
     }
     wave_sync();
     if (C <= npeaks) {
@@ -144,7 +182,25 @@ __device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, i
         wave_sync();
         return C;
     }
-    // ---- C > npeaks: exact radix select of the npeaks-th largest score (bits of a non-negative
+    if (C <= 64) {
+        // ---- a few more candidates than wanted (the usual case): every lane owns one candidate and
+        // counts the candidates that beat it, broadcast one by one with readlane (no LDS round trip).
+        // "beats" = larger score, or equal score and lower bin (np.argmax takes the first maximum).
+        const T mys = (lane < C) ? cs[lane] : (T)0;
+        const int myi = (lane < C) ? ci[lane] : 0;
+        int rank = 0;
+        for (int j = 0; j < C; ++j) {
+            T sj;
+            if constexpr (sizeof(T) == 4) sj = rl_f(mys, j); else sj = rl_d(mys, j);
+            rank += (sj > mys || (sj == mys && j < lane)) ? 1 : 0;
+        }
+        const bool take = (lane < C) && (rank < npeaks);
+        const unsigned long long bk = __ballot(take);
+        if (take) out[lane_prefix(bk)] = myi;                        // list order = ascending bin
+        wave_sync();
+        return __popcll(bk);
+    }
+    // ---- C > 64: exact radix select of the npeaks-th largest score (bits of a non-negative
     // float order like unsigned integers).  Ballot + popcount only.
     using K = Key<T>;
     using KT = typename K::type;
@@ -182,14 +238,28 @@ __device__ inline int peak_select(const T* y, T* cs, int* ci, int* out, int n, i
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
 // [max(p-rad,1), min(p+rad,n)] (clipped to the array) exceeds y[p]
-template <typename T> __device__ inline bool salient(const T* y, int n, int p, int rad) {
+template <typename T> __device__ __forceinline__ bool salient(const T* y, int n, int p, int rad) {
     if (rad < 0) return true;
     const T v = y[p];
     const int lo = p - rad > 1 ? p - rad : 1;
     int hi = p + rad < n ? p + rad : n;
     if (hi > n - 1) hi = n - 1;
     bool keep = true;
-    for (int j = lo; j <= hi; j++) keep = keep && !(y[j] > v);
+    if (rad <= 8) {
+        // fixed trip count, no short-circuit: the (at most 17) loads are independent and issued
+        // together instead of one load -> wait -> branch step per neighbour
+        int bad = 0;
+#pragma unroll
+        for (int d = -8; d <= 8; d++) {
+            const int j = p + d;
+            const int in = (int)(j >= lo) & (int)(j <= hi);
+            const T w = y[in ? j : p];
+            bad |= in & (int)(w > v);
+        }
+        keep = (bad == 0);
+    } else {
+        for (int j = lo; j <= hi; j++) keep = keep && !(y[j] > v);
+    }
     return keep;
 }
 
@@ -210,7 +280,7 @@ struct PeakOut {
 };
 
 template <typename T>
-__device__ inline PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T s3, const PeakConst& c) {
+__device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T s3, const PeakConst& c) {
     PeakOut o;
     bool nanph = false;
     if constexpr (sizeof(T) == 4) {
