@@ -387,18 +387,11 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
                     float2 pv;
                     if (use_prev0) pv = make_float2((float)p.prev0[2 * pb], (float)p.prev0[2 * pb + 1]);
                     else pv = prv[zpad(pb)];
-                    // PV.py:197-199: 3-bin energy, bin 0 excluded
-                    const int imin = pb - 1 > 1 ? pb - 1 : 1;
-                    int imax = pb + 1 < FM ? pb + 1 : FM;
-                    if (imax > FM - 1) imax = FM - 1;
-                    float s3 = 0.f;
-#pragma unroll
-                    for (int d = -1; d <= 1; d++) {                 // independent loads, fixed trip count
-                        const int j = pb + d;
-                        const bool in = (j >= imin) && (j <= imax);
-                        const float2 v = cur[zpad(in ? j : pb)];
-                        s3 += in ? __builtin_fmaf(v.x, v.x, v.y * v.y) : 0.f;
-                    }
+                    // PV.py:197-199: 3-bin energy, bin 0 excluded.  A selected bin is an interior
+                    // local maximum, 1 <= pb <= 1022: pb+1 is always a bin, pb-1 counts unless it is 0
+                    const float2 vm = cur[zpad(pb - 1)], vp = cur[zpad(pb + 1)];
+                    const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
+                    const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
                     L.sbin[slot] = pb;
                     float* sv = L.sval + (size_t)slot * 5;
                     sv[0] = c.x; sv[1] = c.y; sv[2] = pv.x; sv[3] = pv.y; sv[4] = s3;

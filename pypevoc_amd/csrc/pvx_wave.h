@@ -246,16 +246,19 @@ template <typename T> __device__ __forceinline__ bool salient(const T* y, int n,
     if (hi > n - 1) hi = n - 1;
     bool keep = true;
     if (rad <= 8) {
-        // fixed trip count, no short-circuit: the (at most 17) loads are independent and issued
-        // together instead of one load -> wait -> branch step per neighbour
-        int bad = 0;
+        // fixed trip count, no predicates: neighbours outside [lo, hi] are clamped INTO the window
+        // (re-testing a window value cannot change an "any value larger" test), so the 17 loads
+        // depend on nothing but p and are issued back to back; the compares follow
+        T w[17];
 #pragma unroll
         for (int d = -8; d <= 8; d++) {
-            const int j = p + d;
-            const int in = (int)(j >= lo) & (int)(j <= hi);
-            const T w = y[in ? j : p];
-            bad |= in & (int)(w > v);
+            int j = p + (d < -rad ? -rad : (d > rad ? rad : d));
+            j = j < lo ? lo : (j > hi ? hi : j);
+            w[d + 8] = y[j];
         }
+        int bad = 0;
+#pragma unroll
+        for (int d = 0; d < 17; d++) bad |= (int)(w[d] > v);
         keep = (bad == 0);
     } else {
         for (int j = lo; j <= hi; j++) keep = keep && !(y[j] > v);
