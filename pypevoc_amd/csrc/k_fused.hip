@@ -286,7 +286,8 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
             dst[zpad(k)] = make_float2(x0r, x0i);
             dst[zpad(kk)] = make_float2(x1r, x1i);
             if (with_mag) {
-                const float m0 = sqrtf(e0), m1 = sqrtf(e1);
+                // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
+                const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
                 L.y[k] = m0; L.y[kk] = m1;
                 lmax = fmaxf(lmax, fmaxf(m0, m1)); lmin = fminf(lmin, fminf(m0, m1)); ls0 += e0; ls1 += e1;
             }

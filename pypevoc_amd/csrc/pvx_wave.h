@@ -110,6 +110,7 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
     int C = 0;
     if constexpr (NS > 0) {
         constexpr int NIT = (NS + 63) / 64;
+        const float thf = __double2float_rd(th);
         T sv[NIT];
         unsigned long long bals[NIT];
         // read phase: unconditional (index-clamped) loads so that all of them are in flight together
@@ -126,7 +127,11 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
         for (int i = 0; i < NIT; i++) {
             const int k = i * 64 + lane;
             const T s = (T)(yb[i] - miny);
-            const bool cand = ((int)(k >= 1) & (int)(k <= NS - 2) & (int)(ya[i] < yb[i]) & (int)(yb[i] >= yc[i]) & (int)((double)s > th)) != 0;
+            // (double)s > th  <=>  s > thf with thf = th rounded DOWN to float (the next float above
+            // thf is already > th), so the float32 instantiation needs no float64 compare per bin
+            bool above;
+            if constexpr (sizeof(T) == 4) above = s > thf; else above = (double)s > th;
+            const bool cand = ((int)(k >= 1) & (int)(k <= NS - 2) & (int)(ya[i] < yb[i]) & (int)(yb[i] >= yc[i]) & (int)above) != 0;
             sv[i] = s;
             bals[i] = __ballot(cand);
         }
