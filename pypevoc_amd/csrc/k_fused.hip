@@ -101,22 +101,19 @@ __device__ __forceinline__ void dft16(float (&xr)[16], float (&xi)[16]) {
 template <typename InT> __device__ __forceinline__ float ld1(const InT* p) { return (float)*p; }
 
 template <typename InT, bool AL2>
-__device__ __forceinline__ void load_frame(const InT* x, int lane, const float (&w0)[16], const float (&w1)[16],
-                                  float (&xr)[16], float (&xi)[16]) {
-    // lane l takes z[l + 64 r] = (x[2l + 128 r], x[2l + 128 r + 1]) * window: 512 contiguous bytes
-    // per wave-instruction
+__device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[16], float (&rb)[16]) {
+    // lane l takes z[l + 64 r] = (x[2l + 128 r], x[2l + 128 r + 1]): 512 contiguous bytes per
+    // wave-instruction.  Issued one frame ahead of its use (software prefetch): the loads of row
+    // g+1 are in flight while row g is transformed and searched for peaks.
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const InT* p = x + 2 * lane + 128 * r;
-        float a, b;
         if constexpr (AL2 && sizeof(InT) == 4) {
             const float2 v = *(const float2*)p;
-            a = v.x; b = v.y;
+            ra[r] = v.x; rb[r] = v.y;
         } else {
-            a = ld1(p); b = ld1(p + 1);
+            ra[r] = ld1(p); rb[r] = ld1(p + 1);
         }
-        xr[r] = a * w0[r];
-        xi[r] = b * w1[r];
     }
 }
 
@@ -190,6 +187,12 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
         const float2 b = tw2l[r * 4 + L1];                        // W_64^(l1 t2)
         t2r[r] = b.x; t2i[r] = b.y;
     }
+    // keep the lane constants in registers: without this the compiler re-loads the twiddles from
+    // global memory every frame (a full L2 round trip on the critical path) instead of holding them
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        asm volatile("" : "+v"(w0[r]), "+v"(w1[r]), "+v"(t1r[r]), "+v"(t1i[r]), "+v"(t2r[r]), "+v"(t2i[r]));
+    }
     const float sA = (L1 & 2) ? -1.f : 1.f;
     // stage 3 step 2: res = alpha*u + beta*p;  lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
     const float alr = (L1 == 0 || L1 == 2) ? 1.f : (L1 == 1 ? -1.f : 0.f);
@@ -209,21 +212,31 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
 
     float2* cur = L.bufA;
     float2* prv = L.bufB;
+    float ra[16], rb[16];                                         // raw samples of the next row (prefetched)
+    // Rows are addressed as (signal b, row-in-signal q), advanced incrementally: a 64-bit division
+    // per frame costs more than the whole peak search.
+    auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {     // issue the loads of global row gn = (bn, qn)
+        if (gn < 0 || gn >= r1 || qn == 0) return;
+        load_raw<InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, lane, ra, rb);
+    };
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
     // wave-reduced max / min / energy
-    auto spectrum = [&](int64_t g, float2* dst, bool with_mag, float& maxy, float& miny, double& tot) {
-        const int64_t b = g / (p.F + 1);
-        const int64_t q = g - b * (p.F + 1);
+    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxy, float& miny, double& tot) {
+        // (b, q) of row g + 1
+        const int64_t qn = (q == p.F) ? 0 : q + 1;
+        const int64_t bn = (q == p.F) ? b + 1 : b;
         if (g < 0 || q == 0) {
 #pragma unroll
             for (int j = 0; j < 17; j++) dst[lane + 64 * j] = make_float2(0.f, 0.f);
             wave_sync();
+            prefetch(g + 1, bn, qn);
             return;
         }
-        const InT* x = (const InT*)p.x + b * p.sig_stride + (q - 1) * (int64_t)p.hop;
         float xr[16], xi[16];
-        load_frame<InT, AL2>(x, lane, w0, w1, xr, xi);
+#pragma unroll
+        for (int r = 0; r < 16; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
+        prefetch(g + 1, bn, qn);
         dft16(xr, xi);                                            // stage 1
 #pragma unroll
         for (int q2 = 0; q2 < 16; q2++) {
@@ -357,18 +370,23 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     };
 
     // ---- previous spectrum of the first row
+    int64_t gb, gq;                                               // (b, q) of the row being processed
     {
+        const int64_t g0 = r0 - 1;                                // may be -1: treated as a zero row
+        if (g0 >= 0) { gb = g0 / (p.F + 1); gq = g0 - gb * (p.F + 1); }      // the only division
+        else { gb = -1; gq = p.F; }                                         // so that g0 + 1 = (0, 0)
+        prefetch(g0, gb, gq);
         float d0, d1;
         double d2;
-        spectrum(r0 - 1, prv, false, d0, d1, d2);
+        spectrum(g0, gb, gq, prv, false, d0, d1, d2);
     }
     int ng = 0;
     for (int64_t g = r0; g < r1; ++g) {
-        const int64_t b = g / (p.F + 1);
-        const int64_t q = g - b * (p.F + 1);
+        if (gq == p.F) { gq = 0; gb += 1; } else { gq += 1; }
+        const int64_t b = gb, q = gq;
         float maxy = 0.f, miny = 0.f;
         double tot = 0.0;
-        spectrum(g, cur, true, maxy, miny, tot);
+        spectrum(g, b, q, cur, true, maxy, miny, tot);
         if (q != 0) {
             const int64_t orow = b * p.F + (q - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)

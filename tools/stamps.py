@@ -22,7 +22,7 @@ for _ in range(n):
     lib.pvx_analyze_dev(plan, x.data_ptr(), 0, nsamp, 1, nsamp, *ptrs, None, None)
 out = (ctypes.c_uint64 * 12)()
 raw.pvx_debug_stamps(plan, out, 0)
-names = ["0 loads+window", "1 dft16 #1", "2 twiddle+exchange", "3 dft16 #2", "4 tw2+stage3+Zwrite", "5 untangle+mags", "6 reductions", "7 peak_select", "8 salience+staging", "9 flush", "10 pre-load (addr, loop top, swap)", "11"]
+names = ["0 loads+window", "1 dft16 #1", "2 twiddle+exchange", "3 dft16 #2", "4 tw2+stage3+Zwrite", "5 untangle+mags", "6 reductions", "7 peak_select", "8 salience+staging", "9 flush", "10 pre-load (addr, loop top, swap)", "11 prefetch issue"]
 tot = sum(out)
 frames = n * (F + 1024)
 for i in range(12):
