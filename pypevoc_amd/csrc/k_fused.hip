@@ -127,6 +127,7 @@ struct FusedLds {       // per-wave carve
     int* sbin;          // [GF][kpad]
     float* sval;        // [GF][kpad][5]   re, im, pr, pi, s3
     int* cnt;           // [GF]
+    int* frm;           // [GF]  frame index within its signal
     long long* orow;    // [GF]
     double* tot;        // [GF]
 };
@@ -134,7 +135,7 @@ struct FusedLds {       // per-wave carve
 __host__ __device__ __forceinline__ size_t fused_lds_per_wave(int K) {
     const size_t kpad = (size_t)((K + 3) & ~3);
     size_t b = (size_t)BUFC * 8 * 2 + 1024 * 4 + 516 * 4 + 516 * 4 + kpad * 4 + (size_t)GF * kpad * 4 +
-               (size_t)GF * kpad * 5 * 4 + GF * 4;
+               (size_t)GF * kpad * 5 * 4 + GF * 4 + GF * 4;
     b = (b + 7) & ~(size_t)7;
     b += GF * 8 + GF * 8;
     return (b + 15) & ~(size_t)15;
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     L.sbin = L.sel + kpad;
     L.sval = (float*)(L.sbin + GF * kpad);
     L.cnt = (int*)(L.sval + GF * kpad * 5);
-    L.orow = (long long*)(((uintptr_t)(L.cnt + GF) + 7) & ~(uintptr_t)7);
+    L.frm = L.cnt + GF;
+    L.orow = (long long*)(((uintptr_t)(L.frm + GF) + 7) & ~(uintptr_t)7);
     L.tot = (double*)(L.orow + GF);
 
     float2* winl = (float2*)(smem + kTw3Bytes);                   // window as (w[2i], w[2i+1])
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
                 ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
             }
             if (e0 == 0) {
-                const int64_t fr = orow % p.F;
+                const int64_t fr = L.frm[g];
                 if (p.totalmag) p.totalmag[orow] = sqrt(L.tot[g]);                                   // PV.py:210
                 if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + FN / 2.0) / p.sr;              // PV.py:247
             }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
                 }
                 nk += __popcll(bal);
             }
-            if (lane == 0) { L.cnt[ng] = nk; L.orow[ng] = orow; L.tot[ng] = tot; }
+            if (lane == 0) { L.cnt[ng] = nk; L.frm[ng] = (int)(q - 1); L.orow[ng] = orow; L.tot[ng] = tot; }
             ng++;
             if (ng == G) { flush(ng); ng = 0; }
         }
