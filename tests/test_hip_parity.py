@@ -264,6 +264,52 @@ def test_streaming_frame_api(amd, oracle):
     assert abs(fq - (17 * p.fstep + (0.3 - 2 * np.pi * 17 * hop / nfft + 2 * np.pi * round(17 * hop / nfft)) / (2 * np.pi * p.dt))) < 1e-9
 
 
+def test_fused_kernel_variants(amd, oracle):
+    """nfft=2048 at precision=32 runs the fused kernel (fft mode 1).  Cover its input variants
+    (int16 / float32 aligned / float32 with an odd hop / float64), the streaming entry points
+    (previous spectrum handed in, last spectrum handed back) and agreement with the rocFFT path."""
+    import ctypes
+    from pypevoc_amd import _lib
+    x = _rand_signal(21, 30000)
+    sr, nfft, K = 22050.0, 2048, 7
+    for hop, xin in ((512, x.astype(np.float32)), (333, x.astype(np.float32)), (512, x), (700, x)):
+        o = oracle.analyze(x, sr, nfft, hop, K)
+        p = run_pv(amd, xin, sr, nfft, hop, K, precision=32)
+        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1
+        assert_f32(compare_analysis(pv_result(p), o, nfft, hop, sr), absolute=False)
+        # the spectrum handed back as PV.oldfft is the last frame's
+        last = oracle.stft_frame(x, (p.nframes - 1) * hop, nfft)
+        assert np.abs(p.oldfft - last).max() <= 2e-6 * np.abs(last).max()
+    xi = np.round(x * 20000).astype(np.int16)
+    o = oracle.analyze(xi.astype(np.float64), sr, nfft, 512, K)
+    p = run_pv(amd, xi, sr, nfft, 512, K, precision=32)
+    assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
+    # streaming: frame-by-frame calls (prev0 in, last_spec out) reproduce run_pv
+    ref = run_pv(amd, x, sr, nfft, 512, K, precision=32)
+    q = amd.PV(x, sr, nfft=nfft, hop=512, npks=K, progress=False, precision=32)
+    for fr in range(5):
+        f, mag, ph, realph, binno, tm = q.calc_pv_frame(fr * 512)
+        n = len(f)
+        assert binno == [int(b) for b in ref.binno[fr, :n]] and n == int((ref.f[fr] > 0).sum())
+        np.testing.assert_allclose(f, ref.f[fr, :n], atol=2e-3)
+        np.testing.assert_allclose(realph, ref.realph[fr, :n], atol=2e-4)
+    # fused vs rocFFT path on the same plan parameters
+    os.environ["PVX_FFT_MODE"] = "0"
+    try:
+        r0 = run_pv(amd, x.astype(np.float32), sr, nfft, 512, K, precision=32)
+        assert _lib.load().pvx_plan_get_fft_mode(r0._plan.handle) == 0
+    finally:
+        del os.environ["PVX_FFT_MODE"]
+    r1 = run_pv(amd, x.astype(np.float32), sr, nfft, 512, K, precision=32)
+    assert np.array_equal(r0.binno, r1.binno)
+    assert np.abs(r0.f - r1.f).max() <= 1e-3 and np.abs(r0.mag - r1.mag).max() <= 1e-6 * r0.mag.max()
+    # K > 64 and K = 1 through the fused staging paths
+    for K2 in (1, 70):
+        o = oracle.analyze(x, sr, nfft, 512, K2, 0.0005)
+        p = run_pv(amd, x, sr, nfft, 512, K2, 0.0005, precision=32)
+        assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
+
+
 def test_add_frame_incremental_equals_tosinsum(amd):
     g = load_golden("G5a_noise_n1024_k20")
     ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
