@@ -101,3 +101,57 @@ def gather_results(local, nitems, group=None, dst=0):
         return torch.cat([b[: sizes[r]] for r, b in enumerate(bufs)], dim=0)
     dist.gather(pad, gather_list=None, dst=dst, group=group)
     return None
+
+
+class PipelinedGather(object):
+    """Double-buffered result gather for a stream of analysis steps.
+
+    Step i writes its packed result block into `buffer(i)`; `submit(i)` starts the gather of that
+    block to rank `dst` asynchronously (RCCL runs it on its own stream), so the collective of step i
+    overlaps the kernels of step i+1.  A buffer is handed out again only after the gather that read
+    it has completed (`buffer(i)` makes the current stream wait for the gather of step i-2).
+    On rank `dst`, `result(i)` returns the list of per-rank blocks of step i (valid after `drain()`
+    or after `buffer(i+2)` has been requested).  There is no other communication on this path.
+    """
+
+    def __init__(self, numel, dtype, device, group=None, dst=0, depth=2):
+        import torch
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.dst = dst
+        self.depth = depth
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bufs = [torch.empty(numel, dtype=dtype, device=device) for _ in range(depth)]
+        self.lists = None
+        if self.world > 1 and self.rank == dst:
+            self.lists = [[torch.empty(numel, dtype=dtype, device=device) for _ in range(self.world)]
+                          for _ in range(depth)]
+        self.works = [None] * depth
+
+    def buffer(self, step):
+        j = step % self.depth
+        if self.works[j] is not None:
+            self.works[j].wait()           # stream-level wait: the block may be overwritten afterwards
+            self.works[j] = None
+        return self.bufs[j]
+
+    def submit(self, step):
+        if self.world == 1:
+            return
+        j = step % self.depth
+        self.works[j] = self._dist.gather(self.bufs[j], gather_list=self.lists[j] if self.lists else None,
+                                          dst=self.dst, group=self.group, async_op=True)
+
+    def drain(self):
+        for j in range(self.depth):
+            if self.works[j] is not None:
+                self.works[j].wait()
+                self.works[j] = None
+
+    def result(self, step):
+        j = step % self.depth
+        if self.world == 1:
+            return [self.bufs[j]]
+        return self.lists[j] if self.lists else None

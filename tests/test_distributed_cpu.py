@@ -69,3 +69,41 @@ def test_sharded_analysis_gather_world2(tmp_path, nsig):
     exp = np.stack(exp)
     assert got.shape == exp.shape
     assert np.array_equal(got, exp)
+
+
+def _pipe_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pypevoc_amd.batch import PipelinedGather
+        n, steps = 1000, 7
+        pg = PipelinedGather(n, torch.float64, torch.device("cpu"), dst=0)
+        seen = []
+        for i in range(steps):
+            buf = pg.buffer(i)
+            if rank == 0 and i >= 2:
+                # the gather of step i-2 has completed before its buffers are reused
+                seen.append(torch.stack(pg.result(i - 2)).clone())
+            buf.copy_(torch.arange(n, dtype=torch.float64) + 1000.0 * i + 100000.0 * rank)
+            pg.submit(i)
+        pg.drain()
+        if rank == 0:
+            for i in (steps - 2, steps - 1):
+                seen.append(torch.stack(pg.result(i)).clone())
+            np.save(os.path.join(outdir, "pipe.npy"), torch.stack(seen).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2(tmp_path):
+    """The double-buffered asynchronous gather used by bench.py --gpus N: every step's blocks of
+    every rank arrive intact although buffers are reused every second step."""
+    port = _free_port()
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "pipe.npy"))       # [steps, world, n]
+    assert got.shape == (7, 2, 1000)
+    for i in range(7):
+        for r in range(2):
+            assert np.array_equal(got[i, r], np.arange(1000.0) + 1000.0 * i + 100000.0 * r), (i, r)
