@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: nfft in {512..8192} x hop in {nfft/4, nfft/2} on a 60-min 96 kHz signal
+(345.6 M samples, 1.38 GB float32, resident in HBM), npks=8.  Prints one JSON line per point:
+frames/s and the fraction of the 8 TB/s HBM roofline at SURVEY.md 8(d)'s algorithmic bytes."""
+import ctypes, json, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pypevoc_amd import _lib
+
+def signal(n, sr):
+    # G4 generator evaluated in float32 chunks on the GPU (the 1.4 GB signal never exists on the host)
+    dev = torch.device("cuda", 0)
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    step = 1 << 24
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        t = torch.arange(a, b, device=dev, dtype=torch.float64) / sr
+        ph = 2 * np.pi * 220.0 * (t - 0.01 / (2 * np.pi * 5.0) * torch.cos(2 * np.pi * 5.0 * t))
+        s = torch.zeros(b - a, dtype=torch.float64, device=dev)
+        for h in range(1, 9):
+            s += 0.3 / h * torch.sin(h * ph)
+        s += 0.001 * torch.randn(b - a, generator=g, device=dev, dtype=torch.float64)
+        x[a:b] = s.to(torch.float32)
+    return x
+
+def main():
+    sr, secs, K = 96000, int(sys.argv[1]) if len(sys.argv) > 1 else 3600, 8
+    lib = _lib.load(); _lib.init(0)
+    dev = torch.device("cuda", 0)
+    n = sr * secs
+    x = signal(n, sr)
+    stream = torch.cuda.current_stream(dev)
+    for nfft in (512, 1024, 2048, 4096, 8192):
+        for hop in (nfft // 4, nfft // 2):
+            F = int(lib.pvx_nframes(n, nfft, hop))
+            out = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev)
+            base = out.data_ptr()
+            ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
+            plan = ctypes.c_void_p()
+            win = np.hanning(nfft)
+            _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(sr), nfft, hop, K, 0.005, _lib.dptr(win), 32, 0), "plan")
+            def step():
+                _lib.check(lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, ctypes.c_void_p(stream.cuda_stream)), "analyze")
+            step(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            reps = 3
+            e0.record(stream)
+            for _ in range(reps): step()
+            e1.record(stream); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            balg = hop * 4 + 2 * nfft * 4 + 2 * (nfft // 2 + 1) * 8 + (K * 5 * 8 + 16)
+            fps = F / (ms * 1e-3)
+            print(json.dumps(dict(nfft=nfft, hop=hop, frames=F, ms=round(ms, 3), frames_per_s=round(fps, 1),
+                                  alg_bytes_per_frame=balg, achieved_GBps=round(fps * balg / 1e9, 1),
+                                  frac_of_8TBps=round(fps * balg / 8e12, 4),
+                                  fft_mode=int(lib.pvx_plan_get_fft_mode(plan)))))
+            sys.stdout.flush()
+            lib.pvx_plan_destroy(plan)
+            del out
+            torch.cuda.empty_cache()
+
+if __name__ == "__main__":
+    main()
