@@ -77,7 +77,7 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  * FFT mode of the analysis stage:
  *   0  framing kernel -> rocFFT batched real FFT -> phase/peak kernel (any nfft, both precisions)
  *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
- *      intermediate arrays in HBM (nfft = 2048, precision = 32)
+ *      intermediate arrays in HBM (nfft in {512, 1024, 2048}, precision = 32)
  * A new plan uses 1 where it is supported, else 0 (environment PVX_FFT_MODE=0 forces 0).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);

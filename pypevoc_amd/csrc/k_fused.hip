@@ -1,45 +1,74 @@
-// k_fused.hip -- the whole analysis stage of one frame inside one wave64, nothing but the input
-// samples and the <= K peaks ever touching HBM.  For nfft = 2048, float32:
+// k_fused.hip -- the whole analysis stage of one frame inside one wave64: nothing but the input
+// samples and the <= K peaks ever touches HBM.  float32, nfft = 128 R with R in {4, 8, 16}
+// (nfft 512, 1024, 2048; the template also instantiates for R = 32 but is not used there):
 //
 //   PV.calc_fft_frame   pypevoc/PVAnalysis.py:150-158   x[pos:pos+nfft]*win -> FFT -> /wfact
 //   PV.calc_pv_frame    pypevoc/PVAnalysis.py:160-211   abs, PeakFinder, salience, phase difference,
 //                                                        instantaneous frequency, 3-bin energy, realph
 //   PV.run_pv           pypevoc/PVAnalysis.py:213-264   frame loop and zero-padded packing
 //
-// Why: the three-kernel form (k_frames -> rocFFT -> k_peaks) moves 35 KB per frame through HBM /
-// Infinity Cache; here a frame costs hop*4 = 2 KB of input (the 4-fold overlap between frames is
-// served by L2) and (5K+2)*8 B of output.  The kernel is then bound by VALU/LDS work, not by HBM.
+// Why: the three-kernel form (k_frames -> rocFFT -> k_peaks) moves 35 KB per frame (nfft 2048)
+// through HBM / Infinity Cache; here a frame costs hop*4 bytes of input (the overlap between
+// consecutive frames is served by L2: one wave walks consecutive frames) and (5K+2)*8 B of output.
+// The kernel is then bound by instruction issue, not by HBM.
 //
-// Real FFT of nfft = 2048 samples = complex FFT of M = 1024 points z[j] = xw[2j] + i xw[2j+1]
-// followed by the untangle X[k] = E[k] + W_2048^k O[k].  The 1024-point FFT is laid out on the 64
-// lanes x 16 registers of one wave as 1024 = 16 (registers) x 16 (registers, after one LDS
-// exchange) x 4 (across the lanes of a quad, by DPP):
-//   stage 1  lane l holds z[l + 64 r], r < 16: radix-16 DFT over r in registers, twiddle W_1024^(l q)
-//   exchange Y[l][q] -> LDS rows [q][l] (row pitch 68 complex: conflict-free both ways)
-//   stage 2  lane (q, l1) = 4q + l1 reads Y[l1 + 4 l2][q], l2 < 16: radix-16 DFT over l2, twiddle W_64^(l1 t2)
-//   stage 3  4-point DFT over l1 across the quad with two DPP exchanges (quad_perm xor 2, xor 1)
-//   result   lane (q, l1) holds Z[q + 16 t2 + 256 t1], t1 = bitrev2(l1)
-// Z goes to LDS in natural order (8 complex of padding per 256 keeps the writes conflict-free), is
-// untangled in place into X[0..1024), |X| goes to a second LDS array, and from there on the frame is
-// handled exactly like k_peaks.hip does (same PeakFinder core, same per-peak arithmetic), except
-// that the previous frame's spectrum is the LDS buffer the wave filled one iteration earlier.
+// Real FFT of nfft samples = complex FFT of M = nfft/2 = 64 R points z[j] = xw[2j] + i xw[2j+1]
+// followed by the untangle X[k] = E[k] + W_nfft^k O[k].  The M-point FFT is laid out on the 64 lanes
+// x R registers of one wave as M = R (registers) x R (registers, after one LDS exchange) x P (across
+// P = 64/R neighbouring lanes, by DPP / swizzle):
+//   stage 1  lane l holds z[l + 64 r], r < R: radix-R DFT over r in registers, twiddle W_M^(l q)
+//   exchange Y[l][q] -> LDS rows [q][l] (row pitch 64 + P complex: conflict-free both ways)
+//   stage 2  lane (q, l1) = P q + l1 reads Y[l1 + P l2][q], l2 < R: radix-R DFT over l2, twiddle W_64^(l1 t2)
+//   stage 3  P-point DFT over l1 across the P lanes of a group: log2 P decimation-in-frequency steps,
+//            each one lane exchange (xor h) + one lane-constant twiddle W_2h^(l1 mod h)
+//   result   lane (q, l1) holds Z[q + R t2 + R^2 t1], t1 = bitrev(l1)
+// (R = 16: 1024 = 16 x 16 x 4, the quad-level 4-point DFT is hand-written with two DPP quad_perm
+// exchanges.)  Z goes to LDS in natural order (a few complex of padding per R^2 keep the accesses
+// spread over the banks), is untangled in place into X[0..M), |X| goes to a second LDS array, and
+// from there on the frame is handled exactly like k_peaks.hip does (same PeakFinder core, same
+// per-peak arithmetic), except that the previous frame's spectrum is the LDS buffer the wave filled
+// one iteration earlier.  The index maps were validated in numpy for every R before this was written.
 //
-// Work distribution: persistent-style.  The launch has about one wave per SIMD of the chip; wave w
-// owns the contiguous global rows [w*R/W, (w+1)*R/W) and recomputes the spectrum of the row before
-// its first one (1 extra FFT per wave, a few percent).  No inter-wave communication at all.
+// Work distribution: persistent-style.  Wave w owns the contiguous global rows [w*Rows/W, (w+1)*Rows/W)
+// and recomputes the spectrum of the row before its first one (one extra FFT per wave).  No
+// inter-wave communication.  The samples of the next row are prefetched while a row is processed.
+// All float32 arithmetic that must not depend on which wave computes a frame uses explicit fmaf.
 #include "pvx_wave.h"
 
 using namespace pvxw;
 
 namespace {
 
-constexpr int FN = 2048;            // nfft handled by this kernel
-constexpr int FM = 1024;            // complex FFT length
-constexpr int EXP = 68;             // exchange row pitch (complex)
-constexpr int BUFC = 16 * EXP;      // complex slots per spectrum buffer (>= 1024 + 32)
 constexpr int GF = 8;               // frames staged before the per-peak pass
 
-__device__ __host__ __forceinline__ int zpad(int k) { return k + 8 * (k >> 8); }
+// W_64^k = (kW64r[k], kW64i[k])
+constexpr float kW64r[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, 0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
+constexpr float kW64i[64] = {0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, 0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f};
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+constexpr int bitrev_c(int v, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++) if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+    return r;
+}
+
+// ---- compile-time geometry for R registers per lane
+template <int R> struct Geo {
+    static constexpr int M = 64 * R;                 // complex FFT length = bins 0..M-1
+    static constexpr int N = 128 * R;                // nfft
+    static constexpr int P = 64 / R;                 // lanes per cross-lane DFT
+    static constexpr int LOGP = ilog2(P);
+    static constexpr int LOGR = ilog2(R);
+    static constexpr int PITCH = 64 + P;             // exchange row pitch (complex)
+    static constexpr int R2 = R * R;
+    static constexpr int ZP = ((32 / P) - (R2 % 32) + 32) % 32;     // padding per R^2 spectrum bins
+    static constexpr int ZLEN = M + ZP * (P - 1);
+    static constexpr int BUFRAW = (R * PITCH > ZLEN) ? R * PITCH : ZLEN;
+    static constexpr int BUFC = ((BUFRAW + 63) / 64) * 64;           // complex slots per spectrum buffer
+    static constexpr int CAP = M / 2 + 4;            // candidate list capacity
+    static constexpr int HALF = M / 2;
+};
+template <int R> __device__ __host__ __forceinline__ int zpad(int k) { return k + Geo<R>::ZP * (k >> (2 * Geo<R>::LOGR)); }
 
 // complex multiply with explicit fused multiply-adds: the same rounding wherever it is inlined, so
 // results do not depend on which wave computes a frame
@@ -51,6 +80,12 @@ __device__ __forceinline__ void cmul(float& a, float& c, float wr, float wi) {
 
 template <int CTRL> __device__ __forceinline__ float dppf(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// value of lane (l ^ H) for H in {1, 2, 4, 8}
+template <int H> __device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (H == 1) return dppf<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) return dppf<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (H << 10) | 0x1f));
 }
 
 // ---- radix-16 DFT in registers (radix-4 x radix-4), forward, natural order in and out
@@ -98,15 +133,47 @@ __device__ __forceinline__ void dft16(float (&xr)[16], float (&xi)[16]) {
     }
 }
 
+// ---- radix-R DFT in registers for any power of two R <= 64: unrolled radix-2 decimation in
+// frequency with compile-time twiddles, natural order in and out (the bit reversal is a renaming)
+template <int R> __device__ __forceinline__ void dft_regs(float (&xr)[R], float (&xi)[R]) {
+    if constexpr (R == 16) {
+        dft16(xr, xi);
+    } else {
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+                for (int i = 0; i < h; i++) {
+                    const int a = blk + i, b = blk + i + h;
+                    const float sr = xr[a] + xr[b], si = xi[a] + xi[b];
+                    float dr = xr[a] - xr[b], di = xi[a] - xi[b];
+                    const int tw = i * (32 / h);                    // W_2h^i = W_64^(i * 64/(2h))
+                    if (tw == 0) { }
+                    else if (tw == 16) { const float t = dr; dr = di; di = -t; }      // * (-i)
+                    else cmul(dr, di, kW64r[tw], kW64i[tw]);
+                    xr[a] = sr; xi[a] = si; xr[b] = dr; xi[b] = di;
+                }
+            }
+        }
+        constexpr int bits = ilog2(R);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int j = bitrev_c(i, bits);
+            if (i < j) { float t = xr[i]; xr[i] = xr[j]; xr[j] = t; t = xi[i]; xi[i] = xi[j]; xi[j] = t; }
+        }
+    }
+}
+
 template <typename InT> __device__ __forceinline__ float ld1(const InT* p) { return (float)*p; }
 
-template <typename InT, bool AL2>
-__device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[16], float (&rb)[16]) {
+template <int R, typename InT, bool AL2>
+__device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[R], float (&rb)[R]) {
     // lane l takes z[l + 64 r] = (x[2l + 128 r], x[2l + 128 r + 1]): 512 contiguous bytes per
     // wave-instruction.  Issued one frame ahead of its use (software prefetch): the loads of row
     // g+1 are in flight while row g is transformed and searched for peaks.
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < R; r++) {
         const InT* p = x + 2 * lane + 128 * r;
         if constexpr (AL2 && sizeof(InT) == 4) {
             const float2 v = *(const float2*)p;
@@ -120,9 +187,9 @@ __device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[16]
 struct FusedLds {       // per-wave carve
     float2* bufA;       // [BUFC]
     float2* bufB;       // [BUFC]
-    float* y;           // [1024]
-    float* cs;          // [516]
-    int* ci;            // [516]
+    float* y;           // [M]
+    float* cs;          // [CAP]
+    int* ci;            // [CAP]
     int* sel;           // [kpad]
     int* sbin;          // [GF][kpad]
     float* sval;        // [GF][kpad][5]   re, im, pr, pi, s3
@@ -132,21 +199,24 @@ struct FusedLds {       // per-wave carve
     double* tot;        // [GF]
 };
 
-__host__ __device__ __forceinline__ size_t fused_lds_per_wave(int K) {
+template <int R> __host__ __device__ inline size_t fused_lds_per_wave(int K) {
+    using G = Geo<R>;
     const size_t kpad = (size_t)((K + 3) & ~3);
-    size_t b = (size_t)BUFC * 8 * 2 + 1024 * 4 + 516 * 4 + 516 * 4 + kpad * 4 + (size_t)GF * kpad * 4 +
-               (size_t)GF * kpad * 5 * 4 + GF * 4 + GF * 4;
+    size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)G::M * 4 + (size_t)G::CAP * 4 * 2 + kpad * 4 +
+               (size_t)GF * kpad * 4 + (size_t)GF * kpad * 5 * 4 + GF * 4 + GF * 4;
     b = (b + 7) & ~(size_t)7;
     b += GF * 8 + GF * 8;
     return (b + 15) & ~(size_t)15;
 }
-constexpr size_t kTw3Bytes = 520 * 8;      // W_2048^k, k <= 512 (+ padding)
-constexpr size_t kWinBytes = 2048 * 4;     // window / wfact
-constexpr size_t kTw2Bytes = 16 * 4 * 8;   // W_64^(l1 t2) as [t2][l1]
-constexpr size_t kFusedShared = kTw3Bytes + kWinBytes + kTw2Bytes;
+template <int R> __host__ __device__ inline size_t fused_lds_shared() {
+    // W_nfft^k for k <= M/2 (padded) | W_64^(l1 t2) as [t2][l1] (64 entries)
+    return (size_t)((Geo<R>::HALF + 8) & ~7) * 8 + 64 * 8;
+}
 
-template <typename InT, bool AL2>
-__global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
+template <int R, typename InT, bool AL2>
+__global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
+    using G = Geo<R>;
+    constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -154,14 +224,15 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     const int K = p.K;
     const int kpad = (K + 3) & ~3;
     float2* tw3 = (float2*)smem;                                  // shared by the block
-    unsigned char* base = smem + kFusedShared + fused_lds_per_wave(K) * wid;
+    float2* tw2l = (float2*)(smem + (size_t)((G::HALF + 8) & ~7) * 8);
+    unsigned char* base = smem + fused_lds_shared<R>() + fused_lds_per_wave<R>(K) * wid;
     FusedLds L;
     L.bufA = (float2*)base;
-    L.bufB = L.bufA + BUFC;
-    L.y = (float*)(L.bufB + BUFC);
-    L.cs = L.y + 1024;
-    L.ci = (int*)(L.cs + 516);
-    L.sel = L.ci + 516;
+    L.bufB = L.bufA + G::BUFC;
+    L.y = (float*)(L.bufB + G::BUFC);
+    L.cs = L.y + M;
+    L.ci = (int*)(L.cs + G::CAP);
+    L.sel = L.ci + G::CAP;
     L.sbin = L.sel + kpad;
     L.sval = (float*)(L.sbin + GF * kpad);
     L.cnt = (int*)(L.sval + GF * kpad * 5);
@@ -169,39 +240,51 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     L.orow = (long long*)(((uintptr_t)(L.frm + GF) + 7) & ~(uintptr_t)7);
     L.tot = (double*)(L.orow + GF);
 
-    float2* winl = (float2*)(smem + kTw3Bytes);                   // window as (w[2i], w[2i+1])
-    float2* tw2l = (float2*)(smem + kTw3Bytes + kWinBytes);       // [t2][l1]
-    const float2* tab = (const float2*)p.twiddle;                 // W_2048^j, j < 2048
-    for (int k = threadIdx.x; k <= 512; k += blockDim.x) tw3[k] = tab[k];
-    for (int k = threadIdx.x; k < 1024; k += blockDim.x) winl[k] = ((const float2*)p.win)[k];
-    for (int k = threadIdx.x; k < 64; k += blockDim.x) tw2l[k] = tab[(32 * (k & 3) * (k >> 2)) & 2047];
+    const float2* tab = (const float2*)p.twiddle;                 // W_nfft^j, j < nfft
+    constexpr int NMASK = G::N - 1;
+    for (int k = threadIdx.x; k <= G::HALF; k += blockDim.x) tw3[k] = tab[k];
+    for (int k = threadIdx.x; k < 64; k += blockDim.x) tw2l[k] = tab[((G::N / 64) * (k % P) * (k / P)) & NMASK];
     __syncthreads();
 
     // ---- lane constants
-    const int Q = lane >> 2, L1 = lane & 3;
-    float w0[16], w1[16], t1r[16], t1i[16], t2r[16], t2i[16];
+    const int Q = lane / P, L1 = lane % P;
+    float w0[R], w1[R], t1r[R], t1i[R], t2r[R], t2i[R];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float2 wv = winl[lane + 64 * r];
+    for (int r = 0; r < R; r++) {
+        const float2 wv = ((const float2*)p.win)[lane + 64 * r];  // (w[2l + 128 r], w[2l + 128 r + 1])
         w0[r] = wv.x; w1[r] = wv.y;
-        const float2 a = tab[(2 * lane * r) & 2047];              // W_1024^(l q)
+        const float2 a = tab[(2 * lane * r) & NMASK];             // W_M^(l q)
         t1r[r] = a.x; t1i[r] = a.y;
-        const float2 b = tw2l[r * 4 + L1];                        // W_64^(l1 t2)
+        const float2 b = tw2l[r * P + L1];                        // W_64^(l1 t2)
         t2r[r] = b.x; t2i[r] = b.y;
+    }
+    // cross-lane DFT constants: step with half-size h = P >> (s+1): sign and twiddle W_2h^(l1 mod h)
+    float csg[G::LOGP > 0 ? G::LOGP : 1], cwr[G::LOGP > 0 ? G::LOGP : 1], cwi[G::LOGP > 0 ? G::LOGP : 1];
+#pragma unroll
+    for (int s = 0; s < G::LOGP; s++) {
+        const int h = P >> (s + 1);
+        const bool up = (L1 & h) != 0;
+        csg[s] = up ? -1.f : 1.f;
+        const float2 wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+        cwr[s] = up ? wv.x : 1.f;
+        cwi[s] = up ? wv.y : 0.f;
     }
     // keep the lane constants in registers: without this the compiler re-loads the twiddles from
     // global memory every frame (a full L2 round trip on the critical path) instead of holding them
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < R; r++) {
         asm volatile("" : "+v"(w0[r]), "+v"(w1[r]), "+v"(t1r[r]), "+v"(t1i[r]), "+v"(t2r[r]), "+v"(t2i[r]));
     }
+    // R = 16 (P = 4): the hand-written quad DFT.  step 2: res = alpha*u + beta*p;
+    // lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
     const float sA = (L1 & 2) ? -1.f : 1.f;
-    // stage 3 step 2: res = alpha*u + beta*p;  lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
     const float alr = (L1 == 0 || L1 == 2) ? 1.f : (L1 == 1 ? -1.f : 0.f);
     const float ali = (L1 == 3) ? 1.f : 0.f;
     const float ber = (L1 == 2) ? 0.f : 1.f;
     const float bei = (L1 == 2) ? -1.f : 0.f;
-    const int t1v = (L1 == 1) ? 2 : (L1 == 2 ? 1 : L1);
+    int t1v = 0;                                                  // t1 = bitrev(l1)
+#pragma unroll
+    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
 
     // ---- rows of this wave
     const int64_t W = (int64_t)gridDim.x * nwaves;
@@ -210,16 +293,16 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     if (r0 >= r1) return;
 
     PeakConst pc;
-    pc.fstep = p.fstep; pc.dt = p.dt; pc.nfft = FN; pc.hop = p.hop; pc.wfbin = p.wfbin;
+    pc.fstep = p.fstep; pc.dt = p.dt; pc.nfft = G::N; pc.hop = p.hop; pc.wfbin = p.wfbin;
 
     float2* cur = L.bufA;
     float2* prv = L.bufB;
-    float ra[16], rb[16];                                         // raw samples of the next row (prefetched)
+    float ra[R], rb[R];                                           // raw samples of the next row (prefetched)
     // Rows are addressed as (signal b, row-in-signal q), advanced incrementally: a 64-bit division
     // per frame costs more than the whole peak search.
     auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {     // issue the loads of global row gn = (bn, qn)
         if (gn < 0 || gn >= r1 || qn == 0) return;
-        load_raw<InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, lane, ra, rb);
+        load_raw<R, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, lane, ra, rb);
     };
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
@@ -230,76 +313,94 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
         const int64_t bn = (q == p.F) ? b + 1 : b;
         if (g < 0 || q == 0) {
 #pragma unroll
-            for (int j = 0; j < 17; j++) dst[lane + 64 * j] = make_float2(0.f, 0.f);
+            for (int j = 0; j < G::BUFC / 64; j++) dst[lane + 64 * j] = make_float2(0.f, 0.f);
             wave_sync();
             prefetch(g + 1, bn, qn);
             return;
         }
-        float xr[16], xi[16];
+        float xr[R], xi[R];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
+        for (int r = 0; r < R; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
         prefetch(g + 1, bn, qn);
-        dft16(xr, xi);                                            // stage 1
+        dft_regs<R>(xr, xi);                                      // stage 1
 #pragma unroll
-        for (int q2 = 0; q2 < 16; q2++) {
+        for (int q2 = 0; q2 < R; q2++) {
             float a = xr[q2], c = xi[q2];
             if (q2 > 0) cmul(a, c, t1r[q2], t1i[q2]);
-            dst[q2 * EXP + lane] = make_float2(a, c);
+            dst[q2 * PITCH + lane] = make_float2(a, c);
         }
         wave_sync();
 #pragma unroll
-        for (int l2 = 0; l2 < 16; l2++) {
-            const float2 v = dst[Q * EXP + L1 + 4 * l2];
+        for (int l2 = 0; l2 < R; l2++) {
+            const float2 v = dst[Q * PITCH + L1 + P * l2];
             xr[l2] = v.x; xi[l2] = v.y;
         }
         wave_sync();
-        dft16(xr, xi);                                            // stage 2
+        dft_regs<R>(xr, xi);                                      // stage 2
 #pragma unroll
-        for (int t2 = 0; t2 < 16; t2++) {
+        for (int t2 = 0; t2 < R; t2++) {
             float a = xr[t2], c = xi[t2];
             if (t2 > 0) cmul(a, c, t2r[t2], t2i[t2]);
-            // stage 3: 4-point DFT across the quad
-            float pr_ = dppf<0x4E>(a), pi_ = dppf<0x4E>(c);       // lane ^ 2
-            const float ur = __builtin_fmaf(sA, a, pr_), ui = __builtin_fmaf(sA, c, pi_);
-            pr_ = dppf<0xB1>(ur); pi_ = dppf<0xB1>(ui);           // lane ^ 1
-            const float zr = __builtin_fmaf(alr, ur, __builtin_fmaf(-ali, ui, __builtin_fmaf(ber, pr_, -(bei * pi_))));
-            const float zi = __builtin_fmaf(alr, ui, __builtin_fmaf(ali, ur, __builtin_fmaf(ber, pi_, bei * pr_)));
-            dst[zpad(Q + 16 * t2 + 256 * t1v)] = make_float2(zr, zi);
+            float zr, zi;
+            if constexpr (P == 4) {
+                // stage 3: 4-point DFT across the quad
+                float pr_ = dppf<0x4E>(a), pi_ = dppf<0x4E>(c);   // lane ^ 2
+                const float ur = __builtin_fmaf(sA, a, pr_), ui = __builtin_fmaf(sA, c, pi_);
+                pr_ = dppf<0xB1>(ur); pi_ = dppf<0xB1>(ui);       // lane ^ 1
+                zr = __builtin_fmaf(alr, ur, __builtin_fmaf(-ali, ui, __builtin_fmaf(ber, pr_, -(bei * pi_))));
+                zi = __builtin_fmaf(alr, ui, __builtin_fmaf(ali, ur, __builtin_fmaf(ber, pi_, bei * pr_)));
+            } else {
+                // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
+                // upper lane (a - b) W_2h^(l1 mod h)
+                if constexpr (G::LOGP >= 1) {
+                    if constexpr (P >= 16) { const float pr_ = lane_xor<8>(a), pi_ = lane_xor<8>(c);
+                        a = __builtin_fmaf(csg[G::LOGP - 4], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 4], c, pi_); cmul(a, c, cwr[G::LOGP - 4], cwi[G::LOGP - 4]); }
+                    if constexpr (P >= 8) { const float pr_ = lane_xor<4>(a), pi_ = lane_xor<4>(c);
+                        a = __builtin_fmaf(csg[G::LOGP - 3], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 3], c, pi_); cmul(a, c, cwr[G::LOGP - 3], cwi[G::LOGP - 3]); }
+                    if constexpr (P >= 4) { const float pr_ = lane_xor<2>(a), pi_ = lane_xor<2>(c);
+                        a = __builtin_fmaf(csg[G::LOGP - 2], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 2], c, pi_); cmul(a, c, cwr[G::LOGP - 2], cwi[G::LOGP - 2]); }
+                    { const float pr_ = lane_xor<1>(a), pi_ = lane_xor<1>(c);                 // h = 1: twiddle is 1
+                        a = __builtin_fmaf(csg[G::LOGP - 1], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 1], c, pi_); }
+                }
+                zr = a; zi = c;
+            }
+            dst[zpad<R>(Q + R * t2 + G::R2 * t1v)] = make_float2(zr, zi);
         }
         wave_sync();
-        // ---- untangle in place: pairs (k, 1024-k), k = lane + 64 j; bins 0 and 512 have no partner.
+        // ---- untangle in place: pairs (k, M-k), k = lane + 64 j; bins 0 and M/2 have no partner.
         // Phase 1 reads everything (the loads do not wait for the in-place stores of other pairs),
         // phase 2 computes and stores.
+        constexpr int NPAIR = R / 2;
         float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
-        float2 za[8], zb[8], wv8[8];
+        float2 za[NPAIR], zb[NPAIR], wv8[NPAIR];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < NPAIR; j++) {
             const int k = lane + 64 * j;
-            const int km = (FM - k) & (FM - 1);                   // k = 0: Z[1024] == Z[0]
-            za[j] = dst[zpad(k)];
-            zb[j] = dst[zpad(km)];
+            const int km = (M - k) & (M - 1);                     // k = 0: Z[M] == Z[0]
+            za[j] = dst[zpad<R>(k)];
+            zb[j] = dst[zpad<R>(km)];
             wv8[j] = tw3[k];
         }
-        const float2 zc = dst[zpad(512)];
+        const float2 zc = dst[zpad<R>(G::HALF)];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < NPAIR; j++) {
             const int k = lane + 64 * j;
-            const int km = (FM - k) & (FM - 1);
+            const int km = (M - k) & (M - 1);
             const float er = 0.5f * (za[j].x + zb[j].x), ei = 0.5f * (za[j].y - zb[j].y);      // E = (Za + conj Zb)/2
             const float orr = 0.5f * (za[j].y + zb[j].y), oi = -0.5f * (za[j].x - zb[j].x);    // O = (Za - conj Zb)/(2i)
             float pr2 = orr, pi2_ = oi;
             cmul(pr2, pi2_, wv8[j].x, wv8[j].y);                                    // P = W^k O
             const float x0r = er + pr2, x0i = ei + pi2_;                            // X[k]
-            float x1r = er - pr2, x1i = pi2_ - ei;                                  // X[1024-k] = conj(E - P)
+            float x1r = er - pr2, x1i = pi2_ - ei;                                  // X[M-k] = conj(E - P)
             int kk = km;
             if (j == 0) {
                 // lane 0: k = 0 pairs with itself and its "partner" result is not a bin; that slot
-                // takes bin 512, which pairs with itself too: X[512] = conj(Z[512])
-                if (lane == 0) { x1r = zc.x; x1i = -zc.y; kk = 512; }
+                // takes bin M/2, which pairs with itself too: X[M/2] = conj(Z[M/2])
+                if (lane == 0) { x1r = zc.x; x1i = -zc.y; kk = G::HALF; }
             }
             const float e0 = __builtin_fmaf(x0r, x0r, x0i * x0i), e1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
-            dst[zpad(k)] = make_float2(x0r, x0i);
-            dst[zpad(kk)] = make_float2(x1r, x1i);
+            dst[zpad<R>(k)] = make_float2(x0r, x0i);
+            dst[zpad<R>(kk)] = make_float2(x1r, x1i);
             if (with_mag) {
                 // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
                 const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
@@ -320,7 +421,7 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
     const int fpp = 64 / LPF;
-    const int G = (fpp < GF) ? fpp : GF;                          // frames staged per pass
+    const int G_ = (fpp < GF) ? fpp : GF;                         // frames staged per pass
     const int gl = lane / LPF, e0 = lane - gl * LPF;
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
@@ -365,7 +466,7 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
             if (e0 == 0) {
                 const int64_t fr = L.frm[g];
                 if (p.totalmag) p.totalmag[orow] = sqrt(L.tot[g]);                                   // PV.py:210
-                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + FN / 2.0) / p.sr;              // PV.py:247
+                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + G::N / 2.0) / p.sr;            // PV.py:247
             }
         }
         wave_sync();
@@ -393,24 +494,24 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
             const int64_t orow = b * p.F + (q - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
             const double minamp = (double)maxy * p.thr;           // PF.py:60
-            const int nsel = peak_select<float, FM>(L.y, L.cs, L.ci, L.sel, FM, K, minamp, true, miny, lane);
+            const int nsel = peak_select<float, M>(L.y, L.cs, L.ci, L.sel, M, K, minamp, true, miny, lane);
             const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
             int nk = 0;
             for (int eb = 0; eb < nsel; eb += 64) {
                 const int e = eb + lane;
                 int pb = 0;
                 bool keep = false;
-                if (e < nsel) { pb = L.sel[e]; keep = salient<float>(L.y, FM, pb, p.rad); }
+                if (e < nsel) { pb = L.sel[e]; keep = salient<float>(L.y, M, pb, p.rad); }
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     const int slot = ng * kpad + nk + lane_prefix(bal);
-                    const float2 c = cur[zpad(pb)];
+                    const float2 c = cur[zpad<R>(pb)];
                     float2 pv;
                     if (use_prev0) pv = make_float2((float)p.prev0[2 * pb], (float)p.prev0[2 * pb + 1]);
-                    else pv = prv[zpad(pb)];
+                    else pv = prv[zpad<R>(pb)];
                     // PV.py:197-199: 3-bin energy, bin 0 excluded.  A selected bin is an interior
-                    // local maximum, 1 <= pb <= 1022: pb+1 is always a bin, pb-1 counts unless it is 0
-                    const float2 vm = cur[zpad(pb - 1)], vp = cur[zpad(pb + 1)];
+                    // local maximum, 1 <= pb <= M-2: pb+1 is always a bin, pb-1 counts unless it is 0
+                    const float2 vm = cur[zpad<R>(pb - 1)], vp = cur[zpad<R>(pb + 1)];
                     const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
                     const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
                     L.sbin[slot] = pb;
@@ -421,12 +522,12 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
             }
             if (lane == 0) { L.cnt[ng] = nk; L.frm[ng] = (int)(q - 1); L.orow[ng] = orow; L.tot[ng] = tot; }
             ng++;
-            if (ng == G) { flush(ng); ng = 0; }
+            if (ng == G_) { flush(ng); ng = 0; }
         }
         if (p.spec_out != nullptr && g == p.spec_row) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float2 v = cur[zpad(lane + 64 * j)];
+            for (int j = 0; j < R; j++) {
+                const float2 v = cur[zpad<R>(lane + 64 * j)];
                 p.spec_out[2 * (lane + 64 * j)] = v.x;
                 p.spec_out[2 * (lane + 64 * j) + 1] = v.y;
             }
@@ -436,50 +537,70 @@ __global__ __launch_bounds__(128) void k_fused_pv2048(FusedParams p) {
     if (ng > 0) flush(ng);
 }
 
-}  // namespace
-
-int pvx_fused_supported(int nfft, int precision, int K) {
-    if (nfft != FN || precision != 32) return 0;
-    return (kFusedShared + fused_lds_per_wave(K) * 2 <= 160 * 1024 / 1) ? 1 : 0;
-}
-
-int pvx_launch_fused(const FusedParams& p, int x_dtype, hipStream_t s) {
-    if (p.total_rows <= 0) return PVX_OK;
+template <int R> int launch_fused_r(const FusedParams& p, int x_dtype, hipStream_t s) {
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
-    const size_t per_wave = fused_lds_per_wave(p.K);
+    const size_t per_wave = fused_lds_per_wave<R>(p.K), shared = fused_lds_shared<R>();
     int waves = 2;
-    if (kFusedShared + per_wave * waves > 160 * 1024) waves = 1;
-    const size_t lds = kFusedShared + per_wave * waves;
-    if (lds > 160 * 1024) { pvx_set_error("npks=%d needs %zu bytes of LDS in the fused kernel", p.K, lds); return PVX_ERR_UNSUPPORTED; }
-    int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (shared + per_wave * waves > 160 * 1024) waves = 1;
+    const size_t lds = shared + per_wave * waves;
+    if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the fused kernel", Geo<R>::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
+    const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
+    const void* fn = nullptr;
+    switch (x_dtype) {
+        case PVX_F32: fn = al2 ? (const void*)k_fused_pv<R, float, true> : (const void*)k_fused_pv<R, float, false>; break;
+        case PVX_F64: fn = (const void*)k_fused_pv<R, double, false>; break;
+        case PVX_I16: fn = (const void*)k_fused_pv<R, int16_t, false>; break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // resident workgroups per CU: what LDS and registers admit (at most 2 waves per SIMD)
+    int blocks_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, 64 * waves, lds) != hipSuccess || blocks_per_cu < 1)
+        blocks_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     if (blocks_per_cu * waves > 8) blocks_per_cu = 8 / waves;
     int64_t nblocks = (int64_t)ncu * blocks_per_cu;
     if (p.blocks_override > 0) nblocks = p.blocks_override;
-    // never more waves than rows (each wave needs at least one row to be worth its halo FFT)
+    // never more waves than rows (each wave needs a few rows to be worth its halo FFT)
     const int64_t min_rows_per_wave = 4;
     const int64_t maxb = (p.total_rows / min_rows_per_wave + waves - 1) / waves;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
-    const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     dim3 grid((unsigned)nblocks), block(64 * waves);
-#define PVX_FUSED_LAUNCH(IT, AL)                                                                              \
-    do {                                                                                                      \
-        if (lds > 64 * 1024)                                                                                  \
-            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_fused_pv2048<IT, AL>,                            \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-        hipLaunchKernelGGL((k_fused_pv2048<IT, AL>), grid, block, lds, s, p);                                 \
-    } while (0)
     switch (x_dtype) {
-        case PVX_F32: if (al2) PVX_FUSED_LAUNCH(float, true); else PVX_FUSED_LAUNCH(float, false); break;
-        case PVX_F64: PVX_FUSED_LAUNCH(double, false); break;
-        case PVX_I16: PVX_FUSED_LAUNCH(int16_t, false); break;
-        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+        case PVX_F32:
+            if (al2) hipLaunchKernelGGL((k_fused_pv<R, float, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((k_fused_pv<R, float, false>), grid, block, lds, s, p);
+            break;
+        case PVX_F64: hipLaunchKernelGGL((k_fused_pv<R, double, false>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((k_fused_pv<R, int16_t, false>), grid, block, lds, s, p); break;
     }
-#undef PVX_FUSED_LAUNCH
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
+}
+
+}  // namespace
+
+int pvx_fused_supported(int nfft, int precision, int K) {
+    if (precision != 32) return 0;
+    switch (nfft) {
+        case 512: return fused_lds_shared<4>() + fused_lds_per_wave<4>(K) <= 160 * 1024;
+        case 1024: return fused_lds_shared<8>() + fused_lds_per_wave<8>(K) <= 160 * 1024;
+        case 2048: return fused_lds_shared<16>() + fused_lds_per_wave<16>(K) <= 160 * 1024;
+        // nfft = 4096 (R = 32) works but needs > 512 registers per lane (spills) and 52 KB of LDS per
+        // wave: no faster than the rocFFT path, so it stays there until the multi-wave-per-frame form
+        default: return 0;
+    }
+}
+
+int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
+    if (p.total_rows <= 0) return PVX_OK;
+    switch (nfft) {
+        case 512: return launch_fused_r<4>(p, x_dtype, s);
+        case 1024: return launch_fused_r<8>(p, x_dtype, s);
+        case 2048: return launch_fused_r<16>(p, x_dtype, s);
+        default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
+    }
 }

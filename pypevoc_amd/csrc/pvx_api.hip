@@ -137,7 +137,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     if (mode != 0 && mode != 1) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
     if (mode == 1 && !pvx_fused_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the fused kernel handles nfft=2048 at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
+        pvx_set_error("the fused kernel handles nfft in {512, 1024, 2048} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
         return PVX_ERR_UNSUPPORTED;
     }
     plan->fft_mode = mode;
@@ -226,10 +226,10 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
 
     // fused kernel tables
     if (pvx_fused_supported(nfft, precision, npks)) {
-        std::vector<float> tw(2 * 2048);
+        std::vector<float> tw(2 * (size_t)nfft);
         const double pi = 3.141592653589793238462643383279502884;
-        for (int j = 0; j < 2048; j++) { tw[2 * j] = (float)cos(2.0 * pi * j / 2048.0); tw[2 * j + 1] = (float)(-sin(2.0 * pi * j / 2048.0)); }
-        if (hipMalloc(&p->d_twiddle, tw.size() * 4) != hipSuccess || hipMalloc((void**)&p->d_specrow, 2048 * 4) != hipSuccess) { pvx_set_error("hipMalloc(fused tables) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        for (int j = 0; j < nfft; j++) { tw[2 * j] = (float)cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = (float)(-sin(2.0 * pi * j / (double)nfft)); }
+        if (hipMalloc(&p->d_twiddle, tw.size() * 4) != hipSuccess || hipMalloc((void**)&p->d_specrow, (size_t)nfft * 4) != hipSuccess) { pvx_set_error("hipMalloc(fused tables) failed"); plan_free(p); return PVX_ERR_ALLOC; }
         if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         p->fft_mode = 1;
         if (const char* e = getenv("PVX_FFT_MODE")) { if (atoi(e) == 0) p->fft_mode = 0; }
@@ -337,7 +337,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.spec_out = spec_row >= 0 ? p->d_specrow : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
         if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
-        if ((rc = pvx_launch_fused(fp, x_dtype, s)) != PVX_OK) return rc;
+        if ((rc = pvx_launch_fused(fp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }
     if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;

@@ -83,14 +83,14 @@ struct FusedParams {      // k_fused.hip: window + FFT + untangle + peaks in one
     const double* wfbin;
     const double* prev0;
     double *f, *mag, *ph, *realph, *binno, *t, *totalmag;
-    const void* win;      // float[2048] window / wfact
-    const void* twiddle;  // float2[2048] W_2048^j
-    float* spec_out;      // optional: half spectrum (1024 complex) of global row spec_row
+    const void* win;      // float[nfft] window / wfact
+    const void* twiddle;  // float2[nfft] W_nfft^j
+    float* spec_out;      // optional: half spectrum (nfft/2 complex) of global row spec_row
     int64_t spec_row;
     int64_t blocks_override;
 };
 int pvx_fused_supported(int nfft, int precision, int K);
-int pvx_launch_fused(const FusedParams& p, int x_dtype, hipStream_t s);
+int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 
 // launchers (defined in the .hip files)
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);

@@ -303,6 +303,14 @@ def test_fused_kernel_variants(amd, oracle):
     r1 = run_pv(amd, x.astype(np.float32), sr, nfft, 512, K, precision=32)
     assert np.array_equal(r0.binno, r1.binno)
     assert np.abs(r0.f - r1.f).max() <= 1e-3 and np.abs(r0.mag - r1.mag).max() <= 1e-6 * r0.mag.max()
+    # the other fused sizes (nfft 512 and 1024: 2 waves per SIMD, 16- and 8-lane cross-lane DFTs)
+    for nf, hp in ((512, 128), (512, 77), (1024, 256), (1024, 512)):
+        o = oracle.analyze(x, sr, nf, hp, K)
+        p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
+        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1
+        assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
+    p = run_pv(amd, x.astype(np.float32), sr, 4096, 1024, K, precision=32)
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 0          # rocFFT path
     # K > 64 and K = 1 through the fused staging paths
     for K2 in (1, 70):
         o = oracle.analyze(x, sr, nfft, 512, K2, 0.0005)
