@@ -167,7 +167,7 @@ def main():
         ab = alg_bytes()
         frames_total = F * world * args.steps
         value = frames_total / elapsed
-        names = ["k_frames", "rocfft_r2c", "k_phase_peaks", "k_fused_pv2048"]
+        names = ["k_frames", "rocfft_r2c", "k_phase_peaks", "k_fused_pv"]
         # algorithmic bytes per frame of each kernel.  The fused kernel is priced at the
         # stage figure of SURVEY.md 8(d): it does the work of the whole STFT+phase stage.
         abk = [ab["frames"], ab["fft"], ab["peaks"], ab["stage"]]
