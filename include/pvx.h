@@ -78,7 +78,8 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   0  framing kernel -> rocFFT batched real FFT -> phase/peak kernel (any nfft, both precisions)
  *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
  *      intermediate arrays in HBM (nfft in {512, 1024, 2048}, precision = 32)
- * A new plan uses 1 where it is supported, else 0 (environment PVX_FFT_MODE=0 forces 0).
+ *   2  fused kernel with several waves per frame (nfft in {2048, 4096, 8192}, precision = 32)
+ * A new plan uses 1 where it is supported, else 2, else 0 (environment PVX_FFT_MODE overrides).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);

@@ -1,0 +1,480 @@
+// k_fused_mw.hip -- the fused analysis stage with SEVERAL waves per frame: a workgroup of W waves
+// (T = 64 W lanes) transforms one frame at a time, R = 8 complex points per lane, nfft = 2 T R:
+//      nfft 2048 = 2 waves, nfft 4096 = 4 waves, nfft 8192 = 8 waves.
+// Same arithmetic and same reference lines as k_fused.hip (PV.calc_fft_frame / calc_pv_frame / run_pv,
+// pypevoc/PVAnalysis.py:150-264); what changes is the shape: with 8 points per lane the kernel needs
+// ~230 registers instead of ~380, so two waves fit on every SIMD and the issue slots that a lone wave
+// leaves empty (one instruction per 4 cycles) get used.  LDS is per frame, not per wave.
+//
+// M = nfft/2 = T R complex points = R (registers) x R (registers, after the LDS exchange) x P (P = T/R
+// lanes, cross-lane decimation-in-frequency steps: DPP / ds_swizzle inside a wave; for P = 64 the
+// first step pairs lanes 32 apart with ds_bpermute):
+//   stage 1  lane l < T holds z[l + T r]: radix-R DFT over r, twiddle W_M^(l q)        | block barrier
+//   stage 2  lane (q, l1) = P q + l1 reads Y[l1 + P l2][q]: radix-R DFT, twiddle W_T^(l1 t2)
+//   stage 3  P-point DFT over l1 -> Z[q + R t2 + R^2 bitrev(l1)] -> LDS                | block barrier
+//   untangle pairs (k, M-k), k = l + T j, j < R/2; |X| -> LDS; per-wave max/min/energy | block barrier
+//   peaks    every wave scans its M/W bins into its own candidate segment              | block barrier
+//            wave 0 merges the segments, selects, applies the salience test, stages the peaks'
+//            raw data and (every G frames) does the per-peak arithmetic + stores        | block barrier
+// The index maps were validated in numpy (R = 8, W = 2, 4, 8) before this was written.
+#include "pvx_fft.h"
+
+using namespace pvxw;
+using namespace pvxf;
+
+namespace {
+
+constexpr int GFM = 8;              // frames staged before the per-peak pass
+
+template <int R, int W> struct GeoMW {
+    static constexpr int T = 64 * W;                 // lanes per frame
+    static constexpr int M = T * R;                  // complex FFT length = bins 0..M-1
+    static constexpr int N = 2 * M;                  // nfft
+    static constexpr int P = T / R;                  // lanes per cross-lane DFT
+    static constexpr int LOGP = ilog2(P);
+    static constexpr int LOGR = ilog2(R);
+    static constexpr int PITCH = T + (P <= 16 ? P : 0);              // exchange row pitch (complex)
+    static constexpr int R2 = R * R;
+    static constexpr int QH = (P >= 32) ? 1 : 32 / P;                // q values per half wave
+    static constexpr int ZP = (QH - (R2 % 32) + 32) % 32;            // padding per R^2 spectrum bins
+    static constexpr int ZLEN = M + ZP * (P - 1);
+    static constexpr int BUFRAW = (R * PITCH > ZLEN) ? R * PITCH : ZLEN;
+    static constexpr int BUFC = ((BUFRAW + T - 1) / T) * T;          // complex slots per spectrum buffer
+    static constexpr int HALF = M / 2;
+    static constexpr int SCAN = M / W;                               // bins scanned by one wave
+    static constexpr int CAPW = SCAN / 2 + 4;                        // candidate segment capacity
+    static constexpr int CAP = CAPW * W;
+    static constexpr int TW3 = (HALF + 8) & ~7;
+};
+template <int R, int W> __device__ __host__ __forceinline__ int zpadm(int k) { return k + GeoMW<R, W>::ZP * (k >> (2 * GeoMW<R, W>::LOGR)); }
+
+template <int R, int W> __host__ __device__ inline size_t mw_lds_bytes(int K) {
+    using G = GeoMW<R, W>;
+    const size_t kpad = (size_t)((K + 3) & ~3);
+    size_t b = (size_t)G::TW3 * 8 + (size_t)G::T * 8            // tw3 | tw2l
+             + (size_t)G::BUFC * 8 * 2                          // bufA | bufB
+             + (size_t)G::M * 4                                 // y
+             + (size_t)G::CAP * 4 * 2                           // cs | ci
+             + kpad * 4                                         // sel
+             + (size_t)GFM * kpad * 4 + (size_t)GFM * kpad * 5 * 4   // sbin | sval
+             + GFM * 4 * 2 + W * 4 + W * 4 * 2;                 // cnt | frm | Cw | pmax | pmin
+    b = (b + 7) & ~(size_t)7;
+    b += GFM * 8 * 2 + W * 8;                                   // orow | tot | psum
+    return (b + 15) & ~(size_t)15;
+}
+
+// value of lane (l ^ H) within the wave, H up to 32
+template <int H> __device__ __forceinline__ float lane_xor_w(float v, int lane) {
+    if constexpr (H <= 8) return lane_xor<H>(v);
+    else if constexpr (H == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1f));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __builtin_bit_cast(int, v)));
+}
+
+template <int R, int W, typename InT, bool AL2>
+__device__ __forceinline__ void load_raw_mw(const InT* x, int tid, float (&ra)[R], float (&rb)[R]) {
+    constexpr int T = 64 * W;
+    // thread l takes z[l + T r] = (x[2l + 2T r], x[2l + 2T r + 1]): 512 contiguous bytes per wave-instruction
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const InT* p = x + 2 * tid + 2 * T * r;
+        if constexpr (AL2 && sizeof(InT) == 4) {
+            const float2 v = *(const float2*)p;
+            ra[r] = v.x; rb[r] = v.y;
+        } else {
+            ra[r] = ld1(p); rb[r] = ld1(p + 1);
+        }
+    }
+}
+
+template <int R, int W, typename InT, bool AL2>
+__global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
+    using G = GeoMW<R, W>;
+    constexpr int T = G::T, M = G::M, P = G::P, PITCH = G::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int K = p.K;
+    const int kpad = (K + 3) & ~3;
+    // ---- LDS carve (per block = per frame in flight)
+    float2* tw3 = (float2*)smem;
+    float2* tw2l = tw3 + G::TW3;
+    float2* bufA = tw2l + T;
+    float2* bufB = bufA + G::BUFC;
+    float* y = (float*)(bufB + G::BUFC);
+    float* cs = y + M;
+    int* ci = (int*)(cs + G::CAP);
+    int* sel = ci + G::CAP;
+    int* sbin = sel + kpad;
+    float* sval = (float*)(sbin + GFM * kpad);
+    int* cntv = (int*)(sval + GFM * kpad * 5);
+    int* frmv = cntv + GFM;
+    int* Cw = frmv + GFM;
+    float* pmax = (float*)(Cw + W);
+    float* pmin = pmax + W;
+    long long* orowv = (long long*)(((uintptr_t)(pmin + W) + 7) & ~(uintptr_t)7);
+    double* totv = (double*)(orowv + GFM);
+    double* psum = totv + GFM;
+
+    const float2* tab = (const float2*)p.twiddle;                 // W_nfft^j, j < nfft
+    constexpr int NMASK = G::N - 1;
+    for (int k = tid; k <= G::HALF; k += T) tw3[k] = tab[k];
+    for (int k = tid; k < T; k += T) tw2l[k] = tab[((G::N / T) * (k % P) * (k / P)) & NMASK];   // [t2][l1] W_T^(l1 t2)
+    __syncthreads();
+
+    // ---- thread constants
+    const int Q = tid / P, L1 = tid % P;
+    float w0[R], w1[R], t1r[R], t1i[R], t2r[R], t2i[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float2 wv = ((const float2*)p.win)[tid + T * r];    // (w[2l + 2T r], w[2l + 2T r + 1])
+        w0[r] = wv.x; w1[r] = wv.y;
+        const float2 a = tab[(2 * tid * r) & NMASK];              // W_M^(l q)
+        t1r[r] = a.x; t1i[r] = a.y;
+        const float2 b = tw2l[r * P + L1];                        // W_T^(l1 t2)
+        t2r[r] = b.x; t2i[r] = b.y;
+    }
+    float csg[G::LOGP], cwr[G::LOGP], cwi[G::LOGP];               // cross-lane DFT: sign and twiddle per step
+#pragma unroll
+    for (int s = 0; s < G::LOGP; s++) {
+        const int h = P >> (s + 1);
+        const bool up = (L1 & h) != 0;
+        csg[s] = up ? -1.f : 1.f;
+        const float2 wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];     // W_2h^(l1 mod h)
+        cwr[s] = up ? wv.x : 1.f;
+        cwi[s] = up ? wv.y : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        asm volatile("" : "+v"(w0[r]), "+v"(w1[r]), "+v"(t1r[r]), "+v"(t1i[r]), "+v"(t2r[r]), "+v"(t2i[r]));
+    }
+    int t1v = 0;                                                  // t1 = bitrev(l1)
+#pragma unroll
+    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
+
+    // ---- rows of this workgroup
+    const int64_t NB = gridDim.x;
+    const int64_t r0 = p.total_rows * (int64_t)blockIdx.x / NB, r1 = p.total_rows * ((int64_t)blockIdx.x + 1) / NB;
+    if (r0 >= r1) return;                                         // block-uniform
+
+    PeakConst pc;
+    pc.fstep = p.fstep; pc.dt = p.dt; pc.nfft = G::N; pc.hop = p.hop; pc.wfbin = p.wfbin;
+
+    float2* cur = bufA;
+    float2* prv = bufB;
+    float ra[R], rb[R];                                           // raw samples of the next row (prefetched)
+    auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {
+        if (gn < 0 || gn >= r1 || qn == 0) return;
+        load_raw_mw<R, W, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, tid, ra, rb);
+    };
+
+    // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
+    // block-reduced max / min / energy.  Every thread of the block takes part (block barriers inside).
+    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxy, float& miny, double& tot) {
+        const int64_t qn = (q == p.F) ? 0 : q + 1;
+        const int64_t bn = (q == p.F) ? b + 1 : b;
+        if (g < 0 || q == 0) {
+#pragma unroll
+            for (int j = 0; j < G::BUFC / T; j++) dst[tid + T * j] = make_float2(0.f, 0.f);
+            __syncthreads();
+            prefetch(g + 1, bn, qn);
+            return;
+        }
+        float xr[R], xi[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
+        prefetch(g + 1, bn, qn);
+        dft_regs<R>(xr, xi);                                      // stage 1
+#pragma unroll
+        for (int q2 = 0; q2 < R; q2++) {
+            float a = xr[q2], c = xi[q2];
+            if (q2 > 0) cmul(a, c, t1r[q2], t1i[q2]);
+            dst[q2 * PITCH + tid] = make_float2(a, c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l2 = 0; l2 < R; l2++) {
+            const float2 v = dst[Q * PITCH + L1 + P * l2];
+            xr[l2] = v.x; xi[l2] = v.y;
+        }
+        __syncthreads();
+        dft_regs<R>(xr, xi);                                      // stage 2
+#pragma unroll
+        for (int t2 = 0; t2 < R; t2++) {
+            float a = xr[t2], c = xi[t2];
+            if (t2 > 0) cmul(a, c, t2r[t2], t2i[t2]);
+            // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
+            // upper lane (a - b) W_2h^(l1 mod h); the last step (h = 1) has twiddle 1
+#define PVX_XSTEP(H, S, TW)                                                                        \
+            {                                                                                      \
+                const float pr_ = lane_xor_w<H>(a, lane), pi_ = lane_xor_w<H>(c, lane);            \
+                a = __builtin_fmaf(csg[S], a, pr_); c = __builtin_fmaf(csg[S], c, pi_);            \
+                if (TW) cmul(a, c, cwr[S], cwi[S]);                                                \
+            }
+            if constexpr (P >= 64) PVX_XSTEP(32, G::LOGP - 6, true)
+            if constexpr (P >= 32) PVX_XSTEP(16, G::LOGP - 5, true)
+            if constexpr (P >= 16) PVX_XSTEP(8, G::LOGP - 4, true)
+            if constexpr (P >= 8) PVX_XSTEP(4, G::LOGP - 3, true)
+            if constexpr (P >= 4) PVX_XSTEP(2, G::LOGP - 2, true)
+            if constexpr (P >= 2) PVX_XSTEP(1, G::LOGP - 1, false)
+#undef PVX_XSTEP
+            dst[zpadm<R, W>(Q + R * t2 + G::R2 * t1v)] = make_float2(a, c);
+        }
+        __syncthreads();
+        // ---- untangle in place: pairs (k, M-k), k = tid + T j; bins 0 and M/2 have no partner
+        constexpr int NPAIR = R / 2;
+        float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
+        float2 za[NPAIR], zb[NPAIR], wv8[NPAIR];
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            const int k = tid + T * j;
+            const int km = (M - k) & (M - 1);                     // k = 0: Z[M] == Z[0]
+            za[j] = dst[zpadm<R, W>(k)];
+            zb[j] = dst[zpadm<R, W>(km)];
+            wv8[j] = tw3[k];
+        }
+        const float2 zc = dst[zpadm<R, W>(G::HALF)];
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            const int k = tid + T * j;
+            const int km = (M - k) & (M - 1);
+            const float er = 0.5f * (za[j].x + zb[j].x), ei = 0.5f * (za[j].y - zb[j].y);      // E = (Za + conj Zb)/2
+            const float orr = 0.5f * (za[j].y + zb[j].y), oi = -0.5f * (za[j].x - zb[j].x);    // O = (Za - conj Zb)/(2i)
+            float pr2 = orr, pi2_ = oi;
+            cmul(pr2, pi2_, wv8[j].x, wv8[j].y);                                    // P = W^k O
+            const float x0r = er + pr2, x0i = ei + pi2_;                            // X[k]
+            float x1r = er - pr2, x1i = pi2_ - ei;                                  // X[M-k] = conj(E - P)
+            int kk = km;
+            if (j == 0) {
+                // thread 0: k = 0 pairs with itself; its partner slot takes bin M/2: X[M/2] = conj(Z[M/2])
+                if (tid == 0) { x1r = zc.x; x1i = -zc.y; kk = G::HALF; }
+            }
+            const float e0 = __builtin_fmaf(x0r, x0r, x0i * x0i), e1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
+            dst[zpadm<R, W>(k)] = make_float2(x0r, x0i);
+            dst[zpadm<R, W>(kk)] = make_float2(x1r, x1i);
+            if (with_mag) {
+                const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
+                y[k] = m0; y[kk] = m1;
+                lmax = fmaxf(lmax, fmaxf(m0, m1)); lmin = fminf(lmin, fminf(m0, m1)); ls0 += e0; ls1 += e1;
+            }
+        }
+        if (with_mag) {
+            const float wm = wave_max(lmax), wn = wave_min(lmin);
+            const double wsum = wave_sum((double)ls0 + (double)ls1);
+            if (lane == 0) { pmax[wid] = wm; pmin[wid] = wn; psum[wid] = wsum; }
+        }
+        __syncthreads();
+        if (with_mag) {
+            float mx = pmax[0], mn = pmin[0];
+            double sm = psum[0];
+#pragma unroll
+            for (int w = 1; w < W; w++) { mx = fmaxf(mx, pmax[w]); mn = fminf(mn, pmin[w]); sm += psum[w]; }
+            maxy = mx; miny = mn; tot = sm;
+        }
+    };
+
+    // per-peak pass over the staged frames [0, ng): wave 0 only
+    int LPF = 1;
+    while (LPF < K && LPF < 64) LPF <<= 1;
+    const int fpp = 64 / LPF;
+    const int G_ = (fpp < GFM) ? fpp : GFM;                       // frames staged per pass
+    const int gl = lane / LPF, e0 = lane - gl * LPF;
+    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
+    auto flush = [&](int ng) {
+        wave_sync();
+        const int g = gl;
+        const bool gvalid = g < ng;
+        const int cnt = gvalid ? cntv[g] : -1;
+        const int64_t orow = gvalid ? (int64_t)orowv[g] : 0;
+        double* of = p.f + orow * K;
+        double* om = p.mag + orow * K;
+        double* op = p.ph + orow * K;
+        double* orp = p.realph + orow * K;
+        double* ob = p.binno + orow * K;
+        int nout = 0;
+        for (int eb = 0; eb < K; eb += LPF) {
+            const int e = eb + e0;
+            bool valid = (cnt >= 0) && (e < cnt);
+            int nbin = 0;
+            PeakOut o;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            if (valid) {
+                nbin = sbin[g * kpad + e];
+                const float* sv = sval + (size_t)(g * kpad + e) * 5;
+                o = peak_math<float>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                valid = o.valid;
+            }
+            const unsigned long long bal = __ballot(valid) & gmask;
+            if (valid) {
+                const int oi = nout + __popcll(bal & ((1ull << lane) - 1ull));
+                ob[oi] = (double)nbin;
+                of[oi] = o.freq;
+                om[oi] = o.mag;
+                op[oi] = o.thisph;
+                orp[oi] = o.thisph + kPi * o.dfb / p.fstep;       // PV.py:207
+            }
+            nout += __popcll(bal);
+        }
+        if (cnt >= 0) {
+            for (int j = nout + e0; j < K; j += LPF) {            // zero padding, PV.py:226-239
+                ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
+            }
+            if (e0 == 0) {
+                const int64_t fr = frmv[g];
+                if (p.totalmag) p.totalmag[orow] = sqrt(totv[g]);                                    // PV.py:210
+                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + G::N / 2.0) / p.sr;            // PV.py:247
+            }
+        }
+        wave_sync();
+    };
+
+    // ---- previous spectrum of the first row
+    int64_t gb, gq;                                               // (b, q) of the row being processed
+    {
+        const int64_t g0 = r0 - 1;                                // may be -1: treated as a zero row
+        if (g0 >= 0) { gb = g0 / (p.F + 1); gq = g0 - gb * (p.F + 1); }      // the only division
+        else { gb = -1; gq = p.F; }                                         // so that g0 + 1 = (0, 0)
+        prefetch(g0, gb, gq);
+        float d0, d1;
+        double d2;
+        spectrum(g0, gb, gq, prv, false, d0, d1, d2);
+    }
+    int ng = 0;                                                   // staged frames (meaningful in wave 0)
+    for (int64_t g = r0; g < r1; ++g) {
+        if (gq == p.F) { gq = 0; gb += 1; } else { gq += 1; }
+        const int64_t b = gb, q = gq;
+        float maxy = 0.f, miny = 0.f;
+        double tot = 0.0;
+        spectrum(g, b, q, cur, true, maxy, miny, tot);
+        if (q != 0) {                                             // block-uniform
+            const int64_t orow = b * p.F + (q - 1);
+            // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
+            const double minamp = (double)maxy * p.thr;           // PF.py:60
+            const double th = peak_threshold<float>(minamp, true, miny);
+            // every wave scans its share of the bins into its own candidate segment
+            const int C_w = peak_scan<float, G::SCAN / 64>(y, wid * G::SCAN, G::SCAN, M, miny, th,
+                                                           cs + wid * G::CAPW, ci + wid * G::CAPW, lane);
+            if (lane == 0) Cw[wid] = C_w;
+            __syncthreads();
+            if (wid == 0) {
+                // merge the segments (ascending bins) into one list at the head of cs / ci
+                int C = Cw[0];
+#pragma unroll
+                for (int w = 1; w < W; w++) {
+                    const int cw = Cw[w];
+                    for (int c0 = 0; c0 < cw; c0 += 64) {         // moves down: read a chunk, then write it
+                        const int c = c0 + lane;
+                        float sv_ = 0.f; int iv_ = 0;
+                        if (c < cw) { sv_ = cs[w * G::CAPW + c]; iv_ = ci[w * G::CAPW + c]; }
+                        wave_sync();
+                        if (c < cw) { cs[C + c] = sv_; ci[C + c] = iv_; }
+                        wave_sync();
+                    }
+                    C += cw;
+                }
+                wave_sync();
+                const int nsel = peak_pick<float>(y, cs, ci, sel, M, K, C, th, lane);
+                const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
+                int nk = 0;
+                for (int eb = 0; eb < nsel; eb += 64) {
+                    const int e = eb + lane;
+                    int pb = 0;
+                    bool keep = false;
+                    if (e < nsel) { pb = sel[e]; keep = salient<float>(y, M, pb, p.rad); }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {
+                        const int slot = ng * kpad + nk + lane_prefix(bal);
+                        const float2 c = cur[zpadm<R, W>(pb)];
+                        float2 pv;
+                        if (use_prev0) pv = make_float2((float)p.prev0[2 * pb], (float)p.prev0[2 * pb + 1]);
+                        else pv = prv[zpadm<R, W>(pb)];
+                        // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
+                        const float2 vm = cur[zpadm<R, W>(pb - 1)], vp = cur[zpadm<R, W>(pb + 1)];
+                        const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
+                        const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
+                        sbin[slot] = pb;
+                        float* sv = sval + (size_t)slot * 5;
+                        sv[0] = c.x; sv[1] = c.y; sv[2] = pv.x; sv[3] = pv.y; sv[4] = s3;
+                    }
+                    nk += __popcll(bal);
+                }
+                if (lane == 0) { cntv[ng] = nk; frmv[ng] = (int)(q - 1); orowv[ng] = orow; totv[ng] = tot; }
+                ng++;
+                if (ng == G_) { flush(ng); ng = 0; }
+            }
+        }
+        if (p.spec_out != nullptr && g == p.spec_row) {
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const float2 v = cur[zpadm<R, W>(tid + T * j)];
+                p.spec_out[2 * (tid + T * j)] = v.x;
+                p.spec_out[2 * (tid + T * j) + 1] = v.y;
+            }
+        }
+        __syncthreads();                                          // wave 0 is done with cur / prv / y
+        float2* t = cur; cur = prv; prv = t;
+    }
+    if (wid == 0 && ng > 0) flush(ng);
+}
+
+template <int R, int W> int launch_mw(const FusedParams& p, int x_dtype, hipStream_t s) {
+    using G = GeoMW<R, W>;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    const size_t lds = mw_lds_bytes<R, W>(p.K);
+    if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the multi-wave fused kernel", G::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
+    const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
+    const void* fn = nullptr;
+    switch (x_dtype) {
+        case PVX_F32: fn = al2 ? (const void*)k_fused_mw<R, W, float, true> : (const void*)k_fused_mw<R, W, float, false>; break;
+        case PVX_F64: fn = (const void*)k_fused_mw<R, W, double, false>; break;
+        case PVX_I16: fn = (const void*)k_fused_mw<R, W, int16_t, false>; break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, 64 * W, lds) != hipSuccess || blocks_per_cu < 1)
+        blocks_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    if (blocks_per_cu * W > 8) blocks_per_cu = (8 / W) > 0 ? 8 / W : 1;     // 2 waves per SIMD
+    int64_t nblocks = (int64_t)ncu * blocks_per_cu;
+    if (p.blocks_override > 0) nblocks = p.blocks_override;
+    const int64_t min_rows = 4;
+    const int64_t maxb = p.total_rows / min_rows;
+    if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
+    dim3 grid((unsigned)nblocks), block(64 * W);
+    switch (x_dtype) {
+        case PVX_F32:
+            if (al2) hipLaunchKernelGGL((k_fused_mw<R, W, float, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((k_fused_mw<R, W, float, false>), grid, block, lds, s, p);
+            break;
+        case PVX_F64: hipLaunchKernelGGL((k_fused_mw<R, W, double, false>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((k_fused_mw<R, W, int16_t, false>), grid, block, lds, s, p); break;
+    }
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}
+
+}  // namespace
+
+int pvx_fused_mw_supported(int nfft, int precision, int K) {
+    if (precision != 32) return 0;
+    switch (nfft) {
+        case 2048: return mw_lds_bytes<8, 2>(K) <= 160 * 1024;
+        case 4096: return mw_lds_bytes<8, 4>(K) <= 160 * 1024;
+        case 8192: return mw_lds_bytes<8, 8>(K) <= 160 * 1024;
+        default: return 0;
+    }
+}
+
+int pvx_launch_fused_mw(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
+    if (p.total_rows <= 0) return PVX_OK;
+    switch (nfft) {
+        case 2048: return launch_mw<8, 2>(p, x_dtype, s);
+        case 4096: return launch_mw<8, 4>(p, x_dtype, s);
+        case 8192: return launch_mw<8, 8>(p, x_dtype, s);
+        default: pvx_set_error("the multi-wave fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
+    }
+}

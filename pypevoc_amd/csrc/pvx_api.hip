@@ -135,7 +135,11 @@ extern "C" int64_t pvx_plan_workspace_bytes(const pvx_plan* plan) { return plan 
 
 extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
-    if (mode != 0 && mode != 1) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
+    if (mode != 0 && mode != 1 && mode != 2) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
+    if (mode == 2 && !pvx_fused_mw_supported(plan->nfft, plan->precision, plan->npks)) {
+        pvx_set_error("the multi-wave fused kernel handles nfft in {2048, 4096, 8192} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
+        return PVX_ERR_UNSUPPORTED;
+    }
     if (mode == 1 && !pvx_fused_supported(plan->nfft, plan->precision, plan->npks)) {
         pvx_set_error("the fused kernel handles nfft in {512, 1024, 2048} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
         return PVX_ERR_UNSUPPORTED;
@@ -225,14 +229,19 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     }
 
     // fused kernel tables
-    if (pvx_fused_supported(nfft, precision, npks)) {
+    const bool can1 = pvx_fused_supported(nfft, precision, npks) != 0, can2 = pvx_fused_mw_supported(nfft, precision, npks) != 0;
+    if (can1 || can2) {
         std::vector<float> tw(2 * (size_t)nfft);
         const double pi = 3.141592653589793238462643383279502884;
         for (int j = 0; j < nfft; j++) { tw[2 * j] = (float)cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = (float)(-sin(2.0 * pi * j / (double)nfft)); }
         if (hipMalloc(&p->d_twiddle, tw.size() * 4) != hipSuccess || hipMalloc((void**)&p->d_specrow, (size_t)nfft * 4) != hipSuccess) { pvx_set_error("hipMalloc(fused tables) failed"); plan_free(p); return PVX_ERR_ALLOC; }
         if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
-        p->fft_mode = 1;
-        if (const char* e = getenv("PVX_FFT_MODE")) { if (atoi(e) == 0) p->fft_mode = 0; }
+        // default: one wave per frame where it exists (nfft <= 2048), several waves per frame above
+        p->fft_mode = can1 ? 1 : 2;
+        if (const char* e = getenv("PVX_FFT_MODE")) {
+            const int m = atoi(e);
+            if (m == 0 || (m == 1 && can1) || (m == 2 && can2)) p->fft_mode = m;
+        }
         if (const char* e = getenv("PVX_FUSED_BLOCKS")) { const long long v = atoll(e); if (v > 0) p->fused_blocks = v; }
     }
     *out = p;
@@ -325,8 +334,8 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
                         int64_t spec_row = -1) {
     const int64_t total_rows = nsig * (F + 1);
     int rc;
-    if (p->fft_mode == 1) {
-        // one launch: window + FFT + peaks per wave, no intermediate arrays (k_fused.hip)
+    if (p->fft_mode == 1 || p->fft_mode == 2) {
+        // one launch: window + FFT + peaks, no intermediate arrays (k_fused.hip / k_fused_mw.hip)
         FusedParams fp;
         fp.x = d_x; fp.sig_stride = sig_stride; fp.F = F; fp.total_rows = total_rows;
         fp.hop = p->hop; fp.K = p->npks; fp.rad = 5;                                     // PV.py:177
@@ -337,7 +346,8 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.spec_out = spec_row >= 0 ? p->d_specrow : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
         if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
-        if ((rc = pvx_launch_fused(fp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
+        rc = (p->fft_mode == 1) ? pvx_launch_fused(fp, p->nfft, x_dtype, s) : pvx_launch_fused_mw(fp, p->nfft, x_dtype, s);
+        if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }
     if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
@@ -444,7 +454,7 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
     PVX_HIP_CHECK(hipMemcpy(binno, d_binno, fk, hipMemcpyDeviceToHost));
     if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
     if (totalmag) PVX_HIP_CHECK(hipMemcpy(totalmag, d_tm, f1, hipMemcpyDeviceToHost));
-    if (last_spec && p->fft_mode == 1) {
+    if (last_spec && p->fft_mode != 0) {
         std::vector<float> tmp(2 * (size_t)p->N2);
         PVX_HIP_CHECK(hipMemcpy(tmp.data(), p->d_specrow, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = (double)tmp[i];

@@ -1,0 +1,118 @@
+// pvx_fft.h -- in-register / cross-lane FFT building blocks shared by the fused analysis kernels
+// (k_fused.hip: one wave per frame; k_fused_mw.hip: several waves per frame).
+#pragma once
+
+#include "pvx_wave.h"
+
+namespace pvxf {
+
+// W_64^k = (kW64r[k], kW64i[k])
+constexpr float kW64r[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, 0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
+constexpr float kW64i[64] = {0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, 0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f};
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+constexpr int bitrev_c(int v, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++) if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+    return r;
+}
+
+// complex multiply with explicit fused multiply-adds: the same rounding wherever it is inlined, so
+// results do not depend on which wave computes a frame
+__device__ __forceinline__ void cmul(float& a, float& c, float wr, float wi) {
+    const float nr = __builtin_fmaf(a, wr, -(c * wi));
+    c = __builtin_fmaf(a, wi, c * wr);
+    a = nr;
+}
+
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// value of lane (l ^ H) for H in {1, 2, 4, 8}
+template <int H> __device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (H == 1) return dppf<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) return dppf<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (H << 10) | 0x1f));
+}
+
+// ---- radix-16 DFT in registers (radix-4 x radix-4), forward, natural order in and out
+__device__ __forceinline__ void dft16(float (&xr)[16], float (&xi)[16]) {
+    constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f;   // sin(pi/8)
+    constexpr float H = 0.70710678118654752440f;    // sqrt(1/2)
+    // W16^m = (cr[m], ci[m]) for m = n1*k2
+    constexpr float cr[10] = {1.f, C1, H, S1, 0.f, 0.f, -H, 0.f, 0.f, -C1};
+    constexpr float ci[10] = {0.f, -S1, -H, -C1, -1.f, 0.f, -H, 0.f, 0.f, S1};
+    float tr[16], ti[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) {
+        const float ar = xr[n1], ai = xi[n1], br = xr[n1 + 4], bi = xi[n1 + 4];
+        const float cr_ = xr[n1 + 8], ci_ = xi[n1 + 8], dr = xr[n1 + 12], di = xi[n1 + 12];
+        const float Ar = ar + cr_, Ai = ai + ci_, Br = ar - cr_, Bi = ai - ci_;
+        const float Cr = br + dr, Ci = bi + di, Dr = br - dr, Di = bi - di;
+        float yr[4], yi[4];
+        yr[0] = Ar + Cr; yi[0] = Ai + Ci;
+        yr[2] = Ar - Cr; yi[2] = Ai - Ci;
+        yr[1] = Br + Di; yi[1] = Bi - Dr;        // B - i D
+        yr[3] = Br - Di; yi[3] = Bi + Dr;        // B + i D
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const int m = n1 * k2;
+            if (m == 0) { tr[n1 * 4 + k2] = yr[k2]; ti[n1 * 4 + k2] = yi[k2]; }
+            else if (m == 4) { tr[n1 * 4 + k2] = yi[k2]; ti[n1 * 4 + k2] = -yr[k2]; }     // * (-i)
+            else {
+                float a = yr[k2], c = yi[k2];
+                cmul(a, c, cr[m], ci[m]);
+                tr[n1 * 4 + k2] = a; ti[n1 * 4 + k2] = c;
+            }
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) {
+        const float ar = tr[k2], ai = ti[k2], br = tr[4 + k2], bi = ti[4 + k2];
+        const float cr_ = tr[8 + k2], ci_ = ti[8 + k2], dr = tr[12 + k2], di = ti[12 + k2];
+        const float Ar = ar + cr_, Ai = ai + ci_, Br = ar - cr_, Bi = ai - ci_;
+        const float Cr = br + dr, Ci = bi + di, Dr = br - dr, Di = bi - di;
+        xr[k2] = Ar + Cr;      xi[k2] = Ai + Ci;
+        xr[k2 + 8] = Ar - Cr;  xi[k2 + 8] = Ai - Ci;
+        xr[k2 + 4] = Br + Di;  xi[k2 + 4] = Bi - Dr;
+        xr[k2 + 12] = Br - Di; xi[k2 + 12] = Bi + Dr;
+    }
+}
+
+// ---- radix-R DFT in registers for any power of two R <= 64: unrolled radix-2 decimation in
+// frequency with compile-time twiddles, natural order in and out (the bit reversal is a renaming)
+template <int R> __device__ __forceinline__ void dft_regs(float (&xr)[R], float (&xi)[R]) {
+    if constexpr (R == 16) {
+        dft16(xr, xi);
+    } else {
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+                for (int i = 0; i < h; i++) {
+                    const int a = blk + i, b = blk + i + h;
+                    const float sr = xr[a] + xr[b], si = xi[a] + xi[b];
+                    float dr = xr[a] - xr[b], di = xi[a] - xi[b];
+                    const int tw = i * (32 / h);                    // W_2h^i = W_64^(i * 64/(2h))
+                    if (tw == 0) { }
+                    else if (tw == 16) { const float t = dr; dr = di; di = -t; }      // * (-i)
+                    else cmul(dr, di, kW64r[tw], kW64i[tw]);
+                    xr[a] = sr; xi[a] = si; xr[b] = dr; xi[b] = di;
+                }
+            }
+        }
+        constexpr int bits = ilog2(R);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int j = bitrev_c(i, bits);
+            if (i < j) { float t = xr[i]; xr[i] = xr[j]; xr[j] = t; t = xi[i]; xi[i] = xi[j]; xi[j] = t; }
+        }
+    }
+}
+
+template <typename InT> __device__ __forceinline__ float ld1(const InT* p) { return (float)*p; }
+
+
+}  // namespace pvxf

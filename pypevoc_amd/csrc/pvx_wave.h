@@ -96,20 +96,15 @@ template <> struct Key<double> {
 //   taken in ascending index order until npeaks are selected.
 // Output: out[0..count) ascending bin indices (wave-uniform count).
 //   y[n] row; cs[cap]/ci[cap] candidate scratch, cap >= n/2 + 1.
-//   NS > 0: n == NS is known at compile time (fused kernel): the scan is unrolled and split into a
-//   read phase (all LDS loads in flight at once) and a compaction phase, one LDS round trip instead
-//   of one per 64 bins.
-template <typename T, int NS = 0>
-__device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
-                                  bool have_minamp, T miny, int lane) {
-    if (n < 3) return 0;
-    // PF.py:69-70: "if not self.minamp: self.minamp = np.min(self.y)"
-    const double minamp = (have_minamp && minamp_in != 0.0) ? minamp_in : (double)miny;
-    const double th = minamp - (double)miny;                        // PF.py:174
-    // ---- candidates, compacted in ascending bin order
+// peak_scan: candidates among bins [kbase, kbase + nscan) of the row y[0..n), compacted in ascending
+// bin order into cs/ci; returns their number (wave-uniform).
+//   NIT > 0: nscan == 64*NIT is known at compile time (fused kernels): the scan is unrolled and split
+//   into a read phase (all LDS loads in flight at once) and a compaction phase, one LDS round trip
+//   instead of one per 64 bins.
+template <typename T, int NIT = 0>
+__device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n, T miny, double th, T* cs, int* ci, int lane) {
     int C = 0;
-    if constexpr (NS > 0) {
-        constexpr int NIT = (NS + 63) / 64;
+    if constexpr (NIT > 0) {
         const float thf = __double2float_rd(th);
         T sv[NIT];
         unsigned long long bals[NIT];
@@ -117,21 +112,21 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
         T ya[NIT], yb[NIT], yc[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
-            const int k = i * 64 + lane;
-            const int kc = k < NS ? k : NS - 1;
+            const int k = kbase + i * 64 + lane;
+            const int kc = k < n ? k : n - 1;
             ya[i] = y[kc > 0 ? kc - 1 : 0];
             yb[i] = y[kc];
-            yc[i] = y[kc < NS - 1 ? kc + 1 : NS - 1];
+            yc[i] = y[kc < n - 1 ? kc + 1 : n - 1];
         }
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
-            const int k = i * 64 + lane;
+            const int k = kbase + i * 64 + lane;
             const T s = (T)(yb[i] - miny);
             // (double)s > th  <=>  s > thf with thf = th rounded DOWN to float (the next float above
             // thf is already > th), so the float32 instantiation needs no float64 compare per bin
             bool above;
             if constexpr (sizeof(T) == 4) above = s > thf; else above = (double)s > th;
-            const bool cand = ((int)(k >= 1) & (int)(k <= NS - 2) & (int)(ya[i] < yb[i]) & (int)(yb[i] >= yc[i]) & (int)above) != 0;
+            const bool cand = ((int)(k >= 1) & (int)(k <= n - 2) & (int)(ya[i] < yb[i]) & (int)(yb[i] >= yc[i]) & (int)above) != 0;
             sv[i] = s;
             bals[i] = __ballot(cand);
         }
@@ -139,16 +134,16 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
         for (int i = 0; i < NIT; i++) {
             const unsigned long long bal = bals[i];
             if (bal != 0ull) {                                       // wave-uniform
-                if ((bal >> lane) & 1ull) { const int pos = C + lane_prefix(bal); cs[pos] = sv[i]; ci[pos] = i * 64 + lane; }
+                if ((bal >> lane) & 1ull) { const int pos = C + lane_prefix(bal); cs[pos] = sv[i]; ci[pos] = kbase + i * 64 + lane; }
                 C += __popcll(bal);
             }
         }
     } else {
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
+        for (int k0 = 0; k0 < nscan; k0 += 64) {
+            const int k = kbase + k0 + lane;
             bool cand = false;
             T s = (T)0;
-            if (k >= 1 && k <= n - 2) {
+            if (k0 + lane < nscan && k >= 1 && k <= n - 2) {
                 const T a = y[k - 1], b = y[k], c = y[k + 1];
                 s = (T)(b - miny);
                 cand = (a < b) && (b >= c) && ((double)s > th);
@@ -158,7 +153,13 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
             C += __popcll(bal);
         }
     }
-    wave_sync();
+    return C;
+}
+
+// peak_pick: the npeaks best of the C candidates in cs/ci (list in ascending bin order) -> out[],
+// ascending bins; returns the count (wave-uniform).  th < 0 additionally admits the zeros of pkmskamp.
+template <typename T>
+__device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, int n, int npeaks, int C, double th, int lane) {
     if (C <= npeaks) {
         if (th < 0.0 && C < npeaks) {
             // zeros of pkmskamp are above the (negative) threshold: all maxima, then the first
@@ -239,6 +240,24 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
     }
     wave_sync();
     return cnt;
+}
+
+// threshold of PF.py:69-70, 174: th = minamp - miny with "if not self.minamp: minamp = min(y)"
+template <typename T>
+__device__ __forceinline__ double peak_threshold(double minamp_in, bool have_minamp, T miny) {
+    const double minamp = (have_minamp && minamp_in != 0.0) ? minamp_in : (double)miny;
+    return minamp - (double)miny;
+}
+
+//   NS > 0: n == NS is known at compile time (fused kernel)
+template <typename T, int NS = 0>
+__device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
+                                  bool have_minamp, T miny, int lane) {
+    if (n < 3) return 0;
+    const double th = peak_threshold<T>(minamp_in, have_minamp, miny);
+    const int C = peak_scan<T, (NS + 63) / 64>(y, 0, n, n, miny, th, cs, ci, lane);
+    wave_sync();
+    return peak_pick<T>(y, cs, ci, out, n, npeaks, C, th, lane);
 }
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in

@@ -309,8 +309,23 @@ def test_fused_kernel_variants(amd, oracle):
         p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
         assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1
         assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
-    p = run_pv(amd, x.astype(np.float32), sr, 4096, 1024, K, precision=32)
-    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 0          # rocFFT path
+    # nfft 4096 / 8192: the multi-wave-per-frame fused kernel (fft mode 2); nfft 2048 can run it too
+    xl = _rand_signal(22, 70000)
+    for nf, hp, mode in ((4096, 1024, None), (4096, 999, None), (8192, 2048, None), (2048, 512, 2), (2048, 333, 2)):
+        if mode is not None:
+            os.environ["PVX_FFT_MODE"] = str(mode)
+        try:
+            for xin in (xl.astype(np.float32), xl):
+                o = oracle.analyze(xl, sr, nf, hp, K)
+                p = run_pv(amd, xin, sr, nf, hp, K, precision=32)
+                assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 2
+                assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
+                last = oracle.stft_frame(xl, (p.nframes - 1) * hp, nf)
+                assert np.abs(p.oldfft - last).max() <= 2e-6 * np.abs(last).max()
+        finally:
+            os.environ.pop("PVX_FFT_MODE", None)
+    p = run_pv(amd, xl, sr, 16384, 4096, K, precision=32)
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 0          # rocFFT path beyond 8192
     # K > 64 and K = 1 through the fused staging paths
     for K2 in (1, 70):
         o = oracle.analyze(x, sr, nfft, 512, K2, 0.0005)
