@@ -95,8 +95,9 @@ struct FusedLds {       // per-wave carve
 template <int R> __host__ __device__ inline size_t fused_lds_per_wave(int K) {
     using G = Geo<R>;
     const size_t kpad = (size_t)((K + 3) & ~3);
+    const size_t gs = (size_t)staged_frames(K, GF);
     size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)G::M * 4 + (size_t)G::CAP * 4 * 2 + kpad * 4 +
-               (size_t)GF * kpad * 4 + (size_t)GF * kpad * 5 * 4 + GF * 4 + GF * 4;
+               gs * kpad * 4 + gs * kpad * 5 * 4 + GF * 4 + GF * 4;
     b = (b + 7) & ~(size_t)7;
     b += GF * 8 + GF * 8;
     return (b + 15) & ~(size_t)15;
@@ -127,8 +128,9 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     L.ci = (int*)(L.cs + G::CAP);
     L.sel = L.ci + G::CAP;
     L.sbin = L.sel + kpad;
-    L.sval = (float*)(L.sbin + GF * kpad);
-    L.cnt = (int*)(L.sval + GF * kpad * 5);
+    const int gs = staged_frames(K, GF);
+    L.sval = (float*)(L.sbin + gs * kpad);
+    L.cnt = (int*)(L.sval + gs * kpad * 5);
     L.frm = L.cnt + GF;
     L.orow = (long long*)(((uintptr_t)(L.frm + GF) + 7) & ~(uintptr_t)7);
     L.tot = (double*)(L.orow + GF);
@@ -313,8 +315,7 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     // per-peak pass over the staged frames [0, ng)
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
-    const int fpp = 64 / LPF;
-    const int G_ = (fpp < GF) ? fpp : GF;                         // frames staged per pass
+    const int G_ = gs;                                            // frames staged per pass
     const int gl = lane / LPF, e0 = lane - gl * LPF;
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {

@@ -56,7 +56,7 @@ template <int R, int W> __host__ __device__ inline size_t mw_lds_bytes(int K) {
              + (size_t)G::M * 4                                 // y
              + (size_t)G::CAP * 4 * 2                           // cs | ci
              + kpad * 4                                         // sel
-             + (size_t)GFM * kpad * 4 + (size_t)GFM * kpad * 5 * 4   // sbin | sval
+             + (size_t)staged_frames(K, GFM) * kpad * 4 * 6        // sbin | sval
              + GFM * 4 * 2 + W * 4 + W * 4 * 2;                 // cnt | frm | Cw | pmax | pmin
     b = (b + 7) & ~(size_t)7;
     b += GFM * 8 * 2 + W * 8;                                   // orow | tot | psum
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     int* ci = (int*)(cs + G::CAP);
     int* sel = ci + G::CAP;
     int* sbin = sel + kpad;
-    float* sval = (float*)(sbin + GFM * kpad);
-    int* cntv = (int*)(sval + GFM * kpad * 5);
+    const int gs = staged_frames(K, GFM);
+    float* sval = (float*)(sbin + gs * kpad);
+    int* cntv = (int*)(sval + gs * kpad * 5);
     int* frmv = cntv + GFM;
     int* Cw = frmv + GFM;
     float* pmax = (float*)(Cw + W);
@@ -276,8 +277,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     // per-peak pass over the staged frames [0, ng): wave 0 only
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
-    const int fpp = 64 / LPF;
-    const int G_ = (fpp < GFM) ? fpp : GFM;                       // frames staged per pass
+    const int G_ = gs;                                            // frames staged per pass
     const int gl = lane / LPF, e0 = lane - gl * LPF;
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {

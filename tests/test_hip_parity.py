@@ -326,6 +326,10 @@ def test_fused_kernel_variants(amd, oracle):
             os.environ.pop("PVX_FFT_MODE", None)
     p = run_pv(amd, xl, sr, 16384, 4096, K, precision=32)
     assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 0          # rocFFT path beyond 8192
+    # very large npks: too much staging for the fused kernels' LDS -> the rocFFT path takes over
+    o = oracle.analyze(x, sr, nfft, 512, 900, 0.0)
+    p = run_pv(amd, x, sr, nfft, 512, 900, 0.0, precision=32)
+    assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
     # K > 64 and K = 1 through the fused staging paths
     for K2 in (1, 70):
         o = oracle.analyze(x, sr, nfft, 512, K2, 0.0005)
