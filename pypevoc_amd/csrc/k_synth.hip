@@ -158,27 +158,44 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
             // ---- body segment ii (kind 0) or the final phase of the last segment (kind 2)
             // PVAnalysis.py:705-708: ph[m] = 2 pi * sum_{q<m} fsig[h*ii + q] / sr, m = 0..h-1
             const double nbase = dh * (double)ii;
-            double carry = 0.0, myph[1];
+            double carry = 0.0;
             // phase corrections, PVAnalysis.py:711-718
             const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
             const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
             const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
             const double ph0 = pr[ii - j0] + phcor;                       // PVAnalysis.py:721
             double lastph = 0.0;       // ph[h-1] + ph0 (before the discontinuity ramp)
-            // first sweep: prefix sums; keep each thread's values for up to one chunk at a time.
-            // Because the ramp needs ph[h-1] (phend) before any sample can be finalised, run the scan
-            // twice: sweep A computes the total, sweep B produces the samples.
+            // Prefix sums of the per-sample phase increments.  The ramp needs ph[h-1] (phend) before
+            // any sample can be finalised; for h <= CH*NT the prefix of every sample stays in
+            // registers (one scan sweep), longer hops scan twice.
+            constexpr int CH = 4;
+            const int nch = (h + NT - 1) / NT;
+            const bool one_sweep = nch <= CH;
+            double php[CH];
             {
-                double tot_all = 0.0;
-                for (int c0 = 0; c0 < h; c0 += NT) {
+                double run = 0.0;
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    php[c] = 0.0;
+                    if (c < nch) {
+                        const int m = c * NT + tid;
+                        double term = 0.0;
+                        if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                        double tot;
+                        const double inc = block_scan(term, sc, &tot);
+                        php[c] = run + inc;
+                        run += tot;
+                    }
+                }
+                for (int c0 = CH * NT; c0 < h; c0 += NT) {            // only when !one_sweep
                     const int m = c0 + tid;
                     double term = 0.0;
                     if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
                     double tot;
                     (void)block_scan(term, sc, &tot);
-                    tot_all += tot;
+                    run += tot;
                 }
-                lastph = kPi2 * tot_all + ph0;
+                lastph = kPi2 * run + ph0;
             }
             if (kind == 2) {
                 // ---- release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam
@@ -206,18 +223,30 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 const double dph = md - kPi;
                 step = dph / dh;                                          // np.linspace(0, dph, h+1)[:-1]
             }
-            for (int c0 = 0; c0 < h; c0 += NT) {
-                const int m = c0 + tid;
-                double term = 0.0;
-                if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
-                double tot;
-                const double inc = block_scan(term, sc, &tot);
-                if (m < h) {
-                    myph[0] = kPi2 * (carry + inc) + ph0 + ((double)m * step + 0.0);
-                    const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
-                    acc[m] += ms * cos(myph[0]);                          // PVAnalysis.py:734-736
+            if (one_sweep) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const int m = c * NT + tid;
+                    if (c < nch && m < h) {
+                        const double ph_m = kPi2 * php[c] + ph0 + ((double)m * step + 0.0);
+                        const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
+                        acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
+                    }
                 }
-                carry += tot;
+            } else {
+                for (int c0 = 0; c0 < h; c0 += NT) {
+                    const int m = c0 + tid;
+                    double term = 0.0;
+                    if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                    double tot;
+                    const double inc = block_scan(term, sc, &tot);
+                    if (m < h) {
+                        const double ph_m = kPi2 * (carry + inc) + ph0 + ((double)m * step + 0.0);
+                        const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
+                        acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
+                    }
+                    carry += tot;
+                }
             }
         }
     }

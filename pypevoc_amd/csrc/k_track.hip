@@ -10,7 +10,7 @@
 //                  descending magnitude against previous peaks in descending magnitude
 //   k_scan_counts  exclusive scan of "partials created per frame" -> creation-order numbering
 //   k_root_*       pointer jumping along the links: every peak learns the first point of its partial
-//   k_assign_ids   partial_id / part_start / part_len
+//   k_assign_ids   partial_id / part_start / part_len (length written by the partial's last point)
 // Tiny, latency-bound integer work (<= K^2 compares per frame); no roofline claim.
 //
 // Exact-tie rule (measure-zero on real data): equal magnitudes are ordered higher slot first
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
         wave_argmin(best, bi);
         const bool hit = (bi != 0x7fffffff) && (best < p.maxjmp);    // PVAnalysis.py:923
         if (lane == 0) {
-            if (hit) { link[s] = porder[bi]; used[bi] = 1; }
+            if (hit) { link[s] = porder[bi]; used[bi] = 1; p.succ[(fr - 1) * K + porder[bi]] = 1; }
             else { link[s] = -1; nrk[s] = nnew; }                    // add_empty_partial
         }
         if (!hit) nnew++;
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
     p.partial_id[i] = (int32_t)pid;
     if (pid < p.cap) {
         if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
-        atomicAdd(&p.part_len[pid], 1);                              // append_point
+        // the last point of a partial (no peak of the next frame continues it) knows the length:
+        // one plain store per partial instead of one contended atomic per point
+        if (!p.succ[i]) p.part_len[pid] = (int32_t)(i / p.K - rfr + 1);
     }
 }
 
@@ -194,7 +196,7 @@ int pvx_launch_track(const TrackParams& p, hipStream_t s) {
     size_t per_wave = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 3;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
     if (per_wave * waves > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
-    PVX_HIP_CHECK(hipMemsetAsync(p.part_len, 0, sizeof(int32_t) * (size_t)p.cap, s));
+    PVX_HIP_CHECK(hipMemsetAsync(p.succ, 0, (size_t)n, s));
     hipLaunchKernelGGL(k_track_links, dim3((unsigned)((p.F + waves - 1) / waves)), dim3(64 * waves), per_wave * waves, s, p);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
     const unsigned nb = (unsigned)((n + 255) / 256);

@@ -558,14 +558,14 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials int64
     const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
     size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
-    const size_t off_np = off_base + ((size_t)F + 1) * 8, total = off_np + 8;
+    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 8, total = off_succ + n;
     if ((rc = ws.alloc(total)) != PVX_OK) return rc;
     char* w = (char*)ws.p;
     TrackParams tp;
     tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
     tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
     tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
-    tp.root2 = nullptr; tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
+    tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
     tp.npartials = (int64_t*)(w + off_np);
     rc = pvx_launch_track(tp, s);
     if (rc != PVX_OK) return rc;

@@ -116,7 +116,7 @@ struct TrackParams {
     int32_t* newcount;    // [F]     partials created at each frame
     int64_t* newbase;     // [F+1]   exclusive scan of newcount
     int32_t* root;        // [F][K]  flattened index of the first point of the slot's partial
-    int32_t* root2;       // ping-pong
+    unsigned char* succ;  // [F][K]  1 if a peak of the next frame continues this one
     int64_t* npartials;   // [1]
 };
 int pvx_launch_track(const TrackParams& p, hipStream_t s);
