@@ -25,6 +25,7 @@ constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kPi2 = 2.0 * kPi;
 constexpr int NT = 256;
 constexpr int WMAX = 40;   // window of partial points kept in LDS (needs ceil(dfr + .5) + 6 <= WMAX)
+constexpr int NBATCH = 12; // contributions whose windows are gathered together
 
 struct Win {               // a window of one partial's points, j in [j0, j0 + n)
     double f[WMAX], m[WMAX], r[WMAX];
@@ -78,9 +79,12 @@ __device__ inline double block_scan(double v, double* sc, double* total) {
 __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* acc = (double*)smem;                       // [h] output accumulators
-    __shared__ Win win;
+    __shared__ Win wins[NBATCH];
     __shared__ double sc[NT / 64];
-    __shared__ int wslot[WMAX];
+    __shared__ int wslots[NBATCH][WMAX];
+    __shared__ int cb_pid[NBATCH], cb_st[NBATCH], cb_nfr[NBATCH], cb_ii[NBATCH], cb_kind[NBATCH], cb_j0[NBATCH], cb_wn[NBATCH];
+    __shared__ int wcnt[NT / 64];
+    __shared__ int qnext;
 
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
     const int64_t seg = blockIdx.x;                    // output samples [seg*h, seg*h + h)
@@ -97,42 +101,83 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     for (int m = tid; m < h; m += NT) acc[m] = 0.0;
 
     // contributions: kind 0 = body of a peak of frame seg; 1 = attack of a partial starting at
-    // frame seg+1 .. seg+EF; 2 = release of a partial whose last frame is seg-EF .. seg-1
-    const int64_t fr_lo = seg - EF, fr_hi = seg + EF;
-    for (int64_t fr = fr_lo; fr <= fr_hi; ++fr) {
-        if (fr < 0 || fr >= p.F) continue;
-        const int kind = (fr == seg) ? 0 : (fr > seg ? 1 : 2);
-        for (int s = 0; s < K; ++s) {
-            const int pid = p.partial_id[fr * K + s];
-            if (pid < 0) continue;
-            const int st = p.part_start[pid], nfr = p.part_len[pid];
-            if (nfr < p.minframes || nfr < 1) continue;                   // PVAnalysis.py:1061
-            if ((int64_t)st * h - edgsam + edgsamp < 0) continue;         // PVAnalysis.py:1067
-            const int ii = (int)(fr - st);                                // index of this point in its partial
-            if (kind == 1 && ii != 0) continue;
-            if (kind == 2 && ii != nfr - 1) continue;
-            // kind 0 additionally serves nothing else; a 1-point partial can be body + attack + release
-
-            // ---- gather the window of partial points into LDS
-            __syncthreads();
-            const int j0 = (ii - WB > 0) ? ii - WB : 0;
-            int j1 = ii + 3;
-            if (j1 > nfr - 1) j1 = nfr - 1;
-            const int wn = j1 - j0 + 1;                                   // <= WB + 4 <= WMAX (checked on the host)
-            for (int q = tid; q < wn * K; q += NT) {
-                const int d = q / K, s2 = q - d * K;
-                const int64_t f2 = (int64_t)st + j0 + d;
-                if (p.partial_id[f2 * K + s2] == pid) wslot[d] = s2;
+    // frame seg+1 .. seg+EF; 2 = release of a partial whose last frame is seg-EF .. seg-1.
+    // Candidates q = (frame - fr_lo) * K + slot are examined 256 at a time; the valid ones are taken
+    // in order, NBATCH per round, and the windows of partial points of a whole batch are gathered
+    // together: four global round trips per batch instead of four per contribution (this kernel is
+    // bound by those dependent loads, not by arithmetic).
+    const int64_t fr_lo = seg - EF;
+    const int NC = (2 * EF + 1) * K;
+    const int WL = WB + 4;                                            // window length (<= WMAX, host-checked)
+    for (int qbase = 0; qbase < NC;) {
+        // ---- round step 1: examine candidates qbase + [0, NT)
+        __syncthreads();
+        bool valid = false;
+        int c_pid_ = 0, c_st_ = 0, c_nfr_ = 0, c_ii_ = 0, c_kind_ = 0;
+        const int q = qbase + tid;
+        if (q < NC) {
+            const int64_t fr = fr_lo + q / K;
+            const int sl = q % K;
+            if (fr >= 0 && fr < p.F) {
+                const int pid = p.partial_id[fr * K + sl];
+                if (pid >= 0) {
+                    const int st = p.part_start[pid], nfr = p.part_len[pid];
+                    const int kind = (fr == seg) ? 0 : (fr > seg ? 1 : 2);
+                    const int ii = (int)(fr - st);                    // index of this point in its partial
+                    valid = !(nfr < p.minframes || nfr < 1)           // PVAnalysis.py:1061
+                            && !((int64_t)st * h - edgsam + edgsamp < 0)   // PVAnalysis.py:1067
+                            && !(kind == 1 && ii != 0) && !(kind == 2 && ii != nfr - 1);
+                    c_pid_ = pid; c_st_ = st; c_nfr_ = nfr; c_ii_ = ii; c_kind_ = kind;
+                }
             }
-            __syncthreads();
-            if (tid < wn) {
-                const int64_t node = ((int64_t)st + j0 + tid) * K + wslot[tid];
-                win.f[tid] = p.f[node];
-                win.m[tid] = p.mag[node];
-                win.r[tid] = p.realph[node];
+        }
+        // ---- step 2: ordered compaction of the valid candidates
+        const unsigned long long bal = __ballot(valid);
+        const int lane_ = tid & 63, wid_ = tid >> 6;
+        if (lane_ == 0) wcnt[wid_] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) { if (w < wid_) woff += wcnt[w]; total += wcnt[w]; }
+        const int pos = woff + __popcll(bal & ((1ull << lane_) - 1ull));
+        if (tid == 0) qnext = qbase + NT;
+        __syncthreads();
+        if (valid && pos < NBATCH) {
+            cb_pid[pos] = c_pid_; cb_st[pos] = c_st_; cb_nfr[pos] = c_nfr_; cb_ii[pos] = c_ii_; cb_kind[pos] = c_kind_;
+            const int j0 = (c_ii_ - WB > 0) ? c_ii_ - WB : 0;
+            int j1 = c_ii_ + 3;
+            if (j1 > c_nfr_ - 1) j1 = c_nfr_ - 1;
+            cb_j0[pos] = j0; cb_wn[pos] = j1 - j0 + 1;                // <= WB + 4 <= WMAX (checked on the host)
+            if (pos == NBATCH - 1) qnext = q + 1;                     // the rest is re-examined next round
+        }
+        __syncthreads();
+        const int nb = total < NBATCH ? total : NBATCH;
+        // ---- step 3: slots of the window points of the whole batch
+        for (int idx = tid; idx < nb * WL * K; idx += NT) {
+            const int bb = idx / (WL * K), rem = idx - bb * (WL * K);
+            const int d = rem / K, s2 = rem - d * K;
+            if (d < cb_wn[bb]) {
+                const int64_t f2 = (int64_t)cb_st[bb] + cb_j0[bb] + d;
+                if (p.partial_id[f2 * K + s2] == cb_pid[bb]) wslots[bb][d] = s2;
             }
-            if (tid == 0) { win.j0 = j0; win.n = wn; }
-            __syncthreads();
+        }
+        __syncthreads();
+        // ---- step 4: their values
+        for (int idx = tid; idx < nb * WL; idx += NT) {
+            const int bb = idx / WL, d = idx - bb * WL;
+            if (d < cb_wn[bb]) {
+                const int64_t node = ((int64_t)cb_st[bb] + cb_j0[bb] + d) * K + wslots[bb][d];
+                wins[bb].f[d] = p.f[node];
+                wins[bb].m[d] = p.mag[node];
+                wins[bb].r[d] = p.realph[node];
+            }
+        }
+        __syncthreads();
+        const int qn = qnext;
+        // ---- step 5: the contributions of the batch, in candidate order
+        for (int bb = 0; bb < nb; ++bb) {
+            const int st = cb_st[bb], nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
+            const Win& win = wins[bb];
             const double* pf = win.f;
             const double* pm = win.m;
             const double* pr = win.r;
@@ -249,6 +294,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 }
             }
         }
+        qbase = qn;
     }
     __syncthreads();
     for (int m = tid; m < h; m += NT) {
