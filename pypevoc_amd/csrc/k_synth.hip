@@ -53,6 +53,43 @@ __device__ inline double interp_w(double x, double h, double off, int nfr, const
     return slope * (x - xj) + fp[j - j0];
 }
 
+// np.interp restricted to a run of fewer than h consecutive sample positions x0, x0+1, ...: the
+// breakpoints xp[j] = h*(off+j) are h apart, so the run meets at most one of them and two linear
+// pieces (found once per contribution, with one division each) cover it.  Same slope and same
+// evaluation formula as interp_w / numpy, hence the same values.
+struct Piece2 { double b1, xa, fa, sa, xb, fb, sb; };
+
+__device__ inline void piece_of(int j, double h, double off, int nfr, const double* fp, int j0, double& xj, double& fj, double& sj) {
+    if (j < 0) { xj = 0.0; fj = fp[0 - j0]; sj = 0.0; return; }                     // left of xp[0]: fp[0]
+    if (j >= nfr - 1) { xj = 0.0; fj = fp[nfr - 1 - j0]; sj = 0.0; return; }        // at / right of xp[last]
+    xj = h * (off + (double)j);
+    const double xj1 = h * (off + (double)(j + 1));
+    fj = fp[j - j0];
+    sj = (fp[j + 1 - j0] - fp[j - j0]) / (xj1 - xj);
+}
+
+__device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, const double* fp, int j0) {
+    Piece2 q;
+    int j;
+    if (nfr == 1 || x0 < h * (off + 0.0)) j = -1;
+    else {
+        j = (int)floor(x0 / h - off);
+        if (j < 0) j = 0;
+        if (j > nfr - 1) j = nfr - 1;
+        while (j > 0 && x0 < h * (off + (double)j)) j--;
+        while (j < nfr - 1 && x0 >= h * (off + (double)(j + 1))) j++;
+    }
+    if (nfr == 1) j = nfr;                                       // constant everywhere
+    piece_of(j, h, off, nfr, fp, j0, q.xa, q.fa, q.sa);
+    piece_of(j + 1, h, off, nfr, fp, j0, q.xb, q.fb, q.sb);
+    q.b1 = (j + 1 <= nfr - 1 && nfr > 1) ? h * (off + (double)(j + 1)) : INFINITY;
+    return q;
+}
+
+__device__ inline double eval_piece2(const Piece2& q, double x) {
+    return (x < q.b1) ? (q.sa * (x - q.xa) + q.fa) : (q.sb * (x - q.xb) + q.fb);
+}
+
 // block-wide inclusive prefix sum of one double per thread (NT = 256 threads); returns the
 // inclusive value, *total = sum over the block.  Uses sc[4].
 __device__ inline double block_scan(double v, double* sc, double* total) {
@@ -209,6 +246,9 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
             const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
             const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
             const double ph0 = pr[ii - j0] + phcor;                       // PVAnalysis.py:721
+            // fsig over samples nbase .. nbase+h-2 and msig over nbase .. nbase+h-1 (two pieces each)
+            const Piece2 qf = make_piece2(nbase, dh, offf, nfr, pf, j0);
+            const Piece2 qm = make_piece2(nbase, dh, offm, nfr, pm, j0);
             double lastph = 0.0;       // ph[h-1] + ph0 (before the discontinuity ramp)
             // Prefix sums of the per-sample phase increments.  The ramp needs ph[h-1] (phend) before
             // any sample can be finalised; for h <= CH*NT the prefix of every sample stays in
@@ -225,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                     if (c < nch) {
                         const int m = c * NT + tid;
                         double term = 0.0;
-                        if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                        if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
                         double tot;
                         const double inc = block_scan(term, sc, &tot);
                         php[c] = run + inc;
@@ -235,7 +275,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 for (int c0 = CH * NT; c0 < h; c0 += NT) {            // only when !one_sweep
                     const int m = c0 + tid;
                     double term = 0.0;
-                    if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                    if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
                     double tot;
                     (void)block_scan(term, sc, &tot);
                     run += tot;
@@ -274,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                     const int m = c * NT + tid;
                     if (c < nch && m < h) {
                         const double ph_m = kPi2 * php[c] + ph0 + ((double)m * step + 0.0);
-                        const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
+                        const double ms = eval_piece2(qm, nbase + (double)m);
                         acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
                     }
                 }
@@ -282,12 +322,12 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 for (int c0 = 0; c0 < h; c0 += NT) {
                     const int m = c0 + tid;
                     double term = 0.0;
-                    if (m >= 1 && m < h) term = interp_w(nbase + (double)(m - 1), dh, offf, nfr, pf, j0) / p.sr;
+                    if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
                     double tot;
                     const double inc = block_scan(term, sc, &tot);
                     if (m < h) {
                         const double ph_m = kPi2 * (carry + inc) + ph0 + ((double)m * step + 0.0);
-                        const double ms = interp_w(nbase + (double)m, dh, offm, nfr, pm, j0);
+                        const double ms = eval_piece2(qm, nbase + (double)m);
                         acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
                     }
                     carry += tot;
