@@ -12,8 +12,12 @@
 // in LDS accumulators, then stores the segment once (coalesced).  No atomics; the order of the
 // additions is fixed (frame, then slot), so the output is reproducible run to run.
 //
-// Bound: f64 VALU (two interpolations, a block prefix sum and one cos per partial sample);
-// HBM traffic is 8*h bytes written per segment plus a few hundred bytes of table reads.
+// fsig and msig (np.interp of the partial's f / mag, PVAnalysis.py:701-702) are piecewise linear with
+// breakpoints one hop apart, so inside a segment each is two linear pieces and the cumulative phase
+// (PVAnalysis.py:705-708) is a quadratic in the sample index: every sample is evaluated independently
+// (no scan, no barrier), the per-contribution constants are derived once by one thread each.
+// Bound: f64 VALU (one cos per partial sample); HBM traffic is 8*h bytes written per segment plus
+// a few hundred bytes of table reads.
 // All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
 #include <math.h>
 
@@ -90,6 +94,22 @@ __device__ inline double eval_piece2(const Piece2& q, double x) {
     return (x < q.b1) ? (q.sa * (x - q.xa) + q.fa) : (q.sb * (x - q.xb) + q.fb);
 }
 
+// closed-form parameters of one contribution (see step 5 of the kernel)
+struct CParam {
+    int kind, fmb, mmb, pad_;
+    long long o0;
+    double ph0, step, amp, cfr;
+    double fa0, fsa, fb0, fsb, smb, tmb;     // fsig pieces and the sum / triangular number at the break
+    double ma0, msa, mb0, msb;               // msig pieces
+};
+
+// sum_{q=0}^{m-1} fsig(nbase + q) for the two-piece linear fsig of a contribution
+__device__ inline double prefix_sum(const CParam& c, int m) {
+    const double tm = 0.5 * (double)m * (double)(m - 1);
+    if (m <= c.fmb) return c.fa0 * (double)m + c.fsa * tm;
+    return c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
+}
+
 // block-wide inclusive prefix sum of one double per thread (NT = 256 threads); returns the
 // inclusive value, *total = sum over the block.  Uses sc[4].
 __device__ inline double block_scan(double v, double* sc, double* total) {
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     __shared__ int cb_pid[NBATCH], cb_st[NBATCH], cb_nfr[NBATCH], cb_ii[NBATCH], cb_kind[NBATCH], cb_j0[NBATCH], cb_wn[NBATCH];
     __shared__ int wcnt[NT / 64];
     __shared__ int qnext;
+    __shared__ CParam prm[NBATCH];
 
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
     const int64_t seg = blockIdx.x;                    // output samples [seg*h, seg*h + h)
@@ -211,128 +232,92 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
         }
         __syncthreads();
         const int qn = qnext;
-        // ---- step 5: the contributions of the batch, in candidate order
-        for (int bb = 0; bb < nb; ++bb) {
+        // ---- step 5: thread b derives the closed-form parameters of contribution b.  fsig and msig
+        // are piecewise linear (two pieces per hop), so the phase prefix sum of PVAnalysis.py:705-708 is
+        // a quadratic in the sample index: no scan, no barrier, every sample independent.
+        if (tid < nb) {
+            const int bb = tid;
             const int st = cb_st[bb], nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
-            const Win& win = wins[bb];
-            const double* pf = win.f;
-            const double* pm = win.m;
-            const double* pr = win.r;
+            const double* pf = wins[bb].f;
+            const double* pm = wins[bb].m;
+            const double* pr = wins[bb].r;
             const double offf = dfr + .5, offm = dfr;                     // PVAnalysis.py:701-702
-
+            CParam c;
+            c.kind = kind;
             if (kind == 1) {
-                // ---- attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam
-                const int64_t o0 = (int64_t)st * h - edgsam;
-                const double m0 = interp_w(0.0, dh, offm, nfr, pm, j0);   // msig[0]
-                const double c = pf[0 - j0] * 1.0 / p.sr;
-                for (int m = tid; m < h; m += NT) {
-                    const int64_t j = seg * (int64_t)h + m - o0;
-                    if (j >= 0 && j < edgsam) {
-                        const double a = m0 * (1 - cos(kPi * (double)j / (double)edgsam)) / 2.;
-                        // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
-                        const double phb = pr[0 - j0] - kPi2 * ((double)(edgsam - j) * c);
-                        acc[m] += a * cos(phb);
-                    }
-                }
-                continue;
-            }
-
-            // ---- body segment ii (kind 0) or the final phase of the last segment (kind 2)
-            // PVAnalysis.py:705-708: ph[m] = 2 pi * sum_{q<m} fsig[h*ii + q] / sr, m = 0..h-1
-            const double nbase = dh * (double)ii;
-            double carry = 0.0;
-            // phase corrections, PVAnalysis.py:711-718
-            const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
-            const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
-            const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
-            const double ph0 = pr[ii - j0] + phcor;                       // PVAnalysis.py:721
-            // fsig over samples nbase .. nbase+h-2 and msig over nbase .. nbase+h-1 (two pieces each)
-            const Piece2 qf = make_piece2(nbase, dh, offf, nfr, pf, j0);
-            const Piece2 qm = make_piece2(nbase, dh, offm, nfr, pm, j0);
-            double lastph = 0.0;       // ph[h-1] + ph0 (before the discontinuity ramp)
-            // Prefix sums of the per-sample phase increments.  The ramp needs ph[h-1] (phend) before
-            // any sample can be finalised; for h <= CH*NT the prefix of every sample stays in
-            // registers (one scan sweep), longer hops scan twice.
-            constexpr int CH = 4;
-            const int nch = (h + NT - 1) / NT;
-            const bool one_sweep = nch <= CH;
-            double php[CH];
-            {
-                double run = 0.0;
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    php[c] = 0.0;
-                    if (c < nch) {
-                        const int m = c * NT + tid;
-                        double term = 0.0;
-                        if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
-                        double tot;
-                        const double inc = block_scan(term, sc, &tot);
-                        php[c] = run + inc;
-                        run += tot;
-                    }
-                }
-                for (int c0 = CH * NT; c0 < h; c0 += NT) {            // only when !one_sweep
-                    const int m = c0 + tid;
-                    double term = 0.0;
-                    if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
-                    double tot;
-                    (void)block_scan(term, sc, &tot);
-                    run += tot;
-                }
-                lastph = kPi2 * run + ph0;
-            }
-            if (kind == 2) {
-                // ---- release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam
-                const int64_t o0 = ((int64_t)st + nfr) * h;
-                const double mend = interp_w(dh * (double)nfr, dh, offm, nfr, pm, j0);   // msig[hop*(ii+1)]
-                const double c = pf[nfr - 1 - j0] * 1.0 / p.sr;
-                for (int m = tid; m < h; m += NT) {
-                    const int64_t j = seg * (int64_t)h + m - o0;
-                    if (j >= 0 && j < edgsam) {
-                        const double a = mend * (1 + cos(kPi * (double)j / (double)edgsam)) / 2.;
-                        acc[m] += a * cos(lastph + kPi2 * ((double)(j + 1) * c));
-                    }
-                }
-                continue;
-            }
-            // kind 0: discontinuity ramp towards the next point, PVAnalysis.py:724-729
-            double step = 0.0;
-            if (ii < nfr - 1) {
-                const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf, j0);
-                const double phcornext = kPi * (fs2 - fs1) / fstep / 2.;
-                const double phend = lastph + kPi2 * fs1 / p.sr;
-                const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
-                double md = fmod(arg, kPi2);                              // np.mod: sign of the divisor
-                if (md != 0.0 && md < 0.0) md += kPi2;
-                const double dph = md - kPi;
-                step = dph / dh;                                          // np.linspace(0, dph, h+1)[:-1]
-            }
-            if (one_sweep) {
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    const int m = c * NT + tid;
-                    if (c < nch && m < h) {
-                        const double ph_m = kPi2 * php[c] + ph0 + ((double)m * step + 0.0);
-                        const double ms = eval_piece2(qm, nbase + (double)m);
-                        acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
-                    }
-                }
+                // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam
+                c.o0 = (long long)st * h - edgsam;
+                c.amp = interp_w(0.0, dh, offm, nfr, pm, j0);             // msig[0]
+                c.cfr = pf[0 - j0] * 1.0 / p.sr;
+                c.ph0 = pr[0 - j0];
             } else {
-                for (int c0 = 0; c0 < h; c0 += NT) {
-                    const int m = c0 + tid;
-                    double term = 0.0;
-                    if (m >= 1 && m < h) term = eval_piece2(qf, nbase + (double)(m - 1)) / p.sr;
-                    double tot;
-                    const double inc = block_scan(term, sc, &tot);
-                    if (m < h) {
-                        const double ph_m = kPi2 * (carry + inc) + ph0 + ((double)m * step + 0.0);
-                        const double ms = eval_piece2(qm, nbase + (double)m);
-                        acc[m] += ms * cos(ph_m);                         // PVAnalysis.py:734-736
-                    }
-                    carry += tot;
+                const double nbase = dh * (double)ii;
+                // phase corrections, PVAnalysis.py:711-718
+                const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
+                const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
+                const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
+                c.ph0 = pr[ii - j0] + phcor;                              // PVAnalysis.py:721
+                // fsig(nbase + q) = fa0 + fsa q for q < fmb, fb0 + fsb q beyond; msig likewise
+                const Piece2 qf = make_piece2(nbase, dh, offf, nfr, pf, j0);
+                const Piece2 qm = make_piece2(nbase, dh, offm, nfr, pm, j0);
+                c.fa0 = qf.sa * (nbase - qf.xa) + qf.fa; c.fsa = qf.sa;
+                c.fb0 = qf.sb * (nbase - qf.xb) + qf.fb; c.fsb = qf.sb;
+                c.ma0 = qm.sa * (nbase - qm.xa) + qm.fa; c.msa = qm.sa;
+                c.mb0 = qm.sb * (nbase - qm.xb) + qm.fb; c.msb = qm.sb;
+                double d = ceil(qf.b1 - nbase);
+                c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+                d = ceil(qm.b1 - nbase);
+                c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+                const double tm = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
+                c.smb = c.fa0 * (double)c.fmb + c.fsa * tm;               // sum of the first fmb terms
+                c.tmb = tm;
+                // ph[h-1] + ph0 (before the discontinuity ramp): prefix over q = 0 .. h-2
+                const double lastph = kPi2 * (prefix_sum(c, h - 1) / p.sr) + c.ph0;
+                c.step = 0.0;
+                if (kind == 2) {
+                    // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam
+                    c.o0 = ((long long)st + nfr) * h;
+                    c.amp = interp_w(dh * (double)nfr, dh, offm, nfr, pm, j0);        // msig[hop*(ii+1)]
+                    c.cfr = pf[nfr - 1 - j0] * 1.0 / p.sr;
+                    c.ph0 = lastph;
+                } else if (ii < nfr - 1) {
+                    // discontinuity ramp towards the next point, PVAnalysis.py:724-729
+                    const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf, j0);
+                    const double phcornext = kPi * (fs2 - fs1) / fstep / 2.;
+                    const double phend = lastph + kPi2 * fs1 / p.sr;
+                    const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
+                    double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
+                    if (md != 0.0 && md < 0.0) md += kPi2;
+                    c.step = (md - kPi) / dh;                             // np.linspace(0, dph, h+1)[:-1]
                 }
             }
+            prm[bb] = c;
+        }
+        __syncthreads();
+        // ---- step 6: every thread adds the batch's contributions to its own samples, in candidate order
+        for (int m = tid; m < h; m += NT) {
+            double a_ = acc[m];
+            const long long osamp = seg * (long long)h + m;
+            for (int bb = 0; bb < nb; ++bb) {
+                const CParam& c = prm[bb];
+                if (c.kind == 0) {
+                    const double ph_m = kPi2 * (prefix_sum(c, m) / p.sr) + c.ph0 + ((double)m * c.step + 0.0);
+                    const double ms = (m < c.mmb) ? (c.ma0 + c.msa * (double)m) : (c.mb0 + c.msb * (double)m);
+                    a_ += ms * cos(ph_m);                                 // PVAnalysis.py:734-736
+                } else {
+                    const long long j = osamp - c.o0;
+                    if (j >= 0 && j < edgsam) {
+                        const double cw = cos(kPi * (double)j / (double)edgsam);
+                        if (c.kind == 1) {
+                            // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
+                            a_ += (c.amp * (1 - cw) / 2.) * cos(c.ph0 - kPi2 * ((double)(edgsam - j) * c.cfr));
+                        } else {
+                            a_ += (c.amp * (1 + cw) / 2.) * cos(c.ph0 + kPi2 * ((double)(j + 1) * c.cfr));
+                        }
+                    }
+                }
+            }
+            acc[m] = a_;
         }
         qbase = qn;
     }
