@@ -430,3 +430,70 @@ def test_full_size_config2_properties(amd, oracle, monkeypatch):
     seg = slice(10 * sr, 11 * sr)
     xs = x[seg].astype(np.float64)
     assert np.corrcoef(xs, w[seg])[0, 1] > 0.99
+
+
+def test_config4_shard_shape_batch(amd):
+    """BASELINE config 4, one GPU's shard: 128 signals x 30 s @ 48 kHz, nfft=2048, hop=512, npks=8,
+    resident in HBM, analysed by ONE device call (nsig = 128, F = 2809 frames per signal).
+    Property: every signal of the batch equals its own single-signal analysis, bitwise."""
+    import ctypes
+    import torch
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    B, n, sr, nfft, hop, K = 128, 1440000, 48000, 2048, 512, 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    t = torch.arange(n, device=dev, dtype=torch.float64) / sr
+    x = torch.empty((B, n), dtype=torch.float32, device=dev)
+    for b in range(B):                                         # SURVEY 8d C4: f0 = 110 * 2^(b/1024*3)
+        f0 = 110.0 * 2 ** (b / 1024.0 * 3)
+        ph = 2 * np.pi * f0 * (t - 0.01 / (2 * np.pi * 5.0) * torch.cos(2 * np.pi * 5.0 * t))
+        s = torch.zeros(n, dtype=torch.float64, device=dev)
+        for h in range(1, 9):
+            s += 0.3 / h * torch.sin(h * ph)
+        s += 0.001 * torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+        x[b] = s.to(torch.float32)
+    F = int(lib.pvx_nframes(n, nfft, hop))
+    assert F == 2809
+    out = torch.zeros(5 * B * F * K + 2 * B * F, dtype=torch.float64, device=dev)
+    base = out.data_ptr()
+    ptrs = [base + i * B * F * K * 8 for i in range(5)] + [base + 5 * B * F * K * 8, base + 5 * B * F * K * 8 + B * F * 8]
+    plan = ctypes.c_void_p()
+    win = np.hanning(nfft)
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(sr), nfft, hop, K, 0.005, _lib.dptr(win), 32, 0), "plan")
+    stream = torch.cuda.current_stream(dev)
+    r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, n, B, n, *ptrs, None, ctypes.c_void_p(stream.cuda_stream))
+    _lib.check(r, "pvx_analyze_dev")
+    torch.cuda.synchronize()
+    res = out[: 5 * B * F * K].view(5, B, F, K).cpu().numpy()
+    tt = out[5 * B * F * K: 5 * B * F * K + B * F].view(B, F).cpu().numpy()
+    tm = out[5 * B * F * K + B * F:].view(B, F).cpu().numpy()
+    lib.pvx_plan_destroy(plan)
+    for b in (0, 77, 127):
+        p = run_pv(amd, x[b].cpu().numpy(), sr, nfft, hop, K)
+        for i, k in enumerate(("f", "mag", "ph", "realph", "binno")):
+            assert np.array_equal(res[i, b], getattr(p, k)), (b, k)
+        assert np.array_equal(tt[b], p.t) and np.array_equal(tm[b], np.array(p.totalmag))
+        # 8 harmonics of f0 are found in (nearly) every frame
+        f0 = 110.0 * 2 ** (b / 1024.0 * 3)
+        mid = res[0, b, 10:-10, 0]
+        assert np.median(np.abs(mid / f0 - 1.0)) < 0.02
+
+
+def test_multiwave_kernel_batch_and_streaming(amd, oracle):
+    """fft mode 2 (nfft 4096): batch of signals = loop, and frame-by-frame streaming = run_pv."""
+    sr, nfft, hop, K = 22050.0, 4096, 1024, 6
+    xs = np.stack([_rand_signal(30 + i, 40000).astype(np.float32) for i in range(3)])
+    b = amd.PVBatch(xs, sr, nfft=nfft, hop=hop, npks=K).run_pv()
+    for i in range(3):
+        r = run_pv(amd, xs[i], sr, nfft, hop, K)
+        for k in ("f", "mag", "ph", "realph", "binno"):
+            assert np.array_equal(getattr(b, k)[i], getattr(r, k)), (i, k)
+    ref = run_pv(amd, xs[0], sr, nfft, hop, K)
+    q = amd.PV(xs[0], sr, nfft=nfft, hop=hop, npks=K, progress=False)
+    for fr in range(4):
+        f, mag, ph, realph, binno, tm = q.calc_pv_frame(fr * hop)
+        n = len(f)
+        assert binno == [int(v) for v in ref.binno[fr, :n]] and n == int((ref.f[fr] > 0).sum())
+        np.testing.assert_allclose(f, ref.f[fr, :n], atol=2e-3)
