@@ -312,28 +312,40 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
     bool nanph = false;
     if constexpr (sizeof(T) == 4) {
         const float tph = atan2f(im, re);                            // PV.py:188
-        float dph;
         if (pr == 0.f && pi == 0.f) {
             // numpy: (a+bj)/(0+0j) = (a/0) + (b/0)j -> +-inf +-inf j, NaN when a or b is 0; angle()
             // is then +-pi/4, +-3pi/4 by quadrant (PV.py:171, 190: frame 0 and any frame that
-            // follows an all-zero one)
+            // follows an all-zero one).  That angle is the same float64 constant in the reference,
+            // and with hop = nfft/8 it puts two unwrapping candidates at EXACTLY the same distance
+            // from the bin centre, so the reference's own float64 rounding decides: follow its
+            // arithmetic literally here (rare frames, cost irrelevant).
             nanph = (re == 0.f || im == 0.f || re != re || im != im);
-            const float q4 = (float)(kPi / 4);
-            dph = (re > 0.f) ? (im > 0.f ? q4 : -q4) : (im > 0.f ? 3.f * q4 : -3.f * q4);
+            const double dphd = (re > 0.f) ? (im > 0.f ? kPi / 4 : -kPi / 4) : (im > 0.f ? 3 * kPi / 4 : -3 * kPi / 4);
+            const double fb = (double)nbin * c.fstep;
+            const double w0 = dphd + c.wfbin[nbin];
+            double bestabs = 0.0;
+            o.freq = 0.0; o.dfb = 0.0;
+#pragma unroll
+            for (int m = -1; m <= 1; m++) {
+                const double fq = (w0 + kPi2 * (double)m) / c.dt / kPi2;
+                const double df = fb - fq;
+                const double a = fabs(df);
+                if (m == -1 || a < bestabs) { o.freq = fq; o.dfb = df; bestabs = a; }
+            }
         } else {
-            dph = atan2f(im * pr - re * pi, re * pr + im * pi);      // angle(fx * conj(old))
+            const float dph = atan2f(im * pr - re * pi, re * pr + im * pi);   // angle(fx * conj(old))
             nanph = dph != dph;
+            // PV.py:140-147 in closed form: with cyc = nbin*hop/nfft (cycles the bin centre advances per
+            // hop) and w = wfbin/2pi, candidate m has df*dt = cyc - w - dph/2pi - m; cyc - w is exact in
+            // float64 and |cyc - w| <= 1/2
+            const double cw = (double)nbin * (double)c.hop / (double)c.nfft - c.wfbin[nbin] / kPi2;
+            const float u = (float)cw - dph * (float)(1.0 / kPi2);
+            float best = u + 1.f, ab = fabsf(best);                      // m = -1
+            if (fabsf(u) < ab) { best = u; ab = fabsf(u); }              // m = 0   (first minimum wins)
+            if (fabsf(u - 1.f) < ab) { best = u - 1.f; }                 // m = +1
+            o.dfb = (double)best / c.dt;                                 // df = fbin - freq
+            o.freq = (double)nbin * c.fstep - o.dfb;
         }
-        // PV.py:140-147 in closed form: with cyc = nbin*hop/nfft (cycles the bin centre advances per
-        // hop) and w = wfbin/2pi, candidate m has df*dt = cyc - w - dph/2pi - m; cyc - w is exact in
-        // float64 and |cyc - w| <= 1/2
-        const double cw = (double)nbin * (double)c.hop / (double)c.nfft - c.wfbin[nbin] / kPi2;
-        const float u = (float)cw - dph * (float)(1.0 / kPi2);
-        float best = u + 1.f, ab = fabsf(best);                      // m = -1
-        if (fabsf(u) < ab) { best = u; ab = fabsf(u); }              // m = 0   (first minimum wins)
-        if (fabsf(u - 1.f) < ab) { best = u - 1.f; }                 // m = +1
-        o.dfb = (double)best / c.dt;                                 // df = fbin - freq
-        o.freq = (double)nbin * c.fstep - o.dfb;
         o.thisph = (double)tph;
         o.mag = (double)sqrtf(s3);
     } else {
