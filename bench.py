@@ -96,15 +96,7 @@ def main():
     nsamp = x.numel()
     F = int(lib.pvx_nframes(nsamp, NFFT, HOP))
     K = NPKS
-    from pypevoc_amd.batch import PipelinedGather
-    # one packed result block per step -> one gather; double-buffered so that the gather of step i
-    # (RCCL, its own stream) overlaps the kernels of step i+1
-    nres = 5 * F * K + 2 * F
-    pipe = PipelinedGather(nres, torch.float64, dev, dst=0)
-
-    def out_ptrs(buf):
-        base = buf.data_ptr()
-        return [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
+    from pypevoc_amd.batch import PipelinedGather, ResultWire
 
     plan = ctypes.c_void_p()
     win = np.hanning(NFFT)
@@ -114,19 +106,44 @@ def main():
         _lib.check(lib.pvx_plan_set_fft_mode(plan, args.fft_mode), "pvx_plan_set_fft_mode")
     stream = torch.cuda.current_stream(dev)
 
+    # This rank's results in the reference's layout (five float64 [F, K] arrays + totalmag + t,
+    # PV.py:256-264).  With more than one rank every step ends in ONE gather to rank 0: the rows are
+    # packed to the 18 B/slot wire format (include/pvx.h), gathered asynchronously (RCCL, its own
+    # stream, double-buffered so that the gather of step i overlaps the kernels of step i+1) and
+    # unpacked on rank 0 into the full [world, ...] result, bit-identical to what each rank computed.
+    gathered = world > 1 or os.environ.get("PVX_BENCH_FORCE_GATHER") == "1"
+    if gathered and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    wire = ResultWire(plan, F, K)
+    res = torch.zeros(wire.result_numel() + F, dtype=torch.float64, device=dev)
+    rp = wire.result_ptrs(res.data_ptr())                          # f, mag, ph, realph, binno, totalmag
+    t_ptr = res.data_ptr() + wire.result_numel() * 8
+    full = torch.zeros((world, wire.result_numel()), dtype=torch.float64, device=dev) if (gathered and rank == 0) else None
+
+    def consume(step_no, blocks):                                  # rank 0, side stream
+        s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for r, b in enumerate(blocks):
+            wire.unpack(b.data_ptr(), full[r].data_ptr(), s)
+
+    pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume, force=gathered)
+
     counter = [0]
 
     def step():
         i = counter[0]
         counter[0] += 1
-        buf = pipe.buffer(i)                      # waits (on the stream) for the gather that last read it
-        r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp, *out_ptrs(buf), None,
-                                ctypes.c_void_p(stream.cuda_stream))
+        r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp, rp[0], rp[1], rp[2], rp[3], rp[4],
+                                t_ptr, rp[5], None, ctypes.c_void_p(stream.cuda_stream))
         _lib.check(r, "pvx_analyze_dev")
-        pipe.submit(i)                            # asynchronous gather to rank 0 (no-op on one GPU)
+        if gathered:
+            buf = pipe.buffer(i)                  # its previous gather has completed and been unpacked
+            wire.pack(res.data_ptr(), buf.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
+            pipe.submit(i)                        # asynchronous gather to rank 0
 
     def fence():
-        pipe.drain()                              # every outstanding gather has been waited for
+        pipe.drain()                              # every outstanding gather has been waited for and unpacked
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -162,6 +179,17 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    gather_info = None
+    if gathered and rank == 0:
+        # the block rank 0 received from itself must be, bit for bit, what its kernels wrote
+        torch.cuda.synchronize(dev)
+        if not torch.equal(full[0].view(torch.int64), res[: wire.result_numel()].view(torch.int64)):
+            sys.exit("bench.py: the gathered + unpacked block of rank 0 differs from its local result")
+        n_ok = int((full[:, : F * K] > 0).sum().item())
+        gather_info = dict(collective="one asynchronous RCCL gather per step to rank 0, double-buffered",
+                           wire_bytes_per_rank=int(wire.nbytes), result_bytes_per_rank=int(wire.result_numel() * 8),
+                           valid_peaks_gathered=n_ok)
 
     if rank == 0:
         ab = alg_bytes()
@@ -224,10 +252,16 @@ def main():
                        "parallelism": "signals sharded 1/GPU" if world > 1 else "single GPU"},
             "roofline": roofline, "stage": stage, "cpu_baseline": cpu,
         }
+        if gather_info:
+            line["gather"] = gather_info
+        try:
+            ctypes.CDLL(None).fflush(None)        # RCCL's version banner (C stdio) goes out before the JSON line
+        except Exception:
+            pass
         print(json.dumps(line))
         sys.stdout.flush()
     lib.pvx_plan_destroy(plan)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

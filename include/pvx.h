@@ -177,6 +177,25 @@ int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph
                   double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
                   double* d_w, int64_t wlen, void* stream);
 
+/* ---- multi-GPU result gather: compact wire format --------------------------------------
+ *
+ * The reference has no multi-device path; its results are the five float64 [F, K] arrays of
+ * PV.run_pv (PV.py:256-264), 40 B per peak slot.  For the gather of sharded results to one GPU
+ * (RCCL over xGMI, link-bound) a shard's rows are packed to 18 B (precision 32) or 26 B
+ * (precision 64) per slot: f (f64), mag, ph (f32|f64), binno (u16) + totalmag (f64) per row;
+ * realph = ph + pi*(fbin[binno] - f)/fstep (PV.py:146, 207) is recomputed by the receiver.
+ * pvx_unpack_rows_dev(pvx_pack_rows_dev(x)) == x bit for bit for anything pvx_analyze* produced
+ * with the same plan parameters.  `rows` = frames of all signals of the shard; all pointers are
+ * device memory; launches are asynchronous on `stream`.
+ */
+int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows);
+int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
+                      const double* d_ph, const double* d_binno, const double* d_totalmag,
+                      void* d_wire, void* stream);
+int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f,
+                        double* d_mag, double* d_ph, double* d_realph, double* d_binno,
+                        double* d_totalmag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,52 +106,115 @@ def gather_results(local, nitems, group=None, dst=0):
 class PipelinedGather(object):
     """Double-buffered result gather for a stream of analysis steps.
 
-    Step i writes its packed result block into `buffer(i)`; `submit(i)` starts the gather of that
-    block to rank `dst` asynchronously (RCCL runs it on its own stream), so the collective of step i
-    overlaps the kernels of step i+1.  A buffer is handed out again only after the gather that read
-    it has completed (`buffer(i)` makes the current stream wait for the gather of step i-2).
-    On rank `dst`, `result(i)` returns the list of per-rank blocks of step i (valid after `drain()`
-    or after `buffer(i+2)` has been requested).  There is no other communication on this path.
+    Step i writes its result block into `buffer(i)`; `submit(i)` starts the gather of that block to
+    rank `dst` asynchronously (RCCL runs it on its own stream), so the collective of step i overlaps
+    the kernels of step i+1.  A buffer is handed out again only after the gather that read it has
+    completed.  On rank `dst`, `consume(step, blocks)` -- if given -- is called once per step with the
+    list of per-rank blocks as soon as they have arrived and before their receive buffers are reused
+    (on a GPU it runs on a side stream, so unpacking step i also overlaps the kernels of step i+1);
+    without it, `result(i)` returns those blocks (valid after `drain()` or after `buffer(i+depth)`).
+    There is no other communication on this path.
     """
 
-    def __init__(self, numel, dtype, device, group=None, dst=0, depth=2):
+    def __init__(self, numel, dtype, device, group=None, dst=0, depth=2, consume=None, force=False):
         import torch
         import torch.distributed as dist
+        self._torch = torch
         self._dist = dist
         self.group = group
         self.dst = dst
         self.depth = depth
+        self.consume = consume
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # world 1: nothing to gather, unless `force` asks for the collective anyway (single-GPU test
+        # of the RCCL path)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bufs = [torch.empty(numel, dtype=dtype, device=device) for _ in range(depth)]
         self.lists = None
-        if self.world > 1 and self.rank == dst:
+        if self.active and self.rank == dst:
             self.lists = [[torch.empty(numel, dtype=dtype, device=device) for _ in range(self.world)]
                           for _ in range(depth)]
         self.works = [None] * depth
+        self.steps = [None] * depth
+        self.cuda = torch.device(device).type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if (self.cuda and consume is not None and self.rank == dst) else None
+        self.done = [None] * depth            # events: blocks of slot j consumed (side stream)
+
+    def _retire(self, j):
+        """The gather in slot j has been waited for (stream-level on a GPU) and consumed."""
+        w = self.works[j]
+        if w is None:
+            return
+        self.works[j] = None
+        torch = self._torch
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                w.wait()                                   # the side stream waits for the collective
+                self.consume(self.steps[j], self.lists[j])
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.done[j] = ev
+            torch.cuda.current_stream().wait_event(ev)     # before the slot's buffers are written again
+        else:
+            w.wait()
+            if self.consume is not None and self.lists is not None:
+                self.consume(self.steps[j], self.lists[j])
 
     def buffer(self, step):
         j = step % self.depth
-        if self.works[j] is not None:
-            self.works[j].wait()           # stream-level wait: the block may be overwritten afterwards
-            self.works[j] = None
+        self._retire(j)
         return self.bufs[j]
 
     def submit(self, step):
-        if self.world == 1:
+        if not self.active:
             return
         j = step % self.depth
+        self.steps[j] = step
         self.works[j] = self._dist.gather(self.bufs[j], gather_list=self.lists[j] if self.lists else None,
                                           dst=self.dst, group=self.group, async_op=True)
 
     def drain(self):
-        for j in range(self.depth):
-            if self.works[j] is not None:
-                self.works[j].wait()
-                self.works[j] = None
+        order = sorted(range(self.depth), key=lambda j: (self.steps[j] is None, self.steps[j] or 0))
+        for j in order:
+            self._retire(j)
 
     def result(self, step):
         j = step % self.depth
-        if self.world == 1:
+        if not self.active:
             return [self.bufs[j]]
         return self.lists[j] if self.lists else None
+
+
+class ResultWire(object):
+    """Device-side packing of a shard's result rows into the compact wire format of include/pvx.h
+    (pvx_pack_rows_dev / pvx_unpack_rows_dev): 18 B per peak slot instead of 40 B at precision 32,
+    bit-exact round trip.  `plan` is a pvx plan handle, `rows` the frames of all signals of a shard."""
+
+    def __init__(self, plan, rows, npks):
+        self.lib = _lib.load()
+        self.plan = plan
+        self.rows = int(rows)
+        self.npks = int(npks)
+        self.nbytes = int(self.lib.pvx_wire_bytes(plan, self.rows))
+        if self.nbytes < 0:
+            _lib.check(self.nbytes, "pvx_wire_bytes")
+
+    def result_ptrs(self, base):
+        """Device pointers (f, mag, ph, realph, binno, totalmag) inside a float64 block of
+        `result_numel()` elements starting at address `base`."""
+        n = self.rows * self.npks
+        return [base + i * n * 8 for i in range(5)] + [base + 5 * n * 8]
+
+    def result_numel(self):
+        return 5 * self.rows * self.npks + self.rows
+
+    def pack(self, res_base, wire_ptr, stream=None):
+        f, mag, ph, _, binno, tm = self.result_ptrs(res_base)
+        _lib.check(self.lib.pvx_pack_rows_dev(self.plan, self.rows, f, mag, ph, binno, tm, wire_ptr, stream),
+                   "pvx_pack_rows_dev")
+
+    def unpack(self, wire_ptr, res_base, stream=None):
+        f, mag, ph, realph, binno, tm = self.result_ptrs(res_base)
+        _lib.check(self.lib.pvx_unpack_rows_dev(self.plan, self.rows, wire_ptr, f, mag, ph, realph, binno, tm, stream),
+                   "pvx_unpack_rows_dev")

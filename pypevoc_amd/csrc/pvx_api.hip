@@ -601,6 +601,40 @@ extern "C" int64_t pvx_track(const double* f, const double* mag, int64_t F, int 
     return P;
 }
 
+// ---- result wire format for the multi-GPU gather (k_wire.hip) -------------------------------
+extern "C" int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows) {
+    if (!plan || rows < 0) { pvx_set_error("bad wire argument"); return PVX_ERR_INVALID; }
+    if (plan->nfft / 2 > 65536) { pvx_set_error("wire format holds bin numbers in 16 bits (nfft <= 131072)"); return PVX_ERR_UNSUPPORTED; }
+    return (int64_t)pvx_wire_block_bytes(rows, plan->npks, plan->precision);
+}
+
+extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
+                                 const double* d_ph, const double* d_binno, const double* d_totalmag, void* d_wire,
+                                 void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (pvx_wire_bytes(plan, rows) < 0) return PVX_ERR_INVALID;
+    if (rows == 0) return PVX_OK;
+    if (!d_f || !d_mag || !d_ph || !d_binno || !d_totalmag || !d_wire) { pvx_set_error("null wire array"); return PVX_ERR_INVALID; }
+    WireParams wp = {};
+    wp.rows = rows; wp.K = plan->npks; wp.precision = plan->precision; wp.fstep = plan->fstep; wp.wire = d_wire;
+    wp.f = d_f; wp.mag = d_mag; wp.ph = d_ph; wp.binno = d_binno; wp.totalmag = d_totalmag;
+    return pvx_launch_wire(wp, true, (hipStream_t)stream);
+}
+
+extern "C" int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f, double* d_mag,
+                                   double* d_ph, double* d_realph, double* d_binno, double* d_totalmag, void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (pvx_wire_bytes(plan, rows) < 0) return PVX_ERR_INVALID;
+    if (rows == 0) return PVX_OK;
+    if (!d_f || !d_mag || !d_ph || !d_realph || !d_binno || !d_totalmag || !d_wire) { pvx_set_error("null wire array"); return PVX_ERR_INVALID; }
+    WireParams wp = {};
+    wp.rows = rows; wp.K = plan->npks; wp.precision = plan->precision; wp.fstep = plan->fstep; wp.wire = (void*)d_wire;
+    wp.of = d_f; wp.omag = d_mag; wp.oph = d_ph; wp.orealph = d_realph; wp.obinno = d_binno; wp.ototalmag = d_totalmag;
+    return pvx_launch_wire(wp, false, (hipStream_t)stream);
+}
+
 // ---- resynthesis: SinSum.synth (PV.py:1053-1070) -------------------------------------------
 extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge) {
     if (nfft <= 0 || hop_analysis <= 0 || hop_synth <= 0 || max_end_frame < 0) return PVX_ERR_INVALID;

@@ -134,3 +134,15 @@ struct SynthParams {
     int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
+
+// result wire format for the multi-GPU gather (k_wire.hip)
+struct WireParams {
+    int64_t rows;                     // frames (all signals of the shard)
+    int K, precision;
+    double fstep;
+    void* wire;
+    const double *f, *mag, *ph, *binno, *totalmag;                    // pack: inputs
+    double *of, *omag, *oph, *orealph, *obinno, *ototalmag;           // unpack: outputs
+};
+size_t pvx_wire_block_bytes(int64_t rows, int K, int precision);
+int pvx_launch_wire(const WireParams& p, bool pack, hipStream_t s);

@@ -343,8 +343,12 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
             float best = u + 1.f, ab = fabsf(best);                      // m = -1
             if (fabsf(u) < ab) { best = u; ab = fabsf(u); }              // m = 0   (first minimum wins)
             if (fabsf(u - 1.f) < ab) { best = u - 1.f; }                 // m = +1
-            o.dfb = (double)best / c.dt;                                 // df = fbin - freq
-            o.freq = (double)nbin * c.fstep - o.dfb;
+            const double fb = (double)nbin * c.fstep;
+            o.freq = fb - (double)best / c.dt;
+            o.dfb = fb - o.freq;                                         // df = fbin - freq (PV.py:146), in the
+                                                                         // reference's order: realph is then a
+                                                                         // function of (nbin, freq, ph) alone,
+                                                                         // which the result wire format relies on
         }
         o.thisph = (double)tph;
         o.mag = (double)sqrtf(s3);

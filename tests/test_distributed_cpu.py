@@ -107,3 +107,44 @@ def test_pipelined_gather_world2(tmp_path):
     for i in range(7):
         for r in range(2):
             assert np.array_equal(got[i, r], np.arange(1000.0) + 1000.0 * i + 100000.0 * r), (i, r)
+
+
+def _consume_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pypevoc_amd.batch import PipelinedGather
+        n, steps = 257, 9
+        seen = {}
+
+        def consume(step, blocks):
+            assert step not in seen
+            seen[step] = torch.stack(blocks).clone()
+
+        pg = PipelinedGather(n, torch.uint8, torch.device("cpu"), dst=0, consume=consume)
+        for i in range(steps):
+            buf = pg.buffer(i)
+            buf.copy_(((torch.arange(n) + 7 * i + 31 * rank) % 251).to(torch.uint8))
+            pg.submit(i)
+        pg.drain()
+        if rank == 0:
+            assert sorted(seen) == list(range(steps))
+            np.save(os.path.join(outdir, "consume.npy"), torch.stack([seen[i] for i in range(steps)]).numpy())
+        else:
+            assert not seen
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_consume_hook_world2(tmp_path):
+    """bench.py's rank-0 unpack hook: `consume(step, blocks)` runs exactly once per step, in step order,
+    with every rank's block intact, before the receive buffers are reused."""
+    port = _free_port()
+    mp.spawn(_consume_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "consume.npy"))    # [steps, world, n]
+    assert got.shape == (9, 2, 257)
+    for i in range(9):
+        for r in range(2):
+            assert np.array_equal(got[i, r], ((np.arange(257) + 7 * i + 31 * r) % 251).astype(np.uint8)), (i, r)
