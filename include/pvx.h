@@ -177,6 +177,31 @@ int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph
                   double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
                   double* d_w, int64_t wlen, void* stream);
 
+/* ---- PVHarmonic.run_pv / calc_pv_frame (PV.py:419-535) --------------------------------------
+ *
+ * Phase vocoder sampled at the multiples of a caller-supplied fundamental instead of PeakFinder
+ * peaks.  Single signal.  Uses the plan's general path (window -> rocFFT -> k_harmonic_rows), any
+ * nfft, precision 32 or 64.
+ *   f0, nf0        HOST float64 [nf0 >= F]: fundamental of every frame (PV.py:507 indexes it by frame
+ *                  number; a shorter array is the reference's IndexError -> PVX_ERR_SIZE).  Frames
+ *                  with f0 <= 0 or NaN are skipped: zero rows, residual NaN, and they do NOT become
+ *                  the "previous spectrum" of later frames (PV.py:509, 491).
+ *   fmin           PVHarmonic.fmin (30.0 in the reference, PV.py:421)
+ *   f, mag, ph     float64 [F, npks]: first npks harmonics (frequency may be NaN where the reference's
+ *                  is: x/0 with a zero component); residual, t: float64 [F]
+ *   prev0          optional [nfft/2][2] spectrum preceding the first analysed frame; last_spec
+ *                  (host variant) receives PVHarmonic.oldfft after the loop.
+ * A valid f0 below half a bin is rejected (PVX_ERR_INVALID).  Returns F or a negative status.
+ */
+int64_t pvx_harmonic_analyze(pvx_plan* plan, const void* x, int x_dtype, int64_t nsamp,
+                             const double* f0, int64_t nf0, double fmin,
+                             double* f, double* mag, double* ph, double* residual, double* t,
+                             const double* prev0, double* last_spec);
+int64_t pvx_harmonic_analyze_dev(pvx_plan* plan, const void* d_x, int x_dtype, int64_t nsamp,
+                                 const double* f0, int64_t nf0, double fmin,
+                                 double* d_f, double* d_mag, double* d_ph, double* d_residual,
+                                 double* d_t, const double* d_prev0, void* stream);
+
 /* ---- multi-GPU result gather: compact wire format --------------------------------------
  *
  * The reference has no multi-device path; its results are the five float64 [F, K] arrays of

@@ -299,6 +299,87 @@ int64_t pvo_analyze(const double *x, int64_t nsamp, double sr, int nfft, int hop
     return F;
 }
 
+/* PVHarmonic.run_pv (PV.py:493-535) with calc_pv_frame (PV.py:442-491): per frame, the bins at the
+ * multiples of f0[frame] (re-centred on multiples of the measured first harmonic once it exceeds
+ * fmin) instead of PeakFinder peaks.  Outputs caller-allocated: f, mag, ph: F*npks (zero padded);
+ * residual, t: F.  Frames with f0 <= 0 or NaN: zero rows, residual NaN, oldfft untouched.
+ * Returns F, or -3 where the reference raises IndexError (f0 shorter than the frame count). */
+int64_t pvo_harmonic(const double *x, int64_t nsamp, double sr, int nfft, int hop, int npks,
+                     const double *win, const double *f0, int64_t nf0, double fmin,
+                     double *f, double *mag, double *ph, double *residual, double *t) {
+    if (nfft < 4 || hop <= 0 || npks <= 0) return -1;
+    const int nfft2 = nfft / 2;
+    const int64_t F = pvo_nframes(nsamp, nfft, hop);
+    double wsum2 = 0.0;
+    for (int i = 0; i < nfft; i++) wsum2 = wsum2 + win[i] * win[i];
+    const double wfact = sqrt(wsum2 * nfft) / 2.0;
+    const double fstep = sr / (double)nfft;
+    const double dt = (double)hop / sr;
+    double *fbin = (double *)malloc(sizeof(double) * nfft2);
+    double *wfbin = (double *)malloc(sizeof(double) * nfft2);
+    double *xw = (double *)malloc(sizeof(double) * nfft);
+    double *fr_ = (double *)malloc(sizeof(double) * nfft2), *fi_ = (double *)malloc(sizeof(double) * nfft2);
+    double *or_ = (double *)calloc(nfft2, sizeof(double)), *oi_ = (double *)calloc(nfft2, sizeof(double));
+    double *famp = (double *)malloc(sizeof(double) * nfft2);
+    pvo_fft plan;
+    if (!fbin || !wfbin || !xw || !fr_ || !fi_ || !or_ || !oi_ || !famp || fft_init(&plan, nfft) != 0) return -2;
+    for (int k = 0; k < nfft2; k++) {
+        fbin[k] = (double)k * fstep;
+        wfbin[k] = nearbyint(pi2 * fbin[k] * dt / pi2) * pi2;
+    }
+    const double scl = 1.0 / wfact;
+    int64_t rc = F;
+    for (int64_t fr = 0; fr < F; fr++) {
+        const int64_t pos = fr * (int64_t)hop;
+        double *of = f + fr * npks, *om = mag + fr * npks, *op = ph + fr * npks;
+        for (int j = 0; j < npks; j++) of[j] = om[j] = op[j] = 0.0;      /* PV.py:504-506 */
+        if (fr >= nf0) { rc = -3; break; }                               /* PV.py:507 IndexError */
+        const double thisf = f0[fr];
+        residual[fr] = NAN;                                              /* PV.py:508 */
+        t[fr] = ((double)pos + nfft / 2.0) / sr;                         /* PV.py:525 */
+        if (!(thisf > 0.0)) continue;                                    /* PV.py:510 (NaN fails) */
+        for (int i = 0; i < nfft; i++) xw[i] = x[pos + i] * win[i];
+        fft_real_half(&plan, xw, fr_, fi_);
+        double tot = 0.0;
+        for (int k = 0; k < nfft2; k++) { fr_[k] *= scl; fi_[k] *= scl; famp[k] = hypot(fr_[k], fi_[k]); tot += famp[k] * famp[k]; }
+        const double f0bin = thisf / sr * (double)nfft;                  /* PV.py:462 */
+        const double stop = (double)(nfft2 - 1);
+        double nhd = ceil((stop - f0bin) / f0bin);                       /* len(np.arange(f0bin, nfft2-1, f0bin)) */
+        int64_t nh = nhd > 0.0 ? (int64_t)nhd : 0;
+        double cum = 0.0, f1 = 0.0;
+        for (int64_t ipk = 0; ipk < nh; ipk++) {
+            int nbin = (int)nearbyint(f0bin + (double)ipk * f0bin);      /* np.round(arange element).astype(int) */
+            if (ipk > 0 && f1 > fmin) {                                  /* PV.py:465-470 */
+                double corrbin = f1 / sr * (double)nfft * (double)(ipk + 1);
+                if (corrbin < stop) nbin = (int)nearbyint(corrbin);      /* int(round(corrbin)) */
+            }
+            double thisph = atan2(fi_[nbin], fr_[nbin]);                 /* PV.py:472 */
+            double qr, qi;
+            npy_cdiv(fr_[nbin], fi_[nbin], or_[nbin], oi_[nbin], &qr, &qi);
+            double dph = atan2(qi, qr);                                  /* PV.py:474 */
+            double best = 0.0, bestabs = 0.0;
+            for (int m = -1; m <= 1; m++) {                              /* PV.py:140-147; NaN stays candidate 0 */
+                double freq = (dph + wfbin[nbin] + pi2 * (double)m) / dt / pi2;
+                double a = fabs(fbin[nbin] - freq);
+                if (m == -1 || a < bestabs) { best = freq; bestabs = a; }
+            }
+            if (ipk == 0) f1 = best;
+            int imin = nbin - 1 > 1 ? nbin - 1 : 1;                      /* PV.py:481-483, wd = 1 */
+            int imax = nbin + 1 < nfft2 ? nbin + 1 : nfft2;
+            double s = 0.0;
+            for (int j = imin; j <= imax && j < nfft2; j++) s = s + famp[j] * famp[j];
+            cum += s;                                                    /* PV.py:484 */
+            if (ipk < npks) { of[ipk] = best; om[ipk] = sqrt(s); op[ipk] = thisph; }
+        }
+        residual[fr] = sqrt(tot - cum);                                  /* PV.py:490 */
+        memcpy(or_, fr_, sizeof(double) * nfft2);                        /* PV.py:491 */
+        memcpy(oi_, fi_, sizeof(double) * nfft2);
+    }
+    fft_free(&plan);
+    free(fbin); free(wfbin); free(xw); free(fr_); free(fi_); free(or_); free(oi_); free(famp);
+    return rc;
+}
+
 /* Windowed, normalised half spectrum of frame `fr` (PV.py:150-158, 169): for checking the
  * device STFT stage in isolation.  outr/outi: nfft/2. */
 int pvo_stft_frame(const double *x, int64_t pos, int nfft, const double *win, double *outr, double *outi) {

@@ -39,6 +39,9 @@ def lib():
         L.pvo_analyze.restype = ctypes.c_int64
         L.pvo_analyze.argtypes = [_dp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_double, _dp] + [_dp] * 7
+        L.pvo_harmonic.restype = ctypes.c_int64
+        L.pvo_harmonic.argtypes = [_dp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   _dp, _dp, ctypes.c_int64, ctypes.c_double] + [_dp] * 5
         L.pvo_stft_frame.restype = ctypes.c_int
         L.pvo_stft_frame.argtypes = [_dp, ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp]
         L.pvo_peakfinder.restype = ctypes.c_int
@@ -87,6 +90,28 @@ def analyze(x, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, win=None):
                           _d(out["binno"]), _d(out["t"]), _d(out["totalmag"]))
     if r != F:
         raise RuntimeError("pvo_analyze failed: %d" % r)
+    return out
+
+
+def harmonic(x, sr, f0, nfft=1024, hop=None, npks=20, fmin=30.0, win=None):
+    """PVHarmonic(x, sr, nfft, hop, npks).set_f0(f0); run_pv().  Returns dict(f, mag, ph, residuals, t)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f0 = np.ascontiguousarray(f0, dtype=np.float64)
+    if hop is None:
+        hop = int(nfft / 2)
+    hop = int(hop)
+    win = np.hanning(nfft) if win is None else win
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    F = nframes(len(x), nfft, hop)
+    out = {k: np.zeros((F, npks)) for k in ("f", "mag", "ph")}
+    out["residuals"] = np.zeros(F)
+    out["t"] = np.zeros(F)
+    r = lib().pvo_harmonic(_d(x), len(x), float(sr), int(nfft), hop, int(npks), _d(win), _d(f0), len(f0), float(fmin),
+                           _d(out["f"]), _d(out["mag"]), _d(out["ph"]), _d(out["residuals"]), _d(out["t"]))
+    if r == -3:
+        raise IndexError("f0 is shorter than the number of frames")
+    if r != F:
+        raise RuntimeError("pvo_harmonic failed: %d" % r)
     return out
 
 

@@ -215,6 +215,43 @@ class PV(object):
         if self.progress:
             print("\r %d / %d (100%%)" % (self.nsamp, self.nsamp))
 
+    def calc_harmonic_power(self, f_threshold=0.01):
+        """
+        Harmonic power of the individual sine components (PVAnalysis.py:266-297), vectorised over
+        frames.  For each valid peak j of a frame, the peaks c whose frequency is within
+        `f_threshold` (relative) of an integer multiple of f_j form its harmonic set; nharmonics is
+        their number.  NB the reference takes `valid_mag = self.mag[valid_idx]` (:278), i.e. the ROWS
+        of mag numbered like the valid peak slots, so its hpower sums whole rows
+        mag[slot_c, :]**2 over the harmonic set -- reproduced as is (IndexError like the reference
+        when a valid slot index >= number of frames).
+        """
+        ff = np.asarray(self.f, dtype=np.float64)
+        mm = np.asarray(self.mag, dtype=np.float64)
+        F, K = ff.shape
+        hpower = np.zeros((F, K))
+        nharm = np.zeros((F, K))
+        valid = ff > 0
+        if valid.any():
+            top = int(np.max(np.nonzero(valid.any(axis=0))[0]))
+            if top >= mm.shape[0]:
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (top, mm.shape[0]))
+            rowpow = np.zeros(K)
+            rowpow[: top + 1] = np.sum(mm[: top + 1] ** 2, axis=1)
+            step = max(1, int(4e6 // max(K * K, 1)))                  # bound the (frames, K, K) temporaries
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for a in range(0, F, step):
+                    fa = ff[a:a + step]
+                    va = valid[a:a + step]
+                    ratio = fa[:, None, :] / fa[:, :, None]           # [frame, j, c] = f_c / f_j
+                    hn = np.round(ratio)
+                    hn[hn == 0] = 1
+                    inh = np.abs(ratio / hn - 1)                      # |f_c / n / f_j - 1|
+                    comp = (inh < f_threshold) & va[:, None, :] & va[:, :, None]
+                    nharm[a:a + step] = comp.sum(axis=2)
+                    hpower[a:a + step] = (comp * rowpow[None, None, :]).sum(axis=2)
+        self.hpower = hpower
+        self.nharmonics = nharm
+
     def toSinSum(self, maxpitchjmp=0.5):
         '''
         Convert to Sine sum (PVAnalysis.py:299-322).
@@ -275,6 +312,104 @@ class PV(object):
     @property
     def partial_magnitude_ratio(self):
         return self.partial_sum_magnitude / self.totalmag
+
+
+class PVHarmonic(PV):
+    """Phase vocoder sampled at the multiples of a given fundamental (PVAnalysis.py:419-535):
+    `set_f0(f0, t)` then `run_pv()` -> f, mag, ph ((F, npks): first npks harmonics), residuals (F,), t.
+    Runs as window -> rocFFT -> one harmonic kernel in libpvx_hip (pvx_harmonic_analyze)."""
+
+    def __init__(self, *args, **kwargs):
+        self.fmin = 30.0                                        # PVAnalysis.py:421
+        PV.__init__(self, *args, **kwargs)
+        self._frame_plan = None
+
+    def set_f0(self, f0, t=None):
+        '''
+        Assign a f0 vector to the search (PVAnalysis.py:424-440)
+        Argument:
+            * f0: f0 vector over time
+            * t: if present, values of time corresponding to f0
+                 otherwise, the time values correspond to the hop size
+        '''
+        tint = np.arange(round(self.hop + self.nfft / 2), len(self.x), self.hop) / float(self.sr)
+        if t is None:
+            self.f0 = f0
+        else:
+            self.f0 = np.interp(tint, t, f0)
+
+    def _prev0(self):
+        old = np.asarray(self.oldfft)
+        if not np.any(old != 0):
+            return None
+        oc = old.astype(complex)
+        return np.ascontiguousarray(np.stack([oc.real, oc.imag], axis=1), dtype=np.float64)
+
+    def calc_pv_frame(self, pos, f0):
+        '''
+        Harmonics of f0 in the frame at pos, based on the previous frame kept in self.oldfft
+        (PVAnalysis.py:442-491).  Returns f, mag, ph (ALL multiples of f0 below nfft/2 - 1), residual.
+        '''
+        lib = _lib.load()
+        x, dt = self._signal()
+        pos = int(pos)
+        seg = x[pos:pos + self.nfft]
+        if len(seg) < self.nfft:
+            raise ValueError("operands could not be broadcast together: frame at %d leaves the signal" % pos)
+        seg = np.concatenate([seg, np.zeros(1, dtype=seg.dtype)])    # one frame: nsamp = nfft + 1
+        f0bin = f0 / self.sr * self.nfft
+        nh = len(np.arange(f0bin, self.nfft2 - 1, f0bin)) if f0 > 0 else 0
+        kmax = 2 * self.nfft2 + 2                                    # f0 >= half a bin: never more harmonics
+        if self._frame_plan is None:
+            self._frame_plan = _Plan(self.sr, self.nfft, int(self.hop), kmax, self.peakthresh, self.win,
+                                     self.precision, max_rows=2)
+        out = [np.zeros((1, kmax)) for _ in range(3)]
+        res = np.zeros(1)
+        last = np.zeros((self.nfft2, 2))
+        prev0 = self._prev0()
+        f0a = np.array([f0], dtype=np.float64)
+        F = lib.pvx_harmonic_analyze(self._frame_plan.handle, seg.ctypes.data_as(ctypes.c_void_p), dt, len(seg),
+                                     _lib.dptr(f0a), 1, float(self.fmin), *[_lib.dptr(a) for a in out],
+                                     _lib.dptr(res), None, _lib.dptr(prev0) if prev0 is not None else None,
+                                     _lib.dptr(last))
+        _lib.check(F, "pvx_harmonic_analyze")
+        self.oldfft = last[:, 0] + 1j * last[:, 1]                   # PVAnalysis.py:491
+        f, mag, ph = [list(a[0, :nh]) for a in out]
+        return f, mag, ph, float(res[0])
+
+    def run_pv(self):
+        '''The analysis loop (PVAnalysis.py:493-535) as one call into the HIP library.'''
+        lib = _lib.load()
+        x, dt = self._signal()
+        K = self.npeaks
+        F = int(lib.pvx_nframes(self.nsamp, self.nfft, int(self.hop)))
+        if F == 0:
+            self.f = np.array([]); self.mag = np.array([]); self.ph = np.array([])
+            self.residuals = np.array([]); self.t = np.array([])
+            self.nframes = 0
+            return
+        f0 = np.ascontiguousarray(np.asarray(self.f0, dtype=np.float64).ravel())
+        if len(f0) < F:
+            # the reference indexes self.f0[int(curpos / hop)] (PVAnalysis.py:507)
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (len(f0), len(f0)))
+        f = np.empty((F, K)); mag = np.empty((F, K)); ph = np.empty((F, K))
+        res = np.empty(F); t = np.empty(F)
+        last = np.zeros((self.nfft2, 2))
+        prev0 = self._prev0()
+        plan = self._get_plan(rows=F + 1)
+        r = lib.pvx_harmonic_analyze(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), _lib.dptr(f0), len(f0),
+                                     float(self.fmin), _lib.dptr(f), _lib.dptr(mag), _lib.dptr(ph), _lib.dptr(res),
+                                     _lib.dptr(t), _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
+        _lib.check(r, "pvx_harmonic_analyze")
+        self.f = f
+        self.mag = mag
+        self.ph = ph
+        self.residuals = res
+        self.t = t
+        self.nframes = F
+        self.oldfft = last[:, 0] + 1j * last[:, 1]
+        if self.progress:
+            print("\r %d / %d (100%%)" % (self.nsamp, self.nsamp))
 
 
 class RegPartial(object):

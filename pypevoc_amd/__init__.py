@@ -7,9 +7,9 @@ PV.run_pv -> toSinSum -> SinSum.synth path of goiosunsw/PyPeVoc).
 Everything heavy runs in libpvx_hip.so (hand-written HIP kernels for gfx950 + rocFFT), loaded with
 ctypes; see include/pvx.h, DESIGN.md and INTEGRATION.md.
 """
-from .PVAnalysis import PV, SinSum, RegPartial  # noqa: F401  (pypevoc/__init__.py:1 exports these)
+from .PVAnalysis import PV, SinSum, RegPartial, PVHarmonic  # noqa: F401  (pypevoc/__init__.py:1 exports PV, SinSum)
 from .PeakFinder import PeakFinder  # noqa: F401
 from .batch import PVBatch  # noqa: F401
 from ._lib import PvxError  # noqa: F401
 
-__all__ = ["PV", "SinSum", "RegPartial", "PeakFinder", "PVBatch", "PvxError"]
+__all__ = ["PV", "PVHarmonic", "SinSum", "RegPartial", "PeakFinder", "PVBatch", "PvxError"]

@@ -100,6 +100,11 @@ struct pvx_plan {
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
     void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
     float* d_specrow = nullptr;  // 1024 complex: spectrum of one requested row (fused mode)
+    // PVHarmonic: per-frame f0 / previous-row tables and the carried spectrum of the last valid frame
+    double* d_hf0 = nullptr;
+    int32_t* d_hprev = nullptr;
+    void* d_carry = nullptr;
+    int64_t harm_cap = 0;
     int64_t fused_blocks = 0;    // PVX_FUSED_BLOCKS override
     int frames_per_wave = 4;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
@@ -123,6 +128,9 @@ static void plan_free(pvx_plan* p) {
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_specrow) (void)hipFree(p->d_specrow);
+    if (p->d_hf0) (void)hipFree(p->d_hf0);
+    if (p->d_hprev) (void)hipFree(p->d_hprev);
+    if (p->d_carry) (void)hipFree(p->d_carry);
     delete p;
 }
 
@@ -599,6 +607,151 @@ extern "C" int64_t pvx_track(const double* f, const double* mag, int64_t F, int 
     PVX_HIP_CHECK(hipMemcpy(part_start, dst.p, (size_t)P * 4, hipMemcpyDeviceToHost));
     PVX_HIP_CHECK(hipMemcpy(part_len, dln.p, (size_t)P * 4, hipMemcpyDeviceToHost));
     return P;
+}
+
+// ---- PVHarmonic.run_pv (PV.py:493-535): f0-guided analysis on the general path's spectra ------
+static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t F, const double* f0,
+                         double fmin, double* d_f, double* d_mag, double* d_ph, double* d_res, double* d_t,
+                         const double* d_prev0, hipStream_t s, bool* any_valid) {
+    int rc;
+    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+    const size_t rs = real_size(p->precision);
+    // previous-valid-frame table (PV.py:509, 491: oldfft only moves on analysed frames)
+    std::vector<int32_t> prow((size_t)F);
+    int64_t last = -1;
+    for (int64_t fr = 0; fr < F; fr++) {
+        const int64_t R0 = ((fr + 1) / p->max_rows) * p->max_rows;      // chunk holding row fr+1
+        if (last < 0) prow[fr] = -1;
+        else if (last + 1 >= R0 - 1) prow[fr] = (int32_t)(last + 1 - R0 + 1);
+        else prow[fr] = -2;
+        const double v = f0[fr];
+        if (v > 0.0) {
+            if (v / p->sr * (double)p->nfft < 0.5) {
+                pvx_set_error("f0[%lld] = %g Hz is below half a bin (%g Hz): the harmonic series is not resolvable", (long long)fr, v, 0.5 * p->fstep);
+                return PVX_ERR_INVALID;
+            }
+            last = fr;
+        }
+    }
+    *any_valid = last >= 0;
+    if (F > p->harm_cap) {
+        if (p->d_hf0) (void)hipFree(p->d_hf0);
+        if (p->d_hprev) (void)hipFree(p->d_hprev);
+        p->d_hf0 = nullptr; p->d_hprev = nullptr; p->harm_cap = 0;
+        if (hipMalloc((void**)&p->d_hf0, (size_t)F * 8) != hipSuccess || hipMalloc((void**)&p->d_hprev, (size_t)F * 4) != hipSuccess) {
+            pvx_set_error("hipMalloc of the f0 tables failed"); return PVX_ERR_ALLOC;
+        }
+        p->harm_cap = F;
+    }
+    if (!p->d_carry && hipMalloc(&p->d_carry, (size_t)p->ldo * 2 * rs) != hipSuccess) { pvx_set_error("hipMalloc(carry) failed"); return PVX_ERR_ALLOC; }
+    PVX_HIP_CHECK(hipMemcpyAsync(p->d_hf0, f0, (size_t)F * 8, hipMemcpyHostToDevice, s));
+    PVX_HIP_CHECK(hipMemcpyAsync(p->d_hprev, prow.data(), (size_t)F * 4, hipMemcpyHostToDevice, s));
+    PVX_HIP_CHECK(hipStreamSynchronize(s));                              // prow is a local
+    PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
+    const int64_t total_rows = F + 1;
+    for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
+        const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
+        FrameParams fp;
+        fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = nsamp; fp.F = F; fp.R0 = R0;
+        fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
+        fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
+        if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
+        void* in[1] = {p->d_frames};
+        void* out[1] = {p->d_spec};
+        PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        HarmParams hp;
+        hp.spec = p->d_spec; hp.ldo = p->ldo;
+        hp.fr_begin = (R0 > 1 ? R0 : 1) - 1;
+        const int64_t fr_last = R0 + nrows - 2;
+        hp.nfr = fr_last - hp.fr_begin + 1;
+        hp.ws_off = hp.fr_begin + 1 - R0 + 1;
+        hp.nfft = p->nfft; hp.hop = p->hop; hp.N2 = p->N2; hp.K = p->npks;
+        hp.sr = p->sr; hp.fstep = p->fstep; hp.dt = p->dt; hp.fmin = fmin;
+        hp.wfbin = p->d_wfbin; hp.prev0 = d_prev0; hp.carry = p->d_carry;
+        hp.f0 = p->d_hf0; hp.prevrow = p->d_hprev;
+        hp.f = d_f; hp.mag = d_mag; hp.ph = d_ph; hp.residual = d_res; hp.t = d_t;
+        if ((rc = pvx_launch_harmonic(hp, p->precision, s)) != PVX_OK) return rc;
+        // carry the spectrum of the last valid frame of this chunk to the later ones
+        int64_t lv = fr_last;
+        while (lv >= hp.fr_begin && !(f0[lv] > 0.0)) lv--;
+        if (lv >= hp.fr_begin)
+            PVX_HIP_CHECK(hipMemcpyAsync(p->d_carry, (const char*)p->d_spec + (size_t)(lv + 1 - R0 + 1) * p->ldo * 2 * rs,
+                                         (size_t)p->ldo * 2 * rs, hipMemcpyDeviceToDevice, s));
+    }
+    return PVX_OK;
+}
+
+static int check_harmonic_args(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const double* f0, int64_t nf0, int64_t F) {
+    int rc = check_analyze_args(p, x, x_dtype, nsamp, 1, nsamp, nullptr);
+    if (rc != PVX_OK) return rc;
+    if (F > 0 && (!f0 || nf0 < F)) {
+        // the reference indexes f0[int(curpos/hop)] (PV.py:507) and raises IndexError
+        pvx_set_error("index %lld is out of bounds for f0 with size %lld", (long long)(nf0 < 0 ? 0 : nf0), (long long)nf0);
+        return PVX_ERR_SIZE;
+    }
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_harmonic_analyze_dev(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, const double* f0,
+                                            int64_t nf0, double fmin, double* d_f, double* d_mag, double* d_ph,
+                                            double* d_residual, double* d_t, const double* d_prev0, void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if ((rc = check_harmonic_args(p, d_x, x_dtype, nsamp, f0, nf0, F)) != PVX_OK) return rc;
+    if (F == 0) return 0;
+    if (!d_f || !d_mag || !d_ph || !d_residual) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    bool any = false;
+    rc = harmonic_rows(p, d_x, x_dtype, nsamp, F, f0, fmin, d_f, d_mag, d_ph, d_residual, d_t, d_prev0, (hipStream_t)stream, &any);
+    return rc == PVX_OK ? F : rc;
+}
+
+extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const double* f0, int64_t nf0,
+                                        double fmin, double* f, double* mag, double* ph, double* residual, double* t,
+                                        const double* prev0, double* last_spec) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if ((rc = check_harmonic_args(p, x, x_dtype, nsamp, f0, nf0, F)) != PVX_OK) return rc;
+    if (F == 0) return 0;
+    if (!f || !mag || !ph || !residual) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    const size_t xbytes = (size_t)nsamp * dtype_size(x_dtype);
+    const size_t fk = (size_t)F * p->npks * sizeof(double), f1 = (size_t)F * sizeof(double);
+    DevBuf dx, dout, dprev;
+    if ((rc = dx.alloc(xbytes)) != PVX_OK) return rc;
+    if ((rc = dout.alloc(3 * fk + 2 * f1)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dx.p, x, xbytes, hipMemcpyHostToDevice));
+    if (prev0) {
+        if ((rc = dprev.alloc(sizeof(double) * 2 * p->N2)) != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipMemcpy(dprev.p, prev0, sizeof(double) * 2 * p->N2, hipMemcpyHostToDevice));
+    }
+    char* o = (char*)dout.p;
+    double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_res = (double*)(o + 3 * fk),
+           *d_t = (double*)(o + 3 * fk + f1);
+    bool any = false;
+    rc = harmonic_rows(p, dx.p, x_dtype, nsamp, F, f0, fmin, d_f, d_mag, d_ph, d_res, d_t, (const double*)dprev.p, nullptr, &any);
+    if (rc != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(mag, d_mag, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(ph, d_ph, fk, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(residual, d_res, f1, hipMemcpyDeviceToHost));
+    if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
+    if (last_spec) {
+        // oldfft after the loop = spectrum of the last analysed frame (PV.py:491), else unchanged
+        if (any) {
+            const size_t rs = real_size(p->precision);
+            std::vector<unsigned char> tmp((size_t)p->N2 * 2 * rs);
+            PVX_HIP_CHECK(hipMemcpy(tmp.data(), p->d_carry, tmp.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 2 * p->N2; i++)
+                last_spec[i] = p->precision == 32 ? (double)((float*)tmp.data())[i] : ((double*)tmp.data())[i];
+        } else {
+            for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = prev0 ? prev0[i] : 0.0;
+        }
+    }
+    return F;
 }
 
 // ---- result wire format for the multi-GPU gather (k_wire.hip) -------------------------------

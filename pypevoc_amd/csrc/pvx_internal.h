@@ -135,6 +135,24 @@ struct SynthParams {
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
 
+// PVHarmonic.run_pv (k_harmonic.hip): f0-guided bin sampling on the spectra of the general path
+struct HarmParams {
+    const void* spec;     // complex<T> workspace rows of this chunk [nrows+1][ldo]
+    int64_t ldo;
+    int64_t fr_begin, nfr;    // frames [fr_begin, fr_begin + nfr) of the signal are analysed by this launch
+    int64_t ws_off;           // workspace row of frame fr_begin
+    int nfft, hop, N2, K;
+    double sr, fstep, dt, fmin;
+    const double* wfbin;
+    const double* prev0;      // optional [N2][2]: spectrum preceding the first valid frame
+    const void* carry;        // complex<T>[N2]: spectrum of the last valid frame of the earlier chunks
+    const double* f0;         // [F] fundamental per frame (<= 0 or NaN: frame skipped)
+    const int32_t* prevrow;   // [F] workspace row of the previous VALID frame's spectrum; -1: there is
+                              // none (zero spectrum or prev0); -2: it is in `carry`
+    double *f, *mag, *ph, *residual, *t;
+};
+int pvx_launch_harmonic(const HarmParams& p, int precision, hipStream_t s);
+
 // result wire format for the multi-GPU gather (k_wire.hip)
 struct WireParams {
     int64_t rows;                     // frames (all signals of the shard)

@@ -304,6 +304,7 @@ struct PeakConst {
 struct PeakOut {
     double freq, dfb, thisph, mag;
     bool valid;
+    bool nanph;       // the phase difference is NaN (x/0 with a zero real or imaginary part)
 };
 
 template <typename T>
@@ -378,6 +379,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
         }
         o.mag = sqrt((double)s3);
     }
+    o.nanph = nanph;
     o.valid = !nanph && (o.freq > 0.0);                              // PV.py:193 (NaN fails the test)
     return o;
 }

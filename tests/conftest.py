@@ -40,7 +40,10 @@ def load_golden(name):
     for k in ("nfft", "hop", "npks", "nframes"):
         g[k] = int(g[k])
     g["sr"] = float(g["sr"])
-    g["pkthresh"] = float(g["pkthresh"])
+    if "pkthresh" in g:
+        g["pkthresh"] = float(g["pkthresh"])
+    if "fmin" in g:
+        g["fmin"] = float(g["fmin"])
     return g
 
 

@@ -91,3 +91,27 @@ def test_shard_range_partitions():
                 assert a[1] == b[0]
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_frame_descriptors_match_reference():
+    """Host-side consumers of the (F, K) arrays, no GPU involved: calc_f0, fundamental_*,
+    partial_* and calc_harmonic_power (incl. its row-indexing quirk, PV.py:278) against values captured
+    from the reference (tests/golden/make_golden_harmonic.py, D1)."""
+    import pypevoc_amd
+    g = np.load(os.path.join(ROOT, "tests", "golden", "D1_descriptors.npz"))
+    p = pypevoc_amd.PV(np.zeros(4096), 44100, nfft=2048, hop=512, npks=8, progress=False)
+    p.f, p.mag, p.totalmag = g["f"], g["mag"], list(g["totalmag"])
+    f0 = p.calc_f0()
+    assert np.array_equal(f0, g["f0"]) and np.array_equal(p.fundamental_idx, g["fundamental_idx"])
+    assert np.array_equal(p.fundamental_frequency, g["fundamental_frequency"])
+    assert np.array_equal(p.fundamental_magnitude, g["fundamental_magnitude"])
+    assert np.allclose(p.partial_sum_magnitude, g["partial_sum_magnitude"], rtol=1e-14, atol=0)
+    assert np.allclose(p.partial_magnitude_ratio, g["partial_magnitude_ratio"], rtol=1e-14, atol=0)
+    f0b = p.calc_f0(fmin=300, fmax=2000, thr=0.3)
+    assert np.array_equal(f0b, g["f0_b"]) and np.array_equal(p.fundamental_idx, g["fundamental_idx_b"])
+    p.calc_harmonic_power()
+    assert np.array_equal(p.nharmonics, g["nharmonics"])
+    assert np.allclose(p.hpower, g["hpower"], rtol=1e-13, atol=0)
+    p.calc_harmonic_power(f_threshold=0.002)
+    assert np.array_equal(p.nharmonics, g["nharmonics_b"])
+    assert np.allclose(p.hpower, g["hpower_b"], rtol=1e-13, atol=0)

@@ -571,3 +571,122 @@ def test_result_wire_round_trip_is_bit_exact(amd, precision, nfft, mode, monkeyp
     out = d_out.cpu().numpy()
     assert (p.f > 0).sum() > 20 * F
     assert np.array_equal(out.view(np.int64), src.view(np.int64))
+
+
+# ------------------------------------------------------------------ PVHarmonic
+HARMONIC = golden_names(prefix="H", exclude=())
+
+
+def _harm_compare(p, g, precision):
+    """float64: values to rounding.  float32: a harmonic whose re-centred bin round(h*f1*nfft/sr)
+    (PV.py:467-469) sits within float32 error of a .5 boundary may land on the neighbouring bin, so
+    bound the fraction of such flips and compare the rest."""
+    assert p.f.shape == g["f"].shape and p.nframes == g["nframes"]
+    assert np.array_equal(p.t, g["t"])
+    assert np.array_equal(np.isnan(p.residuals), np.isnan(g["residuals"]))
+    assert np.array_equal(p.f == 0, g["f"] == 0)
+    fin = np.isfinite(g["residuals"])
+    tot = (g["mag"] ** 2).sum(axis=1) + np.where(fin, g["residuals"], 0.0) ** 2   # >= frame energy scale
+    if precision == 64:
+        assert np.nanmax(np.abs(p.f - g["f"])) <= 1e-8
+        assert np.abs(p.mag - g["mag"]).max() <= 1e-13
+        assert np.abs(p.ph - g["ph"]).max() <= 1e-9
+        assert (np.abs(p.residuals[fin] ** 2 - g["residuals"][fin] ** 2) <= 1e-12 * np.maximum(tot[fin], 1e-300)).all()
+        return
+    v = g["f"] != 0
+    fmax = np.broadcast_to(g["mag"].max(axis=1, keepdims=True), g["mag"].shape)
+    same_bin = np.abs(p.mag - g["mag"]) <= 1e-5 * fmax + 1e-5 * g["mag"]
+    assert (v & ~same_bin).sum() <= 0.01 * v.sum(), ((v & ~same_bin).sum(), v.sum())
+    ok = v & same_bin & (g["mag"] >= 1e-3 * fmax)          # well-conditioned phases
+    dt = g["hop"] / g["sr"]
+    assert (np.abs(p.f - g["f"])[ok] * 2 * np.pi * dt <= 2e-3).all()
+    assert (np.abs(p.ph - g["ph"])[ok] <= 1e-3).all()
+    assert (np.abs(p.residuals[fin] ** 2 - g["residuals"][fin] ** 2) <= 1e-4 * tot[fin]).all()
+
+
+@pytest.mark.parametrize("precision", [32, 64])
+@pytest.mark.parametrize("name", HARMONIC)
+def test_harmonic_run_pv_matches_reference(amd, name, precision):
+    g = load_golden(name)
+    p = amd.PVHarmonic(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], progress=False, precision=precision)
+    if "t_arg" in g:
+        p.set_f0(g["f0_arg"], g["t_arg"])                  # np.interp onto the frame times, PV.py:433-440
+        assert np.array_equal(np.asarray(p.f0)[: g["nframes"]], g["f0_used"][: g["nframes"]])
+    else:
+        p.set_f0(g["f0_arg"])
+    p.run_pv()
+    _harm_compare(p, g, precision)
+    if precision == 64:
+        assert np.abs(np.stack([p.oldfft.real, p.oldfft.imag], axis=1) - g["oldfft"]).max() <= 1e-13
+
+
+def test_harmonic_chunked_workspace_carries_previous_spectrum(amd, monkeypatch):
+    """PVX_MAX_ROWS=16: the previous VALID frame of a frame may sit in an earlier launch (gaps of NaN
+    f0 longer than a chunk in H2 would need it too): results equal the single-launch ones bitwise."""
+    g = load_golden("H2_harm8_gaps_k24")
+    f0 = g["f0_arg"].copy()
+    f0[20:60] = np.nan                                     # a gap longer than two chunks
+    def run():
+        p = amd.PVHarmonic(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], progress=False, precision=64)
+        p.set_f0(f0)
+        p.run_pv()
+        return p
+    a = run()
+    monkeypatch.setenv("PVX_MAX_ROWS", "16")
+    b = run()
+    for k in ("f", "mag", "ph", "residuals", "t"):
+        assert np.array_equal(getattr(a, k), getattr(b, k), equal_nan=True), k
+    assert np.array_equal(a.oldfft, b.oldfft)
+
+
+def test_harmonic_streaming_frames_match_run_pv(amd, oracle):
+    """PVHarmonic.calc_pv_frame(pos, f0) frame by frame (state in oldfft, only advanced by the frames
+    that are analysed) = run_pv; it returns ALL harmonics, run_pv keeps the first npks."""
+    g = load_golden("H2_harm8_gaps_k24")
+    p = amd.PVHarmonic(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], progress=False, precision=64)
+    p.set_f0(g["f0_arg"])
+    p.run_pv()
+    q = amd.PVHarmonic(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], progress=False, precision=64)
+    K = g["npks"]
+    for fr in range(0, 12):
+        f0 = g["f0_arg"][fr]
+        if not f0 > 0:
+            continue
+        f, mag, ph, res = q.calc_pv_frame(fr * g["hop"], f0)
+        assert len(f) == len(np.arange(f0 / g["sr"] * g["nfft"], g["nfft"] // 2 - 1, f0 / g["sr"] * g["nfft"]))
+        n = min(K, len(f))
+        assert np.array_equal(np.array(f[:n]), p.f[fr, :n]) and np.array_equal(np.array(mag[:n]), p.mag[fr, :n])
+        assert np.array_equal(np.array(ph[:n]), p.ph[fr, :n])
+        assert res == p.residuals[fr] or (np.isnan(res) and np.isnan(p.residuals[fr]))
+
+
+def test_harmonic_argument_errors(amd):
+    g = load_golden("H3_readme_f0const")
+    p = amd.PVHarmonic(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], progress=False)
+    p.set_f0(g["f0_arg"][:10])
+    with pytest.raises(IndexError):                        # PV.py:507
+        p.run_pv()
+    f0 = g["f0_arg"].copy()
+    f0[5] = 1.0                                            # 0.02 bins: not a resolvable harmonic series
+    p.set_f0(f0)
+    with pytest.raises(amd.PvxError):
+        p.run_pv()
+
+
+def test_harmonic_seeded_against_oracle(amd, oracle):
+    """Random f0 tracks (incl. invalid entries) on a noisy harmonic tone, odd nfft/hop, float64."""
+    rng = np.random.default_rng(11)
+    sr, nfft, hop, K = 22050.0, 1000, 333, 10
+    n = nfft + hop * 90 + 5
+    t = np.arange(n) / sr
+    x = sum(0.2 / h * np.sin(2 * np.pi * 310.0 * h * t + h) for h in range(1, 7)) + 0.01 * rng.standard_normal(n)
+    F = int(np.ceil((n - nfft) / hop))
+    f0 = 310.0 * (1 + 0.02 * rng.standard_normal(F))
+    f0[rng.integers(0, F, 12)] = 0.0
+    f0[rng.integers(0, F, 5)] = np.nan
+    p = amd.PVHarmonic(x, sr, nfft=nfft, hop=hop, npks=K, progress=False, precision=64)
+    p.set_f0(f0)
+    p.run_pv()
+    o = oracle.harmonic(x, sr, f0, nfft, hop, K)
+    g = dict(o, nframes=F, hop=hop, sr=sr)
+    _harm_compare(p, g, 64)

@@ -103,3 +103,31 @@ def test_nframes_formula(oracle):
     assert oracle.nframes(1024, 1024, 512) == 0
     assert oracle.nframes(1025, 1024, 512) == 1
     assert oracle.nframes(100, 1024, 512) == 0
+
+
+# ------------------------------------------------------------------ PVHarmonic
+HARMONIC = golden_names(prefix="H", exclude=())
+
+
+@pytest.mark.parametrize("name", HARMONIC)
+def test_harmonic_matches_reference(oracle, name):
+    """pvo_harmonic against PVHarmonic.run_pv of the reference (tests/golden/make_golden_harmonic.py):
+    f0-guided bins, stale previous spectrum over skipped frames, zero padding, NaN residuals."""
+    g = load_golden(name)
+    o = oracle.harmonic(g["x"], g["sr"], g["f0_used"], g["nfft"], g["hop"], g["npks"], g["fmin"])
+    assert o["f"].shape == g["f"].shape == (g["nframes"], g["npks"])
+    assert np.array_equal(o["t"], g["t"])
+    assert np.array_equal(np.isnan(o["residuals"]), np.isnan(g["residuals"]))
+    assert np.array_equal(o["f"] == 0, g["f"] == 0)
+    assert np.nanmax(np.abs(o["f"] - g["f"])) <= 1e-9
+    assert np.abs(o["mag"] - g["mag"]).max() <= 1e-14
+    assert np.abs(o["ph"] - g["ph"]).max() <= 1e-10
+    # residual = sqrt(total - harmonic energy): compare the squares (cancellation)
+    fin = np.isfinite(g["residuals"])
+    assert np.abs(o["residuals"][fin] ** 2 - g["residuals"][fin] ** 2).max() <= 1e-13
+
+
+def test_harmonic_short_f0_is_index_error(oracle):
+    g = load_golden("H3_readme_f0const")
+    with pytest.raises(IndexError):
+        oracle.harmonic(g["x"], g["sr"], g["f0_used"][:10], g["nfft"], g["hop"], g["npks"])
