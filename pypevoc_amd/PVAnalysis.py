@@ -444,6 +444,16 @@ class RegPartial(object):
         else:
             self.realph.append(realph)
 
+    def prepend_point(self, f, mag, ph):
+        '''
+        Add a single point to the start of partial (PVAnalysis.py:628-635; like the reference it
+        leaves realph alone)
+        '''
+        self.f.insert(0, f)
+        self.mag.insert(0, mag)
+        self.ph.insert(0, ph)
+        self.start_idx -= 1
+
     def get_freq_at_frame(self, fr):
         relidx = fr - self.start_idx
         if relidx >= 0:
@@ -639,6 +649,39 @@ class SinSum(object):
     def get_partials_at_frame(self, fr):
         return [self._partial[i] for i in self.get_partials_idx_at_frame(fr)]
 
+    def add_point(self, fr, f, mag, ph, maxpitchjmp=0.5):
+        '''
+        Add a point to the matching partial or create a new one (PVAnalysis.py:832-868).  The
+        reference's slow single-point path, kept on the host: nearest previous partial by
+        semitone distance + |dB difference|, accepted when the semitone distance alone is below
+        maxpitchjmp.  Use add_frame / toSinSum for whole frames (tracker kernels).
+        '''
+        self._materialise()
+        pidx = [int(i) for i in self.get_partials_idx_ending_at_frame(fr - 1)]
+        idx = -1
+        part = None
+        if len(pidx) > 0:
+            pmag = [self._partial[ii].get_mag_at_frame(fr - 1) for ii in pidx]
+            pmag, pidx = zip(*sorted(zip(pmag, pidx), reverse=True))
+            partials = [self._partial[ii] for ii in pidx]
+            prev_f = [pp.get_freq_at_frame(fr - 1) for pp in partials]
+            stonediff = np.array([abs(dpitch2st(ff, f)) for ff in prev_f])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                dbdiff = 20 * np.log10(np.array(pmag) / mag)
+            nearest = np.argmin(stonediff + abs(dbdiff))
+            if stonediff[nearest] < maxpitchjmp:
+                idx = pidx[nearest]
+                part = partials[nearest]
+        if part is None:
+            part = self.add_empty_partial(fr)
+        part.append_point(f, mag, ph)
+        self._end[idx] = fr
+        self._tab_dirty = True
+
+    def get_points_at_frame(self, fr):
+        '''Placeholder in the reference too (PVAnalysis.py:996-1000).'''
+        pass
+
     def add_frame(self, fr, f, mag, ph, realph=None, maxpitchjmp=0.5):
         '''
         Add the peaks of frame fr to the matching partials or start new ones (PVAnalysis.py:871-957).
@@ -742,6 +785,30 @@ class SinSum(object):
                         dtype=[('idx', 'i4'), ('n', 'i4'), ('f', 'f4'), ('mag', 'f4')])
         psum.sort(order='mag')
         return psum
+
+    def get_part_data_around_freq(self, fc, semitones=.5):
+        '''
+        Frame-indexed f, mag, ph of the partials whose mean frequency lies within `semitones` of fc
+        (PVAnalysis.py:1091-1112); where several overlap in time, the one with the larger mean
+        magnitude wins (partials are written in ascending-magnitude order).
+        '''
+        nframes = self.get_nframes() + 1
+        t = np.arange(nframes) / float(self.sr) * self.hop
+        f = np.zeros(nframes)
+        mag = np.zeros(nframes)
+        ph = np.zeros(nframes)
+        ss = self.get_summary(minlen=0)
+        ss.sort(order='mag')
+        with np.errstate(divide="ignore", invalid="ignore"):
+            idx = ss['idx'][(abs(12 * np.log2(abs(ss['f'] / fc))) < semitones).nonzero()]
+        for i in idx:
+            part = self.partial[i]
+            sti = part.start_idx
+            endi = sti + len(part.mag)
+            f[sti:endi] = part.f
+            mag[sti:endi] = part.mag
+            ph[sti:endi] = part.ph
+        return t, f, mag, ph
 
     # table access without building Python objects (large analyses)
     def partial_table(self):
