@@ -230,7 +230,7 @@ def main():
                      kernels=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in per],
                      step_ms_hip_events=round(ev_ms / args.steps, 4))
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                  # contract: rank 0 at N=1 only
             from oracle import pvoracle
             pvoracle.build()
             xs = x_host.astype(np.float64)

