@@ -84,6 +84,16 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);
 /*
+ * Progress reporting: replaces Progress.update (pypevoc/ProgressDisplay.py:82-88), which the
+ * reference calls once per frame (PV.py:250-254, 528).  The HOST entry points pvx_analyze and
+ * pvx_harmonic_analyze call fn(frames_done, frames_total, user) after every launch chunk has
+ * completed on the device and once when all results are back (done == total).  fn = NULL disables.
+ * The asynchronous *_dev variants never call it.
+ */
+typedef void (*pvx_progress_fn)(int64_t frames_done, int64_t frames_total, void* user);
+int pvx_plan_set_progress(pvx_plan* plan, pvx_progress_fn fn, void* user);
+
+/*
  * Stage timing for bench.py's roofline line.  While enabled, hipEvents recorded on the launch
  * stream bracket every stage of every chunk.  pvx_plan_get_timing synchronises with those events
  * and returns, accumulated since the last call: ms[0] framing kernel, ms[1] rocFFT, ms[2]

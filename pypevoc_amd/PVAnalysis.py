@@ -9,6 +9,7 @@ What is host Python here is only what the reference also does once per object (c
 PV.__init__, PVAnalysis.py:84-121) and the list-like views over device results.
 """
 import ctypes
+import sys
 
 import numpy as np
 
@@ -94,10 +95,13 @@ class PV(object):
         self.f = []
         self.ph = []
         self.mag = []
-        # PVAnalysis.py:128-131 builds a console progress bar that prints once per frame; the whole
-        # analysis is a handful of kernel launches here, so `progress` only gates one final line.
-        self.progress = bool(progress)
+        # PVAnalysis.py:128-131 builds a console progress display that prints once per frame.  Here
+        # the analysis is a handful of kernel launches: libpvx_hip reports after every launch chunk
+        # (pvx_plan_set_progress) and the same "cur / max (pct%)" line is printed in samples.
+        # Extension: `progress` may be a callable(frames_done, frames_total).
+        self.progress = progress if callable(progress) else bool(progress)
         self._plan = None
+        self._progress_cb = None
 
     # ------------------------------------------------------------------ device plumbing
     def _get_plan(self, rows=None):
@@ -109,7 +113,26 @@ class PV(object):
                 want = max(2, int(rows))
             self._plan = _Plan(self.sr, self.nfft, int(self.hop), self.npeaks, self.peakthresh,
                                self.win, self.precision, max_rows=want)
+            self._install_progress(self._plan)
         return self._plan
+
+    def _install_progress(self, plan):
+        if not self.progress:
+            return
+        user = self.progress if callable(self.progress) else None
+        hop, nsamp = int(self.hop), int(self.nsamp)
+
+        def report(done, total, _):
+            if user is not None:
+                user(int(done), int(total))
+                return
+            cur = nsamp if done >= total else min(int(done) * hop, nsamp)      # PVAnalysis.py:249-254
+            pct = cur / float(max(nsamp, 1)) * 100
+            print('\r' + '%d / %d (%.2f%%)' % (cur, nsamp, pct), end=" ")      # ProgressDisplay.py:95-101
+            sys.stdout.flush()
+
+        self._progress_cb = _lib.PROGRESS_FN(report)                           # keep the thunk alive
+        _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, self._progress_cb, None), "pvx_plan_set_progress")
 
     def _signal(self):
         if self.x.ndim != 1:
@@ -212,8 +235,6 @@ class PV(object):
         self.nframes = F
         self.totalmag = list(tm)                                 # PVAnalysis.py:264 (a Python list)
         self.oldfft = last[:, 0] + 1j * last[:, 1]
-        if self.progress:
-            print("\r %d / %d (100%%)" % (self.nsamp, self.nsamp))
 
     def calc_harmonic_power(self, f_threshold=0.01):
         """
@@ -408,8 +429,6 @@ class PVHarmonic(PV):
         self.t = t
         self.nframes = F
         self.oldfft = last[:, 0] + 1j * last[:, 1]
-        if self.progress:
-            print("\r %d / %d (100%%)" % (self.nsamp, self.nsamp))
 
 
 class RegPartial(object):

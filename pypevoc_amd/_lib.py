@@ -65,10 +65,14 @@ SIGNATURES = {
                                               c_double_p, ctypes.c_int64, ctypes.c_double] + [c_double_p] * 7),
     "pvx_harmonic_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   c_double_p, ctypes.c_int64, ctypes.c_double] + [ctypes.c_void_p] * 7),
+    "pvx_plan_set_progress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_wire_bytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "pvx_pack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 7),
     "pvx_unpack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8),
 }
+
+
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)
 
 
 class PvxError(RuntimeError):

@@ -105,6 +105,10 @@ struct pvx_plan {
     int32_t* d_hprev = nullptr;
     void* d_carry = nullptr;
     int64_t harm_cap = 0;
+    // progress callback of the host entry points
+    pvx_progress_fn progress_fn = nullptr;
+    void* progress_user = nullptr;
+    bool progress_live = false;   // inside a host entry point: chunk completions are reported
     int64_t fused_blocks = 0;    // PVX_FUSED_BLOCKS override
     int frames_per_wave = 4;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
@@ -297,6 +301,25 @@ static int ensure_rocfft(pvx_plan* p) {
     return PVX_OK;
 }
 
+extern "C" int pvx_plan_set_progress(pvx_plan* plan, pvx_progress_fn fn, void* user) {
+    if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    plan->progress_fn = fn;
+    plan->progress_user = user;
+    return PVX_OK;
+}
+
+// after a launch chunk: rows [0, rows_done) of total_rows are in flight; report once they are done
+static int plan_progress(pvx_plan* p, hipStream_t s, int64_t rows_done, int64_t total_rows, int64_t nsig) {
+    if (!p->progress_live || !p->progress_fn) return PVX_OK;
+    PVX_HIP_CHECK(hipStreamSynchronize(s));
+    // rows include one zero row per signal; report frames
+    const int64_t per = total_rows / nsig;                            // F + 1
+    const int64_t full = rows_done / per, rem = rows_done - full * per;
+    const int64_t frames = full * (per - 1) + (rem > 0 ? rem - 1 : 0);
+    if (frames < nsig * (per - 1)) p->progress_fn(frames, nsig * (per - 1), p->progress_user);   // the last report comes from the entry point
+    return PVX_OK;
+}
+
 extern "C" int pvx_plan_set_timing(pvx_plan* plan, int enable) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     plan->timing = enable != 0;
@@ -382,6 +405,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
         if ((rc = pvx_launch_phase_peaks(pp, p->precision, s)) != PVX_OK) return rc;
         if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
+        if ((rc = plan_progress(p, s, R0 + nrows, total_rows, nsig)) != PVX_OK) return rc;
     }
     return PVX_OK;
 }
@@ -451,8 +475,10 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
     double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_realph = (double*)(o + 3 * fk),
            *d_binno = (double*)(o + 4 * fk), *d_t = (double*)(o + 5 * fk), *d_tm = (double*)(o + 5 * fk + f1);
     const int64_t all_rows = nsig * (F + 1);
+    p->progress_live = true;
     rc = analyze_rows(p, dx.p, x_dtype, nsamp, nsig, sig_stride, F, d_f, d_mag, d_ph, d_realph, d_binno, d_t, d_tm,
                       (const double*)dprev.p, nullptr, last_spec ? all_rows - 1 : -1);
+    p->progress_live = false;
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
     PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
@@ -477,6 +503,7 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
         for (int i = 0; i < 2 * p->N2; i++)
             last_spec[i] = p->precision == 32 ? (double)((float*)tmp.data())[i] : ((double*)tmp.data())[i];
     }
+    if (p->progress_fn) p->progress_fn(nsig * F, nsig * F, p->progress_user);
     return F;
 }
 
@@ -677,6 +704,7 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
         if (lv >= hp.fr_begin)
             PVX_HIP_CHECK(hipMemcpyAsync(p->d_carry, (const char*)p->d_spec + (size_t)(lv + 1 - R0 + 1) * p->ldo * 2 * rs,
                                          (size_t)p->ldo * 2 * rs, hipMemcpyDeviceToDevice, s));
+        if ((rc = plan_progress(p, s, R0 + nrows, total_rows, 1)) != PVX_OK) return rc;
     }
     return PVX_OK;
 }
@@ -731,7 +759,9 @@ extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype,
     double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_res = (double*)(o + 3 * fk),
            *d_t = (double*)(o + 3 * fk + f1);
     bool any = false;
+    p->progress_live = true;
     rc = harmonic_rows(p, dx.p, x_dtype, nsamp, F, f0, fmin, d_f, d_mag, d_ph, d_res, d_t, (const double*)dprev.p, nullptr, &any);
+    p->progress_live = false;
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
     PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
@@ -751,6 +781,7 @@ extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype,
             for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = prev0 ? prev0[i] : 0.0;
         }
     }
+    if (p->progress_fn) p->progress_fn(F, F, p->progress_user);
     return F;
 }
 

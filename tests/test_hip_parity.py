@@ -690,3 +690,28 @@ def test_harmonic_seeded_against_oracle(amd, oracle):
     o = oracle.harmonic(x, sr, f0, nfft, hop, K)
     g = dict(o, nframes=F, hop=hop, sr=sr)
     _harm_compare(p, g, 64)
+
+
+# ------------------------------------------------------------------ progress reporting
+def test_progress_callback_and_console_line(amd, capsys, monkeypatch):
+    """pvx_plan_set_progress: the host entry point reports after every launch chunk (general path,
+    PVX_MAX_ROWS=64 -> several chunks) and once at the end; progress=True prints the reference's
+    'cur / max (pct%)' line in samples (ProgressDisplay.py:95-101)."""
+    monkeypatch.setenv("PVX_MAX_ROWS", "64")
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+    rng = np.random.default_rng(2)
+    x = 0.1 * rng.standard_normal(1024 + 256 * 300)
+    seen = []
+    p = amd.PV(x, 44100, nfft=1024, hop=256, npks=4, progress=lambda d, t: seen.append((d, t)))
+    p.run_pv()
+    F = p.nframes
+    assert len(seen) >= 4 and seen[-1] == (F, F)
+    assert all(t == F for _, t in seen) and [d for d, _ in seen] == sorted(d for d, _ in seen)
+    q = amd.PV(x, 44100, nfft=1024, hop=256, npks=4, progress=True)
+    q.run_pv()
+    out = capsys.readouterr().out
+    assert out.rstrip().endswith("%d / %d (100.00%%)" % (len(x), len(x)))
+    assert np.array_equal(p.f, q.f)
+    r = amd.PV(x, 44100, nfft=1024, hop=256, npks=4, progress=False)
+    r.run_pv()
+    assert capsys.readouterr().out == ""
