@@ -212,6 +212,27 @@ int64_t pvx_harmonic_analyze_dev(pvx_plan* plan, const void* d_x, int x_dtype, i
                                  double* d_f, double* d_mag, double* d_ph, double* d_residual,
                                  double* d_t, const double* d_prev0, void* stream);
 
+/* ---- windowed reductions with the analysis framing ---------------------
+ *
+ * Frames start at i*hop for i*hop < n - wlen: pvx_nframes(n, wlen, hop) of them.  float64.
+ *
+ * pvx_heterodyne: Heterodyne.heterodyne(x, hetsig, wind, hop) (pypevoc/Heterodyne.py:35-60):
+ *   out[i] = 2 * sum_j x[i*hop+j] * hetsig[i*hop+j] * wind[j] / sum(wind)   complex, [nfr][2]
+ *   icent[i] = i*hop + wlen/2 (optional).  hetsig: complex128 [n] as [n][2].
+ *   (SoundUtils.Heterodyn / HeterodynWithF0Track, SoundUtils.py:106-138, are this with
+ *    hetsig = exp(+-2j*pi*phase) built by the caller and wind = windfunc(nwind).)
+ * pvx_rms_frames: SoundUtils.RMSWind (SoundUtils.py:71-103):
+ *   out[i] = sqrt(sum_j (x[i*hop+j]*wind[j])**2 / sum(wind**2))
+ * `wind` is a HOST array in both variants.  Return nfr or a negative status.
+ */
+int64_t pvx_heterodyne(const double* x, const double* hetsig, int64_t n, const double* wind,
+                       int wlen, int hop, double* out, int64_t* icent);
+int64_t pvx_heterodyne_dev(const double* d_x, const double* d_hetsig, int64_t n, const double* wind,
+                           int wlen, int hop, double* d_out, int64_t* d_icent, void* stream);
+int64_t pvx_rms_frames(const double* x, int64_t n, const double* wind, int wlen, int hop, double* out);
+int64_t pvx_rms_frames_dev(const double* d_x, int64_t n, const double* wind, int wlen, int hop,
+                           double* d_out, void* stream);
+
 /* ---- multi-GPU result gather: compact wire format --------------------------------------
  *
  * The reference has no multi-device path; its results are the five float64 [F, K] arrays of

@@ -380,6 +380,41 @@ int64_t pvo_harmonic(const double *x, int64_t nsamp, double sr, int nfft, int ho
     return rc;
 }
 
+/* Heterodyne.heterodyne (Heterodyne.py:35-60): out[i] = 2*sum(x*hetsig*wind)/sum(wind) over the frame at
+ * i*hop, i*hop < n - wlen; hetsig and out are complex as [.][2].  Returns the number of frames. */
+int64_t pvo_heterodyne(const double *x, const double *hetsig, int64_t n, const double *wind, int wlen, int hop,
+                       double *out, int64_t *icent) {
+    if (wlen <= 0 || hop <= 0) return -1;
+    double wnorm = 0.0;
+    for (int j = 0; j < wlen; j++) wnorm += wind[j];
+    int64_t nfr = 0;
+    for (int64_t ii = 0; ii < n - wlen; ii += hop, nfr++) {
+        double sr = 0.0, si = 0.0;
+        for (int j = 0; j < wlen; j++) {
+            sr += (x[ii + j] * hetsig[2 * (ii + j)]) * wind[j];
+            si += (x[ii + j] * hetsig[2 * (ii + j) + 1]) * wind[j];
+        }
+        out[2 * nfr] = sr / wnorm * 2.0;
+        out[2 * nfr + 1] = si / wnorm * 2.0;
+        if (icent) icent[nfr] = ii + wlen / 2;
+    }
+    return nfr;
+}
+
+/* SoundUtils.RMSWind (SoundUtils.py:71-103): sqrt(sum((x*wind)**2 / sum(wind**2))) per frame. */
+int64_t pvo_rms_frames(const double *x, int64_t n, const double *wind, int wlen, int hop, double *out) {
+    if (wlen <= 0 || hop <= 0) return -1;
+    double wsum2 = 0.0;
+    for (int j = 0; j < wlen; j++) wsum2 += wind[j] * wind[j];
+    int64_t nfr = 0;
+    for (int64_t ist = 0; ist + wlen < n; ist += hop, nfr++) {
+        double s = 0.0;
+        for (int j = 0; j < wlen; j++) { double xw = x[ist + j] * wind[j]; s += xw * xw / wsum2; }
+        out[nfr] = sqrt(s);
+    }
+    return nfr;
+}
+
 /* Windowed, normalised half spectrum of frame `fr` (PV.py:150-158, 169): for checking the
  * device STFT stage in isolation.  outr/outi: nfft/2. */
 int pvo_stft_frame(const double *x, int64_t pos, int nfft, const double *win, double *outr, double *outi) {

@@ -42,6 +42,11 @@ def lib():
         L.pvo_harmonic.restype = ctypes.c_int64
         L.pvo_harmonic.argtypes = [_dp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    _dp, _dp, ctypes.c_int64, ctypes.c_double] + [_dp] * 5
+        L.pvo_heterodyne.restype = ctypes.c_int64
+        L.pvo_heterodyne.argtypes = [_dp, _dp, ctypes.c_int64, _dp, ctypes.c_int, ctypes.c_int, _dp,
+                                     ctypes.POINTER(ctypes.c_int64)]
+        L.pvo_rms_frames.restype = ctypes.c_int64
+        L.pvo_rms_frames.argtypes = [_dp, ctypes.c_int64, _dp, ctypes.c_int, ctypes.c_int, _dp]
         L.pvo_stft_frame.restype = ctypes.c_int
         L.pvo_stft_frame.argtypes = [_dp, ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp]
         L.pvo_peakfinder.restype = ctypes.c_int
@@ -112,6 +117,33 @@ def harmonic(x, sr, f0, nfft=1024, hop=None, npks=20, fmin=30.0, win=None):
         raise IndexError("f0 is shorter than the number of frames")
     if r != F:
         raise RuntimeError("pvo_harmonic failed: %d" % r)
+    return out
+
+
+def heterodyne(x, hetsig, wind, hop):
+    """Heterodyne.heterodyne(x, hetsig, wind, hop) -> (complex amplitudes, centre samples)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.ascontiguousarray(hetsig, dtype=np.complex128)
+    wind = np.ascontiguousarray(wind, dtype=np.float64)
+    nfr = nframes(len(x), len(wind), hop)
+    out = np.zeros(nfr, dtype=np.complex128)
+    ic = np.zeros(nfr, dtype=np.int64)
+    r = lib().pvo_heterodyne(_d(x), h.view(np.float64).ctypes.data_as(_dp), len(x), _d(wind), len(wind), int(hop),
+                             out.view(np.float64).ctypes.data_as(_dp), ic.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    if r != nfr:
+        raise RuntimeError("pvo_heterodyne: %d frames, expected %d" % (r, nfr))
+    return out, ic
+
+
+def rms_frames(x, wind, hop):
+    """SoundUtils.RMSWind values for window `wind` and step `hop`."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    wind = np.ascontiguousarray(wind, dtype=np.float64)
+    nfr = nframes(len(x), len(wind), hop)
+    out = np.zeros(nfr)
+    r = lib().pvo_rms_frames(_d(x), len(x), _d(wind), len(wind), int(hop), _d(out))
+    if r != nfr:
+        raise RuntimeError("pvo_rms_frames: %d frames, expected %d" % (r, nfr))
     return out
 
 

@@ -65,6 +65,13 @@ SIGNATURES = {
                                               c_double_p, ctypes.c_int64, ctypes.c_double] + [c_double_p] * 7),
     "pvx_harmonic_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   c_double_p, ctypes.c_int64, ctypes.c_double] + [ctypes.c_void_p] * 7),
+    "pvx_heterodyne": (ctypes.c_int64, [c_double_p, c_double_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int,
+                                        c_double_p, c_int64_p]),
+    "pvx_heterodyne_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_double_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvx_rms_frames": (ctypes.c_int64, [c_double_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p]),
+    "pvx_rms_frames_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_plan_set_progress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_wire_bytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "pvx_pack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 7),

@@ -785,6 +785,93 @@ extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype,
     return F;
 }
 
+// ---- windowed reductions with the analysis framing (Heterodyne.py:35-60, SoundUtils.py:71-103) ----
+static int reduce_args(int64_t n, const double* wind, int wlen, int hop, double* norm, int power) {
+    if (n < 0 || wlen <= 0 || hop <= 0 || !wind) { pvx_set_error("bad windowed-reduction argument"); return PVX_ERR_INVALID; }
+    double s = 0.0;
+    for (int i = 0; i < wlen; i++) s += power == 2 ? wind[i] * wind[i] : wind[i];
+    *norm = s;
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_heterodyne_dev(const double* d_x, const double* d_hetsig, int64_t n, const double* wind, int wlen, int hop,
+                                      double* d_out, int64_t* d_icent, void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    double norm;
+    if ((rc = reduce_args(n, wind, wlen, hop, &norm, 1)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!d_x || !d_hetsig || !d_out) { pvx_set_error("null heterodyne array"); return PVX_ERR_INVALID; }
+    DevBuf dw;
+    if ((rc = dw.alloc((size_t)wlen * 8)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dw.p, wind, (size_t)wlen * 8, hipMemcpyHostToDevice));
+    ReduceParams rp = {};
+    rp.x = d_x; rp.hetsig = d_hetsig; rp.wind = (const double*)dw.p; rp.nfr = nfr; rp.wlen = wlen; rp.hop = hop;
+    rp.norm = norm; rp.out = d_out; rp.icent = d_icent;
+    if ((rc = pvx_launch_reduce(rp, 0, (hipStream_t)stream)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));            // dw is a local
+    return nfr;
+}
+
+extern "C" int64_t pvx_heterodyne(const double* x, const double* hetsig, int64_t n, const double* wind, int wlen, int hop,
+                                  double* out, int64_t* icent) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    double norm;
+    if ((rc = reduce_args(n, wind, wlen, hop, &norm, 1)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!x || !hetsig || !out) { pvx_set_error("null heterodyne array"); return PVX_ERR_INVALID; }
+    DevBuf dx, dh, dout, dic;
+    if ((rc = dx.alloc((size_t)n * 8)) != PVX_OK || (rc = dh.alloc((size_t)n * 16)) != PVX_OK ||
+        (rc = dout.alloc((size_t)nfr * 16)) != PVX_OK || (rc = dic.alloc((size_t)nfr * 8)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    PVX_HIP_CHECK(hipMemcpy(dh.p, hetsig, (size_t)n * 16, hipMemcpyHostToDevice));
+    const int64_t r = pvx_heterodyne_dev((const double*)dx.p, (const double*)dh.p, n, wind, wlen, hop, (double*)dout.p,
+                                         (int64_t*)dic.p, nullptr);
+    if (r < 0) return r;
+    PVX_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)nfr * 16, hipMemcpyDeviceToHost));
+    if (icent) PVX_HIP_CHECK(hipMemcpy(icent, dic.p, (size_t)nfr * 8, hipMemcpyDeviceToHost));
+    return nfr;
+}
+
+extern "C" int64_t pvx_rms_frames_dev(const double* d_x, int64_t n, const double* wind, int wlen, int hop, double* d_out,
+                                      void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    double norm;
+    if ((rc = reduce_args(n, wind, wlen, hop, &norm, 2)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!d_x || !d_out) { pvx_set_error("null rms array"); return PVX_ERR_INVALID; }
+    DevBuf dw;
+    if ((rc = dw.alloc((size_t)wlen * 8)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dw.p, wind, (size_t)wlen * 8, hipMemcpyHostToDevice));
+    ReduceParams rp = {};
+    rp.x = d_x; rp.wind = (const double*)dw.p; rp.nfr = nfr; rp.wlen = wlen; rp.hop = hop; rp.norm = norm; rp.out = d_out;
+    if ((rc = pvx_launch_reduce(rp, 1, (hipStream_t)stream)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return nfr;
+}
+
+extern "C" int64_t pvx_rms_frames(const double* x, int64_t n, const double* wind, int wlen, int hop, double* out) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    double norm;
+    if ((rc = reduce_args(n, wind, wlen, hop, &norm, 2)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!x || !out) { pvx_set_error("null rms array"); return PVX_ERR_INVALID; }
+    DevBuf dx, dout;
+    if ((rc = dx.alloc((size_t)n * 8)) != PVX_OK || (rc = dout.alloc((size_t)nfr * 8)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    const int64_t r = pvx_rms_frames_dev((const double*)dx.p, n, wind, wlen, hop, (double*)dout.p, nullptr);
+    if (r < 0) return r;
+    PVX_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)nfr * 8, hipMemcpyDeviceToHost));
+    return nfr;
+}
+
 // ---- result wire format for the multi-GPU gather (k_wire.hip) -------------------------------
 extern "C" int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows) {
     if (!plan || rows < 0) { pvx_set_error("bad wire argument"); return PVX_ERR_INVALID; }

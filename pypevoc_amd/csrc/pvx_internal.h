@@ -153,6 +153,19 @@ struct HarmParams {
 };
 int pvx_launch_harmonic(const HarmParams& p, int precision, hipStream_t s);
 
+// windowed reductions with the analysis framing (k_reduce.hip)
+struct ReduceParams {
+    const double* x;          // [n]
+    const double* hetsig;     // [n][2] complex (heterodyne only)
+    const double* wind;       // [wlen]
+    int64_t nfr;
+    int wlen, hop;
+    double norm;              // sum(wind) | sum(wind**2)
+    double* out;              // [nfr][2] | [nfr]
+    int64_t* icent;           // [nfr] optional (heterodyne)
+};
+int pvx_launch_reduce(const ReduceParams& p, int mode, hipStream_t s);
+
 // result wire format for the multi-GPU gather (k_wire.hip)
 struct WireParams {
     int64_t rows;                     // frames (all signals of the shard)

@@ -715,3 +715,43 @@ def test_progress_callback_and_console_line(amd, capsys, monkeypatch):
     r = amd.PV(x, 44100, nfft=1024, hop=256, npks=4, progress=False)
     r.run_pv()
     assert capsys.readouterr().out == ""
+
+
+# ------------------------------------------------------------------ windowed reductions
+def test_windowed_reductions_match_reference(amd, oracle):
+    """heterodyne / RMSWind / Heterodyn / HeterodynWithF0Track through the Python drop-ins (HIP kernels in
+    k_reduce.hip) against values captured from the reference (W1) and against the oracle on a seeded case.
+    float64; the only difference is summation order: 1e-13 absolute on O(0.1) amplitudes."""
+    from pypevoc_amd.Heterodyne import heterodyne
+    from pypevoc_amd import SoundUtils as su
+    g = dict(np.load(os.path.join(GOLDEN, "W1_windowed.npz")))
+    x = g["x"].astype(np.float64)
+    sr = float(g["sr"])
+    hetsig = np.exp(-2j * np.pi * np.cumsum(g["het_fvec"]))
+    c2 = lambda z: np.stack([z.real, z.imag], axis=1)
+    h, ic = heterodyne(x, hetsig, wind=np.hanning(1024), hop=256)
+    assert np.array_equal(ic, g["het_icent"]) and np.abs(c2(h) - g["het"]).max() <= 1e-13
+    h2, ic2 = heterodyne(x, hetsig, hop=100)
+    assert np.array_equal(ic2, g["het_rect_icent"]) and np.abs(c2(h2) - g["het_rect"]).max() <= 1e-13
+    with pytest.raises(TypeError):
+        heterodyne(x, hetsig)                              # hop=None fails in the reference's range() too
+    r, t = su.RMSWind(x, sr=sr, nwind=1024, nhop=512)
+    assert np.array_equal(t, g["rms_t"]) and np.abs(r - g["rms"]).max() <= 1e-14
+    r3, t3 = su.RMSWind(x, sr=sr, nwind=1000, nhop=333, windfunc=np.hanning)
+    assert np.array_equal(t3, g["rms_odd_t"]) and np.abs(r3 - g["rms_odd"]).max() <= 1e-14
+    a, ta = su.Heterodyn(x, 1000.0, sr=sr, nwind=1024, nhop=512)
+    assert np.array_equal(ta, g["heterodyn_t"]) and np.abs(c2(a) - g["heterodyn"]).max() <= 1e-13
+    b, tb = su.HeterodynWithF0Track(x, g["tf0"], g["f0"], sr=sr, nwind=2048, nhop=512)
+    assert np.array_equal(tb, g["heterodyn_f0_t"]) and np.abs(c2(b) - g["heterodyn_f0"]).max() <= 1e-13
+    # seeded, larger, odd sizes, against the oracle; and empty results for short inputs
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal(300001)
+    hs = np.exp(-2j * np.pi * np.cumsum(np.full(len(y), 0.0123)))
+    w = np.hanning(4097)
+    hh, ii = heterodyne(y, hs, wind=w, hop=1000)
+    oh, oi = oracle.heterodyne(y, hs, w, 1000)
+    assert np.array_equal(ii, oi) and np.abs(hh - oh).max() <= 1e-13
+    rr, _ = su.RMSWind(y, nwind=4097, nhop=1000, windfunc=np.hanning)
+    assert np.abs(rr - oracle.rms_frames(y, w, 1000)).max() <= 1e-13
+    e, ie = heterodyne(y[:100], hs[:100], wind=np.ones(256), hop=10)
+    assert len(e) == 0 and len(ie) == 0

@@ -131,3 +131,26 @@ def test_harmonic_short_f0_is_index_error(oracle):
     g = load_golden("H3_readme_f0const")
     with pytest.raises(IndexError):
         oracle.harmonic(g["x"], g["sr"], g["f0_used"][:10], g["nfft"], g["hop"], g["npks"])
+
+
+# ------------------------------------------------------------------ windowed reductions
+def _w1():
+    g = dict(np.load(os.path.join(GOLDEN, "W1_windowed.npz")))
+    g["x"] = g["x"].astype(np.float64)
+    return g
+
+
+def test_windowed_reductions_match_reference(oracle):
+    """pvo_heterodyne / pvo_rms_frames against Heterodyne.heterodyne and SoundUtils.RMSWind of the
+    reference (tests/golden/make_golden_harmonic.py, W1).  numpy sums pairwise, the oracle left to right:
+    tolerance 1e-13 of the window's mean amplitude scale."""
+    g = _w1()
+    hetsig = np.exp(-2j * np.pi * np.cumsum(g["het_fvec"]))
+    h, ic = oracle.heterodyne(g["x"], hetsig, np.hanning(1024), 256)
+    assert np.array_equal(ic, g["het_icent"])
+    assert np.abs(np.stack([h.real, h.imag], axis=1) - g["het"]).max() <= 1e-13
+    h2, ic2 = oracle.heterodyne(g["x"], hetsig, np.ones(256), 100)
+    assert np.array_equal(ic2, g["het_rect_icent"])
+    assert np.abs(np.stack([h2.real, h2.imag], axis=1) - g["het_rect"]).max() <= 1e-13
+    assert np.abs(oracle.rms_frames(g["x"], np.blackman(1024), 512) - g["rms"]).max() <= 1e-14
+    assert np.abs(oracle.rms_frames(g["x"], np.hanning(1000), 333) - g["rms_odd"]).max() <= 1e-14
