@@ -61,7 +61,7 @@ template <int R> struct Geo {
 template <int R> __device__ __host__ __forceinline__ int zpad(int k) { return k + Geo<R>::ZP * (k >> (2 * Geo<R>::LOGR)); }
 
 template <int R, typename InT, bool AL2>
-__device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[R], float (&rb)[R]) {
+__device__ __forceinline__ void load_raw(const InT* x, int lane, v2f (&raw)[R]) {
     // lane l takes z[l + 64 r] = (x[2l + 128 r], x[2l + 128 r + 1]): 512 contiguous bytes per
     // wave-instruction.  Issued one frame ahead of its use (software prefetch): the loads of row
     // g+1 are in flight while row g is transformed and searched for peaks.
@@ -69,10 +69,9 @@ __device__ __forceinline__ void load_raw(const InT* x, int lane, float (&ra)[R],
     for (int r = 0; r < R; r++) {
         const InT* p = x + 2 * lane + 128 * r;
         if constexpr (AL2 && sizeof(InT) == 4) {
-            const float2 v = *(const float2*)p;
-            ra[r] = v.x; rb[r] = v.y;
+            raw[r] = *(const v2f*)p;
         } else {
-            ra[r] = ld1(p); rb[r] = ld1(p + 1);
+            raw[r] = pvxc::mk(ld1(p), ld1(p + 1));
         }
     }
 }
@@ -141,42 +140,38 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     for (int k = threadIdx.x; k < 64; k += blockDim.x) tw2l[k] = tab[((G::N / 64) * (k % P) * (k / P)) & NMASK];
     __syncthreads();
 
-    // ---- lane constants
+    // ---- lane constants (complex values are register pairs, pvx_cplx.h)
     const int Q = lane / P, L1 = lane % P;
-    float w0[R], w1[R], t1r[R], t1i[R], t2r[R], t2i[R];
+    v2f wv[R], t1[R], t2[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const float2 wv = ((const float2*)p.win)[lane + 64 * r];  // (w[2l + 128 r], w[2l + 128 r + 1])
-        w0[r] = wv.x; w1[r] = wv.y;
-        const float2 a = tab[(2 * lane * r) & NMASK];             // W_M^(l q)
-        t1r[r] = a.x; t1i[r] = a.y;
-        const float2 b = tw2l[r * P + L1];                        // W_64^(l1 t2)
-        t2r[r] = b.x; t2i[r] = b.y;
+        wv[r] = ((const v2f*)p.win)[lane + 64 * r];               // (w[2l + 128 r], w[2l + 128 r + 1])
+        t1[r] = ((const v2f*)tab)[(2 * lane * r) & NMASK];        // W_M^(l q)
+        t2[r] = ((const v2f*)tw2l)[r * P + L1];                   // W_64^(l1 t2)
     }
     // cross-lane DFT constants: step with half-size h = P >> (s+1): sign and twiddle W_2h^(l1 mod h)
-    float csg[G::LOGP > 0 ? G::LOGP : 1], cwr[G::LOGP > 0 ? G::LOGP : 1], cwi[G::LOGP > 0 ? G::LOGP : 1];
+    float csg[G::LOGP > 0 ? G::LOGP : 1];
+    v2f cw[G::LOGP > 0 ? G::LOGP : 1];
 #pragma unroll
     for (int s = 0; s < G::LOGP; s++) {
         const int h = P >> (s + 1);
         const bool up = (L1 & h) != 0;
         csg[s] = up ? -1.f : 1.f;
-        const float2 wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
-        cwr[s] = up ? wv.x : 1.f;
-        cwi[s] = up ? wv.y : 0.f;
+        const float2 wvv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+        cw[s] = up ? pvxc::mk(wvv.x, wvv.y) : pvxc::mk(1.f, 0.f);
     }
     // keep the lane constants in registers: without this the compiler re-loads the twiddles from
     // global memory every frame (a full L2 round trip on the critical path) instead of holding them
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        asm volatile("" : "+v"(w0[r]), "+v"(w1[r]), "+v"(t1r[r]), "+v"(t1i[r]), "+v"(t2r[r]), "+v"(t2i[r]));
+        asm volatile("" : "+v"(wv[r]), "+v"(t1[r]), "+v"(t2[r]));
     }
-    // R = 16 (P = 4): the hand-written quad DFT.  step 2: res = alpha*u + beta*p;
-    // lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
+    // R = 16 (P = 4): the hand-written quad DFT.  step 1: u = sA*z + z[lane^2]; step 2:
+    // res = alpha*u + beta*u[lane^1];  lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
     const float sA = (L1 & 2) ? -1.f : 1.f;
-    const float alr = (L1 == 0 || L1 == 2) ? 1.f : (L1 == 1 ? -1.f : 0.f);
-    const float ali = (L1 == 3) ? 1.f : 0.f;
-    const float ber = (L1 == 2) ? 0.f : 1.f;
-    const float bei = (L1 == 2) ? -1.f : 0.f;
+    v2f qal = pvxc::mk((L1 == 0 || L1 == 2) ? 1.f : (L1 == 1 ? -1.f : 0.f), (L1 == 3) ? 1.f : 0.f);
+    v2f qbe = pvxc::mk((L1 == 2) ? 0.f : 1.f, (L1 == 2) ? -1.f : 0.f);
+    asm volatile("" : "+v"(qal), "+v"(qbe));
     int t1v = 0;                                                  // t1 = bitrev(l1)
 #pragma unroll
     for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
@@ -192,12 +187,12 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
 
     float2* cur = L.bufA;
     float2* prv = L.bufB;
-    float ra[R], rb[R];                                           // raw samples of the next row (prefetched)
+    v2f raw[R];                                                   // raw samples of the next row (prefetched)
     // Rows are addressed as (signal b, row-in-signal q), advanced incrementally: a 64-bit division
     // per frame costs more than the whole peak search.
     auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {     // issue the loads of global row gn = (bn, qn)
         if (gn < 0 || gn >= r1 || qn == 0) return;
-        load_raw<R, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, lane, ra, rb);
+        load_raw<R, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, lane, raw);
     };
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
@@ -213,89 +208,88 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             prefetch(g + 1, bn, qn);
             return;
         }
-        float xr[R], xi[R];
+        v2f z[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
+        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
         prefetch(g + 1, bn, qn);
-        dft_regs<R>(xr, xi);                                      // stage 1
+        dft_regs<R>(z);                                           // stage 1
+        v2f* dz = (v2f*)dst;
 #pragma unroll
         for (int q2 = 0; q2 < R; q2++) {
-            float a = xr[q2], c = xi[q2];
-            if (q2 > 0) cmul(a, c, t1r[q2], t1i[q2]);
-            dst[q2 * PITCH + lane] = make_float2(a, c);
+            dz[q2 * PITCH + lane] = (q2 > 0) ? pvxc::cmul(z[q2], t1[q2]) : z[q2];
         }
         wave_sync();
 #pragma unroll
-        for (int l2 = 0; l2 < R; l2++) {
-            const float2 v = dst[Q * PITCH + L1 + P * l2];
-            xr[l2] = v.x; xi[l2] = v.y;
-        }
+        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
         wave_sync();
-        dft_regs<R>(xr, xi);                                      // stage 2
+        dft_regs<R>(z);                                           // stage 2
 #pragma unroll
-        for (int t2 = 0; t2 < R; t2++) {
-            float a = xr[t2], c = xi[t2];
-            if (t2 > 0) cmul(a, c, t2r[t2], t2i[t2]);
-            float zr, zi;
+        for (int t2i = 0; t2i < R; t2i++) {
+            v2f a = (t2i > 0) ? pvxc::cmul(z[t2i], t2[t2i]) : z[t2i];
+            v2f res;
             if constexpr (P == 4) {
                 // stage 3: 4-point DFT across the quad
-                float pr_ = dppf<0x4E>(a), pi_ = dppf<0x4E>(c);   // lane ^ 2
-                const float ur = __builtin_fmaf(sA, a, pr_), ui = __builtin_fmaf(sA, c, pi_);
-                pr_ = dppf<0xB1>(ur); pi_ = dppf<0xB1>(ui);       // lane ^ 1
-                zr = __builtin_fmaf(alr, ur, __builtin_fmaf(-ali, ui, __builtin_fmaf(ber, pr_, -(bei * pi_))));
-                zi = __builtin_fmaf(alr, ui, __builtin_fmaf(ali, ur, __builtin_fmaf(ber, pi_, bei * pr_)));
+                const v2f p1 = dpp2<0x4E>(a);                     // lane ^ 2
+                const v2f u = pvxc::fma_s(sA, a, p1);
+                const v2f p2 = dpp2<0xB1>(u);                     // lane ^ 1
+                // alpha*u + beta*p2, every product exact (alpha, beta in {+-1, +-i, 0})
+                v2f tq;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(tq) : "v"(p2), "v"(qbe));
+                tq = __builtin_elementwise_fma(p2.xx, qbe, tq);   // beta * p2
+                v2f tu;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(tu) : "v"(u), "v"(qal), "v"(tq));
+                res = __builtin_elementwise_fma(u.xx, qal, tu);   // + alpha * u
             } else {
                 // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
                 // upper lane (a - b) W_2h^(l1 mod h)
                 if constexpr (G::LOGP >= 1) {
-                    if constexpr (P >= 16) { const float pr_ = lane_xor<8>(a), pi_ = lane_xor<8>(c);
-                        a = __builtin_fmaf(csg[G::LOGP - 4], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 4], c, pi_); cmul(a, c, cwr[G::LOGP - 4], cwi[G::LOGP - 4]); }
-                    if constexpr (P >= 8) { const float pr_ = lane_xor<4>(a), pi_ = lane_xor<4>(c);
-                        a = __builtin_fmaf(csg[G::LOGP - 3], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 3], c, pi_); cmul(a, c, cwr[G::LOGP - 3], cwi[G::LOGP - 3]); }
-                    if constexpr (P >= 4) { const float pr_ = lane_xor<2>(a), pi_ = lane_xor<2>(c);
-                        a = __builtin_fmaf(csg[G::LOGP - 2], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 2], c, pi_); cmul(a, c, cwr[G::LOGP - 2], cwi[G::LOGP - 2]); }
-                    { const float pr_ = lane_xor<1>(a), pi_ = lane_xor<1>(c);                 // h = 1: twiddle is 1
-                        a = __builtin_fmaf(csg[G::LOGP - 1], a, pr_); c = __builtin_fmaf(csg[G::LOGP - 1], c, pi_); }
+                    if constexpr (P >= 16) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 4], a, lane_xor2<8>(a)), cw[G::LOGP - 4]); }
+                    if constexpr (P >= 8) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 3], a, lane_xor2<4>(a)), cw[G::LOGP - 3]); }
+                    if constexpr (P >= 4) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 2], a, lane_xor2<2>(a)), cw[G::LOGP - 2]); }
+                    a = pvxc::fma_s(csg[G::LOGP - 1], a, lane_xor2<1>(a));                    // h = 1: twiddle is 1
                 }
-                zr = a; zi = c;
+                res = a;
             }
-            dst[zpad<R>(Q + R * t2 + G::R2 * t1v)] = make_float2(zr, zi);
+            dz[zpad<R>(Q + R * t2i + G::R2 * t1v)] = res;
         }
         wave_sync();
         // ---- untangle in place: pairs (k, M-k), k = lane + 64 j; bins 0 and M/2 have no partner.
         // Phase 1 reads everything (the loads do not wait for the in-place stores of other pairs),
         // phase 2 computes and stores.
+        //   S = Za + conj Zb, D = Za - conj Zb;  E = S/2, O = -i D/2, P = W^k O
+        //   X[k] = E + P,  X[M-k] = conj(E - P)
         constexpr int NPAIR = R / 2;
         float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
-        float2 za[NPAIR], zb[NPAIR], wv8[NPAIR];
+        v2f za[NPAIR], zb[NPAIR], wv8[NPAIR];
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
             const int k = lane + 64 * j;
             const int km = (M - k) & (M - 1);                     // k = 0: Z[M] == Z[0]
-            za[j] = dst[zpad<R>(k)];
-            zb[j] = dst[zpad<R>(km)];
-            wv8[j] = tw3[k];
+            za[j] = dz[zpad<R>(k)];
+            zb[j] = dz[zpad<R>(km)];
+            wv8[j] = ((const v2f*)tw3)[k];
         }
-        const float2 zc = dst[zpad<R>(G::HALF)];
+        const v2f zc = dz[zpad<R>(G::HALF)];
+        const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f);
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
             const int k = lane + 64 * j;
             const int km = (M - k) & (M - 1);
-            const float er = 0.5f * (za[j].x + zb[j].x), ei = 0.5f * (za[j].y - zb[j].y);      // E = (Za + conj Zb)/2
-            const float orr = 0.5f * (za[j].y + zb[j].y), oi = -0.5f * (za[j].x - zb[j].x);    // O = (Za - conj Zb)/(2i)
-            float pr2 = orr, pi2_ = oi;
-            cmul(pr2, pi2_, wv8[j].x, wv8[j].y);                                    // P = W^k O
-            const float x0r = er + pr2, x0i = ei + pi2_;                            // X[k]
-            float x1r = er - pr2, x1i = pi2_ - ei;                                  // X[M-k] = conj(E - P)
+            const v2f S = pvxc::add_conj(za[j], zb[j]);
+            const v2f D = pvxc::sub_conj(za[j], zb[j]);
+            const v2f O = pvxc::mul_swap(D, kmih);                // (D.y/2, -D.x/2)
+            const v2f Pk = pvxc::cmul(O, wv8[j]);                 // W^k O
+            const v2f x0 = __builtin_elementwise_fma(khalf, S, Pk);               // X[k] = S/2 + P
+            v2f x1 = pvxc::fms_conj(khalf, S, Pk);                                // X[M-k] = conj(S/2 - P)
             int kk = km;
             if (j == 0) {
                 // lane 0: k = 0 pairs with itself and its "partner" result is not a bin; that slot
                 // takes bin M/2, which pairs with itself too: X[M/2] = conj(Z[M/2])
-                if (lane == 0) { x1r = zc.x; x1i = -zc.y; kk = G::HALF; }
+                if (lane == 0) { x1 = pvxc::mk(zc.x, -zc.y); kk = G::HALF; }
             }
-            const float e0 = __builtin_fmaf(x0r, x0r, x0i * x0i), e1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
-            dst[zpad<R>(k)] = make_float2(x0r, x0i);
-            dst[zpad<R>(kk)] = make_float2(x1r, x1i);
+            const float e0 = __builtin_fmaf(x0.x, x0.x, x0.y * x0.y), e1 = __builtin_fmaf(x1.x, x1.x, x1.y * x1.y);
+            dz[zpad<R>(k)] = x0;
+            dz[zpad<R>(kk)] = x1;
             if (with_mag) {
                 // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
                 const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);

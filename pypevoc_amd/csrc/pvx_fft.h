@@ -3,6 +3,7 @@
 #pragma once
 
 #include "pvx_wave.h"
+#include "pvx_cplx.h"
 
 namespace pvxf {
 
@@ -116,6 +117,76 @@ template <int R> __device__ __forceinline__ void dft_regs(float (&xr)[R], float 
         for (int i = 0; i < R; i++) {
             const int j = bitrev_c(i, bits);
             if (i < j) { float t = xr[i]; xr[i] = xr[j]; xr[j] = t; t = xi[i]; xi[i] = xi[j]; xi[j] = t; }
+        }
+    }
+}
+
+// ======== the same DFTs on complex register pairs (pvx_cplx.h): one packed instruction per complex
+// add, two per complex multiply, multiply-by-(-i) folded into the adds' operand modifiers.  Same
+// arithmetic in the same order as the scalar versions above (bit-identical results).
+using pvxc::v2f;
+
+template <int CTRL> __device__ __forceinline__ v2f dpp2(v2f v) { return pvxc::mk(dppf<CTRL>(v.x), dppf<CTRL>(v.y)); }
+template <int H> __device__ __forceinline__ v2f lane_xor2(v2f v) { return pvxc::mk(lane_xor<H>(v.x), lane_xor<H>(v.y)); }
+
+__device__ __forceinline__ void dft16(v2f (&x)[16]) {
+    using namespace pvxc;
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
+    constexpr float cr[10] = {1.f, C1, H, S1, 0.f, 0.f, -H, 0.f, 0.f, -C1};
+    constexpr float ci[10] = {0.f, -S1, -H, -C1, -1.f, 0.f, -H, 0.f, 0.f, S1};
+    v2f t[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) {
+        const v2f a = x[n1], b = x[n1 + 4], c = x[n1 + 8], d = x[n1 + 12];
+        const v2f A = a + c, B = a - c, C = b + d, D = b - d;
+        v2f y[4];
+        y[0] = A + C; y[2] = A - C;
+        y[1] = add_mni(B, D);                    // B - i D
+        y[3] = add_pi(B, D);                     // B + i D
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const int m = n1 * k2;
+            if (m == 0) t[n1 * 4 + k2] = y[k2];
+            else if (m == 4) t[n1 * 4 + k2] = mni(y[k2]);
+            else t[n1 * 4 + k2] = cmul_k(y[k2], mk(cr[m], ci[m]));
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) {
+        const v2f a = t[k2], b = t[4 + k2], c = t[8 + k2], d = t[12 + k2];
+        const v2f A = a + c, B = a - c, C = b + d, D = b - d;
+        x[k2] = A + C; x[k2 + 8] = A - C;
+        x[k2 + 4] = add_mni(B, D); x[k2 + 12] = add_pi(B, D);
+    }
+}
+
+template <int R> __device__ __forceinline__ void dft_regs(v2f (&x)[R]) {
+    using namespace pvxc;
+    if constexpr (R == 16) {
+        dft16(x);
+    } else {
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+                for (int i = 0; i < h; i++) {
+                    const int a = blk + i, b = blk + i + h;
+                    const v2f s = x[a] + x[b];
+                    v2f d = x[a] - x[b];
+                    const int tw = i * (32 / h);
+                    if (tw == 0) { }
+                    else if (tw == 16) d = mni(d);
+                    else d = cmul_k(d, mk(kW64r[tw], kW64i[tw]));
+                    x[a] = s; x[b] = d;
+                }
+            }
+        }
+        constexpr int bits = ilog2(R);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int j = bitrev_c(i, bits);
+            if (i < j) { const v2f t = x[i]; x[i] = x[j]; x[j] = t; }
         }
     }
 }
