@@ -22,8 +22,10 @@
 //   stage 3  P-point DFT over l1 across the P lanes of a group: log2 P decimation-in-frequency steps,
 //            each one lane exchange (xor h) + one lane-constant twiddle W_2h^(l1 mod h)
 //   result   lane (q, l1) holds Z[q + R t2 + R^2 t1], t1 = bitrev(l1)
-// (R = 16: 1024 = 16 x 16 x 4, the quad-level 4-point DFT is hand-written with two DPP quad_perm
-// exchanges.)  Z goes to LDS in natural order (a few complex of padding per R^2 keep the accesses
+// (R = 16: 1024 = 16 x 16 x 4, the quad-level 4-point DFT is two DPP quad_perm exchange steps.)
+// Complex values are even-aligned register pairs (pvx_cplx.h): one packed instruction per complex add,
+// two per complex multiply, conjugations and multiplications by -i folded into operand modifiers.
+// Z goes to LDS in natural order (a few complex of padding per R^2 keep the accesses
 // spread over the banks), is untangled in place into X[0..M), |X| goes to a second LDS array, and
 // from there on the frame is handled exactly like k_peaks.hip does (same PeakFinder core, same
 // per-peak arithmetic), except that the previous frame's spectrum is the LDS buffer the wave filled
@@ -166,12 +168,6 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     for (int r = 0; r < R; r++) {
         asm volatile("" : "+v"(wv[r]), "+v"(t1[r]), "+v"(t2[r]));
     }
-    // R = 16 (P = 4): the hand-written quad DFT.  step 1: u = sA*z + z[lane^2]; step 2:
-    // res = alpha*u + beta*u[lane^1];  lanes 0..3: alpha = 1,-1,1,i   beta = 1,1,-i,1
-    const float sA = (L1 & 2) ? -1.f : 1.f;
-    v2f qal = pvxc::mk((L1 == 0 || L1 == 2) ? 1.f : (L1 == 1 ? -1.f : 0.f), (L1 == 3) ? 1.f : 0.f);
-    v2f qbe = pvxc::mk((L1 == 2) ? 0.f : 1.f, (L1 == 2) ? -1.f : 0.f);
-    asm volatile("" : "+v"(qal), "+v"(qbe));
     int t1v = 0;                                                  // t1 = bitrev(l1)
 #pragma unroll
     for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
@@ -226,30 +222,15 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
 #pragma unroll
         for (int t2i = 0; t2i < R; t2i++) {
             v2f a = (t2i > 0) ? pvxc::cmul(z[t2i], t2[t2i]) : z[t2i];
-            v2f res;
-            if constexpr (P == 4) {
-                // stage 3: 4-point DFT across the quad
-                const v2f p1 = dpp2<0x4E>(a);                     // lane ^ 2
-                const v2f u = pvxc::fma_s(sA, a, p1);
-                const v2f p2 = dpp2<0xB1>(u);                     // lane ^ 1
-                // alpha*u + beta*p2, every product exact (alpha, beta in {+-1, +-i, 0})
-                v2f tq;
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(tq) : "v"(p2), "v"(qbe));
-                tq = __builtin_elementwise_fma(p2.xx, qbe, tq);   // beta * p2
-                v2f tu;
-                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(tu) : "v"(u), "v"(qal), "v"(tq));
-                res = __builtin_elementwise_fma(u.xx, qal, tu);   // + alpha * u
-            } else {
-                // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
-                // upper lane (a - b) W_2h^(l1 mod h)
-                if constexpr (G::LOGP >= 1) {
-                    if constexpr (P >= 16) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 4], a, lane_xor2<8>(a)), cw[G::LOGP - 4]); }
-                    if constexpr (P >= 8) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 3], a, lane_xor2<4>(a)), cw[G::LOGP - 3]); }
-                    if constexpr (P >= 4) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 2], a, lane_xor2<2>(a)), cw[G::LOGP - 2]); }
-                    a = pvxc::fma_s(csg[G::LOGP - 1], a, lane_xor2<1>(a));                    // h = 1: twiddle is 1
-                }
-                res = a;
+            // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
+            // upper lane (a - b) W_2h^(l1 mod h)
+            if constexpr (G::LOGP >= 1) {
+                if constexpr (P >= 16) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 4], a, lane_xor2<8>(a)), cw[G::LOGP - 4]); }
+                if constexpr (P >= 8) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 3], a, lane_xor2<4>(a)), cw[G::LOGP - 3]); }
+                if constexpr (P >= 4) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 2], a, lane_xor2<2>(a)), cw[G::LOGP - 2]); }
+                a = pvxc::fma_s(csg[G::LOGP - 1], a, lane_xor2<1>(a));                        // h = 1: twiddle is 1
             }
+            const v2f res = a;
             dz[zpad<R>(Q + R * t2i + G::R2 * t1v)] = res;
         }
         wave_sync();

@@ -34,8 +34,10 @@ __device__ __forceinline__ void cmul(float& a, float& c, float wr, float wi) {
     a = nr;
 }
 
+// full-wave DPP move: every lane is written (row/bank masks 0xf, the permutations used here have no
+// invalid source lane), so there is no "old" value to preserve and none has to be materialised
 template <int CTRL> __device__ __forceinline__ float dppf(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 // value of lane (l ^ H) for H in {1, 2, 4, 8}
 template <int H> __device__ __forceinline__ float lane_xor(float v) {

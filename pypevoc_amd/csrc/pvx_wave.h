@@ -30,12 +30,13 @@ __device__ __forceinline__ int lane_prefix(unsigned long long bal) {   // set bi
 // ---- DPP reductions: 4 in-row steps (quad xor 1, xor 2, half mirror, mirror), then one readlane
 // per row of 16.  Result is wave-uniform.
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    // all four permutations used below write every lane: no "old" value to materialise
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
     long long b = __builtin_bit_cast(long long, v);
-    int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ float rl_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
