@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_raw(const InT* x, int lane, v2f (&raw)[R]) 
 struct FusedLds {       // per-wave carve
     float2* bufA;       // [BUFC]
     float2* bufB;       // [BUFC]
-    float* y;           // [M]
+    float* y;           // [M + 4 R], padded layout ymap<1>
     float* cs;          // [CAP]
     int* ci;            // [CAP]
     int* sel;           // [kpad]
@@ -97,7 +97,7 @@ template <int R> __host__ __device__ inline size_t fused_lds_per_wave(int K) {
     using G = Geo<R>;
     const size_t kpad = (size_t)((K + 3) & ~3);
     const size_t gs = (size_t)staged_frames(K, GF);
-    size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)G::M * 4 + (size_t)G::CAP * 4 * 2 + kpad * 4 +
+    size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)(G::M + 4 * R) * 4 + (size_t)(G::CAP * 2 + 64) * 4 + kpad * 4 +
                gs * kpad * 4 + gs * kpad * 5 * 4 + GF * 4 + GF * 4;
     b = (b + 7) & ~(size_t)7;
     b += GF * 8 + GF * 8;
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     L.bufA = (float2*)base;
     L.bufB = L.bufA + G::BUFC;
     L.y = (float*)(L.bufB + G::BUFC);
-    L.cs = L.y + M;
+    L.cs = L.y + M + 4 * R;                                       // y is padded: ymap<1>
     L.ci = (int*)(L.cs + G::CAP);
-    L.sel = L.ci + G::CAP;
+    L.sel = L.ci + G::CAP + 64;                                   // 64 trash slots after the candidate list
     L.sbin = L.sel + kpad;
     const int gs = staged_frames(K, GF);
     L.sval = (float*)(L.sbin + gs * kpad);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             if (with_mag) {
                 // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
                 const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
-                L.y[k] = m0; L.y[kk] = m1;
+                L.y[k + 4 * j] = m0; L.y[ymap<1>(kk)] = m1;       // padded row: ymap<1>(lane + 64 j) = k + 4 j
                 lmax = fmaxf(lmax, fmaxf(m0, m1)); lmin = fminf(lmin, fminf(m0, m1)); ls0 += e0; ls1 += e1;
             }
         }
@@ -363,14 +363,14 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             const int64_t orow = b * p.F + (q - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
             const double minamp = (double)maxy * p.thr;           // PF.py:60
-            const int nsel = peak_select<float, M>(L.y, L.cs, L.ci, L.sel, M, K, minamp, true, miny, lane);
+            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, minamp, miny, lane);
             const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
             int nk = 0;
             for (int eb = 0; eb < nsel; eb += 64) {
                 const int e = eb + lane;
                 int pb = 0;
                 bool keep = false;
-                if (e < nsel) { pb = L.sel[e]; keep = salient<float>(L.y, M, pb, p.rad); }
+                if (e < nsel) { pb = L.sel[e]; keep = salient<float, 1>(L.y, M, pb, p.rad); }
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     const int slot = ng * kpad + nk + lane_prefix(bal);

@@ -159,7 +159,11 @@ __device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n
 
 // peak_pick: the npeaks best of the C candidates in cs/ci (list in ascending bin order) -> out[],
 // ascending bins; returns the count (wave-uniform).  th < 0 additionally admits the zeros of pkmskamp.
-template <typename T>
+// Optional padded layout of a magnitude row in LDS: YP = 1 keeps 4 spare floats after every 64 so that
+// the per-lane block reads of peak_scan_block below are bank-conflict free.
+template <int YP> __device__ __forceinline__ int ymap(int k) { return YP ? k + ((k >> 6) << 2) : k; }
+
+template <typename T, int YP = 0>
 __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, int n, int npeaks, int C, double th, int lane) {
     if (C <= npeaks) {
         if (th < 0.0 && C < npeaks) {
@@ -171,7 +175,7 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
                 const int k = k0 + lane;
                 bool ismax = false, isz = false;
                 if (k >= 1 && k <= n - 2) {
-                    const T a = y[k - 1], b = y[k], c = y[k + 1];
+                    const T a = y[ymap<YP>(k - 1)], b = y[ymap<YP>(k)], c = y[ymap<YP>(k + 1)];
                     ismax = (a < b) && (b >= c);
                     isz = !ismax;
                 }
@@ -261,11 +265,87 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
     return peak_pick<T>(y, cs, ci, out, n, npeaks, C, th, lane);
 }
 
+// peak_scan_block: the same candidate list as peak_scan for a float row of n = 64*R bins held in the
+// padded layout (ymap<1>), with lane l owning the R CONSECUTIVE bins R*l .. R*l+R-1: R/4 16-byte LDS
+// reads per lane instead of 3*R 4-byte ones, and everything after that is integer VALU work on the
+// float bit patterns (magnitudes are >= +0, so they order like their bits):
+//   rise_i  = sign(bits(y[k-1]) - bits(y[k]))            one subtract per bin boundary; "y[k] >= y[k+1]"
+//                                                         of bin k is the complement of rise_{k+1}
+//   above_i = sign(bits(thf) - bits(y[k] - miny))        the same float subtraction as peak_scan
+//   cand_i  = rise_i & ~rise_{i+1} & above_i             one 3-input bit operation
+// and the sign bits are funnel-shifted into a per-lane 16-bit mask.  No compare results travel through
+// SGPRs and there is no branch: with one wave per SIMD those round trips and taken branches cost far
+// more than the arithmetic.  List positions come from a ballot prefix over the per-lane counts
+// (<= R/2 <= 8); every lane then stores its R bins unconditionally, non-candidates into a per-lane
+// trash slot (ci[trash + lane]).  Only the bins are listed; scores are re-read where they are needed.
+template <int R>
+__device__ __forceinline__ int peak_scan_block(const float* y, float miny, double th, int* ci, int trash, int lane) {
+    static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
+    constexpr int n = 64 * R;
+    const float thf = __double2float_rd(th);                         // see peak_scan
+    // thf < 0: every score (>= 0) is above it; -1 keeps the integer subtraction below from wrapping
+    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
+    const int k0 = R * lane;
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R / 4; j++) {
+        const float4 q = *(const float4*)(y + ymap<1>(k0 + 4 * j));
+        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+    // lane 0: "left" is bin 0 itself, so bin 0 never rises; lane 63: "right" is bin n-1 itself
+    const float left = y[ymap<1>(k0 > 0 ? k0 - 1 : 0)];
+    const float right = y[ymap<1>(k0 + R < n ? k0 + R : n - 1)];
+    int rise[R + 1];                                                 // sign bit set: y[k-1] < y[k]
+    rise[0] = __float_as_int(left) - __float_as_int(v[0]);
+#pragma unroll
+    for (int i = 1; i < R; i++) rise[i] = __float_as_int(v[i - 1]) - __float_as_int(v[i]);
+    rise[R] = __float_as_int(v[R - 1]) - __float_as_int(right);
+    unsigned m = 0;
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int above = thb - __float_as_int(v[i] - miny);         // sign bit set: score > thf
+        const unsigned t = (unsigned)(rise[i] & ~rise[i + 1] & above);
+        m = (m << 1) | (t >> 31);
+    }
+    if (lane == 63) m &= ~(1u << (R - 1));                           // bin n-1 is not interior
+    // exclusive prefix of the per-lane counts (<= 8: four bits)
+    const int cnt = __popc(m);
+    int pos = 0, C = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const unsigned long long bal = __ballot(((cnt >> b) & 1) != 0);
+        pos += lane_prefix(bal) << b;
+        C += __popcll(bal) << b;
+    }
+    const int tr = trash + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int bit = (int)((m >> i) & 1u);
+        ci[tr + bit * (pos - tr)] = k0 + i;                          // bit ? pos : trash
+        pos += bit;
+    }
+    return C;
+}
+
+// ci must have 64 spare ints at [trash, trash + 64)
+template <int R>
+__device__ __forceinline__ int peak_select_block(const float* y, float* cs, int* ci, int trash, int* out, int npeaks,
+                                                 double minamp_in, float miny, int lane) {
+    const double th = peak_threshold<float>(minamp_in, true, miny);
+    const int C = peak_scan_block<R>(y, miny, th, ci, trash, lane);
+    wave_sync();
+    if (C > npeaks) {                                                // the ranking paths of peak_pick want the scores
+        for (int c = lane; c < C; c += 64) cs[c] = y[ymap<1>(ci[c])] - miny;
+        wave_sync();
+    }
+    return peak_pick<float, 1>(y, cs, ci, out, 64 * R, npeaks, C, th, lane);
+}
+
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
 // [max(p-rad,1), min(p+rad,n)] (clipped to the array) exceeds y[p]
-template <typename T> __device__ __forceinline__ bool salient(const T* y, int n, int p, int rad) {
+template <typename T, int YP = 0> __device__ __forceinline__ bool salient(const T* y, int n, int p, int rad) {
     if (rad < 0) return true;
-    const T v = y[p];
+    const T v = y[ymap<YP>(p)];
     const int lo = p - rad > 1 ? p - rad : 1;
     int hi = p + rad < n ? p + rad : n;
     if (hi > n - 1) hi = n - 1;
@@ -279,14 +359,14 @@ template <typename T> __device__ __forceinline__ bool salient(const T* y, int n,
         for (int d = -8; d <= 8; d++) {
             int j = p + (d < -rad ? -rad : (d > rad ? rad : d));
             j = j < lo ? lo : (j > hi ? hi : j);
-            w[d + 8] = y[j];
+            w[d + 8] = y[ymap<YP>(j)];
         }
         int bad = 0;
 #pragma unroll
         for (int d = 0; d < 17; d++) bad |= (int)(w[d] > v);
         keep = (bad == 0);
     } else {
-        for (int j = lo; j <= hi; j++) keep = keep && !(y[j] > v);
+        for (int j = lo; j <= hi; j++) keep = keep && !(y[ymap<YP>(j)] > v);
     }
     return keep;
 }
