@@ -369,8 +369,9 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             for (int eb = 0; eb < nsel; eb += 64) {
                 const int e = eb + lane;
                 int pb = 0;
-                bool keep = false;
-                if (e < nsel) { pb = L.sel[e]; keep = salient<float, 1>(L.y, M, pb, p.rad); }
+                if (e < nsel) pb = L.sel[e];
+                const bool keep = (p.rad <= 8) ? salient_groups<1>(L.y, M, L.sel, eb, nsel, p.rad, lane)
+                                               : ((e < nsel) && salient<float, 1>(L.y, M, pb, p.rad));
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     const int slot = ng * kpad + nk + lane_prefix(bal);

@@ -371,6 +371,39 @@ template <typename T, int YP = 0> __device__ __forceinline__ bool salient(const 
     return keep;
 }
 
+// filter_by_salience for up to 64 selected peaks with ALL lanes working: 8 lanes per peak, lane o of a
+// group tests the two neighbours at distance min(o + 1, rad) (rad <= 8; indices clamped into the window
+// like `salient` does), one ballot per pass of 8 peaks.  `pb`/`mine`: this lane's own peak (list entry
+// eb + lane) and whether it exists; returns its keep flag.  sel[] = the selected bins.
+template <int YP>
+__device__ __forceinline__ bool salient_groups(const float* y, int n, const int* sel, int eb, int nsel, int rad, int lane) {
+    const int e = eb + lane;
+    if (rad < 0) return e < nsel;
+    bool keep = false;
+    const int left = nsel - eb;
+    const int npass = ((left < 64 ? left : 64) + 7) >> 3;            // wave-uniform
+    const int grp = lane >> 3;
+    int d = (lane & 7) + 1;
+    d = d > rad ? rad : d;
+    for (int g = 0; g < npass; g++) {
+        const int eq = eb + 8 * g + grp;
+        const bool act = eq < nsel;
+        const int pq = sel[act ? eq : eb];
+        const int lo = pq - rad > 1 ? pq - rad : 1;
+        int hi = pq + rad < n ? pq + rad : n;
+        hi = hi > n - 1 ? n - 1 : hi;
+        int j0 = pq - d, j1 = pq + d;
+        j0 = j0 < lo ? lo : j0;                                      // lo <= pq <= hi always
+        j1 = j1 > hi ? hi : j1;
+        const float v = y[ymap<YP>(pq)], a = y[ymap<YP>(j0)], b = y[ymap<YP>(j1)];
+        const bool bad = act && ((int)(a > v) | (int)(b > v)) != 0;
+        const unsigned long long bal = __ballot(bad);
+        const bool k = ((bal >> (8 * (lane & 7))) & 0xFFull) == 0ull;   // the group of peak 8 g + (lane & 7)
+        keep = (grp == g) ? k : keep;
+    }
+    return keep && (e < nsel);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-peak phase-vocoder arithmetic (PV.py:187-207 with dphase2freq, PV.py:133-148).
 // Inputs: bin, current (re, im), previous (pr, pi), s3 = 3-bin energy sum (PV.py:197-199).
