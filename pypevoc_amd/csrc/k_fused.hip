@@ -220,18 +220,20 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
         wave_sync();
         dft_regs<R>(z);                                           // stage 2
 #pragma unroll
-        for (int t2i = 0; t2i < R; t2i++) {
-            v2f a = (t2i > 0) ? pvxc::cmul(z[t2i], t2[t2i]) : z[t2i];
-            // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
-            // upper lane (a - b) W_2h^(l1 mod h)
+        for (int t0 = 0; t0 < R; t0 += 4) {
+            // twiddle W_64^(l1 t2), then stage 3: P-point DFT across P lanes, decimation in frequency
+            // (lower lane a + b, upper lane (a - b) W_2h^(l1 mod h)), four values at a time
+            v2f a[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2[t0 + j]) : z[t0 + j];
             if constexpr (G::LOGP >= 1) {
-                if constexpr (P >= 16) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 4], a, lane_xor2<8>(a)), cw[G::LOGP - 4]); }
-                if constexpr (P >= 8) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 3], a, lane_xor2<4>(a)), cw[G::LOGP - 3]); }
-                if constexpr (P >= 4) { a = pvxc::cmul(pvxc::fma_s(csg[G::LOGP - 2], a, lane_xor2<2>(a)), cw[G::LOGP - 2]); }
-                a = pvxc::fma_s(csg[G::LOGP - 1], a, lane_xor2<1>(a));                        // h = 1: twiddle is 1
+                if constexpr (P >= 16) xstep4<8, true>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
+                if constexpr (P >= 8) xstep4<4, true>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
+                if constexpr (P >= 4) xstep4<2, true>(a, csg[G::LOGP - 2], cw[G::LOGP - 2]);
+                xstep4<1, false>(a, csg[G::LOGP - 1], cw[G::LOGP - 1]);           // h = 1: twiddle is 1
             }
-            const v2f res = a;
-            dz[zpad<R>(Q + R * t2i + G::R2 * t1v)] = res;
+#pragma unroll
+            for (int j = 0; j < 4; j++) dz[zpad<R>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
         }
         wave_sync();
         // ---- untangle in place: pairs (k, M-k), k = lane + 64 j; bins 0 and M/2 have no partner.

@@ -193,6 +193,22 @@ template <int R> __device__ __forceinline__ void dft_regs(v2f (&x)[R]) {
     }
 }
 
+// One decimation-in-frequency step of the cross-lane DFT on four independent values at once: exchange
+// with lane ^ H, a' = sg * a + partner (sg = -1 in the upper lane), then the lane's twiddle.  Written
+// phase by phase over the four values so that the DPP exchanges (which need wait states after the VALU
+// write of their source) and the dependent multiply-adds of different values interleave.
+template <int H, bool TW> __device__ __forceinline__ void xstep4(v2f (&a)[4], float sg, v2f w) {
+    v2f q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = lane_xor2<H>(a[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = pvxc::fma_s(sg, a[j], q[j]);
+    if constexpr (TW) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = pvxc::cmul(a[j], w);
+    }
+}
+
 template <typename InT> __device__ __forceinline__ float ld1(const InT* p) { return (float)*p; }
 
 
