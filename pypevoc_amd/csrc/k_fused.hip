@@ -114,7 +114,9 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
+    // the wave index is wave-uniform but the compiler cannot know: readfirstlane moves it -- and with it
+    // the whole row bookkeeping (loop counters, row addresses, branches) -- to the scalar unit
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
     const int K = p.K;
     const int kpad = (K + 3) & ~3;
