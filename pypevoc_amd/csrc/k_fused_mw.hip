@@ -70,19 +70,31 @@ template <int H> __device__ __forceinline__ float lane_xor_w(float v, int lane) 
     else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __builtin_bit_cast(int, v)));
 }
 
+template <int H> __device__ __forceinline__ v2f lane_xor_w2(v2f v, int lane) {
+    return pvxc::mk(lane_xor_w<H>(v.x, lane), lane_xor_w<H>(v.y, lane));
+}
+// xstep4 of pvx_fft.h with the exchanges that reach across rows of 16 lanes (H = 16, 32)
+template <int H, bool TW> __device__ __forceinline__ void xstep4w(v2f (&a)[4], float sg, v2f w, int lane) {
+    v2f q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = lane_xor_w2<H>(a[j], lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = pvxc::fma_s(sg, a[j], q[j]);
+    if constexpr (TW) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = pvxc::cmul(a[j], w);
+    }
+}
+
 template <int R, int W, typename InT, bool AL2>
-__device__ __forceinline__ void load_raw_mw(const InT* x, int tid, float (&ra)[R], float (&rb)[R]) {
+__device__ __forceinline__ void load_raw_mw(const InT* x, int tid, v2f (&raw)[R]) {
     constexpr int T = 64 * W;
     // thread l takes z[l + T r] = (x[2l + 2T r], x[2l + 2T r + 1]): 512 contiguous bytes per wave-instruction
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const InT* p = x + 2 * tid + 2 * T * r;
-        if constexpr (AL2 && sizeof(InT) == 4) {
-            const float2 v = *(const float2*)p;
-            ra[r] = v.x; rb[r] = v.y;
-        } else {
-            ra[r] = ld1(p); rb[r] = ld1(p + 1);
-        }
+        if constexpr (AL2 && sizeof(InT) == 4) raw[r] = *(const v2f*)p;
+        else raw[r] = pvxc::mk(ld1(p), ld1(p + 1));
     }
 }
 
@@ -123,31 +135,28 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     for (int k = tid; k < T; k += T) tw2l[k] = tab[((G::N / T) * (k % P) * (k / P)) & NMASK];   // [t2][l1] W_T^(l1 t2)
     __syncthreads();
 
-    // ---- thread constants
+    // ---- thread constants (complex values are register pairs, pvx_cplx.h)
     const int Q = tid / P, L1 = tid % P;
-    float w0[R], w1[R], t1r[R], t1i[R], t2r[R], t2i[R];
+    v2f wv[R], t1[R], t2[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const float2 wv = ((const float2*)p.win)[tid + T * r];    // (w[2l + 2T r], w[2l + 2T r + 1])
-        w0[r] = wv.x; w1[r] = wv.y;
-        const float2 a = tab[(2 * tid * r) & NMASK];              // W_M^(l q)
-        t1r[r] = a.x; t1i[r] = a.y;
-        const float2 b = tw2l[r * P + L1];                        // W_T^(l1 t2)
-        t2r[r] = b.x; t2i[r] = b.y;
+        wv[r] = ((const v2f*)p.win)[tid + T * r];                 // (w[2l + 2T r], w[2l + 2T r + 1])
+        t1[r] = ((const v2f*)tab)[(2 * tid * r) & NMASK];         // W_M^(l q)
+        t2[r] = ((const v2f*)tw2l)[r * P + L1];                   // W_T^(l1 t2)
     }
-    float csg[G::LOGP], cwr[G::LOGP], cwi[G::LOGP];               // cross-lane DFT: sign and twiddle per step
+    float csg[G::LOGP];                                           // cross-lane DFT: sign and twiddle per step
+    v2f cw[G::LOGP];
 #pragma unroll
     for (int s = 0; s < G::LOGP; s++) {
         const int h = P >> (s + 1);
         const bool up = (L1 & h) != 0;
         csg[s] = up ? -1.f : 1.f;
-        const float2 wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];     // W_2h^(l1 mod h)
-        cwr[s] = up ? wv.x : 1.f;
-        cwi[s] = up ? wv.y : 0.f;
+        const float2 wvv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];    // W_2h^(l1 mod h)
+        cw[s] = up ? pvxc::mk(wvv.x, wvv.y) : pvxc::mk(1.f, 0.f);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        asm volatile("" : "+v"(w0[r]), "+v"(w1[r]), "+v"(t1r[r]), "+v"(t1i[r]), "+v"(t2r[r]), "+v"(t2i[r]));
+        asm volatile("" : "+v"(wv[r]), "+v"(t1[r]), "+v"(t2[r]));
     }
     int t1v = 0;                                                  // t1 = bitrev(l1)
 #pragma unroll
@@ -163,10 +172,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
 
     float2* cur = bufA;
     float2* prv = bufB;
-    float ra[R], rb[R];                                           // raw samples of the next row (prefetched)
+    v2f raw[R];                                                   // raw samples of the next row (prefetched)
     auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {
         if (gn < 0 || gn >= r1 || qn == 0) return;
-        load_raw_mw<R, W, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, tid, ra, rb);
+        load_raw_mw<R, W, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, tid, raw);
     };
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
@@ -181,78 +190,70 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             prefetch(g + 1, bn, qn);
             return;
         }
-        float xr[R], xi[R];
+        v2f z[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { xr[r] = ra[r] * w0[r]; xi[r] = rb[r] * w1[r]; }
+        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
         prefetch(g + 1, bn, qn);
-        dft_regs<R>(xr, xi);                                      // stage 1
+        dft_regs<R>(z);                                           // stage 1
+        v2f* dz = (v2f*)dst;
 #pragma unroll
-        for (int q2 = 0; q2 < R; q2++) {
-            float a = xr[q2], c = xi[q2];
-            if (q2 > 0) cmul(a, c, t1r[q2], t1i[q2]);
-            dst[q2 * PITCH + tid] = make_float2(a, c);
-        }
+        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + tid] = (q2 > 0) ? pvxc::cmul(z[q2], t1[q2]) : z[q2];
         __syncthreads();
 #pragma unroll
-        for (int l2 = 0; l2 < R; l2++) {
-            const float2 v = dst[Q * PITCH + L1 + P * l2];
-            xr[l2] = v.x; xi[l2] = v.y;
-        }
+        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
         __syncthreads();
-        dft_regs<R>(xr, xi);                                      // stage 2
+        dft_regs<R>(z);                                           // stage 2
 #pragma unroll
-        for (int t2 = 0; t2 < R; t2++) {
-            float a = xr[t2], c = xi[t2];
-            if (t2 > 0) cmul(a, c, t2r[t2], t2i[t2]);
-            // stage 3: P-point DFT across P lanes, decimation in frequency: lower lane a + b,
-            // upper lane (a - b) W_2h^(l1 mod h); the last step (h = 1) has twiddle 1
-#define PVX_XSTEP(H, S, TW)                                                                        \
-            {                                                                                      \
-                const float pr_ = lane_xor_w<H>(a, lane), pi_ = lane_xor_w<H>(c, lane);            \
-                a = __builtin_fmaf(csg[S], a, pr_); c = __builtin_fmaf(csg[S], c, pi_);            \
-                if (TW) cmul(a, c, cwr[S], cwi[S]);                                                \
-            }
-            if constexpr (P >= 64) PVX_XSTEP(32, G::LOGP - 6, true)
-            if constexpr (P >= 32) PVX_XSTEP(16, G::LOGP - 5, true)
-            if constexpr (P >= 16) PVX_XSTEP(8, G::LOGP - 4, true)
-            if constexpr (P >= 8) PVX_XSTEP(4, G::LOGP - 3, true)
-            if constexpr (P >= 4) PVX_XSTEP(2, G::LOGP - 2, true)
-            if constexpr (P >= 2) PVX_XSTEP(1, G::LOGP - 1, false)
-#undef PVX_XSTEP
-            dst[zpadm<R, W>(Q + R * t2 + G::R2 * t1v)] = make_float2(a, c);
+        for (int t0 = 0; t0 < R; t0 += 4) {
+            // twiddle W_T^(l1 t2), then stage 3: P-point DFT across P lanes, decimation in frequency:
+            // lower lane a + b, upper lane (a - b) W_2h^(l1 mod h); the last step (h = 1) has twiddle 1
+            v2f a[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2[t0 + j]) : z[t0 + j];
+            if constexpr (P >= 64) xstep4w<32, true>(a, csg[G::LOGP - 6], cw[G::LOGP - 6], lane);
+            if constexpr (P >= 32) xstep4w<16, true>(a, csg[G::LOGP - 5], cw[G::LOGP - 5], lane);
+            if constexpr (P >= 16) xstep4<8, true>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
+            if constexpr (P >= 8) xstep4<4, true>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
+            if constexpr (P >= 4) xstep4<2, true>(a, csg[G::LOGP - 2], cw[G::LOGP - 2]);
+            if constexpr (P >= 2) xstep4<1, false>(a, csg[G::LOGP - 1], cw[G::LOGP - 1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) dz[zpadm<R, W>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
         }
         __syncthreads();
         // ---- untangle in place: pairs (k, M-k), k = tid + T j; bins 0 and M/2 have no partner
+        //   S = Za + conj Zb, D = Za - conj Zb;  E = S/2, O = -i D/2, P = W^k O
+        //   X[k] = E + P,  X[M-k] = conj(E - P)
         constexpr int NPAIR = R / 2;
         float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
-        float2 za[NPAIR], zb[NPAIR], wv8[NPAIR];
+        v2f za[NPAIR], zb[NPAIR], wv8[NPAIR];
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
             const int k = tid + T * j;
             const int km = (M - k) & (M - 1);                     // k = 0: Z[M] == Z[0]
-            za[j] = dst[zpadm<R, W>(k)];
-            zb[j] = dst[zpadm<R, W>(km)];
-            wv8[j] = tw3[k];
+            za[j] = dz[zpadm<R, W>(k)];
+            zb[j] = dz[zpadm<R, W>(km)];
+            wv8[j] = ((const v2f*)tw3)[k];
         }
-        const float2 zc = dst[zpadm<R, W>(G::HALF)];
+        const v2f zc = dz[zpadm<R, W>(G::HALF)];
+        const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f);
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
             const int k = tid + T * j;
             const int km = (M - k) & (M - 1);
-            const float er = 0.5f * (za[j].x + zb[j].x), ei = 0.5f * (za[j].y - zb[j].y);      // E = (Za + conj Zb)/2
-            const float orr = 0.5f * (za[j].y + zb[j].y), oi = -0.5f * (za[j].x - zb[j].x);    // O = (Za - conj Zb)/(2i)
-            float pr2 = orr, pi2_ = oi;
-            cmul(pr2, pi2_, wv8[j].x, wv8[j].y);                                    // P = W^k O
-            const float x0r = er + pr2, x0i = ei + pi2_;                            // X[k]
-            float x1r = er - pr2, x1i = pi2_ - ei;                                  // X[M-k] = conj(E - P)
+            const v2f S = pvxc::add_conj(za[j], zb[j]);
+            const v2f D = pvxc::sub_conj(za[j], zb[j]);
+            const v2f O = pvxc::mul_swap(D, kmih);                // (D.y/2, -D.x/2)
+            const v2f Pk = pvxc::cmul(O, wv8[j]);                 // W^k O
+            const v2f x0 = __builtin_elementwise_fma(khalf, S, Pk);               // X[k] = S/2 + P
+            v2f x1 = pvxc::fms_conj(khalf, S, Pk);                                // X[M-k] = conj(S/2 - P)
             int kk = km;
             if (j == 0) {
                 // thread 0: k = 0 pairs with itself; its partner slot takes bin M/2: X[M/2] = conj(Z[M/2])
-                if (tid == 0) { x1r = zc.x; x1i = -zc.y; kk = G::HALF; }
+                if (tid == 0) { x1 = pvxc::mk(zc.x, -zc.y); kk = G::HALF; }
             }
-            const float e0 = __builtin_fmaf(x0r, x0r, x0i * x0i), e1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
-            dst[zpadm<R, W>(k)] = make_float2(x0r, x0i);
-            dst[zpadm<R, W>(kk)] = make_float2(x1r, x1i);
+            const float e0 = __builtin_fmaf(x0.x, x0.x, x0.y * x0.y), e1 = __builtin_fmaf(x1.x, x1.x, x1.y * x1.y);
+            dz[zpadm<R, W>(k)] = x0;
+            dz[zpadm<R, W>(kk)] = x1;
             if (with_mag) {
                 const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
                 y[k] = m0; y[kk] = m1;
@@ -379,8 +380,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
                 for (int eb = 0; eb < nsel; eb += 64) {
                     const int e = eb + lane;
                     int pb = 0;
-                    bool keep = false;
-                    if (e < nsel) { pb = sel[e]; keep = salient<float>(y, M, pb, p.rad); }
+                    if (e < nsel) pb = sel[e];
+                    const bool keep = (p.rad <= 8) ? salient_groups<0>(y, M, sel, eb, nsel, p.rad, lane)
+                                                   : ((e < nsel) && salient<float>(y, M, pb, p.rad));
                     const unsigned long long bal = __ballot(keep);
                     if (keep) {
                         const int slot = ng * kpad + nk + lane_prefix(bal);
