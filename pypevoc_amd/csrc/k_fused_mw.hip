@@ -13,8 +13,9 @@
 //   stage 2  lane (q, l1) = P q + l1 reads Y[l1 + P l2][q]: radix-R DFT, twiddle W_T^(l1 t2)
 //   stage 3  P-point DFT over l1 -> Z[q + R t2 + R^2 bitrev(l1)] -> LDS                | block barrier
 //   untangle pairs (k, M-k), k = l + T j, j < R/2; |X| -> LDS; per-wave max/min/energy | block barrier
-//   peaks    every wave scans its M/W bins into its own candidate segment              | block barrier
-//            wave 0 merges the segments, selects, applies the salience test, stages the peaks'
+//   peaks    every wave scans its M/W bins (8 consecutive bins per lane), counts are exchanged  | block barrier
+//            and every wave writes its candidates into the one ascending list          | block barrier
+//            wave 0 selects, applies the salience test, stages the peaks'
 //            raw data and (every G frames) does the per-peak arithmetic + stores        | block barrier
 // The index maps were validated in numpy (R = 8, W = 2, 4, 8) before this was written.
 #include "pvx_fft.h"
@@ -54,7 +55,7 @@ template <int R, int W> __host__ __device__ inline size_t mw_lds_bytes(int K) {
     size_t b = (size_t)G::TW3 * 8 + (size_t)G::T * 8            // tw3 | tw2l
              + (size_t)G::BUFC * 8 * 2                          // bufA | bufB
              + (size_t)G::M * 4                                 // y
-             + (size_t)G::CAP * 4 * 2                           // cs | ci
+             + (size_t)(G::CAP * 2 + G::T) * 4                  // cs | ci | trash
              + kpad * 4                                         // sel
              + (size_t)staged_frames(K, GFM) * kpad * 4 * 6        // sbin | sval
              + GFM * 4 * 2 + W * 4 + W * 4 * 2;                 // cnt | frm | Cw | pmax | pmin
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     float* y = (float*)(bufB + G::BUFC);
     float* cs = y + M;
     int* ci = (int*)(cs + G::CAP);
-    int* sel = ci + G::CAP;
+    int* sel = ci + G::CAP + T;                                   // T trash slots after the candidate list
     int* sbin = sel + kpad;
     const int gs = staged_frames(K, GFM);
     float* sval = (float*)(sbin + gs * kpad);
@@ -352,28 +353,23 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
             const double minamp = (double)maxy * p.thr;           // PF.py:60
             const double th = peak_threshold<float>(minamp, true, miny);
-            // every wave scans its share of the bins into its own candidate segment
-            const int C_w = peak_scan<float, G::SCAN / 64>(y, wid * G::SCAN, G::SCAN, M, miny, th,
-                                                           cs + wid * G::CAPW, ci + wid * G::CAPW, lane);
+            // every wave scans its share of the bins (8 consecutive bins per lane); the waves' counts are
+            // exchanged through LDS and each wave writes its candidates straight to their place in the
+            // one ascending list -- nothing to merge
+            unsigned cm; int cpos;
+            const int C_w = peak_block_masks<R, 0>(y, wid * G::SCAN, M, miny, th, lane, cm, cpos);
             if (lane == 0) Cw[wid] = C_w;
             __syncthreads();
-            if (wid == 0) {
-                // merge the segments (ascending bins) into one list at the head of cs / ci
-                int C = Cw[0];
+            int cbase = 0, C = 0;
 #pragma unroll
-                for (int w = 1; w < W; w++) {
-                    const int cw = Cw[w];
-                    for (int c0 = 0; c0 < cw; c0 += 64) {         // moves down: read a chunk, then write it
-                        const int c = c0 + lane;
-                        float sv_ = 0.f; int iv_ = 0;
-                        if (c < cw) { sv_ = cs[w * G::CAPW + c]; iv_ = ci[w * G::CAPW + c]; }
-                        wave_sync();
-                        if (c < cw) { cs[C + c] = sv_; ci[C + c] = iv_; }
-                        wave_sync();
-                    }
-                    C += cw;
+            for (int w = 0; w < W; w++) { const int c = Cw[w]; cbase += (w < wid) ? c : 0; C += c; }
+            peak_block_write<R>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
+            __syncthreads();
+            if (wid == 0) {
+                if (C > K) {                                         // the ranking paths of peak_pick want the scores
+                    for (int c = lane; c < C; c += 64) cs[c] = y[ci[c]] - miny;
+                    wave_sync();
                 }
-                wave_sync();
                 const int nsel = peak_pick<float>(y, cs, ci, sel, M, K, C, th, lane);
                 const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
                 int nk = 0;

@@ -278,23 +278,28 @@ __device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out,
 // more than the arithmetic.  List positions come from a ballot prefix over the per-lane counts
 // (<= R/2 <= 8); every lane then stores its R bins unconditionally, non-candidates into a per-lane
 // trash slot (ci[trash + lane]).  Only the bins are listed; scores are re-read where they are needed.
-template <int R>
-__device__ __forceinline__ int peak_scan_block(const float* y, float miny, double th, int* ci, int trash, int lane) {
+// Two halves so that several waves can scan segments of one row and write one list (k_fused_mw.hip):
+//   peak_block_masks  lane owns bins kbase + R*lane .. + R-1 of the n-bin row: candidate bit mask `m`,
+//                     list position of its first candidate within this wave `pos`; returns the wave's
+//                     candidate count (wave-uniform)
+//   peak_block_write  stores the lane's bins at base + pos.. (non-candidates into the trash slot `tr`)
+template <int R, int YP>
+__device__ __forceinline__ int peak_block_masks(const float* y, int kbase, int n, float miny, double th, int lane,
+                                                unsigned& m_out, int& pos_out) {
     static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
-    constexpr int n = 64 * R;
     const float thf = __double2float_rd(th);                         // see peak_scan
     // thf < 0: every score (>= 0) is above it; -1 keeps the integer subtraction below from wrapping
     const int thb = thf < 0.f ? -1 : __float_as_int(thf);
-    const int k0 = R * lane;
+    const int k0 = kbase + R * lane;
     float v[R];
 #pragma unroll
     for (int j = 0; j < R / 4; j++) {
-        const float4 q = *(const float4*)(y + ymap<1>(k0 + 4 * j));
+        const float4 q = *(const float4*)(y + ymap<YP>(k0 + 4 * j));
         v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
     }
-    // lane 0: "left" is bin 0 itself, so bin 0 never rises; lane 63: "right" is bin n-1 itself
-    const float left = y[ymap<1>(k0 > 0 ? k0 - 1 : 0)];
-    const float right = y[ymap<1>(k0 + R < n ? k0 + R : n - 1)];
+    // first lane of the row: "left" is bin 0 itself, so bin 0 never rises; last lane: "right" is bin n-1
+    const float left = y[ymap<YP>(k0 > 0 ? k0 - 1 : 0)];
+    const float right = y[ymap<YP>(k0 + R < n ? k0 + R : n - 1)];
     int rise[R + 1];                                                 // sign bit set: y[k-1] < y[k]
     rise[0] = __float_as_int(left) - __float_as_int(v[0]);
 #pragma unroll
@@ -307,7 +312,7 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
         const unsigned t = (unsigned)(rise[i] & ~rise[i + 1] & above);
         m = (m << 1) | (t >> 31);
     }
-    if (lane == 63) m &= ~(1u << (R - 1));                           // bin n-1 is not interior
+    if (k0 + R == n) m &= ~(1u << (R - 1));                          // bin n-1 is not interior
     // exclusive prefix of the per-lane counts (<= 8: four bits)
     const int cnt = __popc(m);
     int pos = 0, C = 0;
@@ -317,13 +322,26 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
         pos += lane_prefix(bal) << b;
         C += __popcll(bal) << b;
     }
-    const int tr = trash + lane;
+    m_out = m; pos_out = pos;
+    return C;
+}
+
+template <int R>
+__device__ __forceinline__ void peak_block_write(int* ci, int kbase, int lane, unsigned m, int pos, int tr) {
+    const int k0 = kbase + R * lane;
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int bit = (int)((m >> i) & 1u);
         ci[tr + bit * (pos - tr)] = k0 + i;                          // bit ? pos : trash
         pos += bit;
     }
+}
+
+template <int R>
+__device__ __forceinline__ int peak_scan_block(const float* y, float miny, double th, int* ci, int trash, int lane) {
+    unsigned m; int pos;
+    const int C = peak_block_masks<R, 1>(y, 0, 64 * R, miny, th, lane, m, pos);
+    peak_block_write<R>(ci, 0, lane, m, pos, trash + lane);
     return C;
 }
 
