@@ -221,8 +221,15 @@ def main():
                             peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(dom["achieved_GBps"] * 1e9 / HBM_PEAK, 4),
                             traffic=traffic, ms_per_launch=round(dom["ms_per_launch"], 4),
                             alg_bytes_per_launch=int(dom["alg_bytes_per_frame"] * F * args.steps / dom["launches"]),
-                            note="algorithmic bytes = SURVEY.md 8(d) contract figure for the STFT+phase stage; "
-                                 "`traffic` = HBM bytes per launch from rocprofv3 PMC (profiles/)")
+                            note="algorithmic bytes = SURVEY.md 8(d) contract figure for the STFT+phase stage "
+                                 "(the three-kernel split north_star describes); `traffic` = HBM bytes per launch "
+                                 "from rocprofv3 PMC (profiles/).  The fused kernel moves 13x fewer bytes than "
+                                 "that figure (its own floor is hop*4 + outputs = %d B/frame, `fused` below), which "
+                                 "is how frac can exceed 1: the kernel is bound by VALU issue, not by HBM" % (HOP * 4 + NPKS * 40 + 16))
+            if dom["kernel"] == "k_fused_pv":
+                fb = HOP * 4 + NPKS * 40 + 16
+                fa = fb * F * args.steps / dom["launches"] / (dom["ms_per_launch"] * 1e-3)
+                roofline["fused"] = dict(alg_bytes_per_frame=fb, achieved=round(fa / 1e9, 1), frac=round(fa / HBM_PEAK, 4))
         stage_s = sum(ms[i] for i in range(4)) * 1e-3 / args.steps
         stage = dict(fft_mode=fft_mode, alg_bytes_per_frame=ab["stage"], ms_per_step_kernels=round(stage_s * 1e3, 4),
                      achieved_GBps=round(ab["stage"] * F / stage_s / 1e9, 1) if stage_s > 0 else None,
