@@ -7,6 +7,9 @@
 // swap or a one-sided negation into the packed instruction's op_sel / neg modifiers (it emits
 // v_xor + v_mov to build the swizzled operand first), and those are exactly the FFT's multiply-by-(-i)
 // and complex-conjugate patterns -- so these few are spelled as one instruction each.
+// Hazard rule: the compiler's hazard recogniser does not see inside inline asm, so the result of one of
+// these primitives must not be the direct source of a DPP move (VALU write -> DPP read needs two wait
+// states); in the FFTs every exchanged value is the result of a compiler-emitted instruction.
 // VOP3P modifiers: op_sel[i] / op_sel_hi[i] pick the half (0 = .x, 1 = .y) of source i that feeds the
 // low / high result lane; neg_lo[i] / neg_hi[i] negate source i in the low / high lane.
 #pragma once

@@ -329,11 +329,14 @@ __device__ __forceinline__ int peak_block_masks(const float* y, int kbase, int n
 template <int R>
 __device__ __forceinline__ void peak_block_write(int* ci, int kbase, int lane, unsigned m, int pos, int tr) {
     const int k0 = kbase + R * lane;
-#pragma unroll
-    for (int i = 0; i < R; i++) {
-        const int bit = (int)((m >> i) & 1u);
-        ci[tr + bit * (pos - tr)] = k0 + i;                          // bit ? pos : trash
-        pos += bit;
+    // one round per candidate of the busiest lane (1-3 on music, <= R/2): every lane pops its lowest
+    // set bit; lanes that have run out write to their trash slot, so the body has no divergence
+    while (__ballot(m != 0u) != 0ull) {                              // wave-uniform
+        const bool has = m != 0u;
+        const int i = __ffs((int)m) - 1;
+        ci[has ? pos : tr] = k0 + i;
+        pos += has ? 1 : 0;
+        m &= m - 1u;
     }
 }
 
