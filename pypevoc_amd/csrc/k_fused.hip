@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_raw(const InT* x, int lane, v2f (&raw)[R]) 
 struct FusedLds {       // per-wave carve
     float2* bufA;       // [BUFC]
     float2* bufB;       // [BUFC]
-    float* y;           // [M + 4 R], padded layout ymap<1>
+    float* y;           // [M + 4 R] |X|^2, padded layout ymap<1>
     float* cs;          // [CAP]
     int* ci;            // [CAP]
     int* sel;           // [kpad]
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
     // wave-reduced max / min / energy
-    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxy, float& miny, double& tot) {
+    // (maxe, mine = largest / smallest |X|^2 of the row)
+    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxe, float& mine, double& tot) {
         // (b, q) of row g + 1
         const int64_t qn = (q == p.F) ? 0 : q + 1;
         const int64_t bn = (q == p.F) ? b + 1 : b;
@@ -276,16 +277,16 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             dz[zpad<R>(k)] = x0;
             dz[zpad<R>(kk)] = x1;
             if (with_mag) {
-                // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
-                const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
-                L.y[k + 4 * j] = m0; L.y[ymap<1>(kk)] = m1;       // padded row: ymap<1>(lane + 64 j) = k + 4 j
-                lmax = fmaxf(lmax, fmaxf(m0, m1)); lmin = fminf(lmin, fminf(m0, m1)); ls0 += e0; ls1 += e1;
+                // the peak search runs on |X|^2: every test it makes (local maximum, threshold, ranking,
+                // salience) is monotone in |X|, and the square roots are a quarter-rate instruction
+                L.y[k + 4 * j] = e0; L.y[ymap<1>(kk)] = e1;       // padded row: ymap<1>(lane + 64 j) = k + 4 j
+                lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
             }
         }
         const double lsum = (double)ls0 + (double)ls1;
         if (with_mag) {
-            maxy = wave_max(lmax);
-            miny = wave_min(lmin);
+            maxe = wave_max(lmax);
+            mine = wave_min(lmin);
             tot = wave_sum(lsum);
         }
         wave_sync();
@@ -360,14 +361,20 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     for (int64_t g = r0; g < r1; ++g) {
         if (gq == p.F) { gq = 0; gb += 1; } else { gq += 1; }
         const int64_t b = gb, q = gq;
-        float maxy = 0.f, miny = 0.f;
+        float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
-        spectrum(g, b, q, cur, true, maxy, miny, tot);
+        spectrum(g, b, q, cur, true, maxe, mine, tot);
         if (q != 0) {
             const int64_t orow = b * p.F + (q - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
+            // v_sqrt_f32 (1 ulp) instead of the 15-instruction correctly rounded sequence
+            const float maxy = __builtin_amdgcn_sqrtf(maxe);
             const double minamp = (double)maxy * p.thr;           // PF.py:60
-            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, minamp, miny, lane);
+            // PF.py:69-70, 174: a bin qualifies when |X| - miny > minamp - miny, i.e. |X| > minamp; on the
+            // squared row: |X|^2 - mine > minamp^2 - mine.  minamp == 0 means minamp = miny there: the
+            // threshold is then EXACTLY 0 (its sign selects the "zeros qualify too" rule of findpos)
+            const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
+            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);
             const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
             int nk = 0;
             for (int eb = 0; eb < nsel; eb += 64) {

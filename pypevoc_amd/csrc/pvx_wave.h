@@ -349,10 +349,11 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
 }
 
 // ci must have 64 spare ints at [trash, trash + 64)
+// `th`: a bin qualifies when y - miny > th (the caller derives it from PF.py:60, 69-70; y may be any
+// monotone function of the magnitudes as long as th and miny are in the same domain)
 template <int R>
 __device__ __forceinline__ int peak_select_block(const float* y, float* cs, int* ci, int trash, int* out, int npeaks,
-                                                 double minamp_in, float miny, int lane) {
-    const double th = peak_threshold<float>(minamp_in, true, miny);
+                                                 double th, float miny, int lane) {
     const int C = peak_scan_block<R>(y, miny, th, ci, trash, lane);
     wave_sync();
     if (C > npeaks) {                                                // the ranking paths of peak_pick want the scores
