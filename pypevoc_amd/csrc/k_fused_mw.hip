@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
 
     // spectrum of global row g into `dst` (zeros for a zero row); with_mag: also |X| -> y and the
     // block-reduced max / min / energy.  Every thread of the block takes part (block barriers inside).
-    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxy, float& miny, double& tot) {
+    // (maxe, mine = largest / smallest |X|^2 of the row)
+    auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxe, float& mine, double& tot) {
         const int64_t qn = (q == p.F) ? 0 : q + 1;
         const int64_t bn = (q == p.F) ? b + 1 : b;
         if (g < 0 || q == 0) {
@@ -256,9 +257,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             dz[zpadm<R, W>(k)] = x0;
             dz[zpadm<R, W>(kk)] = x1;
             if (with_mag) {
-                const float m0 = __builtin_amdgcn_sqrtf(e0), m1 = __builtin_amdgcn_sqrtf(e1);
-                y[k] = m0; y[kk] = m1;
-                lmax = fmaxf(lmax, fmaxf(m0, m1)); lmin = fminf(lmin, fminf(m0, m1)); ls0 += e0; ls1 += e1;
+                // the peak search runs on |X|^2 (every test it makes is monotone in |X|; v_sqrt_f32 is a
+                // quarter-rate instruction)
+                y[k] = e0; y[kk] = e1;
+                lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
             }
         }
         if (with_mag) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             double sm = psum[0];
 #pragma unroll
             for (int w = 1; w < W; w++) { mx = fmaxf(mx, pmax[w]); mn = fminf(mn, pmin[w]); sm += psum[w]; }
-            maxy = mx; miny = mn; tot = sm;
+            maxe = mx; mine = mn; tot = sm;
         }
     };
 
@@ -345,19 +347,21 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     for (int64_t g = r0; g < r1; ++g) {
         if (gq == p.F) { gq = 0; gb += 1; } else { gq += 1; }
         const int64_t b = gb, q = gq;
-        float maxy = 0.f, miny = 0.f;
+        float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
-        spectrum(g, b, q, cur, true, maxy, miny, tot);
+        spectrum(g, b, q, cur, true, maxe, mine, tot);
         if (q != 0) {                                             // block-uniform
             const int64_t orow = b * p.F + (q - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
-            const double minamp = (double)maxy * p.thr;           // PF.py:60
-            const double th = peak_threshold<float>(minamp, true, miny);
+            const double minamp = (double)__builtin_amdgcn_sqrtf(maxe) * p.thr;   // PF.py:60
+            // PF.py:69-70, 174 on the squared row: |X|^2 - mine > minamp^2 - mine; minamp == 0 means
+            // minamp = miny there, the threshold is then exactly 0 (see k_fused.hip)
+            const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
             // every wave scans its share of the bins (8 consecutive bins per lane); the waves' counts are
             // exchanged through LDS and each wave writes its candidates straight to their place in the
             // one ascending list -- nothing to merge
             unsigned cm; int cpos;
-            const int C_w = peak_block_masks<R, 0>(y, wid * G::SCAN, M, miny, th, lane, cm, cpos);
+            const int C_w = peak_block_masks<R, 0>(y, wid * G::SCAN, M, mine, th, lane, cm, cpos);
             if (lane == 0) Cw[wid] = C_w;
             __syncthreads();
             int cbase = 0, C = 0;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             __syncthreads();
             if (wid == 0) {
                 if (C > K) {                                         // the ranking paths of peak_pick want the scores
-                    for (int c = lane; c < C; c += 64) cs[c] = y[ci[c]] - miny;
+                    for (int c = lane; c < C; c += 64) cs[c] = y[ci[c]] - mine;
                     wave_sync();
                 }
                 const int nsel = peak_pick<float>(y, cs, ci, sel, M, K, C, th, lane);
