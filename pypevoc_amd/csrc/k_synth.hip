@@ -90,10 +90,6 @@ __device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, c
     return q;
 }
 
-__device__ inline double eval_piece2(const Piece2& q, double x) {
-    return (x < q.b1) ? (q.sa * (x - q.xa) + q.fa) : (q.sb * (x - q.xb) + q.fb);
-}
-
 // closed-form parameters of one contribution (see step 5 of the kernel)
 struct CParam {
     int kind, fmb, mmb, pad_;
@@ -110,34 +106,10 @@ __device__ inline double prefix_sum(const CParam& c, int m) {
     return c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
 }
 
-// block-wide inclusive prefix sum of one double per thread (NT = 256 threads); returns the
-// inclusive value, *total = sum over the block.  Uses sc[4].
-__device__ inline double block_scan(double v, double* sc, double* total) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-    }
-    __syncthreads();
-    if (lane == 63) sc[wid] = inc;
-    __syncthreads();
-    double off = 0.0, tot = 0.0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; w++) {
-        if (w < wid) off += sc[w];
-        tot += sc[w];
-    }
-    *total = tot;
-    return inc + off;
-}
-
 __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* acc = (double*)smem;                       // [h] output accumulators
     __shared__ Win wins[NBATCH];
-    __shared__ double sc[NT / 64];
     __shared__ int wslots[NBATCH][WMAX];
     __shared__ int cb_pid[NBATCH], cb_st[NBATCH], cb_nfr[NBATCH], cb_ii[NBATCH], cb_kind[NBATCH], cb_j0[NBATCH], cb_wn[NBATCH];
     __shared__ int wcnt[NT / 64];

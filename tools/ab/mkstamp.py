@@ -14,7 +14,7 @@ rep("        wave_sync();\n        dft_regs<R>(z);                              
 rep("        wave_sync();\n        // ---- untangle in place","        wave_sync();\n        STAMP(4);\n        // ---- untangle in place")
 rep("        const double lsum = (double)ls0 + (double)ls1;","        STAMP(5);\n        const double lsum = (double)ls0 + (double)ls1;")
 rep("            tot = wave_sum(lsum);\n        }\n        wave_sync();\n    };","            tot = wave_sum(lsum);\n        }\n        wave_sync();\n        STAMP(6);\n    };")
-rep("            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, minamp, miny, lane);\n","            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, minamp, miny, lane);\n            STAMP(7);\n")
+rep("            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);\n","            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);\n            STAMP(7);\n")
 rep("            if (ng == G_) { flush(ng); ng = 0; }","            STAMP(8);\n            if (ng == G_) { flush(ng); ng = 0; }\n            STAMP(9);")
 rep("    if (ng > 0) flush(ng);\n}","    if (ng > 0) flush(ng);\n    if (p.spec_out != nullptr && p.spec_row == -7 && lane == 0) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)p.spec_out + i, stacc[i]); }\n}")
 open(dst_k,'w').write(s)
