@@ -141,3 +141,17 @@ def test_sinsum_host_bookkeeping_matches_reference():
     s0, f0 = p0.start_idx, list(p0.f)
     p0.prepend_point(1.0, 2.0, 3.0)
     assert p0.start_idx == s0 - 1 and p0.f == [1.0] + f0 and p0.mag[0] == 2.0 and p0.ph[0] == 3.0
+
+
+def test_generated_isa_has_no_asm_to_dpp_hazard():
+    """The packed complex primitives of pvx_cplx.h are inline asm; the compiler's hazard recogniser does
+    not see inside them, so a DPP move reading one of their results too early would silently read a stale
+    register.  tools/check_dpp_hazard.py compiles the fused kernels to gfx950 assembly and scans for it."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which(os.environ.get("HIPCC", "hipcc")) is None:
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 asm -> DPP hazard candidates" in r.stdout
