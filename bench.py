@@ -117,9 +117,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     wire = ResultWire(plan, F, K)
-    res = torch.zeros(wire.result_numel() + F, dtype=torch.float64, device=dev)
-    rp = wire.result_ptrs(res.data_ptr())                          # f, mag, ph, realph, binno, totalmag
-    t_ptr = res.data_ptr() + wire.result_numel() * 8
+    # two result blocks: while step i+1 is analysed into one, the other is packed and gathered
+    nres = wire.result_numel() + F
+    res2 = [torch.zeros(nres, dtype=torch.float64, device=dev) for _ in range(2 if gathered else 1)]
+    rp2 = [wire.result_ptrs(r.data_ptr()) for r in res2]           # f, mag, ph, realph, binno, totalmag
+    tp2 = [r.data_ptr() + wire.result_numel() * 8 for r in res2]
     full = torch.zeros((world, wire.result_numel()), dtype=torch.float64, device=dev) if (gathered and rank == 0) else None
 
     def consume(step_no, blocks):                                  # rank 0, side stream
@@ -128,22 +130,43 @@ def main():
             wire.unpack(b.data_ptr(), full[r].data_ptr(), s)
 
     pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume, force=gathered)
+    # The analysis kernel is bound by instruction issue, packing by HBM: they overlap almost for free.
+    # So the compute stream only ever runs the analysis; packing and the gather of step i go to a side
+    # stream (RCCL then orders itself after that stream) while step i+1 is analysed.
+    pack_stream = torch.cuda.Stream(device=dev) if gathered else None
+    packed = [None, None]                                          # events: res2[j] has been packed
 
     counter = [0]
 
     def step():
         i = counter[0]
         counter[0] += 1
+        j = i % len(res2)
+        if packed[j] is not None:
+            stream.wait_event(packed[j])          # the pack of step i-2 has read this block
+        rp = rp2[j]
         r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp, rp[0], rp[1], rp[2], rp[3], rp[4],
-                                t_ptr, rp[5], None, ctypes.c_void_p(stream.cuda_stream))
+                                tp2[j], rp[5], None, ctypes.c_void_p(stream.cuda_stream))
         _lib.check(r, "pvx_analyze_dev")
         if gathered:
-            buf = pipe.buffer(i)                  # its previous gather has completed and been unpacked
-            wire.pack(res.data_ptr(), buf.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
-            pipe.submit(i)                        # asynchronous gather to rank 0
+            done = torch.cuda.Event()
+            done.record(stream)
+            with torch.cuda.stream(pack_stream):
+                pack_stream.wait_event(done)
+                buf = pipe.buffer(i)              # its previous gather has completed and been unpacked
+                wire.pack(res2[j].data_ptr(), buf.data_ptr(), ctypes.c_void_p(pack_stream.cuda_stream))
+                ev = torch.cuda.Event()
+                ev.record(pack_stream)
+                packed[j] = ev
+                pipe.submit(i)                    # asynchronous gather to rank 0
+    res = res2[0]
 
     def fence():
-        pipe.drain()                              # every outstanding gather has been waited for and unpacked
+        if gathered:
+            with torch.cuda.stream(pack_stream):
+                pipe.drain()                      # every outstanding gather has been waited for and unpacked
+        else:
+            pipe.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
