@@ -186,6 +186,8 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     float2* cur = L.bufA;
     float2* prv = L.bufB;
     v2f raw[R];                                                   // raw samples of the next row (prefetched)
+#pragma unroll
+    for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
     // Rows are addressed as (signal b, row-in-signal q), advanced incrementally: a 64-bit division
     // per frame costs more than the whole peak search.
     auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {     // issue the loads of global row gn = (bn, qn)
@@ -200,17 +202,20 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
         // (b, q) of row g + 1
         const int64_t qn = (q == p.F) ? 0 : q + 1;
         const int64_t bn = (q == p.F) ? b + 1 : b;
+        // One prefetch site, after the multiplies, for both kinds of row: with the prefetch duplicated into
+        // the zero-row branch the compiler hoists it above the branch and copies all of `raw` every frame.
+        // (For a zero row `raw` is stale and z is garbage that nobody reads.)
+        v2f z[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(g + 1, bn, qn);
         if (g < 0 || q == 0) {
 #pragma unroll
             for (int j = 0; j < G::BUFC / 64; j++) dst[lane + 64 * j] = make_float2(0.f, 0.f);
             wave_sync();
-            prefetch(g + 1, bn, qn);
             return;
         }
-        v2f z[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
-        prefetch(g + 1, bn, qn);
         dft_regs<R>(z);                                           // stage 1
         v2f* dz = (v2f*)dst;
 #pragma unroll
