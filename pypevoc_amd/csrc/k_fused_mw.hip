@@ -174,6 +174,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     float2* cur = bufA;
     float2* prv = bufB;
     v2f raw[R];                                                   // raw samples of the next row (prefetched)
+#pragma unroll
+    for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
     auto prefetch = [&](int64_t gn, int64_t bn, int64_t qn) {
         if (gn < 0 || gn >= r1 || qn == 0) return;
         load_raw_mw<R, W, InT, AL2>((const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop, tid, raw);
@@ -185,17 +187,19 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     auto spectrum = [&](int64_t g, int64_t b, int64_t q, float2* dst, bool with_mag, float& maxe, float& mine, double& tot) {
         const int64_t qn = (q == p.F) ? 0 : q + 1;
         const int64_t bn = (q == p.F) ? b + 1 : b;
-        if (g < 0 || q == 0) {
-#pragma unroll
-            for (int j = 0; j < G::BUFC / T; j++) dst[tid + T * j] = make_float2(0.f, 0.f);
-            __syncthreads();
-            prefetch(g + 1, bn, qn);
-            return;
-        }
+        // one prefetch site, after the multiplies, for both kinds of row (see k_fused.hip); for a zero row
+        // `raw` is stale and z is garbage that nobody reads
         v2f z[R];
 #pragma unroll
         for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
+        __builtin_amdgcn_sched_barrier(0);
         prefetch(g + 1, bn, qn);
+        if (g < 0 || q == 0) {                                    // block-uniform
+#pragma unroll
+            for (int j = 0; j < G::BUFC / T; j++) dst[tid + T * j] = make_float2(0.f, 0.f);
+            __syncthreads();
+            return;
+        }
         dft_regs<R>(z);                                           // stage 1
         v2f* dz = (v2f*)dst;
 #pragma unroll
