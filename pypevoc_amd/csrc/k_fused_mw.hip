@@ -191,7 +191,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
         // `raw` is stale and z is garbage that nobody reads
         v2f z[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];
+        for (int r = 0; r < R; r++) {
+            z[r] = raw[r] * wv[r];
+            asm volatile("" : "+v"(z[r]));                        // the multiply stays here: it must not sink below the loads
+        }
         __builtin_amdgcn_sched_barrier(0);
         prefetch(g + 1, bn, qn);
         if (g < 0 || q == 0) {                                    // block-uniform
