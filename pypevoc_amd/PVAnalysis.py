@@ -66,8 +66,18 @@ class PV(object):
             * precision = 32: float32 frames/spectra on the device (outputs float64, tolerances in
                           DESIGN.md); 64: float64 end to end
         '''
-        self.x = np.array(x)                                   # PVAnalysis.py:84
-        self.nsamp = len(self.x)
+        self._xdev = None
+        if _lib.is_device_array(x):
+            # Extension: a signal that is already in GPU memory (torch tensor on the GPU, anything with
+            # __cuda_array_interface__) is analysed in place -- no host copy, no PCIe transfer of the input
+            self._xdev = _lib.DeviceSignal(x)
+            if len(self._xdev.shape) != 1:
+                raise ValueError("PV expects a 1-D signal")
+            self.x = x
+            self.nsamp = self._xdev.shape[0]
+        else:
+            self.x = np.array(x)                               # PVAnalysis.py:84
+            self.nsamp = len(self.x)
         self.sr = sr
         self.nfft = nfft
         self.nfft2 = int(nfft / 2)
@@ -135,9 +145,33 @@ class PV(object):
         _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, self._progress_cb, None), "pvx_plan_set_progress")
 
     def _signal(self):
+        if self._xdev is not None:
+            # the per-frame / streaming helpers work on host copies (they are CPU-side conveniences)
+            import torch
+            return _lib.as_signal(torch.as_tensor(self.x).cpu().numpy())
         if self.x.ndim != 1:
             raise ValueError("PV expects a 1-D signal")
         return _lib.as_signal(self.x)
+
+    def _run_pv_device(self, F, K, prev0):
+        """run_pv for a device-resident signal: pvx_analyze_dev on torch's current stream."""
+        lib = _lib.load()
+        _lib.init()
+        import torch
+        dprev = torch.from_numpy(prev0).to("cuda") if prev0 is not None else None
+        n = F * K
+        plan = self._get_plan(rows=F + 1)
+
+        def launch(o, stream):
+            ptrs = [ctypes.c_void_p(o + i * n * 8) for i in range(5)]
+            r = lib.pvx_analyze_dev(plan.handle, ctypes.c_void_p(self._xdev.ptr), self._xdev.dtype_code, self.nsamp, 1,
+                                    self.nsamp, *ptrs, ctypes.c_void_p(o + 5 * n * 8), ctypes.c_void_p(o + 5 * n * 8 + F * 8),
+                                    ctypes.c_void_p(dprev.data_ptr()) if dprev is not None else None, stream)
+            _lib.check(r, "pvx_analyze_dev")
+
+        blk = _lib.device_run((5 * n + 2 * F) * 8, launch)
+        arrs = [blk[i * n:(i + 1) * n].reshape(F, K).copy() for i in range(5)]
+        return arrs, blk[5 * n:5 * n + F].copy(), blk[5 * n + F:].copy()
 
     # ------------------------------------------------------------------ reference API
     def dphase2freq(self, dph, nbin):
@@ -201,7 +235,7 @@ class PV(object):
     def run_pv(self):
         '''The analysis loop (PVAnalysis.py:213-264) as one call into the HIP library.'''
         lib = _lib.load()
-        x, dt = self._signal()
+        x, dt = (None, None) if self._xdev is not None else self._signal()
         K = self.npeaks
         F = int(lib.pvx_nframes(self.nsamp, self.nfft, int(self.hop)))
         if F == 0:
@@ -220,12 +254,27 @@ class PV(object):
         if np.any(old != 0):                                     # run_pv after manual calc_pv_frame calls
             oc = old.astype(complex)
             prev0 = np.ascontiguousarray(np.stack([oc.real, oc.imag], axis=1), dtype=np.float64)
-        plan = self._get_plan(rows=F + 1)
-        r = lib.pvx_analyze(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), 1, len(x),
-                            _lib.dptr(f), _lib.dptr(mag), _lib.dptr(ph), _lib.dptr(realph), _lib.dptr(binno),
-                            _lib.dptr(t), _lib.dptr(tm),
-                            _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
-        _lib.check(r, "pvx_analyze")
+        if self._xdev is not None:
+            (f, mag, ph, realph, binno), t, tm = self._run_pv_device(F, K, prev0)
+            # PV.oldfft after the loop = spectrum of the last frame (PVAnalysis.py:209): one frame's worth
+            # of samples comes back to the host for it
+            import torch
+            pos = (F - 1) * int(self.hop)
+            tail = torch.as_tensor(self.x)[pos:pos + self.nfft].cpu().numpy()
+            tail_sig, tail_dt = _lib.as_signal(tail)
+            posa = np.zeros(1, dtype=np.int64)
+            spec = np.zeros((1, self.nfft2 + 1, 2))
+            _lib.check(lib.pvx_stft_frames(self._get_plan().handle, tail_sig.ctypes.data_as(ctypes.c_void_p), tail_dt,
+                                           len(tail_sig), posa.ctypes.data_as(_lib.c_int64_p), 1, _lib.dptr(spec)),
+                       "pvx_stft_frames")
+            last = spec[0, :self.nfft2, :]
+        else:
+            plan = self._get_plan(rows=F + 1)
+            r = lib.pvx_analyze(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), 1, len(x),
+                                _lib.dptr(f), _lib.dptr(mag), _lib.dptr(ph), _lib.dptr(realph), _lib.dptr(binno),
+                                _lib.dptr(t), _lib.dptr(tm),
+                                _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
+            _lib.check(r, "pvx_analyze")
         self.f = f
         self.mag = mag
         self.ph = ph

@@ -89,6 +89,27 @@ class PvxError(RuntimeError):
 _LIB = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if
+    libpvx_hip.so pulled in the system one first, a later `import torch` would bring a second runtime
+    into the process and fail with "No HIP GPUs are available".  libpvx_hip.so binds to whichever
+    libamdhip64.so.7 is already loaded, so when torch is installed (and not yet imported) its copy is
+    loaded first.  PVX_SYSTEM_HIP=1 skips this."""
+    import sys
+    if os.environ.get("PVX_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass            # no torch, or an unusual layout: the system runtime is used
+
+
 def load():
     """Load libpvx_hip.so and bind every entry point.  Fails loudly if the library is missing."""
     global _LIB
@@ -98,6 +119,7 @@ def load():
         raise ImportError(
             "pypevoc_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C pypevoc_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
@@ -145,3 +167,42 @@ def as_signal(x):
     if x.dtype == np.int16:
         return np.ascontiguousarray(x), PVX_I16
     return np.ascontiguousarray(x, dtype=np.float64), PVX_F64
+
+
+class DeviceSignal(object):
+    """A signal that already lives in GPU memory (anything with __cuda_array_interface__, e.g. a torch
+    tensor on the GPU; float32, float64 or int16, C-contiguous).  The analysis reads it in place."""
+
+    def __init__(self, obj):
+        cai = obj.__cuda_array_interface__
+        ts = cai["typestr"]
+        if ts not in ("<f4", "<f8", "<i2"):
+            raise TypeError("device signal must be float32, float64 or int16, got %s" % ts)
+        if cai.get("strides") is not None:
+            item = int(ts[2:])
+            expect = []
+            acc = item
+            for n in reversed(cai["shape"]):
+                expect.insert(0, acc)
+                acc *= n
+            if tuple(cai["strides"]) != tuple(expect):
+                raise ValueError("device signal must be C-contiguous")
+        self.obj = obj                       # keeps the memory alive
+        self.ptr = int(cai["data"][0])
+        self.shape = tuple(int(v) for v in cai["shape"])
+        self.dtype_code = {"<f4": PVX_F32, "<f8": PVX_F64, "<i2": PVX_I16}[ts]
+
+
+def is_device_array(x):
+    return hasattr(x, "__cuda_array_interface__") and not isinstance(x, np.ndarray)
+
+
+def device_run(nbytes_out, launch):
+    """Run `launch(out_ptr, stream_ptr)` with a float64 device output block of nbytes_out/8 elements
+    on torch's current stream, return the block as a host numpy array."""
+    import torch
+    out = torch.empty(nbytes_out // 8, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    stream = torch.cuda.current_stream()
+    launch(out.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
+    stream.synchronize()
+    return out.cpu().numpy()

@@ -31,11 +31,20 @@ class PVBatch(object):
 
     def __init__(self, x, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, wind=np.hanning,
                  precision=32):
-        x = np.asarray(x)
-        if x.ndim != 2:
-            raise ValueError("PVBatch expects x[B, nsamp]")
-        self.x, self.x_dtype = _lib.as_signal(x)
-        self.nsig, self.nsamp = self.x.shape
+        self._xdev = None
+        if _lib.is_device_array(x):
+            # a batch that already lives in GPU memory (e.g. a torch tensor on the GPU) is analysed in place
+            self._xdev = _lib.DeviceSignal(x)
+            if len(self._xdev.shape) != 2:
+                raise ValueError("PVBatch expects x[B, nsamp]")
+            self.x, self.x_dtype = x, self._xdev.dtype_code
+            self.nsig, self.nsamp = self._xdev.shape
+        else:
+            x = np.asarray(x)
+            if x.ndim != 2:
+                raise ValueError("PVBatch expects x[B, nsamp]")
+            self.x, self.x_dtype = _lib.as_signal(x)
+            self.nsig, self.nsamp = self.x.shape
         self.sr = sr
         self.nfft = nfft
         self.nfft2 = int(nfft / 2)
@@ -60,10 +69,26 @@ class PVBatch(object):
             if self._plan is None:
                 self._plan = _Plan(self.sr, self.nfft, self.hop, K, self.peakthresh, self.win, self.precision,
                                    max_rows=B * (F + 1))
-            r = lib.pvx_analyze(self._plan.handle, self.x.ctypes.data_as(ctypes.c_void_p), self.x_dtype,
-                                self.nsamp, B, self.nsamp, *[_lib.dptr(out[k]) for k in FIELDS],
-                                _lib.dptr(t), _lib.dptr(tm), None, None)
-            _lib.check(r, "pvx_analyze")
+            if self._xdev is not None:
+                n = B * F * K
+
+                def launch(o, stream):
+                    ptrs = [ctypes.c_void_p(o + i * n * 8) for i in range(5)]
+                    r = lib.pvx_analyze_dev(self._plan.handle, ctypes.c_void_p(self._xdev.ptr), self.x_dtype, self.nsamp, B,
+                                            self.nsamp, *ptrs, ctypes.c_void_p(o + 5 * n * 8),
+                                            ctypes.c_void_p(o + 5 * n * 8 + B * F * 8), None, stream)
+                    _lib.check(r, "pvx_analyze_dev")
+
+                blk = _lib.device_run((5 * n + 2 * B * F) * 8, launch)
+                for i, k in enumerate(FIELDS):
+                    out[k] = blk[i * n:(i + 1) * n].reshape(shape).copy()
+                t = blk[5 * n:5 * n + B * F].reshape(B, F).copy()
+                tm = blk[5 * n + B * F:].reshape(B, F).copy()
+            else:
+                r = lib.pvx_analyze(self._plan.handle, self.x.ctypes.data_as(ctypes.c_void_p), self.x_dtype,
+                                    self.nsamp, B, self.nsamp, *[_lib.dptr(out[k]) for k in FIELDS],
+                                    _lib.dptr(t), _lib.dptr(tm), None, None)
+                _lib.check(r, "pvx_analyze")
         for k in FIELDS:
             setattr(self, k, out[k])
         self.t = t[0] if B > 0 else np.zeros(F)

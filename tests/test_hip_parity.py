@@ -755,3 +755,54 @@ def test_windowed_reductions_match_reference(amd, oracle):
     assert np.abs(rr - oracle.rms_frames(y, w, 1000)).max() <= 1e-13
     e, ie = heterodyne(y[:100], hs[:100], wind=np.ones(256), hop=10)
     assert len(e) == 0 and len(ie) == 0
+
+
+# ------------------------------------------------------------------ device-resident input
+def test_device_resident_signal_is_analysed_in_place(amd):
+    """PV(x) with x a torch tensor on the GPU (float32 / float64 / int16): pvx_analyze_dev reads it in
+    place; results are bit-identical to the host-array path, toSinSum/synth work on them as usual."""
+    import torch
+    rng = np.random.default_rng(31)
+    n = 44100
+    t = np.arange(n) / 44100.0
+    x = (0.3 * np.sin(2 * np.pi * 330 * t) + 0.1 * np.sin(2 * np.pi * 1234 * t) + 0.01 * rng.standard_normal(n))
+    for arr in (x.astype(np.float32), x, np.round(x * 20000).astype(np.int16)):
+        for prec in (32, 64):
+            h = run_pv(amd, arr, 44100, 2048, 512, 8, precision=prec)
+            d = run_pv(amd, torch.from_numpy(arr).cuda(), 44100, 2048, 512, 8, precision=prec)
+            assert d.nframes == h.nframes and isinstance(d.totalmag, list)
+            for k in ("f", "mag", "ph", "realph", "binno", "t"):
+                assert np.array_equal(getattr(h, k), getattr(d, k)), (arr.dtype, prec, k)
+            assert np.array_equal(np.asarray(h.totalmag), np.asarray(d.totalmag))
+            assert np.abs(d.oldfft - h.oldfft).max() <= 2e-6 * np.abs(h.oldfft).max()
+    w_h = h.toSinSum().synth(44100, 512)
+    w_d = d.toSinSum().synth(44100, 512)
+    assert np.array_equal(w_h, w_d)
+    with pytest.raises(ValueError):
+        amd.PV(torch.zeros((2, 4096), device="cuda"), 44100, nfft=1024)
+    # a batch on the device
+    xb = np.stack([np.roll(x, 1000 * i) for i in range(5)]).astype(np.float32)
+    hb = amd.PVBatch(xb, 44100, nfft=2048, hop=512, npks=8).run_pv()
+    db = amd.PVBatch(torch.from_numpy(xb).cuda(), 44100, nfft=2048, hop=512, npks=8).run_pv()
+    for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+        assert np.array_equal(getattr(hb, k), getattr(db, k)), k
+
+
+def test_library_first_then_torch_in_a_fresh_process():
+    """`import pypevoc_amd` + an analysis BEFORE `import torch` must leave torch usable: both have to end
+    up on the same HIP runtime (pypevoc_amd/_lib.py::_share_hip_runtime_with_torch)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import pypevoc_amd\n"
+        "x = np.random.default_rng(0).standard_normal(20000).astype(np.float32)\n"
+        "p = pypevoc_amd.PV(x, 44100, nfft=2048, hop=512, npks=8, progress=False); p.run_pv()\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "y = torch.ones(8, device='cuda')\n"
+        "q = pypevoc_amd.PV(torch.from_numpy(x).cuda(), 44100, nfft=2048, hop=512, npks=8, progress=False); q.run_pv()\n"
+        "assert np.array_equal(p.f, q.f)\n"
+        "print('ok', p.nframes, float(y.sum()))\n" % os.path.dirname(os.path.dirname(GOLDEN)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
