@@ -52,7 +52,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: row bookkeeping on the scalar unit
     const int nwaves = blockDim.x >> 6;
     const int N2 = p.N2, K = p.K;
     const int n2pad = (N2 + 3) & ~3;
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
             for (int i = lane; i < nvec; i += 64) {
                 const V v = cv[i];
                 if constexpr (CPV == 2) {
+                    // float32: the peak search runs on |X|^2 -- every test it makes is monotone in |X|
                     const float e0 = v.x * v.x + v.y * v.y, e1 = v.z * v.z + v.w * v.w;
-                    const float m0 = sqrtf(e0), m1 = sqrtf(e1);
-                    *(float2*)(y + 2 * i) = make_float2(m0, m1);
-                    lmax = fmaxf(lmax, fmaxf(m0, m1));
-                    lmin = fminf(lmin, fminf(m0, m1));
+                    *(float2*)(y + 2 * i) = make_float2(e0, e1);
+                    lmax = fmaxf(lmax, fmaxf(e0, e1));
+                    lmin = fminf(lmin, fminf(e0, e1));
                     lsum += (double)e0 + (double)e1;
                 } else {
                     const T m0 = hypot(v.x, v.y);                    // np.abs of complex128
@@ -111,20 +111,29 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
             }
             for (int k = nvec * CPV + lane; k < N2; k += 64) {       // odd tail (CPV == 2, N2 odd)
                 const T re = cur[2 * k], im = cur[2 * k + 1];
-                const T m0 = (T)sqrt((double)re * re + (double)im * im);
+                const T m0 = re * re + im * im;                      // float32 only: |X|^2 like the vector body
                 y[k] = m0;
                 lmax = m0 > lmax ? m0 : lmax;
                 lmin = m0 < lmin ? m0 : lmin;
-                lsum += (double)m0 * (double)m0;
+                lsum += (double)m0;
             }
         }
-        const T maxy = wave_max(lmax);
-        const T miny = wave_min(lmin);
+        const T maxv = wave_max(lmax);
+        const T minv = wave_min(lmin);
         const double tot = wave_sum(lsum);
         wave_sync();
         // ---- PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
-        const double minamp = (double)maxy * p.thr;                  // PF.py:60
-        const int nsel = peak_select<T>(y, cs, ci, sel, N2, K, minamp, true, miny, lane);
+        int nsel;
+        if constexpr (sizeof(T) == 4) {
+            // the row holds |X|^2: |X| - miny > minamp - miny  <=>  |X|^2 - mine > minamp^2 - mine; minamp == 0
+            // means minamp = miny (PF.py:69-70) and the threshold is then exactly 0 (see k_fused.hip)
+            const double minamp = (double)sqrtf(maxv) * p.thr;       // PF.py:60
+            const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
+            nsel = peak_select_th<T>(y, cs, ci, sel, N2, K, th, minv, lane);
+        } else {
+            const double minamp = (double)maxv * p.thr;              // PF.py:60
+            nsel = peak_select<T>(y, cs, ci, sel, N2, K, minamp, true, minv, lane);
+        }
         int nk = 0;
         for (int e0 = 0; e0 < nsel; e0 += 64) {
             const int e = e0 + lane;

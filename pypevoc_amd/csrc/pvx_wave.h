@@ -255,14 +255,19 @@ __device__ __forceinline__ double peak_threshold(double minamp_in, bool have_min
 }
 
 //   NS > 0: n == NS is known at compile time (fused kernel)
+// peak_select_th: a bin qualifies when y - miny > th; y may be any monotone function of the magnitudes
+// as long as th and miny are in the same domain (the float32 kernels search |X|^2)
 template <typename T, int NS = 0>
-__device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
-                                  bool have_minamp, T miny, int lane) {
+__device__ __forceinline__ int peak_select_th(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double th, T miny, int lane) {
     if (n < 3) return 0;
-    const double th = peak_threshold<T>(minamp_in, have_minamp, miny);
     const int C = peak_scan<T, (NS + 63) / 64>(y, 0, n, n, miny, th, cs, ci, lane);
     wave_sync();
     return peak_pick<T>(y, cs, ci, out, n, npeaks, C, th, lane);
+}
+template <typename T, int NS = 0>
+__device__ __forceinline__ int peak_select(const T* y, T* cs, int* ci, int* out, int n, int npeaks, double minamp_in,
+                                  bool have_minamp, T miny, int lane) {
+    return peak_select_th<T, NS>(y, cs, ci, out, n, npeaks, peak_threshold<T>(minamp_in, have_minamp, miny), miny, lane);
 }
 
 // peak_scan_block: the same candidate list as peak_scan for a float row of n = 64*R bins held in the

@@ -158,7 +158,8 @@ def check32(p, o, c, S):
                 continue
             g = gset[b]
             worst["f"] = max(worst["f"], abs(p.f[i][g] - o["f"][i][j]) * 2 * np.pi * dt)
-            worst["ph"] = max(worst["ph"], abs(p.ph[i][g] - o["ph"][i][j]))
+            dph = abs(p.ph[i][g] - o["ph"][i][j])
+            worst["ph"] = max(worst["ph"], min(dph, abs(dph - 2 * np.pi)))       # +pi and -pi are the same phase
             worst["mag"] = max(worst["mag"], abs(p.mag[i][g] - o["mag"][i][j]) / o["mag"][i][j])
     # a strong peak can only go missing when more than K strong peaks compete (rank decided by rounding)
     if nbad > 0.01 * nchk + (1 if K < 100 else 3):
