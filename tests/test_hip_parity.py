@@ -45,6 +45,12 @@ def run_pv(amd, x, sr, nfft, hop, npks, pkthresh=0.005, precision=32, **kw):
     return p
 
 
+def run_golden(amd, g, precision):
+    """run_pv on a golden fixture's input with its parameters (incl. a non-default window callable)."""
+    kw = dict(wind=lambda n: g["win"]) if "win" in g else {}
+    return run_pv(amd, g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], precision, **kw)
+
+
 def assert_f64(c):
     assert c["bad_peaks"] == 0 and c["frames_diff"] == 0, c
     assert c["f_abs"] <= 1e-9 and c["mag_rel"] <= 1e-12 and c["ph_abs"] <= 1e-10 and c["realph_abs"] <= 1e-10, c
@@ -64,7 +70,7 @@ def assert_f32(c, absolute=True):
 @pytest.mark.parametrize("name", ANALYSIS)
 def test_run_pv_matches_reference(amd, name, precision):
     g = load_golden(name)
-    p = run_pv(amd, g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], precision)
+    p = run_golden(amd, g, precision)
     assert p.nframes == g["nframes"] and p.f.shape == g["f"].shape
     assert isinstance(p.totalmag, list) and p.f.dtype == np.float64
     assert np.array_equal(p.t, g["t"])
@@ -92,7 +98,7 @@ def test_tosinsum_matches_reference(amd, name, oracle):
     assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
     assert np.array_equal(oracle.part_slots(pid, st, ln), g["part_slot"])
     # end to end (float64 analysis): same table, and the Python views carry the reference's values
-    p = run_pv(amd, g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], 64)
+    p = run_golden(amd, g, 64)
     s2 = p.toSinSum()
     pid2, st2, ln2 = s2.partial_table()
     assert np.array_equal(st2, g["part_start"]) and np.array_equal(ln2, g["part_len"])
@@ -117,7 +123,7 @@ def test_synth_matches_reference(amd, name):
         pytest.skip("no waveform in this fixture")
     ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
     ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
-    p32 = run_pv(amd, g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], 32)
+    p32 = run_golden(amd, g, 32)
     s32 = p32.toSinSum()
     for h in hops:
         ref = g["w_hop%d" % h].astype(np.float64)

@@ -23,7 +23,7 @@ def _same_peaks(g, o):
 @pytest.mark.parametrize("name", ANALYSIS)
 def test_analysis_matches_reference(oracle, name):
     g = load_golden(name)
-    o = oracle.analyze(g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"])
+    o = oracle.analyze(g["x"], g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], win=g.get("win"))
     assert o["f"].shape == g["f"].shape == (g["nframes"], g["npks"])
     _same_peaks(g, o)
     # stated float64 tolerances: |df| <= 1e-9 Hz, rel mag 1e-12 (+ a floor for
