@@ -812,3 +812,32 @@ def test_library_first_then_torch_in_a_fresh_process():
         "print('ok', p.nframes, float(y.sum()))\n" % os.path.dirname(os.path.dirname(GOLDEN)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------ the reference's own PeakFinder unit tests
+def _parabolic_peak(max_pos=1.0, max_val=1.0, n=3, a=-1.):
+    x = np.arange(n)
+    b = -max_pos * 2 * a
+    c = max_val - a * max_pos * (b + max_pos)
+    return a * x * x + b * x + c
+
+
+def test_reference_peak_finder_unit_tests(amd):
+    """tests/test_peak_finder.py of the reference, case by case (findpos runs in the HIP kernel, the
+    parabolic refinement is host numpy as in the reference)."""
+    pf = amd.PeakFinder
+    x = np.concatenate((np.linspace(0, 1, 10), np.linspace(.9, 1, 9)))
+    peaks = pf(x)                                                    # testFindOnePeak
+    assert len(peaks.pos) == 1 and peaks.pos == 9
+    peaks = pf(_parabolic_peak(max_pos=1.0))                         # test_refine_one_peak_centered
+    peaks.refine_all()
+    assert len(peaks.pos) == 1 and peaks.pos == 1.0
+    peaks = pf(_parabolic_peak(max_pos=1.2, n=4))                    # test_refine_one_peak_at_random_pos
+    peaks.refine_all()
+    assert peaks.fpos.tolist() == [1.2]
+    peaks = pf(_parabolic_peak(max_pos=1.5, n=4))                    # test_refine_one_peak_between_samples
+    peaks.refine_all()
+    assert peaks.fpos.tolist() == [1.5]
+    peaks = pf(_parabolic_peak(max_pos=1.499, n=4))                  # test_refine_one_peak_almost_between_samples
+    peaks.refine_all()
+    assert len(peaks.fpos) == 1 and abs(peaks.fpos[0] - 1.499) < 1e-7
