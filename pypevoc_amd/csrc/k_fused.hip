@@ -26,10 +26,13 @@
 // Complex values are even-aligned register pairs (pvx_cplx.h): one packed instruction per complex add,
 // two per complex multiply, conjugations and multiplications by -i folded into operand modifiers.
 // Z goes to LDS in natural order (a few complex of padding per R^2 keep the accesses
-// spread over the banks), is untangled in place into X[0..M), |X| goes to a second LDS array, and
-// from there on the frame is handled exactly like k_peaks.hip does (same PeakFinder core, same
-// per-peak arithmetic), except that the previous frame's spectrum is the LDS buffer the wave filled
-// one iteration earlier.  The index maps were validated in numpy for every R before this was written.
+// spread over the banks), is untangled in place into X[0..M), |X|^2 goes to a second (bank-padded) LDS
+// row.  Peak search (pvx_wave.h): every lane owns R consecutive bins, candidate flags are sign bits of
+// integer subtractions on the float bit patterns, list positions a ballot prefix (peak_block_masks /
+// peak_block_write); ranking / radix select when there are more candidates than npks (peak_pick); the
+// salience test with 8 lanes per peak (salient_groups).  The per-peak arithmetic (peak_math) is the same
+// as in k_peaks.hip; the previous frame's spectrum is the LDS buffer the wave filled one iteration
+// earlier.  The index maps were validated in numpy for every R before this was written.
 //
 // Work distribution: persistent-style.  Wave w owns the contiguous global rows [w*Rows/W, (w+1)*Rows/W)
 // and recomputes the spectrum of the row before its first one (one extra FFT per wave).  No
