@@ -104,7 +104,18 @@ def main():
                                    args.precision, 0), "pvx_plan_create")
     if args.fft_mode >= 0:
         _lib.check(lib.pvx_plan_set_fft_mode(plan, args.fft_mode), "pvx_plan_set_fft_mode")
+    # Consecutive steps alternate between two streams (each with its own plan and result block): a step
+    # is one persistent kernel whose waves finish at slightly different times, and the ~5 us the GPU
+    # needs to start the next kernel of the SAME stream would sit on top of that tail.  With two streams
+    # the waves of step i+1 move in as those of step i drain.  Every step is still a complete pass.
+    plan_b = ctypes.c_void_p()
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan_b), float(SR), NFFT, HOP, K, 0.005, _lib.dptr(win),
+                                   args.precision, 0), "pvx_plan_create")
+    if args.fft_mode >= 0:
+        _lib.check(lib.pvx_plan_set_fft_mode(plan_b, args.fft_mode), "pvx_plan_set_fft_mode")
+    plans = [plan, plan_b]
     stream = torch.cuda.current_stream(dev)
+    cstreams = [stream, torch.cuda.Stream(device=dev)]
 
     # This rank's results in the reference's layout (five float64 [F, K] arrays + totalmag + t,
     # PV.py:256-264).  With more than one rank every step ends in ONE gather to rank 0: the rows are
@@ -119,7 +130,7 @@ def main():
     wire = ResultWire(plan, F, K)
     # two result blocks: while step i+1 is analysed into one, the other is packed and gathered
     nres = wire.result_numel() + F
-    res2 = [torch.zeros(nres, dtype=torch.float64, device=dev) for _ in range(2 if gathered else 1)]
+    res2 = [torch.zeros(nres, dtype=torch.float64, device=dev) for _ in range(2)]
     rp2 = [wire.result_ptrs(r.data_ptr()) for r in res2]           # f, mag, ph, realph, binno, totalmag
     tp2 = [r.data_ptr() + wire.result_numel() * 8 for r in res2]
     full = torch.zeros((world, wire.result_numel()), dtype=torch.float64, device=dev) if (gathered and rank == 0) else None
@@ -138,19 +149,20 @@ def main():
 
     counter = [0]
 
-    def step():
+    def step(single=False):
         i = counter[0]
         counter[0] += 1
-        j = i % len(res2)
+        j = i % 2
+        cs = cstreams[0] if single else cstreams[j]
         if packed[j] is not None:
-            stream.wait_event(packed[j])          # the pack of step i-2 has read this block
+            cs.wait_event(packed[j])              # the pack of step i-2 has read this block
         rp = rp2[j]
-        r = lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp, rp[0], rp[1], rp[2], rp[3], rp[4],
-                                tp2[j], rp[5], None, ctypes.c_void_p(stream.cuda_stream))
+        r = lib.pvx_analyze_dev(plans[0] if single else plans[j], x.data_ptr(), _lib.PVX_F32, nsamp, 1, nsamp,
+                                rp[0], rp[1], rp[2], rp[3], rp[4], tp2[j], rp[5], None, ctypes.c_void_p(cs.cuda_stream))
         _lib.check(r, "pvx_analyze_dev")
         if gathered:
             done = torch.cuda.Event()
-            done.record(stream)
+            done.record(cs)
             with torch.cuda.stream(pack_stream):
                 pack_stream.wait_event(done)
                 buf = pipe.buffer(i)              # its previous gather has completed and been unpacked
@@ -179,10 +191,12 @@ def main():
     e1 = torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
-    e0.record(stream)
+    e0.record(cstreams[0])
+    cstreams[1].wait_event(e0)
     for _ in range(args.steps):
         step()
-    e1.record(stream)
+    cstreams[0].wait_stream(cstreams[1])
+    e1.record(cstreams[0])
     fence()
     elapsed = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
@@ -191,7 +205,7 @@ def main():
     # cost a few percent)
     _lib.check(lib.pvx_plan_set_timing(plan, 1), "pvx_plan_set_timing")
     for _ in range(args.steps):
-        step()
+        step(single=True)                         # one stream, one plan: launches do not overlap here
     fence()
     ms = (ctypes.c_double * 4)()
     nl = (ctypes.c_int64 * 4)()
@@ -279,7 +293,8 @@ def main():
                                    "analysis only (PV.run_pv), F=%d frames/signal%s" %
                                    (args.seconds, F, "; results gathered to rank 0 over RCCL" if world > 1 else ""),
                        "nfft": NFFT, "hop": HOP, "npks": NPKS, "sr": SR, "frames_per_gpu": F,
-                       "parallelism": "signals sharded 1/GPU" if world > 1 else "single GPU"},
+                       "parallelism": "signals sharded 1/GPU" if world > 1 else "single GPU",
+                       "pipelining": "consecutive steps alternate between two streams"},
             "roofline": roofline, "stage": stage, "cpu_baseline": cpu,
         }
         if gather_info:
@@ -291,6 +306,7 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     lib.pvx_plan_destroy(plan)
+    lib.pvx_plan_destroy(plan_b)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
