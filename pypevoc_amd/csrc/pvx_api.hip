@@ -110,7 +110,7 @@ struct pvx_plan {
     void* progress_user = nullptr;
     bool progress_live = false;   // inside a host entry point: chunk completions are reported
     int64_t fused_blocks = 0;    // PVX_FUSED_BLOCKS override
-    int frames_per_wave = 4;
+    int frames_per_wave = 2;     // k_phase_peaks: frames a wave handles one after the other (latency floor of a chunked launch; PVX_FPW)
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
