@@ -169,6 +169,13 @@ def as_signal(x):
     return np.ascontiguousarray(x, dtype=np.float64), PVX_F64
 
 
+def nframes_host(nsamp, nfft, hop):
+    """Number of frames of run_pv (PVAnalysis.py:224-225, 249): positions 0, hop, ... < nsamp - nfft.
+    Pure arithmetic, usable without the library (partitioning helpers)."""
+    nsamp, nfft, hop = int(nsamp), int(nfft), int(hop)
+    return (nsamp - nfft + hop - 1) // hop if nsamp > nfft else 0
+
+
 class DeviceSignal(object):
     """A signal that already lives in GPU memory (anything with __cuda_array_interface__, e.g. a torch
     tensor on the GPU; float32, float64 or int16, C-contiguous).  The analysis reads it in place."""

@@ -24,6 +24,48 @@ def shard_range(nitems, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
+def frame_shard(nsamp, nfft, hop, rank, world):
+    """Shard ONE long signal over `world` ranks by frame ranges (no exchange step).
+
+    A frame needs the spectrum of the frame before it, so a rank that starts at frame f0 > 0 also
+    analyses frame f0 - 1 (one frame of halo) and drops that row.  Returns (f0, f1, a, b, drop):
+    this rank owns frames [f0, f1); it analyses samples x[a:b], whose first `drop` result rows are
+    the halo.  The per-shard results are bit-identical to the corresponding rows of the unsharded
+    analysis (the kernels' results do not depend on where a frame sits in a launch)."""
+    F = _lib.nframes_host(nsamp, nfft, hop)
+    f0, f1 = shard_range(F, rank, world)
+    if f1 <= f0:
+        return f0, f1, 0, 0, 0
+    h0 = max(f0 - 1, 0)
+    a = h0 * hop
+    b = min(a + (f1 - h0 - 1) * hop + nfft + 1, nsamp)         # nframes(b - a) == f1 - h0
+    return f0, f1, a, b, f0 - h0
+
+
+def analyze_frame_shard(x, sr, nfft, hop, npks, rank, world, pkthresh=0.005, wind=np.hanning, precision=32):
+    """This rank's rows of PV(x, sr, nfft, hop, npks, pkthresh).run_pv() under `frame_shard`:
+    dict(f, mag, ph, realph, binno [n, npks], t, totalmag [n], f0, f1).  Concatenating the ranks' blocks
+    in rank order (e.g. with `gather_results` on padded blocks) gives the unsharded arrays; the tracker
+    (toSinSum) then runs once on the gathered (F, npks) arrays -- links only need adjacent rows."""
+    from .PVAnalysis import PV
+    f0, f1, a, b, drop = frame_shard(len(x), nfft, hop, rank, world)
+    out = dict(f0=f0, f1=f1)
+    if f1 <= f0:
+        for k in FIELDS:
+            out[k] = np.zeros((0, npks))
+        out["t"] = np.zeros(0)
+        out["totalmag"] = np.zeros(0)
+        return out
+    p = PV(x[a:b], sr, nfft=nfft, hop=hop, npks=npks, pkthresh=pkthresh, wind=wind, progress=False, precision=precision)
+    p.run_pv()
+    assert p.nframes == f1 - f0 + drop
+    for k in FIELDS:
+        out[k] = getattr(p, k)[drop:]
+    out["t"] = (np.arange(f0, f1) * hop + nfft / 2.0) / sr        # PVAnalysis.py:247 with the global position
+    out["totalmag"] = np.asarray(p.totalmag)[drop:]
+    return out
+
+
 class PVBatch(object):
     """run_pv for a batch of equal-length signals `x[B, nsamp]` with shared parameters.
 

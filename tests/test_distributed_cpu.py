@@ -148,3 +148,42 @@ def test_pipelined_gather_consume_hook_world2(tmp_path):
     for i in range(9):
         for r in range(2):
             assert np.array_equal(got[i, r], ((np.arange(257) + 7 * i + 31 * r) % 251).astype(np.uint8)), (i, r)
+
+
+# ------------------------------------------------------------------ one long signal, sharded by frame ranges
+def _frame_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pvoracle
+        from pypevoc_amd.batch import frame_shard, gather_results
+        x = _signals(1, n=20000)[0] + 0.01 * np.random.default_rng(3).standard_normal(20000)
+        nfft, hop, K = 512, 128, 4
+        F = pvoracle.nframes(len(x), nfft, hop)
+        f0, f1, a, b, drop = frame_shard(len(x), nfft, hop, rank, world)
+        o = pvoracle.analyze(x[a:b], 8000.0, nfft, hop, K)       # the oracle stands in for the device
+        rows = np.stack([o[k][drop:] for k in ("f", "mag", "ph", "realph", "binno")], axis=1)   # [n, 5, K]
+        assert rows.shape[0] == f1 - f0
+        full = gather_results(torch.from_numpy(np.ascontiguousarray(rows)), F, dst=0)
+        if rank == 0:
+            np.save(os.path.join(outdir, "frames.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_range_sharding_of_one_signal_world2(tmp_path):
+    """a single long signal shards by frame ranges with a one-frame halo and no exchange step.
+    Each rank analyses its sample range (the oracle stands in for the device), drops the halo row, one
+    gather concatenates the rows: equal to the unsharded analysis (phase differences across the seam too)."""
+    from oracle import pvoracle
+    pvoracle.build()
+    port = _free_port()
+    mp.spawn(_frame_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "frames.npy"))     # [F, 5, K]
+    x = _signals(1, n=20000)[0] + 0.01 * np.random.default_rng(3).standard_normal(20000)
+    o = pvoracle.analyze(x, 8000.0, 512, 128, 4)
+    exp = np.stack([o[k] for k in ("f", "mag", "ph", "realph", "binno")], axis=1)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)

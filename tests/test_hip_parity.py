@@ -841,3 +841,24 @@ def test_reference_peak_finder_unit_tests(amd):
     peaks = pf(_parabolic_peak(max_pos=1.499, n=4))                  # test_refine_one_peak_almost_between_samples
     peaks.refine_all()
     assert len(peaks.fpos) == 1 and abs(peaks.fpos[0] - 1.499) < 1e-7
+
+
+def test_frame_range_shards_equal_the_unsharded_analysis(amd):
+    """One long signal sharded by frame ranges with a one-frame halo (pypevoc_amd.batch.frame_shard /
+    analyze_frame_shard): the concatenated shards are bit-identical to the unsharded run_pv, for the fused
+    kernel, the rocFFT path (float64) and an odd hop; the tracker then runs once on the gathered arrays."""
+    from pypevoc_amd.batch import analyze_frame_shard
+    rng = np.random.default_rng(17)
+    n = 90000
+    t = np.arange(n) / 44100.0
+    x = (0.3 * np.sin(2 * np.pi * 441.0 * t * (1 + 0.05 * t)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    for nfft, hop, prec, world in ((2048, 512, 32, 3), (2048, 512, 64, 2), (1024, 300, 32, 4), (4096, 1024, 32, 5)):
+        ref = run_pv(amd, x, 44100, nfft, hop, 8, precision=prec)
+        parts = [analyze_frame_shard(x, 44100, nfft, hop, 8, r, world, precision=prec) for r in range(world)]
+        assert [p["f0"] for p in parts][0] == 0 and parts[-1]["f1"] == ref.nframes
+        for k in ("f", "mag", "ph", "realph", "binno", "t"):
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), getattr(ref, k)), (nfft, hop, prec, k)
+        assert np.array_equal(np.concatenate([p["totalmag"] for p in parts]), np.asarray(ref.totalmag))
+    # more ranks than frames: the surplus ranks hold nothing
+    tiny = analyze_frame_shard(x[:2048 + 600], 44100, 2048, 512, 8, 3, 4)
+    assert tiny["f"].shape == (0, 8) and tiny["f0"] == tiny["f1"]
