@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default (fused where supported), 0: rocFFT path, 1: fused")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="2: consecutive steps alternate between two streams (hides the launch gap and the kernel tail, "
+                         "+2.5 %%; per-kernel durations then overlap and no longer compare with rocprofv3's)")
     ap.add_argument("--seconds", type=int, default=SECONDS, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -104,18 +107,25 @@ def main():
                                    args.precision, 0), "pvx_plan_create")
     if args.fft_mode >= 0:
         _lib.check(lib.pvx_plan_set_fft_mode(plan, args.fft_mode), "pvx_plan_set_fft_mode")
-    # Consecutive steps alternate between two streams (each with its own plan and result block): a step
-    # is one persistent kernel whose waves finish at slightly different times, and the ~5 us the GPU
-    # needs to start the next kernel of the SAME stream would sit on top of that tail.  With two streams
-    # the waves of step i+1 move in as those of step i drain.  Every step is still a complete pass.
-    plan_b = ctypes.c_void_p()
-    _lib.check(lib.pvx_plan_create(ctypes.byref(plan_b), float(SR), NFFT, HOP, K, 0.005, _lib.dptr(win),
-                                   args.precision, 0), "pvx_plan_create")
-    if args.fft_mode >= 0:
-        _lib.check(lib.pvx_plan_set_fft_mode(plan_b, args.fft_mode), "pvx_plan_set_fft_mode")
-    plans = [plan, plan_b]
-    stream = torch.cuda.current_stream(dev)
-    cstreams = [stream, torch.cuda.Stream(device=dev)]
+    # --streams 2: consecutive steps alternate between two streams (each with its own plan and result
+    # block): a step is one persistent kernel whose waves finish at slightly different times, and the
+    # ~5 us the GPU needs to start the next kernel of the SAME stream sits on top of that tail; with two
+    # streams the waves of step i+1 move in as those of step i drain.  Off by default: overlapping
+    # launches have no well-defined individual duration, and the roofline line wants one that agrees
+    # with rocprofv3's.
+    # compute runs on an explicit stream, never on the legacy default stream: launches there synchronise
+    # implicitly with other streams (with a second stream alive, ~0.27 ms per step were lost to that)
+    stream = torch.cuda.Stream(device=dev)
+    plans, cstreams = [plan, plan], [stream, stream]
+    plan_b = None
+    if args.streams == 2:
+        plan_b = ctypes.c_void_p()
+        _lib.check(lib.pvx_plan_create(ctypes.byref(plan_b), float(SR), NFFT, HOP, K, 0.005, _lib.dptr(win),
+                                       args.precision, 0), "pvx_plan_create")
+        if args.fft_mode >= 0:
+            _lib.check(lib.pvx_plan_set_fft_mode(plan_b, args.fft_mode), "pvx_plan_set_fft_mode")
+        plans = [plan, plan_b]
+        cstreams = [stream, torch.cuda.Stream(device=dev)]
 
     # This rank's results in the reference's layout (five float64 [F, K] arrays + totalmag + t,
     # PV.py:256-264).  With more than one rank every step ends in ONE gather to rank 0: the rows are
@@ -153,6 +163,7 @@ def main():
         i = counter[0]
         counter[0] += 1
         j = i % 2
+        single = single or args.streams == 1
         cs = cstreams[0] if single else cstreams[j]
         if packed[j] is not None:
             cs.wait_event(packed[j])              # the pack of step i-2 has read this block
@@ -192,10 +203,12 @@ def main():
     fence()
     t0 = time.perf_counter()
     e0.record(cstreams[0])
-    cstreams[1].wait_event(e0)
+    if args.streams == 2:
+        cstreams[1].wait_event(e0)
     for _ in range(args.steps):
         step()
-    cstreams[0].wait_stream(cstreams[1])
+    if args.streams == 2:
+        cstreams[0].wait_stream(cstreams[1])
     e1.record(cstreams[0])
     fence()
     elapsed = time.perf_counter() - t0
@@ -294,7 +307,7 @@ def main():
                                    (args.seconds, F, "; results gathered to rank 0 over RCCL" if world > 1 else ""),
                        "nfft": NFFT, "hop": HOP, "npks": NPKS, "sr": SR, "frames_per_gpu": F,
                        "parallelism": "signals sharded 1/GPU" if world > 1 else "single GPU",
-                       "pipelining": "consecutive steps alternate between two streams"},
+                       "streams": args.streams},
             "roofline": roofline, "stage": stage, "cpu_baseline": cpu,
         }
         if gather_info:
@@ -306,7 +319,8 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     lib.pvx_plan_destroy(plan)
-    lib.pvx_plan_destroy(plan_b)
+    if plan_b is not None:
+        lib.pvx_plan_destroy(plan_b)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
