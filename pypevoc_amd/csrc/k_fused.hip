@@ -85,7 +85,6 @@ struct FusedLds {       // per-wave carve
     float2* bufA;       // [BUFC]
     float2* bufB;       // [BUFC]
     float* y;           // [M + 4 R] |X|^2, padded layout ymap<1>
-    float* cs;          // [CAP]
     int* ci;            // [CAP]
     int* sel;           // [kpad]
     int* sbin;          // [GF][kpad]
@@ -100,7 +99,7 @@ template <int R> __host__ __device__ inline size_t fused_lds_per_wave(int K) {
     using G = Geo<R>;
     const size_t kpad = (size_t)((K + 3) & ~3);
     const size_t gs = (size_t)staged_frames(K, GF);
-    size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)(G::M + 4 * R) * 4 + (size_t)(G::CAP * 2 + 64) * 4 + kpad * 4 +
+    size_t b = (size_t)G::BUFC * 8 * 2 + (size_t)(G::M + 4 * R) * 4 + (size_t)(G::CAP + 64) * 4 + kpad * 4 +
                gs * kpad * 4 + gs * kpad * 5 * 4 + GF * 4 + GF * 4;
     b = (b + 7) & ~(size_t)7;
     b += GF * 8 + GF * 8;
@@ -130,8 +129,7 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
     L.bufA = (float2*)base;
     L.bufB = L.bufA + G::BUFC;
     L.y = (float*)(L.bufB + G::BUFC);
-    L.cs = L.y + M + 4 * R;                                       // y is padded: ymap<1>
-    L.ci = (int*)(L.cs + G::CAP);
+    L.ci = (int*)(L.y + M + 4 * R);                               // y is padded: ymap<1>
     L.sel = L.ci + G::CAP + 64;                                   // 64 trash slots after the candidate list
     L.sbin = L.sel + kpad;
     const int gs = staged_frames(K, GF);
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(128) void k_fused_pv(FusedParams p) {
             // squared row: |X|^2 - mine > minamp^2 - mine.  minamp == 0 means minamp = miny there: the
             // threshold is then EXACTLY 0 (its sign selects the "zeros qualify too" rule of findpos)
             const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
-            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);
+            const int nsel = peak_select_block<R>(L.y, L.ci, G::CAP, L.sel, K, th, mine, lane);
             const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
             int nk = 0;
             for (int eb = 0; eb < nsel; eb += 64) {

@@ -377,11 +377,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             peak_block_write<R>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
             __syncthreads();
             if (wid == 0) {
-                if (C > K) {                                         // the ranking paths of peak_pick want the scores
-                    for (int c = lane; c < C; c += 64) cs[c] = y[ci[c]] - mine;
-                    wave_sync();
-                }
-                const int nsel = peak_pick<float>(y, cs, ci, sel, M, K, C, th, lane);
+                // at most M/2 candidates: M/128 list entries per lane, ranked / radix-selected in registers
+                const int nsel = peak_pick_regs<M / 128, 0>(y, ci, sel, M, K, C, th, mine, lane);
                 const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
                 int nk = 0;
                 for (int eb = 0; eb < nsel; eb += 64) {

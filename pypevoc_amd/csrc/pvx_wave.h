@@ -353,19 +353,119 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
     return C;
 }
 
-// ci must have 64 spare ints at [trash, trash + 64)
+// The dense-candidate branch of peak_pick_regs, kept out of line: it runs on noise-like frames only, and
+// inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
+// layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).
+template <int NCH, int YP>
+__device__ __attribute__((noinline)) int peak_radix_regs(const float* y, const int* ci, int* out, int npeaks, int C,
+                                                         float miny, int lane) {
+    int cb[NCH];
+    unsigned key[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) { const int c = lane + 64 * j; cb[j] = ci[c < C ? c : 0]; }
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int c = lane + 64 * j;
+        const float s = y[ymap<YP>(cb[j])] - miny;
+        key[j] = (c < C) ? __float_as_uint(s) : 0u;                  // scores are >= 0: bits order like the values
+    }
+    // ---- exact radix select of the npeaks-th largest key
+    unsigned prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned trial = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) cnt += __popcll(__ballot(key[j] >= trial));
+        if (cnt >= npeaks) prefix = trial;
+    }
+    // prefix = key of the npeaks-th best; strictly greater ones all go, ties in list (= bin) order
+    int ngt = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) ngt += __popcll(__ballot(key[j] > prefix));
+    const int need = npeaks - ngt;
+    int tc = 0, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const bool valid = lane + 64 * j < C;
+        const bool tie = valid && (key[j] == prefix);
+        const unsigned long long bt = __ballot(tie);
+        const bool take = valid && ((key[j] > prefix) || (tie && (tc + lane_prefix(bt)) < need));
+        const unsigned long long bk = __ballot(take);
+        if (take) out[cnt + lane_prefix(bk)] = cb[j];
+        tc += __popcll(bt);
+        cnt += __popcll(bk);
+    }
+    wave_sync();
+    return cnt;
+}
+
+// peak_pick with the candidate scores and bins in REGISTERS: lane owns list entries c = lane + 64 j,
+// j < NCH (NCH * 64 >= the list's capacity).  Same selection as peak_pick; the dense-candidate case
+// (noise-like frames: hundreds of maxima above the threshold) is a radix select on register keys --
+// 31 rounds of NCH compares + scalar popcounts, no LDS in the loop -- where the LDS-resident version
+// paid a memory round trip per bit.
+template <int NCH, int YP>
+__device__ __forceinline__ int peak_pick_regs(const float* y, const int* ci, int* out, int n, int npeaks, int C,
+                                              double th, float miny, int lane) {
+    if (C <= npeaks) {
+        if (th < 0.0 && C < npeaks) {
+            // zeros of pkmskamp are above the (negative) threshold: all maxima, then the first
+            // non-maximum interior bins, emitted together in ascending bin order
+            const int need = npeaks - C;
+            int zc = 0, cnt = 0;
+            for (int k0 = 0; k0 < n && cnt < npeaks; k0 += 64) {
+                const int k = k0 + lane;
+                bool ismax = false, isz = false;
+                if (k >= 1 && k <= n - 2) {
+                    const float a = y[ymap<YP>(k - 1)], b = y[ymap<YP>(k)], c = y[ymap<YP>(k + 1)];
+                    ismax = (a < b) && (b >= c);
+                    isz = !ismax;
+                }
+                const unsigned long long bz = __ballot(isz);
+                const bool take = ismax || (isz && (zc + lane_prefix(bz)) < need);
+                const unsigned long long bt = __ballot(take);
+                if (take) out[cnt + lane_prefix(bt)] = k;
+                zc += __popcll(bz);
+                cnt += __popcll(bt);
+            }
+            wave_sync();
+            return cnt;
+        }
+        for (int c = lane; c < C; c += 64) out[c] = ci[c];
+        wave_sync();
+        return C;
+    }
+    // ---- more candidates than wanted: bins, then scores, of this lane's list entries (two LDS round
+    // trips in all); key 0 marks "no entry" (a real entry's score can only be 0 when th < 0)
+    if (C <= 64) {
+        const int cb0 = ci[lane < C ? lane : 0];
+        const unsigned mine = (lane < C) ? __float_as_uint(y[ymap<YP>(cb0)] - miny) : 0u;   // scores >= 0: bits order like values
+        // a few more candidates than wanted (the usual case): every lane owns one and counts the
+        // candidates that beat it, broadcast one by one with readlane.  "beats" = larger score, or equal
+        // score and lower bin (np.argmax takes the first maximum).
+        int rank = 0;
+        for (int j = 0; j < C; ++j) {
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mine, j);
+            rank += (kj > mine || (kj == mine && j < lane)) ? 1 : 0;
+        }
+        const bool take = (lane < C) && (rank < npeaks);
+        const unsigned long long bk = __ballot(take);
+        if (take) out[lane_prefix(bk)] = cb0;                        // list order = ascending bin
+        wave_sync();
+        return __popcll(bk);
+    }
+    return peak_radix_regs<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+}
+
 // `th`: a bin qualifies when y - miny > th (the caller derives it from PF.py:60, 69-70; y may be any
-// monotone function of the magnitudes as long as th and miny are in the same domain)
+// monotone function of the magnitudes as long as th and miny are in the same domain).
+// ci must have 64 spare ints at [trash, trash + 64).
 template <int R>
-__device__ __forceinline__ int peak_select_block(const float* y, float* cs, int* ci, int trash, int* out, int npeaks,
+__device__ __forceinline__ int peak_select_block(const float* y, int* ci, int trash, int* out, int npeaks,
                                                  double th, float miny, int lane) {
     const int C = peak_scan_block<R>(y, miny, th, ci, trash, lane);
     wave_sync();
-    if (C > npeaks) {                                                // the ranking paths of peak_pick want the scores
-        for (int c = lane; c < C; c += 64) cs[c] = y[ymap<1>(ci[c])] - miny;
-        wave_sync();
-    }
-    return peak_pick<float, 1>(y, cs, ci, out, 64 * R, npeaks, C, th, lane);
+    return peak_pick_regs<R / 2, 1>(y, ci, out, 64 * R, npeaks, C, th, miny, lane);
 }
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
