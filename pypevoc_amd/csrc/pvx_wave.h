@@ -357,8 +357,8 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
 // inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
 // layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).
 template <int NCH, int YP>
-__device__ __attribute__((noinline)) int peak_radix_regs(const float* y, const int* ci, int* out, int npeaks, int C,
-                                                         float miny, int lane) {
+__device__ __forceinline__ int peak_radix_body(const float* y, const int* ci, int* out, int npeaks, int C,
+                                               float miny, int lane) {
     int cb[NCH];
     unsigned key[NCH];
 #pragma unroll
@@ -397,6 +397,20 @@ __device__ __attribute__((noinline)) int peak_radix_regs(const float* y, const i
     }
     wave_sync();
     return cnt;
+}
+
+template <int NCH, int YP>
+__device__ __attribute__((noinline)) int peak_radix_out(const float* y, const int* ci, int* out, int npeaks, int C,
+                                                        float miny, int lane) {
+    return peak_radix_body<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+}
+// out of line only where the arrays are big (NCH > 4: nfft >= 2048); the small kernels inline it -- a
+// call makes them reserve stack / callee registers, which costs the 2-waves-per-SIMD variants ~4 %
+template <int NCH, int YP>
+__device__ __forceinline__ int peak_radix_regs(const float* y, const int* ci, int* out, int npeaks, int C,
+                                               float miny, int lane) {
+    if constexpr (NCH <= 4) return peak_radix_body<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+    else return peak_radix_out<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // peak_pick with the candidate scores and bins in REGISTERS: lane owns list entries c = lane + 64 j,
