@@ -225,7 +225,10 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
             const bool p = (c < C) && (K::of(cs[c]) >= trial);
             cnt += __popcll(__ballot(p));
         }
-        if (cnt >= npeaks) prefix = trial;
+        if (cnt >= npeaks) {
+            prefix = trial;
+            if (cnt == npeaks) break;                                // exactly the keys >= trial: nothing left to resolve
+        }
     }
     // prefix = key of the npeaks-th best; strictly greater ones all go, ties in index order
     int ngt = __popcll(__ballot(k0r > prefix)) + __popcll(__ballot(k1r > prefix));
@@ -376,7 +379,10 @@ __device__ __forceinline__ int peak_radix_body(const float* y, const int* ci, in
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < NCH; j++) cnt += __popcll(__ballot(key[j] >= trial));
-        if (cnt >= npeaks) prefix = trial;
+        if (cnt >= npeaks) {
+            prefix = trial;
+            if (cnt == npeaks) break;                                // exactly the keys >= trial: nothing left to resolve
+        }
     }
     // prefix = key of the npeaks-th best; strictly greater ones all go, ties in list (= bin) order
     int ngt = 0;
