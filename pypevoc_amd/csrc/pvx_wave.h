@@ -372,24 +372,49 @@ __device__ __forceinline__ int peak_radix_body(const float* y, const int* ci, in
         const float s = y[ymap<YP>(cb[j])] - miny;
         key[j] = (c < C) ? __float_as_uint(s) : 0u;                  // scores are >= 0: bits order like the values
     }
-    // ---- exact radix select of the npeaks-th largest key
+    // ---- exact radix select of the npeaks-th largest key, two bits per round (three trial values, their
+    // counts from ballots + scalar popcounts: the compares of a round are independent, so the VALU ->
+    // SGPR -> SALU latency is paid once per round, and half as many rounds means half as many taken loop
+    // branches).  The loop stops as soon as exactly npeaks keys are at or above the prefix.
     unsigned prefix = 0;
-    for (int bit = 30; bit >= 0; --bit) {
-        const unsigned trial = prefix | (1u << bit);
-        int cnt = 0;
+    bool exact = false;
+    for (int bit = 30; bit >= 0; bit -= 2) {
+        const int lo = bit >= 1 ? bit - 1 : 0;
+        const unsigned t1 = prefix | (1u << lo);
+        const unsigned t2 = bit >= 1 ? (prefix | (2u << lo)) : 0xffffffffu;      // last round (bit 0 alone): one trial
+        const unsigned t3 = bit >= 1 ? (prefix | (3u << lo)) : 0xffffffffu;
+        int c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-        for (int j = 0; j < NCH; j++) cnt += __popcll(__ballot(key[j] >= trial));
-        if (cnt >= npeaks) {
-            prefix = trial;
-            if (cnt == npeaks) break;                                // exactly the keys >= trial: nothing left to resolve
+        for (int j = 0; j < NCH; j++) {
+            c1 += __popcll(__ballot(key[j] >= t1));
+            c2 += __popcll(__ballot(key[j] >= t2));
+            c3 += __popcll(__ballot(key[j] >= t3));
         }
+        int cnt = -1;
+        if (c3 >= npeaks) { prefix = t3; cnt = c3; }
+        else if (c2 >= npeaks) { prefix = t2; cnt = c2; }
+        else if (c1 >= npeaks) { prefix = t1; cnt = c1; }
+        if (cnt == npeaks) { exact = true; break; }                  // exactly the keys >= prefix: nothing left to resolve
+    }
+    int cnt = 0;
+    if (exact) {
+        // no ties to order: everything at or above the prefix goes, in list (= bin) order
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            const bool take = key[j] >= prefix;                      // key 0 ("no entry") is below any prefix >= 1
+            const unsigned long long bk = __ballot(take);
+            if (take) out[cnt + lane_prefix(bk)] = cb[j];
+            cnt += __popcll(bk);
+        }
+        wave_sync();
+        return cnt;
     }
     // prefix = key of the npeaks-th best; strictly greater ones all go, ties in list (= bin) order
     int ngt = 0;
 #pragma unroll
     for (int j = 0; j < NCH; j++) ngt += __popcll(__ballot(key[j] > prefix));
     const int need = npeaks - ngt;
-    int tc = 0, cnt = 0;
+    int tc = 0;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const bool valid = lane + 64 * j < C;

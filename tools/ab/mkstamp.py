@@ -8,13 +8,15 @@ def rep(a,b,cnt=1):
 rep("constexpr int GF = 8;",'''#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); stacc[i] += t__ - stprev; stprev = t__; } while (0)
 constexpr int GF = 8;''')
 rep("    float2* prv = L.bufB;\n","    float2* prv = L.bufB;\n    unsigned long long stacc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long stprev = 0;\n    { unsigned long long t0__; asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t0__) :: \"memory\"); stprev = t0__; }\n")
-rep("        v2f z[R];\n#pragma unroll\n        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];\n        prefetch(g + 1, bn, qn);\n        dft_regs<R>(z);                                           // stage 1\n",
-    "        v2f z[R];\n        STAMP(10);\n#pragma unroll\n        for (int r = 0; r < R; r++) z[r] = raw[r] * wv[r];\n        STAMP(0);\n        prefetch(g + 1, bn, qn);\n        STAMP(11);\n        dft_regs<R>(z);                                           // stage 1\n        STAMP(1);\n")
+rep("        __builtin_amdgcn_sched_barrier(0);\n        prefetch(g + 1, bn, qn);\n        if (g < 0 || q == 0) {",
+    "        __builtin_amdgcn_sched_barrier(0);\n        STAMP(0);\n        prefetch(g + 1, bn, qn);\n        STAMP(11);\n        if (g < 0 || q == 0) {")
+rep("        dft_regs<R>(z);                                           // stage 1\n", "        dft_regs<R>(z);                                           // stage 1\n        STAMP(1);\n")
+rep("        // One prefetch site, after the multiplies, for both kinds of row:", "        STAMP(10);\n        // One prefetch site, after the multiplies, for both kinds of row:")
 rep("        wave_sync();\n        dft_regs<R>(z);                                           // stage 2\n","        wave_sync();\n        STAMP(2);\n        dft_regs<R>(z);                                           // stage 2\n        STAMP(3);\n")
 rep("        wave_sync();\n        // ---- untangle in place","        wave_sync();\n        STAMP(4);\n        // ---- untangle in place")
 rep("        const double lsum = (double)ls0 + (double)ls1;","        STAMP(5);\n        const double lsum = (double)ls0 + (double)ls1;")
 rep("            tot = wave_sum(lsum);\n        }\n        wave_sync();\n    };","            tot = wave_sum(lsum);\n        }\n        wave_sync();\n        STAMP(6);\n    };")
-rep("            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);\n","            const int nsel = peak_select_block<R>(L.y, L.cs, L.ci, G::CAP, L.sel, K, th, mine, lane);\n            STAMP(7);\n")
+rep("            const int nsel = peak_select_block<R>(L.y, L.ci, G::CAP, L.sel, K, th, mine, lane);\n","            const int nsel = peak_select_block<R>(L.y, L.ci, G::CAP, L.sel, K, th, mine, lane);\n            STAMP(7);\n")
 rep("            if (ng == G_) { flush(ng); ng = 0; }","            STAMP(8);\n            if (ng == G_) { flush(ng); ng = 0; }\n            STAMP(9);")
 rep("    if (ng > 0) flush(ng);\n}","    if (ng > 0) flush(ng);\n    if (p.spec_out != nullptr && p.spec_row == -7 && lane == 0) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)p.spec_out + i, stacc[i]); }\n}")
 open(dst_k,'w').write(s)

@@ -5,7 +5,8 @@ import bench
 from pypevoc_amd import _lib
 lib = _lib.load(); _lib.init(0)
 dev = torch.device("cuda", 0)
-x = torch.from_numpy(bench.c2_signal(600)).to(dev); nsamp = x.numel()
+noise = len(sys.argv) > 1 and sys.argv[1] == "noise"       # python tools/stamps.py noise: dense-candidate input
+x = (0.1 * torch.randn(44100 * 600, device=dev)) if noise else torch.from_numpy(bench.c2_signal(600)).to(dev); nsamp = x.numel()
 F = int(lib.pvx_nframes(nsamp, 2048, 512)); K = 8
 packed = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev); base = packed.data_ptr()
 ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
