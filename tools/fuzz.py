@@ -115,7 +115,9 @@ def check64(p, o, c, S):
     wp = np.where(smax[prev] > 0, smax[prev] / np.maximum(S[prev, b], 1e-300), 1.0)
     wp[0] = 1.0
     with np.errstate(invalid="ignore", divide="ignore"):
-        ph = (np.abs(p.ph - o["ph"]) / wc)[v].max()
+        dph = np.abs(p.ph - o["ph"])
+        dph = np.minimum(dph, np.abs(dph - 2 * np.pi))                # +pi and -pi are the same phase
+        ph = (dph / wc)[v].max()
     mg = (np.abs(p.mag - o["mag"]) / np.maximum(smax[:, None], 1e-300))[v].max()
     # + the rounding of (dphase + wfbin) itself: wfbin reaches 2*pi*nfft/2, one ulp there is ~4e-12 rad
     fn = (np.maximum(np.abs(p.f - o["f"]) * (2 * np.pi * dt) - 2e-11, 0.0) / (wc + wp))[v].max()
@@ -157,7 +159,14 @@ def check32(p, o, c, S):
                 nbad += 1
                 continue
             g = gset[b]
-            worst["f"] = max(worst["f"], abs(p.f[i][g] - o["f"][i][j]) * 2 * np.pi * dt)
+            df = abs(p.f[i][g] - o["f"][i][j])
+            alias = sr / hop
+            # dphase2freq keeps the unwrapping candidate nearest the bin centre (PV.py:144-145); a peak whose
+            # frequency sits half an alias from the centre is a coin toss between two candidates in ANY
+            # arithmetic: an exact one-alias difference there is not an error
+            if abs(df - alias) < 1e-3 * alias and abs(abs(o["f"][i][j] - b * sr / nfft) - alias / 2) < 1e-3 * alias:
+                continue
+            worst["f"] = max(worst["f"], df * 2 * np.pi * dt)
             dph = abs(p.ph[i][g] - o["ph"][i][j])
             worst["ph"] = max(worst["ph"], min(dph, abs(dph - 2 * np.pi)))       # +pi and -pi are the same phase
             worst["mag"] = max(worst["mag"], abs(p.mag[i][g] - o["mag"][i][j]) / o["mag"][i][j])
