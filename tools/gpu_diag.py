@@ -22,7 +22,8 @@ def main():
         for name in golden_names():
             g = load_golden(name)
             t0 = time.time()
-            p = pypevoc_amd.PV(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"],
+            kw = dict(wind=lambda n, _w=g.get("win"): _w) if "win" in g else {}   # fixtures with a custom window
+            p = pypevoc_amd.PV(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], **kw,
                                pkthresh=g["pkthresh"], progress=False, precision=prec)
             p.run_pv()
             c = compare_analysis(pv_result(p), g, g["nfft"], g["hop"], g["sr"])
