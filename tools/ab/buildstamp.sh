@@ -1,6 +1,17 @@
+#!/bin/bash
+# Instrumented build of libpvx_hip.so for tools/stamps.py: s_memtime stamps inside k_fused_pv
+# (tools/ab/mkstamp.py patches a scratch copy of the sources; the tree itself is not touched).
+#   bash tools/ab/buildstamp.sh && PVX_LIB=tools/ab/libpvx_st.so python tools/stamps.py [noise]
 set -e
-rm -rf /tmp/st && mkdir -p /tmp/st && cp /root/repo/pypevoc_amd/csrc/*.hip /root/repo/pypevoc_amd/csrc/*.h /tmp/st/
-python /tmp/mkstamp.py /root/repo/pypevoc_amd/csrc/k_fused.hip /tmp/st/k_fused.hip /root/repo/pypevoc_amd/csrc/pvx_api.hip /tmp/st/pvx_api.hip
-cd /tmp/st
-for f in pvx_api k_frames k_peaks k_fused k_fused_mw k_track k_synth k_wire k_harmonic k_reduce; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I/root/repo/include -c $f.hip -o $f.o 2>/dev/null & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 *.o -shared -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib -o /root/repo/tools/ab/libpvx_st.so
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+ST="${TMPDIR:-/tmp}/pvx_stamp_build"
+rm -rf "$ST" && mkdir -p "$ST" && cp "$ROOT"/pypevoc_amd/csrc/*.hip "$ROOT"/pypevoc_amd/csrc/*.h "$ST"/
+python "$HERE/mkstamp.py" "$ROOT/pypevoc_amd/csrc/k_fused.hip" "$ST/k_fused.hip" "$ROOT/pypevoc_amd/csrc/pvx_api.hip" "$ST/pvx_api.hip"
+cd "$ST"
+for f in pvx_api k_frames k_peaks k_fused k_fused_mw k_track k_synth k_wire k_harmonic k_reduce; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I"$ROOT/include" -c $f.hip -o $f.o 2>/dev/null &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 *.o -shared -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib -o "$HERE/libpvx_st.so"
+echo "built $HERE/libpvx_st.so"
