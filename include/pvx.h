@@ -79,7 +79,10 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
  *      intermediate arrays in HBM (nfft in {512, 1024, 2048}, precision = 32)
  *   2  fused kernel with several waves per frame (nfft in {2048, 4096, 8192}, precision = 32)
- * A new plan uses 1 where it is supported, else 2, else 0 (environment PVX_FFT_MODE overrides).
+ *   3  mode 1's arithmetic (bit-identical results) with a workgroup of 8 waves walking 8 consecutive
+ *      frames over a shared ring of spectra in LDS: two waves per SIMD at nfft 2048 (precision = 32,
+ *      npks <= 120: the staging has to fit the LDS next to the ring)
+ * A new plan uses 3 where it is supported, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);
@@ -97,7 +100,7 @@ int pvx_plan_set_progress(pvx_plan* plan, pvx_progress_fn fn, void* user);
  * Stage timing for bench.py's roofline line.  While enabled, hipEvents recorded on the launch
  * stream bracket every stage of every chunk.  pvx_plan_get_timing synchronises with those events
  * and returns, accumulated since the last call: ms[0] framing kernel, ms[1] rocFFT, ms[2]
- * phase/peak kernel, ms[3] fused kernel (fft mode 1); launches[i] = stage launches counted.
+ * phase/peak kernel, ms[3] fused kernel (fft modes 1-3); launches[i] = stage launches counted.
  */
 int pvx_plan_set_timing(pvx_plan* plan, int enable);
 int pvx_plan_get_timing(pvx_plan* plan, double* ms /*[4]*/, int64_t* launches /*[4]*/);

@@ -374,11 +374,11 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             int cbase = 0, C = 0;
 #pragma unroll
             for (int w = 0; w < W; w++) { const int c = Cw[w]; cbase += (w < wid) ? c : 0; C += c; }
-            peak_block_write<R>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
+            peak_block_write<R, int>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
             __syncthreads();
             if (wid == 0) {
                 // at most M/2 candidates: M/128 list entries per lane, ranked / radix-selected in registers
-                const int nsel = peak_pick_regs<M / 128, 0>(y, ci, sel, M, K, C, th, mine, lane);
+                const int nsel = peak_pick_regs<M / 128, 0, int>(y, ci, sel, M, K, C, th, mine, lane);
                 const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
                 int nk = 0;
                 for (int eb = 0; eb < nsel; eb += 64) {

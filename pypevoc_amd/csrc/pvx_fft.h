@@ -211,5 +211,41 @@ template <int H, bool TW> __device__ __forceinline__ void xstep4(v2f (&a)[4], fl
 
 template <typename InT> __device__ __forceinline__ float ld1(const InT* p) { return (float)*p; }
 
+// ======== one wave per frame (k_fused.hip, k_fused_ring.hip): geometry and the sample loads
+// ---- compile-time geometry for R registers per lane
+template <int R> struct Geo {
+    static constexpr int M = 64 * R;                 // complex FFT length = bins 0..M-1
+    static constexpr int N = 128 * R;                // nfft
+    static constexpr int P = 64 / R;                 // lanes per cross-lane DFT
+    static constexpr int LOGP = ilog2(P);
+    static constexpr int LOGR = ilog2(R);
+    static constexpr int PITCH = 64 + P;             // exchange row pitch (complex)
+    static constexpr int R2 = R * R;
+    static constexpr int ZP = ((32 / P) - (R2 % 32) + 32) % 32;     // padding per R^2 spectrum bins
+    static constexpr int ZLEN = M + ZP * (P - 1);
+    static constexpr int BUFRAW = (R * PITCH > ZLEN) ? R * PITCH : ZLEN;
+    static constexpr int BUFC = ((BUFRAW + 63) / 64) * 64;           // complex slots per spectrum buffer
+    static constexpr int CAP = M / 2 + 4;            // candidate list capacity
+    static constexpr int HALF = M / 2;
+};
+template <int R> __device__ __host__ __forceinline__ int zpad(int k) { return k + Geo<R>::ZP * (k >> (2 * Geo<R>::LOGR)); }
+
+template <int R, typename InT, bool AL2>
+__device__ __forceinline__ void load_raw(const InT* x, int lane, v2f (&raw)[R]) {
+    // lane l takes z[l + 64 r] = (x[2l + 128 r], x[2l + 128 r + 1]): 512 contiguous bytes per
+    // wave-instruction.  Issued one frame ahead of its use (software prefetch): the loads of row
+    // g+1 are in flight while row g is transformed and searched for peaks.
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const InT* p = x + 2 * lane + 128 * r;
+        if constexpr (AL2 && sizeof(InT) == 4) {
+            raw[r] = *(const v2f*)p;
+        } else {
+            raw[r] = pvxc::mk(ld1(p), ld1(p + 1));
+        }
+    }
+}
+
+
 
 }  // namespace pvxf

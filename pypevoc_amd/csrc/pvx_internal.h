@@ -93,6 +93,8 @@ int pvx_fused_supported(int nfft, int precision, int K);
 int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_fused_mw_supported(int nfft, int precision, int K);     // k_fused_mw.hip: several waves per frame
 int pvx_launch_fused_mw(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
+int pvx_fused_ring_supported(int nfft, int precision, int K);   // k_fused_ring.hip: workgroup-shared spectrum ring
+int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 
 // launchers (defined in the .hip files)
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);

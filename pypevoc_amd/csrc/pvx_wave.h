@@ -334,38 +334,38 @@ __device__ __forceinline__ int peak_block_masks(const float* y, int kbase, int n
     return C;
 }
 
-template <int R>
-__device__ __forceinline__ void peak_block_write(int* ci, int kbase, int lane, unsigned m, int pos, int tr) {
+template <int R, typename CI>
+__device__ __forceinline__ void peak_block_write(CI* ci, int kbase, int lane, unsigned m, int pos, int tr) {
     const int k0 = kbase + R * lane;
     // one round per candidate of the busiest lane (1-3 on music, <= R/2): every lane pops its lowest
     // set bit; lanes that have run out write to their trash slot, so the body has no divergence
     while (__ballot(m != 0u) != 0ull) {                              // wave-uniform
         const bool has = m != 0u;
         const int i = __ffs((int)m) - 1;
-        ci[has ? pos : tr] = k0 + i;
+        ci[has ? pos : tr] = (CI)(k0 + i);
         pos += has ? 1 : 0;
         m &= m - 1u;
     }
 }
 
-template <int R>
-__device__ __forceinline__ int peak_scan_block(const float* y, float miny, double th, int* ci, int trash, int lane) {
+template <int R, typename CI>
+__device__ __forceinline__ int peak_scan_block(const float* y, float miny, double th, CI* ci, int trash, int lane) {
     unsigned m; int pos;
     const int C = peak_block_masks<R, 1>(y, 0, 64 * R, miny, th, lane, m, pos);
-    peak_block_write<R>(ci, 0, lane, m, pos, trash + lane);
+    peak_block_write<R, CI>(ci, 0, lane, m, pos, trash + lane);
     return C;
 }
 
 // The dense-candidate branch of peak_pick_regs, kept out of line: it runs on noise-like frames only, and
 // inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
 // layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).
-template <int NCH, int YP>
-__device__ __forceinline__ int peak_radix_body(const float* y, const int* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI>
+__device__ __forceinline__ int peak_radix_body(const float* y, const CI* ci, int* out, int npeaks, int C,
                                                float miny, int lane) {
     int cb[NCH];
     unsigned key[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; j++) { const int c = lane + 64 * j; cb[j] = ci[c < C ? c : 0]; }
+    for (int j = 0; j < NCH; j++) { const int c = lane + 64 * j; cb[j] = (int)ci[c < C ? c : 0]; }
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const int c = lane + 64 * j;
@@ -430,18 +430,18 @@ __device__ __forceinline__ int peak_radix_body(const float* y, const int* ci, in
     return cnt;
 }
 
-template <int NCH, int YP>
-__device__ __attribute__((noinline)) int peak_radix_out(const float* y, const int* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI>
+__device__ __attribute__((noinline)) int peak_radix_out(const float* y, const CI* ci, int* out, int npeaks, int C,
                                                         float miny, int lane) {
-    return peak_radix_body<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+    return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
 }
 // out of line only where the arrays are big (NCH > 4: nfft >= 2048); the small kernels inline it -- a
 // call makes them reserve stack / callee registers, which costs the 2-waves-per-SIMD variants ~4 %
-template <int NCH, int YP>
-__device__ __forceinline__ int peak_radix_regs(const float* y, const int* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI>
+__device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int* out, int npeaks, int C,
                                                float miny, int lane) {
-    if constexpr (NCH <= 4) return peak_radix_body<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
-    else return peak_radix_out<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+    if constexpr (NCH <= 4) return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
+    else return peak_radix_out<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // peak_pick with the candidate scores and bins in REGISTERS: lane owns list entries c = lane + 64 j,
@@ -449,8 +449,8 @@ __device__ __forceinline__ int peak_radix_regs(const float* y, const int* ci, in
 // (noise-like frames: hundreds of maxima above the threshold) is a radix select on register keys --
 // 31 rounds of NCH compares + scalar popcounts, no LDS in the loop -- where the LDS-resident version
 // paid a memory round trip per bit.
-template <int NCH, int YP>
-__device__ __forceinline__ int peak_pick_regs(const float* y, const int* ci, int* out, int n, int npeaks, int C,
+template <int NCH, int YP, typename CI>
+__device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int* out, int n, int npeaks, int C,
                                               double th, float miny, int lane) {
     if (C <= npeaks) {
         if (th < 0.0 && C < npeaks) {
@@ -476,14 +476,14 @@ __device__ __forceinline__ int peak_pick_regs(const float* y, const int* ci, int
             wave_sync();
             return cnt;
         }
-        for (int c = lane; c < C; c += 64) out[c] = ci[c];
+        for (int c = lane; c < C; c += 64) out[c] = (int)ci[c];
         wave_sync();
         return C;
     }
     // ---- more candidates than wanted: bins, then scores, of this lane's list entries (two LDS round
     // trips in all); key 0 marks "no entry" (a real entry's score can only be 0 when th < 0)
     if (C <= 64) {
-        const int cb0 = ci[lane < C ? lane : 0];
+        const int cb0 = (int)ci[lane < C ? lane : 0];
         const unsigned mine = (lane < C) ? __float_as_uint(y[ymap<YP>(cb0)] - miny) : 0u;   // scores >= 0: bits order like values
         // a few more candidates than wanted (the usual case): every lane owns one and counts the
         // candidates that beat it, broadcast one by one with readlane.  "beats" = larger score, or equal
@@ -499,18 +499,18 @@ __device__ __forceinline__ int peak_pick_regs(const float* y, const int* ci, int
         wave_sync();
         return __popcll(bk);
     }
-    return peak_radix_regs<NCH, YP>(y, ci, out, npeaks, C, miny, lane);
+    return peak_radix_regs<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // `th`: a bin qualifies when y - miny > th (the caller derives it from PF.py:60, 69-70; y may be any
 // monotone function of the magnitudes as long as th and miny are in the same domain).
 // ci must have 64 spare ints at [trash, trash + 64).
-template <int R>
-__device__ __forceinline__ int peak_select_block(const float* y, int* ci, int trash, int* out, int npeaks,
+template <int R, typename CI>
+__device__ __forceinline__ int peak_select_block(const float* y, CI* ci, int trash, int* out, int npeaks,
                                                  double th, float miny, int lane) {
-    const int C = peak_scan_block<R>(y, miny, th, ci, trash, lane);
+    const int C = peak_scan_block<R, CI>(y, miny, th, ci, trash, lane);
     wave_sync();
-    return peak_pick_regs<R / 2, 1>(y, ci, out, 64 * R, npeaks, C, th, miny, lane);
+    return peak_pick_regs<R / 2, 1, CI>(y, ci, out, 64 * R, npeaks, C, th, miny, lane);
 }
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in

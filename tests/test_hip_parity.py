@@ -271,8 +271,9 @@ def test_streaming_frame_api(amd, oracle):
 
 
 def test_fused_kernel_variants(amd, oracle):
-    """nfft=2048 at precision=32 runs the fused kernel (fft mode 1).  Cover its input variants
-    (int16 / float32 aligned / float32 with an odd hop / float64), the streaming entry points
+    """nfft=2048 at precision=32 runs the fused kernels (fft mode 3, the workgroup-ring form, by default;
+    mode 1, one independent wave per frame, on request: same arithmetic, bit-identical results).  Cover the
+    input variants (int16 / float32 aligned / float32 with an odd hop / float64), the streaming entry points
     (previous spectrum handed in, last spectrum handed back) and agreement with the rocFFT path."""
     import ctypes
     from pypevoc_amd import _lib
@@ -280,12 +281,26 @@ def test_fused_kernel_variants(amd, oracle):
     sr, nfft, K = 22050.0, 2048, 7
     for hop, xin in ((512, x.astype(np.float32)), (333, x.astype(np.float32)), (512, x), (700, x)):
         o = oracle.analyze(x, sr, nfft, hop, K)
-        p = run_pv(amd, xin, sr, nfft, hop, K, precision=32)
-        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1
-        assert_f32(compare_analysis(pv_result(p), o, nfft, hop, sr), absolute=False)
-        # the spectrum handed back as PV.oldfft is the last frame's
-        last = oracle.stft_frame(x, (p.nframes - 1) * hop, nfft)
-        assert np.abs(p.oldfft - last).max() <= 2e-6 * np.abs(last).max()
+        res = {}
+        for mode in (3, 1):
+            os.environ["PVX_FFT_MODE"] = str(mode)
+            try:
+                p = run_pv(amd, xin, sr, nfft, hop, K, precision=32)
+            finally:
+                del os.environ["PVX_FFT_MODE"]
+            assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == mode
+            assert_f32(compare_analysis(pv_result(p), o, nfft, hop, sr), absolute=False)
+            # the spectrum handed back as PV.oldfft is the last frame's
+            last = oracle.stft_frame(x, (p.nframes - 1) * hop, nfft)
+            assert np.abs(p.oldfft - last).max() <= 2e-6 * np.abs(last).max()
+            res[mode] = p
+        for name in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(res[3], name)), np.asarray(getattr(res[1], name))), name
+        assert np.array_equal(res[3].oldfft, res[1].oldfft)
+    p = run_pv(amd, x, sr, nfft, 512, K, precision=32)
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 3          # the default where it fits
+    p = run_pv(amd, x, sr, nfft, 512, 200, precision=32)
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1          # npks too large for the LDS next to the ring
     xi = np.round(x * 20000).astype(np.int16)
     o = oracle.analyze(xi.astype(np.float64), sr, nfft, 512, K)
     p = run_pv(amd, xi, sr, nfft, 512, K, precision=32)
@@ -341,6 +356,66 @@ def test_fused_kernel_variants(amd, oracle):
         o = oracle.analyze(x, sr, nfft, 512, K2, 0.0005)
         p = run_pv(amd, x, sr, nfft, 512, K2, 0.0005, precision=32)
         assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
+
+
+def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch):
+    """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
+    of spectra, hand-off through progress counters in LDS) does the arithmetic of mode 1 (k_fused.hip, which the
+    other tests pin to the reference and the oracle): every output must be bit-identical, whatever the signal
+    (dense candidates -> radix select, exact silence -> zero rows and x/0 frames, threshold 0 -> zero fill),
+    npks, hop, input type, number of signals in the call (zero rows between signals; F = 1) or grid."""
+    from pypevoc_amd import _lib
+    rng = np.random.default_rng(77)
+    sr, nfft = 44100.0, 2048
+    n = 60000
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[9000:9000 + 3 * nfft] = 0.0; gaps[30000:30000 + nfft + 100] = 0.0
+    quant = np.round(harm * 50) / 50
+
+    def both(make):
+        out = {}
+        for mode in (1, 3):
+            monkeypatch.setenv("PVX_FFT_MODE", str(mode))
+            out[mode] = make()
+            monkeypatch.delenv("PVX_FFT_MODE")
+        return out[1], out[3]
+
+    def same(a, b, what):
+        for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
+
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant)):
+        for K, thr, hop in ((8, 0.005, 512), (1, 0.005, 333), (3, 0.0, 512), (20, 0.3, 2047), (24, 0.005, 256)):
+            a, b = both(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
+            assert _lib.load().pvx_plan_get_fft_mode(b._plan.handle) == 3
+            assert _lib.load().pvx_plan_get_fft_mode(a._plan.handle) == 1
+            same(a, b, (name, K, thr, hop))
+    for xin in (noise.astype(np.float32), np.round(harm * 20000).astype(np.int16)):
+        a, b = both(lambda: run_pv(amd, xin, sr, nfft, 512, 8, precision=32))
+        same(a, b, xin.dtype)
+    # several signals per call (a zero row in front of each), down to one frame per signal
+    for ns in (nfft + 1, nfft + 513, nfft + 512 * 9 + 5):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[8000:8000 + ns], quant[:ns], noise[100:100 + ns]]).astype(np.float32)
+        a, b = both(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=512, npks=8).run_pv())
+        for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
+    # other grids: one workgroup; more workgroups than fit the rows two iterations each
+    ref = run_pv(amd, harm, sr, nfft, 512, 8, precision=32)
+    for nb in ("1", "3", "1000"):
+        monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
+        q = run_pv(amd, harm, sr, nfft, 512, 8, precision=32)
+        monkeypatch.delenv("PVX_FUSED_BLOCKS")
+        same(ref, q, ("blocks", nb))
+    # streaming entry points: previous spectrum handed in, frame by frame
+    q = amd.PV(gaps, sr, nfft=nfft, hop=512, npks=8, progress=False, precision=32)
+    full = run_pv(amd, gaps, sr, nfft, 512, 8, precision=32)
+    for fr in range(20):
+        f, mag, ph, realph, binno, tm = q.calc_pv_frame(fr * 512)
+        nv = len(f)
+        assert nv == int((full.f[fr] > 0).sum()) and binno == [int(v) for v in full.binno[fr, :nv]]
+        assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
 
 
 def test_add_frame_incremental_equals_tosinsum(amd):
@@ -407,6 +482,15 @@ def test_full_size_config2_properties(amd, oracle, monkeypatch):
     for k in ("f", "mag", "ph", "realph", "binno", "t"):
         assert np.array_equal(getattr(p, k), getattr(q, k)), k
     assert p.totalmag == q.totalmag
+    # the fused kernels: another grid (37 workgroups instead of one per CU: other row ranges per wave,
+    # other halo rows), and the one-wave-per-frame form (fft mode 1) against the workgroup-ring default
+    for env in (("PVX_FUSED_BLOCKS", "37"), ("PVX_FFT_MODE", "1")):
+        monkeypatch.setenv(*env)
+        q = run_pv(amd, x, sr, nfft, hop, K)
+        monkeypatch.delenv(env[0])
+        for k in ("f", "mag", "ph", "realph", "binno", "t"):
+            assert np.array_equal(getattr(p, k), getattr(q, k)), (env, k)
+        assert p.totalmag == q.totalmag
     k0 = 40000
     s = run_pv(amd, x[k0 * hop:], sr, nfft, hop, K)
     assert s.nframes == p.nframes - k0
