@@ -13,9 +13,20 @@
 //   k_assign_ids   partial_id / part_start / part_len (length written by the partial's last point)
 // Tiny, latency-bound integer work (<= K^2 compares per frame); no roofline claim.
 //
-// Exact-tie rule (measure-zero on real data): equal magnitudes are ordered higher slot first
-// (np.argsort(mag)[::-1] with a stable sort, PVAnalysis.py:874-875); the reference's secondary key
-// for previous partials is the partial index (PVAnalysis.py:893), here the slot index.
+// Exact ties.
+//  * Previous partials are tried in the order sorted(zip(pmag, pidx), reverse=True) (PVAnalysis.py:893):
+//    magnitude descending, then PARTIAL INDEX descending.  That order only ever decides between two unused
+//    previous partials that are EXACTLY equally far (in semitones) from the new peak and have exactly equal
+//    magnitudes -- and a partial's index is not known while frames are linked in parallel.  k_track_links
+//    detects that situation (one extra ballot per new peak) and raises a flag; the host then re-runs the
+//    whole table with k_track_sequential, the reference's loop on one wave with the partial indices at
+//    hand.  Never taken on analysis output (two peaks of one frame cannot have bit-equal frequencies
+//    ratios), pinned by fixture T1 (hand-built arrays through the reference).
+//  * New peaks are processed in np.argsort(mag)[::-1] order (PVAnalysis.py:873-875).  For equal magnitudes
+//    that order is not a property of the reference: numpy's default argsort is an unstable sort whose tie
+//    order depends on the CPU it runs on (x86-simd-sort networks with AVX-512 / AVX2, insertion sort
+//    elsewhere; on the AVX-512 host of this build 57 % of 8-element rows with ties come out differently from
+//    kind="stable").  Here, as in the oracle: the stable order reversed, i.e. higher slot first.
 #include <math.h>
 
 #include "pvx_internal.h"
@@ -106,6 +117,19 @@ __global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
         }
         wave_argmin(best, bi);
         const bool hit = (bi != 0x7fffffff) && (best < p.maxjmp);    // PVAnalysis.py:923
+        // another unused previous partial exactly as near AND exactly as strong as the winner: the reference
+        // would let the partial index decide (see the header)
+        if (hit) {
+            bool amb = false;
+            const double wm = pm[porder[bi]];
+            for (int i = lane; i < np; i += 64) {
+                if (!used[i] && i != bi) {
+                    const double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));
+                    amb = amb || (st == best && pm[porder[i]] == wm);
+                }
+            }
+            if (__ballot(amb) != 0ull && lane == 0) *p.ambiguous = 1;
+        }
         if (lane == 0) {
             if (hit) { link[s] = porder[bi]; used[bi] = 1; p.succ[(fr - 1) * K + porder[bi]] = 1; }
             else { link[s] = -1; nrk[s] = nnew; }                    // add_empty_partial
@@ -114,6 +138,89 @@ __global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
         wave_sync_t();
     }
     if (lane == 0) p.newcount[fr] = nnew;
+}
+
+// The reference's loop as it stands (PVAnalysis.py:871-957), one wave, frames in order, partial indices at
+// hand: previous partials ordered by (magnitude, partial index) descending.  Only launched when
+// k_track_links met an exact double tie (see the header); O(F K) steps of one wave.
+// LDS: cm cf pm pf doubles [K] | corder porder used ppid(prev partial id by slot) cpid ints [K]
+__global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    const int kp = (K + 1) & ~1;
+    double* cm = (double*)smem;
+    double* cf = cm + kp;
+    double* pm = cf + kp;
+    double* pf = pm + kp;
+    int* corder = (int*)(pf + kp);
+    int* porder = corder + kp;
+    int* used = porder + kp;
+    int* ppid = used + kp;
+    int* cpid = ppid + kp;
+    long long P = 0;
+    for (int s = lane; s < K; s += 64) { pf[s] = 0.0; pm[s] = 0.0; ppid[s] = -1; }
+    wave_sync_t();
+    for (int64_t fr = 0; fr < p.F; fr++) {
+        const double* fc = p.f + fr * K;
+        const double* mc = p.mag + fr * K;
+        for (int s = lane; s < K; s += 64) { cf[s] = fc[s]; cm[s] = mc[s]; cpid[s] = -1; }
+        wave_sync_t();
+        int nc = 0, np = 0;
+        for (int s0 = 0; s0 < K; s0 += 64) {
+            const int s = s0 + lane;
+            bool vc = false, vp = false;
+            if (s < K) {
+                vc = cf[s] > 0.0 && cm[s] > 0.0;
+                vp = pf[s] > 0.0 && pm[s] > 0.0;
+                if (vc) {
+                    int r = 0;
+                    for (int j = 0; j < K; j++)
+                        if (cf[j] > 0.0 && cm[j] > 0.0 && (cm[j] > cm[s] || (cm[j] == cm[s] && j > s))) r++;
+                    corder[r] = s;
+                }
+                if (vp) {
+                    int r = 0;                                     // (mag, partial index) descending, PVAnalysis.py:893
+                    for (int j = 0; j < K; j++)
+                        if (pf[j] > 0.0 && pm[j] > 0.0 && (pm[j] > pm[s] || (pm[j] == pm[s] && ppid[j] > ppid[s]))) r++;
+                    porder[r] = s;
+                    used[r] = 0;
+                }
+            }
+            nc += __popcll(__ballot(vc));
+            np += __popcll(__ballot(vp));
+        }
+        wave_sync_t();
+        for (int c = 0; c < nc; c++) {
+            const int s = corder[c];
+            const double fcur = cf[s];
+            double best = INFINITY;
+            int bi = 0x7fffffff;
+            for (int i = lane; i < np; i += 64) {
+                if (!used[i]) {
+                    double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));
+                    if (st < best) { best = st; bi = i; }
+                }
+            }
+            wave_argmin(best, bi);
+            const bool hit = (bi != 0x7fffffff) && (best < p.maxjmp);
+            if (lane == 0) {
+                int32_t id;
+                if (hit) { id = ppid[porder[bi]]; used[bi] = 1; }
+                else { id = (int32_t)P; if (P < p.cap) { p.part_start[P] = (int32_t)fr; p.part_len[P] = 0; } }
+                cpid[s] = id;
+                if (id < p.cap) p.part_len[id] += 1;
+            }
+            if (!hit) P++;
+            wave_sync_t();
+        }
+        for (int s = lane; s < K; s += 64) {
+            p.partial_id[fr * K + s] = cpid[s];
+            pf[s] = cf[s]; pm[s] = cm[s]; ppid[s] = cpid[s];
+        }
+        wave_sync_t();
+    }
+    if (lane == 0) *p.npartials = P;
 }
 
 // exclusive scan of newcount[F] -> newbase[F+1] (single workgroup, 1024 threads, chunked)
@@ -197,6 +304,7 @@ int pvx_launch_track(const TrackParams& p, hipStream_t s) {
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
     if (per_wave * waves > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
     PVX_HIP_CHECK(hipMemsetAsync(p.succ, 0, (size_t)n, s));
+    PVX_HIP_CHECK(hipMemsetAsync(p.ambiguous, 0, sizeof(int64_t), s));
     hipLaunchKernelGGL(k_track_links, dim3((unsigned)((p.F + waves - 1) / waves)), dim3(64 * waves), per_wave * waves, s, p);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -205,6 +313,16 @@ int pvx_launch_track(const TrackParams& p, hipStream_t s) {
     while ((1LL << rounds) < p.F) rounds++;
     for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_root_jump, dim3(nb), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_assign_ids, dim3(nb), dim3(256), 0, s, p);
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}
+
+int pvx_launch_track_sequential(const TrackParams& p, hipStream_t s) {
+    if (p.F <= 0) return PVX_OK;
+    const int kp = (p.K + 1) & ~1;
+    const size_t lds = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 5;
+    if (lds > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_track_sequential, dim3(1), dim3(64), lds, s, p);
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
 }

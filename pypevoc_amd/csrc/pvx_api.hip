@@ -600,7 +600,7 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials int64
     const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
     size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
-    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 8, total = off_succ + n;
+    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 16, total = off_succ + n;
     if ((rc = ws.alloc(total)) != PVX_OK) return rc;
     char* w = (char*)ws.p;
     TrackParams tp;
@@ -609,11 +609,20 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
     tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
     tp.npartials = (int64_t*)(w + off_np);
+    tp.ambiguous = tp.npartials + 1;
     rc = pvx_launch_track(tp, s);
     if (rc != PVX_OK) return rc;
-    int64_t P = 0;
-    PVX_HIP_CHECK(hipMemcpyAsync(&P, tp.npartials, 8, hipMemcpyDeviceToHost, s));
+    int64_t pa[2] = {0, 0};
+    PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 16, hipMemcpyDeviceToHost, s));
     PVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
+        // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
+        // table with the sequential kernel, which has the partial indices at hand
+        if ((rc = pvx_launch_track_sequential(tp, s)) != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 8, hipMemcpyDeviceToHost, s));
+        PVX_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    int64_t P = pa[0];
     if (P > cap) { pvx_set_error("%lld partials exceed the table capacity %lld", (long long)P, (long long)cap); return PVX_ERR_SIZE; }
     return P;
 }

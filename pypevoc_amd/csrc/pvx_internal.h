@@ -120,8 +120,11 @@ struct TrackParams {
     int32_t* root;        // [F][K]  flattened index of the first point of the slot's partial
     unsigned char* succ;  // [F][K]  1 if a peak of the next frame continues this one
     int64_t* npartials;   // [1]
+    int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
+                          //      the previous partials would decide an assignment (k_track.hip header)
 };
 int pvx_launch_track(const TrackParams& p, hipStream_t s);
+int pvx_launch_track_sequential(const TrackParams& p, hipStream_t s);   // exact loop on one wave, after a flag
 
 struct SynthParams {
     const double *f, *mag, *realph;   // [F][K]

@@ -115,6 +115,36 @@ def test_tosinsum_matches_reference(amd, name, oracle):
         assert parts[i].overlap == g["hop"] / float(g["nfft"]) and parts[i].fstep == g["sr"] / float(g["nfft"])
 
 
+def test_tracker_exact_ties_follow_reference(amd, oracle):
+    """Fixture T1 (reference-generated, tests/golden/make_golden_ties.py): two previous partials of equal
+    magnitude exactly equally far from a new peak -- sorted(zip(pmag, pidx), reverse=True) (PVAnalysis.py:893)
+    lets the higher partial index win, in whichever slot it sits.  The frame-parallel link kernel cannot know
+    partial indices; it detects the double tie and the table is rebuilt by the sequential kernel."""
+    g = dict(np.load(os.path.join(GOLDEN, "T1_tracker_ties.npz")))
+    ss = amd.SinSum(float(g["sr"]), nfft=int(g["nfft"]), hop=int(g["hop"]))
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    pid, st, ln = ss.partial_table()
+    assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+    assert np.array_equal(oracle.part_slots(pid, st, ln), g["part_slot"])
+
+
+@pytest.mark.parametrize("name", ["G1_two_sines", "G5a_noise_n1024_k20", "G6_silence_gaps", "G7_perlman"])
+def test_sequential_tracker_kernel_equals_parallel(amd, name, monkeypatch):
+    """k_track_sequential (the fallback after an exact double tie) on ordinary fixtures: the same table as the
+    frame-parallel kernels and the reference."""
+    g = load_golden(name)
+    monkeypatch.setenv("PVX_TRACK_SEQUENTIAL", "1")
+    ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    pid, st, ln = ss.partial_table()
+    assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+    monkeypatch.delenv("PVX_TRACK_SEQUENTIAL")
+    s2 = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    s2._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    pid2, st2, ln2 = s2.partial_table()
+    assert np.array_equal(pid, pid2) and np.array_equal(st, st2) and np.array_equal(ln, ln2)
+
+
 @pytest.mark.parametrize("name", TRACKED)
 def test_synth_matches_reference(amd, name):
     g = load_golden(name)

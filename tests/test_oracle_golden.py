@@ -46,6 +46,15 @@ def test_tracker_matches_reference(oracle, name):
     assert np.array_equal(oracle.part_slots(pid, st, ln), g["part_slot"])
 
 
+def test_tracker_exact_ties_follow_reference(oracle):
+    """Fixture T1 (tests/golden/make_golden_ties.py): previous partials of equal magnitude, exactly equally far
+    from a new peak -> the higher partial index wins (PVAnalysis.py:893), whichever slot it sits in."""
+    g = dict(np.load(os.path.join(GOLDEN, "T1_tracker_ties.npz")))
+    pid, st, ln = oracle.track(g["f"], g["mag"])
+    assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+    assert np.array_equal(oracle.part_slots(pid, st, ln), g["part_slot"])
+
+
 @pytest.mark.parametrize("name", TRACKED)
 def test_synth_matches_reference(oracle, name):
     g = load_golden(name)

@@ -215,12 +215,7 @@ def run_case(seed, idx, verbose=False):
         pid, st, ln = ss.partial_table()
         opid, ost, oln = pvoracle.track(p64.f, p64.mag)
         P = len(st)
-        # documented deviation: EXACTLY equal magnitudes inside a frame are ordered by slot,
-        # not by partial index -- only flat-spectrum frames produce them; skip the comparison there
-        ties = any(len(np.unique(r[r > 0])) < np.count_nonzero(r > 0) for r in p64.mag)
-        if ties:
-            pass
-        elif not (np.array_equal(pid, opid) and np.array_equal(st, ost[:P]) and np.array_equal(ln, oln[:P])):
+        if not (np.array_equal(pid, opid) and np.array_equal(st, ost[:P]) and np.array_equal(ln, oln[:P])):
             fails.append("%s: tracker differs" % tag)
         elif P and (ln >= 3).any() and nfft / hop <= 16:
             w = ss.synth(sr, c["h2"])
