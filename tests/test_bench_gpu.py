@@ -1,0 +1,52 @@
+"""bench.py end to end on the GPU box (short signal): the JSON contract, the oracle self-check of the timed output,
+the RCCL gather path forced on one GPU, and the refusal of more ranks than GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_line_and_self_check():
+    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "20", "--no-extras"])
+    assert rc == 0 and j is not None, err[-2000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and 0.0 < r["frac"] <= 1.0 and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert j["self_check"]["ok"] and j["self_check"]["bad_peaks"] == 0 and j["self_check"]["frames"] == j["config"]["frames_per_gpu"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"]["cores"] == 1 and c["value"] > 0
+    if r.get("issue"):
+        assert 0.0 < r["issue"]["valu_issue"]["frac"] <= 1.0
+
+
+def test_bench_forced_gather_exercises_rccl():
+    rc, j, err = _run(["--steps", "4", "--warmup", "1", "--seconds", "20", "--no-extras", "--no-cpu-baseline"],
+                      env={"PVX_BENCH_FORCE_GATHER": "1", "MASTER_PORT": "29641"})
+    assert rc == 0 and j is not None, err[-2000:]
+    g = j["gather"]
+    assert g["rccl_world"] == 1 and g["valid_peaks_gathered"] > 0 and g["wire_bytes_per_rank"] < g["result_bytes_per_rank"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    rc, j, err = _run(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], timeout=120)
+    assert rc != 0 and j is None and "GPU" in err
