@@ -27,6 +27,14 @@ namespace {
 
 constexpr int GFM = 8;              // frames staged before the per-peak pass
 
+// Workgroup barrier for LDS hand-offs: LDS traffic drained, then s_barrier.  Not __syncthreads(): that also
+// waits for vmcnt(0), i.e. for the prefetched samples of the next frame, at every one of the ~8 barriers of
+// a frame.
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int R, int W> struct GeoMW {
     static constexpr int T = 64 * W;                 // lanes per frame
     static constexpr int M = T * R;                  // complex FFT length = bins 0..M-1
@@ -200,17 +208,17 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
         if (g < 0 || q == 0) {                                    // block-uniform
 #pragma unroll
             for (int j = 0; j < G::BUFC / T; j++) dst[tid + T * j] = make_float2(0.f, 0.f);
-            __syncthreads();
+            block_sync_lds();
             return;
         }
         dft_regs<R>(z);                                           // stage 1
         v2f* dz = (v2f*)dst;
 #pragma unroll
         for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + tid] = (q2 > 0) ? pvxc::cmul(z[q2], t1[q2]) : z[q2];
-        __syncthreads();
+        block_sync_lds();
 #pragma unroll
         for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
-        __syncthreads();
+        block_sync_lds();
         dft_regs<R>(z);                                           // stage 2
 #pragma unroll
         for (int t0 = 0; t0 < R; t0 += 4) {
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dz[zpadm<R, W>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
         }
-        __syncthreads();
+        block_sync_lds();
         // ---- untangle in place: pairs (k, M-k), k = tid + T j; bins 0 and M/2 have no partner
         //   S = Za + conj Zb, D = Za - conj Zb;  E = S/2, O = -i D/2, P = W^k O
         //   X[k] = E + P,  X[M-k] = conj(E - P)
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             const double wsum = wave_sum((double)ls0 + (double)ls1);
             if (lane == 0) { pmax[wid] = wm; pmin[wid] = wn; psum[wid] = wsum; }
         }
-        __syncthreads();
+        block_sync_lds();
         if (with_mag) {
             float mx = pmax[0], mn = pmin[0];
             double sm = psum[0];
@@ -370,12 +378,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             unsigned cm; int cpos;
             const int C_w = peak_block_masks<R, 0>(y, wid * G::SCAN, M, mine, th, lane, cm, cpos);
             if (lane == 0) Cw[wid] = C_w;
-            __syncthreads();
+            block_sync_lds();
             int cbase = 0, C = 0;
 #pragma unroll
             for (int w = 0; w < W; w++) { const int c = Cw[w]; cbase += (w < wid) ? c : 0; C += c; }
             peak_block_write<R, int>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
-            __syncthreads();
+            block_sync_lds();
             if (wid == 0) {
                 // at most M/2 candidates: M/128 list entries per lane, ranked / radix-selected in registers
                 const int nsel = peak_pick_regs<M / 128, 0, int>(y, ci, sel, M, K, C, th, mine, lane);
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
                 p.spec_out[2 * (tid + T * j) + 1] = v.y;
             }
         }
-        __syncthreads();                                          // wave 0 is done with cur / prv / y
+        block_sync_lds();                                          // wave 0 is done with cur / prv / y
         float2* t = cur; cur = prv; prv = t;
     }
     if (wid == 0 && ng > 0) flush(ng);

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Frames/s of the analysis stage over the nfft sweep of BASELINE config 5 (hop = nfft/4, npks 8, 10 min of 44.1 kHz
+harmonic signal and of white noise), plan default fft mode.   python tools/ab_nfft.py [nfft,...]"""
+import ctypes, json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from pypevoc_amd import _lib
+from bench import c2_signal
+nffts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048,4096,8192").split(",")]
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+lib = _lib.load(); _lib.init(0)
+dev = torch.device("cuda", 0); s = torch.cuda.Stream(device=dev); sp = ctypes.c_void_p(s.cuda_stream)
+g = torch.Generator(device=dev); g.manual_seed(1)
+inputs = {"harmonic": torch.from_numpy(c2_signal(600)).to(dev), "noise": 0.1 * torch.randn(44100 * 600, device=dev, generator=g)}
+K = 8
+for nfft in nffts:
+    hop = nfft // 4
+    for name, x in inputs.items():
+        n = x.numel(); F = int(lib.pvx_nframes(n, nfft, hop))
+        out = torch.zeros(5 * F * K + 2 * F, dtype=torch.float64, device=dev); b = out.data_ptr()
+        ptrs = [b + i * F * K * 8 for i in range(5)] + [b + 5 * F * K * 8, b + 5 * F * K * 8 + F * 8]
+        plan = ctypes.c_void_p(); win = np.hanning(nfft)
+        _lib.check(lib.pvx_plan_create(ctypes.byref(plan), 44100.0, nfft, hop, K, 0.005, _lib.dptr(win), prec, 0), "plan")
+        for _ in range(2): _lib.check(lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, sp), "a")
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); reps = 10
+        e0.record(s)
+        for _ in range(reps): lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, sp)
+        e1.record(s); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print(json.dumps(dict(nfft=nfft, hop=hop, input=name, precision=prec, fft_mode=int(lib.pvx_plan_get_fft_mode(plan)), ms=round(ms, 4),
+                              Mframes_per_s=round(F / ms / 1e3, 1), checksum=float(out[: F * K].sum().item()))))
+        sys.stdout.flush(); lib.pvx_plan_destroy(plan)
