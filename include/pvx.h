@@ -51,6 +51,8 @@ const char* pvx_last_error(void);
 int pvx_version(void);
 /* Name of the device the library is bound to ("" before pvx_init). */
 const char* pvx_device_name(void);
+/* HIP device index the library is bound to (-1 before pvx_init) */
+int pvx_device(void);
 
 /* Number of frames run_pv produces: pos = 0, hop, ... while pos < nsamp - nfft (PV.py:223-249). */
 int64_t pvx_nframes(int64_t nsamp, int nfft, int hop);
@@ -129,6 +131,46 @@ int64_t pvx_analyze(pvx_plan* plan, const void* x, int x_dtype, int64_t nsamp,
                     double* f, double* mag, double* ph, double* realph, double* binno,
                     double* t, double* totalmag, const double* prev0, double* last_spec);
 
+/*
+ * The host entry points keep their device buffers in the plan (grow-only; no hipMalloc per call), take the
+ * input in chunks that fit PVX_MAX_DEVICE_BYTES (environment; default 2 GiB per buffer), double-buffered --
+ * the copy of chunk i+1 and the results of chunk i-1 move while the kernels of chunk i run -- and carry the
+ * last spectrum from chunk to chunk on the device (PV.py:209), so a signal larger than HBM runs and the
+ * result does not depend on the chunking (bit for bit).  Calls of a few MB go through pinned staging and
+ * synchronise once.
+ *
+ * Resident results: pvx_analyze_resident is pvx_analyze without the copy back -- the reference's arrays
+ * stay in the plan, in HBM, in the layout of pvx_analyze_dev.  What follows in the reference's pipeline then
+ * runs where the data is, on the plan's stream, and only what the caller asks for crosses PCIe:
+ *   pvx_resident_fetch(plan, which, host)   one array; which = PVX_RES_F .. PVX_RES_TOTALMAG
+ *   pvx_resident_ptr(plan, which)           its device address (valid until the plan's next analysis)
+ *   pvx_track_resident                      PV.toSinSum (PV.py:299-322): returns the number of partials, the
+ *                                           table stays resident; *max_end_frame = max(SinSum.end)
+ *   pvx_resident_fetch_table                partial_id int32 [F, K], part_start / part_len int32 [P] (any may be NULL)
+ *   pvx_synth_resident                      SinSum.synth (PV.py:1053-1070) from the resident arrays and table;
+ *                                           w: host float64 [wlen = pvx_synth_len(max_end_frame, ...)]
+ *   pvx_f0_resident                         PV.calc_f0 (PV.py:371-391): fm float64 [F], idx int32 [F]
+ *   pvx_harmonic_power_resident             PV.calc_harmonic_power (PV.py:266-297, including the row indexing
+ *                                           of :278; PVX_ERR_SIZE where the reference raises IndexError):
+ *                                           hpower, nharmonics float64 [F, K]
+ */
+#define PVX_RES_F 0
+#define PVX_RES_MAG 1
+#define PVX_RES_PH 2
+#define PVX_RES_REALPH 3
+#define PVX_RES_BINNO 4
+#define PVX_RES_T 5
+#define PVX_RES_TOTALMAG 6
+int64_t pvx_analyze_resident(pvx_plan* plan, const void* x, int x_dtype, int64_t nsamp, int64_t nsig,
+                             int64_t sig_stride, const double* prev0, double* last_spec);
+int pvx_resident_fetch(pvx_plan* plan, int which, double* host);
+const double* pvx_resident_ptr(pvx_plan* plan, int which);
+int64_t pvx_track_resident(pvx_plan* plan, double maxpitchjmp, int64_t* max_end_frame);
+int pvx_resident_fetch_table(pvx_plan* plan, int32_t* partial_id, int32_t* part_start, int32_t* part_len);
+int pvx_synth_resident(pvx_plan* plan, double sr, int hop_synth, double edge, int minframes, double* w, int64_t wlen);
+int pvx_f0_resident(pvx_plan* plan, double fmin, double fmax, double thr, double* fm, int32_t* idx);
+int pvx_harmonic_power_resident(pvx_plan* plan, double f_threshold, double* hpower, double* nharmonics);
+
 /* calc_fft_frame (PV.py:150-158): windowed, 1/wfact-normalised spectra of `nfr` frames starting
  * at sample positions pos[0..nfr); spec: host float64 [nfr][nfft/2+1][2] (bins 0..nfft/2; the
  * remaining bins of the reference's length-nfft result are the conjugate mirror). */
@@ -189,6 +231,21 @@ int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph
                   const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
                   double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
                   double* d_w, int64_t wlen, void* stream);
+/*
+ * The same with flags.  PVX_SYNTH_NO_PHCOR: RegPartial.synth of a partial built with fstep=None
+ * (PV.py:710-713): no frequency-slope phase correction (phcor = phcornext = 0); nfft / hop_analysis then
+ * only carry the overlap (hop_analysis / nfft).
+ */
+#define PVX_SYNTH_NO_PHCOR 1
+int pvx_synth_flags(const double* f, const double* mag, const double* realph, const int32_t* partial_id,
+                    int64_t F, int K, const int32_t* part_start, const int32_t* part_len, int64_t P,
+                    double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                    double* w, int64_t wlen, int flags);
+int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph,
+                        const int32_t* d_partial_id, int64_t F, int K,
+                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
+                        double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                        double* d_w, int64_t wlen, void* stream, int flags);
 
 /* ---- PVHarmonic.run_pv / calc_pv_frame (PV.py:419-535) --------------------------------------
  *

@@ -9,6 +9,7 @@ What is host Python here is only what the reference also does once per object (c
 PV.__init__, PVAnalysis.py:84-121) and the list-like views over device results.
 """
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -28,8 +29,79 @@ def dpitch2st(f1, f2):
     return 17.312 * (float(f2) / f1 - 1.0)
 
 
+_MISSING = object()
+
+
+class _Result(object):
+    """A result array of PV.run_pv that lives in the plan's resident block (HBM) until somebody touches it:
+    the first read copies that one array to the host and caches it; assigning to the attribute (the
+    reference's attributes are plain, writable ndarray members) makes the host value authoritative and
+    takes the object off the device-resident toSinSum / synth / calc_f0 chain."""
+
+    def __init__(self, name, which):
+        self.key = "_res_" + name
+        self.which = which
+
+    def __get__(self, obj, cls):
+        if obj is None:
+            return self
+        v = obj.__dict__.get(self.key, _MISSING)
+        if v is _MISSING:
+            v = obj._fetch_result(self.which)
+            obj.__dict__[self.key] = v
+        return v
+
+    def __set__(self, obj, v):
+        obj.__dict__[self.key] = v
+        obj.__dict__["_results_edited"] = True
+
+
 class _Plan(object):
-    """Owner of a pvx_plan handle."""
+    """Owner of a pvx_plan handle (constants, tables and every device / pinned buffer of the host entry points).
+
+    Plans are pooled per parameter set: the reference's API makes one PV object per signal, and a plan's
+    creation plus the first-call allocation of its buffers costs more than analysing a short signal.  A plan
+    serves one PV at a time (`owner`: it may hold that PV's resident results); a PV whose plan is wanted by
+    another one first brings its results to the host (PV._release_resident)."""
+
+    _pool = {}
+    _POOL_MAX = 4
+
+    @classmethod
+    def acquire(cls, owner, sr, nfft, hop, npks, pkthresh, win, precision, max_rows=0):
+        import weakref
+        win = np.ascontiguousarray(win, dtype=np.float64)
+        # the rows hint sizes the general path's workspace (and its rocFFT batch): pool per power-of-two bucket
+        bucket = 0
+        if max_rows and max_rows > 0:
+            bucket = 64
+            while bucket < max_rows and bucket < (1 << 16):
+                bucket <<= 1
+        key = (float(sr), int(nfft), int(hop), int(npks), float(pkthresh), int(precision), win.tobytes(), bucket,
+               os.environ.get("PVX_FFT_MODE"), os.environ.get("PVX_MAX_ROWS"), os.environ.get("PVX_FUSED_BLOCKS"), os.environ.get("PVX_FPW"))
+        plans = cls._pool.setdefault(key, [])
+        free = [pl for pl in plans if pl.owner is None or pl.owner() is None]
+        if free:
+            pl = free[0]
+        elif len(plans) < cls._POOL_MAX:
+            pl = cls(sr, nfft, hop, npks, pkthresh, win, precision, max_rows=bucket)
+            plans.append(pl)
+        else:
+            pl = plans[0]                                    # the oldest: its owner keeps its results on the host
+            prev = pl.owner() if pl.owner is not None else None
+            if prev is not None:
+                prev._release_resident()
+                prev._plan = None
+        plans.remove(pl) if pl in plans else None
+        plans.append(pl)                                     # most recently used last
+        pl.owner = weakref.ref(owner)
+        if len(cls._pool) > 16:                              # bound the number of parameter sets kept alive
+            for k in list(cls._pool)[:-16]:
+                if all(q.owner is None or q.owner() is None for q in cls._pool[k]):
+                    del cls._pool[k]
+        return pl
+
+    owner = None
 
     def __init__(self, sr, nfft, hop, npks, pkthresh, win, precision, max_rows=0):
         lib = _lib.load()
@@ -52,6 +124,14 @@ class _Plan(object):
 
 
 class PV(object):
+    f = _Result("f", 0)
+    mag = _Result("mag", 1)
+    ph = _Result("ph", 2)
+    realph = _Result("realph", 3)
+    binno = _Result("binno", 4)
+    t = _Result("t", 5)
+    totalmag = _Result("totalmag", 6)
+
     def __init__(self, x, sr, nfft=1024, hop=None, npks=20,
                  pkthresh=0.005, wind=np.hanning, progress=True, precision=32):
         '''
@@ -67,6 +147,9 @@ class PV(object):
                           DESIGN.md); 64: float64 end to end
         '''
         self._xdev = None
+        self._resident = False          # run_pv results are in the plan's resident block
+        self._results_edited = False
+        self._dependents = []           # weak references to SinSum objects that read the resident block
         if _lib.is_device_array(x):
             # Extension: a signal that is already in GPU memory (torch tensor on the GPU, anything with
             # __cuda_array_interface__) is analysed in place -- no host copy, no PCIe transfer of the input
@@ -91,8 +174,11 @@ class PV(object):
         self.precision = precision
 
         self.win = wind(nfft)
-        self.wsum = sum(self.win)
-        self.wsum2 = sum(self.win ** 2)
+        # PVAnalysis.py:98-99 use Python's sum(): left-to-right float64 additions, which is what a cumulative
+        # sum does too (np.sum would add pairwise and round differently)
+        w = np.asarray(self.win, dtype=np.float64)
+        self.wsum = np.cumsum(w)[-1] if len(w) else 0
+        self.wsum2 = np.cumsum(w ** 2)[-1] if len(w) else 0
         self.wfact = np.sqrt(self.wsum2 * self.nfft) / 2.0     # PVAnalysis.py:102
         self.fstep = float(self.sr) / float(self.nfft)
         self.dt = float(self.hop) / float(self.sr)
@@ -121,13 +207,16 @@ class PV(object):
             want = 0
             if rows is not None:
                 want = max(2, int(rows))
-            self._plan = _Plan(self.sr, self.nfft, int(self.hop), self.npeaks, self.peakthresh,
-                               self.win, self.precision, max_rows=want)
-            self._install_progress(self._plan)
+            self._plan = _Plan.acquire(self, self.sr, self.nfft, int(self.hop), self.npeaks, self.peakthresh,
+                                       self.win, self.precision, max_rows=want)
+        self._install_progress(self._plan)
         return self._plan
 
     def _install_progress(self, plan):
         if not self.progress:
+            _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, _lib.PROGRESS_FN(), None), "pvx_plan_set_progress")
+            return
+        if self._progress_cb is not None and getattr(self, "_progress_plan", None) is plan:
             return
         user = self.progress if callable(self.progress) else None
         hop, nsamp = int(self.hop), int(self.nsamp)
@@ -142,6 +231,7 @@ class PV(object):
             sys.stdout.flush()
 
         self._progress_cb = _lib.PROGRESS_FN(report)                           # keep the thunk alive
+        self._progress_plan = plan
         _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, self._progress_cb, None), "pvx_plan_set_progress")
 
     def _signal(self):
@@ -152,6 +242,32 @@ class PV(object):
         if self.x.ndim != 1:
             raise ValueError("PV expects a 1-D signal")
         return _lib.as_signal(self.x)
+
+    def _fetch_result(self, which):
+        """One resident result array -> host (PV.py:256-264 layouts: (F, K) float64, t (F,), totalmag a list)."""
+        if not self._resident:
+            raise AttributeError("no analysis results yet (run_pv)")
+        F, K = self.nframes, self.npeaks
+        a = np.empty((F, K) if which < 5 else (F,))
+        _lib.check(_lib.load().pvx_resident_fetch(self._plan.handle, which, _lib.dptr(a)), "pvx_resident_fetch")
+        return list(a) if which == 6 else a
+
+    def _on_device(self):
+        """True while the results of run_pv are in HBM and nobody has replaced them on the host."""
+        return self._resident and not self._results_edited
+
+    def _release_resident(self):
+        """Before the plan's resident block is overwritten: bring what is still only there to the host."""
+        if not self._resident:
+            return
+        for d in self._dependents:
+            ss = d()
+            if ss is not None:
+                ss._detach_resident()
+        self._dependents = []
+        for name in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            getattr(self, name)
+        self._resident = False
 
     def _run_pv_device(self, F, K, prev0):
         """run_pv for a device-resident signal: pvx_analyze_dev on torch's current stream."""
@@ -245,15 +361,13 @@ class PV(object):
             self.nframes = 0
             self.totalmag = []
             return
-        f = np.empty((F, K)); mag = np.empty((F, K)); ph = np.empty((F, K))
-        realph = np.empty((F, K)); binno = np.empty((F, K))
-        t = np.empty(F); tm = np.empty(F)
         last = np.zeros((self.nfft2, 2))
         old = np.asarray(self.oldfft)
         prev0 = None
         if np.any(old != 0):                                     # run_pv after manual calc_pv_frame calls
             oc = old.astype(complex)
             prev0 = np.ascontiguousarray(np.stack([oc.real, oc.imag], axis=1), dtype=np.float64)
+        self._release_resident()
         if self._xdev is not None:
             (f, mag, ph, realph, binno), t, tm = self._run_pv_device(F, K, prev0)
             # PV.oldfft after the loop = spectrum of the last frame (PVAnalysis.py:209): one frame's worth
@@ -268,21 +382,25 @@ class PV(object):
                                            len(tail_sig), posa.ctypes.data_as(_lib.c_int64_p), 1, _lib.dptr(spec)),
                        "pvx_stft_frames")
             last = spec[0, :self.nfft2, :]
+            self.f = f
+            self.mag = mag
+            self.ph = ph
+            self.realph = realph
+            self.binno = binno
+            self.t = t
+            self.totalmag = list(tm)                             # PVAnalysis.py:264 (a Python list)
         else:
+            # The results stay in HBM (the plan's resident block): toSinSum, SinSum.synth, calc_f0 and
+            # calc_harmonic_power run there; an attribute comes to the host when it is first read.
             plan = self._get_plan(rows=F + 1)
-            r = lib.pvx_analyze(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), 1, len(x),
-                                _lib.dptr(f), _lib.dptr(mag), _lib.dptr(ph), _lib.dptr(realph), _lib.dptr(binno),
-                                _lib.dptr(t), _lib.dptr(tm),
-                                _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
-            _lib.check(r, "pvx_analyze")
-        self.f = f
-        self.mag = mag
-        self.ph = ph
-        self.realph = realph
-        self.binno = binno
-        self.t = t
+            r = lib.pvx_analyze_resident(plan.handle, x.ctypes.data_as(ctypes.c_void_p), dt, len(x), 1, len(x),
+                                         _lib.dptr(prev0) if prev0 is not None else None, _lib.dptr(last))
+            _lib.check(r, "pvx_analyze_resident")
+            for name in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+                self.__dict__.pop("_res_" + name, None)
+            self._resident = True
+        self._results_edited = self._xdev is not None
         self.nframes = F
-        self.totalmag = list(tm)                                 # PVAnalysis.py:264 (a Python list)
         self.oldfft = last[:, 0] + 1j * last[:, 1]
 
     def calc_harmonic_power(self, f_threshold=0.01):
@@ -295,6 +413,17 @@ class PV(object):
         mag[slot_c, :]**2 over the harmonic set -- reproduced as is (IndexError like the reference
         when a valid slot index >= number of frames).
         """
+        if self._on_device() and self.nframes > 0:
+            # on the arrays where they are (k_desc.hip): only hpower and nharmonics cross PCIe
+            F, K = self.nframes, self.npeaks
+            hpower = np.empty((F, K)); nharm = np.empty((F, K))
+            rc = _lib.load().pvx_harmonic_power_resident(self._plan.handle, float(f_threshold), _lib.dptr(hpower), _lib.dptr(nharm))
+            if rc == _lib.PVX_ERR_SIZE:
+                raise IndexError(_lib.load().pvx_last_error().decode())
+            _lib.check(rc, "pvx_harmonic_power_resident")
+            self.hpower = hpower
+            self.nharmonics = nharm
+            return
         ff = np.asarray(self.f, dtype=np.float64)
         mm = np.asarray(self.mag, dtype=np.float64)
         F, K = ff.shape
@@ -330,7 +459,10 @@ class PV(object):
         '''
         ss = SinSum(self.sr, nfft=self.nfft, hop=self.hop)
         if self.nframes > 0:
-            ss._from_analysis(self.f, self.mag, self.ph, self.realph)
+            if self._on_device():
+                ss._from_resident(self)                          # tracker on the arrays in HBM, table stays there
+            else:
+                ss._from_analysis(self.f, self.mag, self.ph, self.realph)
         return ss
 
     def get_time_vector(self):
@@ -341,9 +473,18 @@ class PV(object):
 
     def calc_f0(self, fmin=50, fmax=10000, thr=0.1):
         """
-        Lowest-frequency strong peak per frame (PVAnalysis.py:371-391), vectorised over frames on
-        the (F, K) result arrays.
+        Lowest-frequency strong peak per frame (PVAnalysis.py:371-391): one small kernel over the resident
+        (F, K) arrays (only the F frequencies and indices come back), or vectorised numpy when the arrays
+        were replaced on the host.
         """
+        if self._on_device() and self.nframes > 0:
+            F = self.nframes
+            fm = np.empty(F)
+            im = np.empty(F, dtype=np.int32)
+            _lib.check(_lib.load().pvx_f0_resident(self._plan.handle, float(fmin), float(fmax), float(thr), _lib.dptr(fm),
+                                                   im.ctypes.data_as(_lib.c_int32_p)), "pvx_f0_resident")
+            self.fundamental_idx = im.astype('i')
+            return fm
         ff = np.asarray(self.f)
         mm = np.asarray(self.mag)
         fm = np.zeros(ff.shape[0])
@@ -458,6 +599,7 @@ class PVHarmonic(PV):
             self.residuals = np.array([]); self.t = np.array([])
             self.nframes = 0
             return
+        self._release_resident()
         f0 = np.ascontiguousarray(np.asarray(self.f0, dtype=np.float64).ravel())
         if len(f0) < F:
             # the reference indexes self.f0[int(curpos / hop)] (PVAnalysis.py:507)
@@ -512,16 +654,6 @@ class RegPartial(object):
         else:
             self.realph.append(realph)
 
-    def prepend_point(self, f, mag, ph):
-        '''
-        Add a single point to the start of partial (PVAnalysis.py:628-635; like the reference it
-        leaves realph alone)
-        '''
-        self.f.insert(0, f)
-        self.mag.insert(0, mag)
-        self.ph.insert(0, ph)
-        self.start_idx -= 1
-
     def get_freq_at_frame(self, fr):
         relidx = fr - self.start_idx
         if relidx >= 0:
@@ -539,22 +671,30 @@ class RegPartial(object):
     def synth(self, sr, hop, intermediate=False, edge=.5):
         '''
         Phase-preserving resynthesis of this partial (PVAnalysis.py:684-756) on the device.
-        Returns (signal, first sample index).  fstep=None (no frequency-slope phase correction) is
-        not implemented by the kernel; SinSum always sets it (PVAnalysis.py:824-825).
+        Returns (signal, first sample index).  fstep=None: no frequency-slope phase correction
+        (PVAnalysis.py:710-713); SinSum always sets fstep (PVAnalysis.py:824-825).
         '''
         if intermediate:
             raise NameError("name 'phsig' is not defined")      # what the reference raises (PVAnalysis.py:754)
-        if self.fstep is None:
-            raise NotImplementedError("RegPartial.synth without fstep is outside the device path")
         hop = int(hop)
         nfr = len(self.f)
         dfr = 1. / self.overlap / 2.
         edgsam = int(dfr * hop * edge)
-        # derive (nfft, hop_analysis) with hop_a/nfft == overlap and sr/nfft == fstep
-        nfft = int(round(sr / float(self.fstep)))
-        hop_a = int(round(self.overlap * nfft))
-        if abs(hop_a / float(nfft) - self.overlap) > 1e-15 or abs(sr / float(nfft) - self.fstep) > 1e-9 * self.fstep:
-            raise NotImplementedError("overlap/fstep do not correspond to integer nfft and hop")
+        flags = 0
+        if self.fstep is None:
+            # only the overlap matters: any integer pair with hop_a / nfft == overlap
+            from fractions import Fraction
+            fr = Fraction(self.overlap).limit_denominator(1 << 20)
+            hop_a, nfft = fr.numerator, fr.denominator
+            flags = _lib.PVX_SYNTH_NO_PHCOR
+            if hop_a <= 0 or hop_a / float(nfft) != self.overlap:
+                raise NotImplementedError("overlap %r is not a ratio of integers" % (self.overlap,))
+        else:
+            # derive (nfft, hop_analysis) with hop_a/nfft == overlap and sr/nfft == fstep
+            nfft = int(round(sr / float(self.fstep)))
+            hop_a = int(round(self.overlap * nfft))
+            if abs(hop_a / float(nfft) - self.overlap) > 1e-15 or abs(sr / float(nfft) - self.fstep) > 1e-9 * self.fstep:
+                raise NotImplementedError("overlap/fstep do not correspond to integer nfft and hop")
         pad = (edgsam + hop - 1) // hop + 1                     # frames of head room so the attack is not clipped
         F = pad + nfr
         f = np.zeros((F, 1)); mag = np.zeros((F, 1)); rp = np.zeros((F, 1))
@@ -563,12 +703,12 @@ class RegPartial(object):
         pid[pad:, 0] = 0
         st = np.array([pad], dtype=np.int32)
         ln = np.array([nfr], dtype=np.int32)
-        w = _device_synth(f, mag, rp, pid, st, ln, sr, nfft, hop_a, hop, edge, 1)
+        w = _device_synth(f, mag, rp, pid, st, ln, sr, nfft, hop_a, hop, edge, 1, flags)
         a = pad * hop - edgsam
         return w[a:a + hop * nfr + 2 * edgsam].copy(), int((self.start_idx) * hop - edgsam)
 
 
-def _device_synth(f, mag, realph, pid, st, ln, sr, nfft, hop_a, hop_s, edge, minframes):
+def _device_synth(f, mag, realph, pid, st, ln, sr, nfft, hop_a, hop_s, edge, minframes, flags=0):
     lib = _lib.load()
     _lib.init()
     F, K = f.shape
@@ -583,9 +723,9 @@ def _device_synth(f, mag, realph, pid, st, ln, sr, nfft, hop_a, hop_s, edge, min
     st = np.ascontiguousarray(st, dtype=np.int32)
     ln = np.ascontiguousarray(ln, dtype=np.int32)
     i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
-    _lib.check(lib.pvx_synth(_lib.dptr(f), _lib.dptr(mag), _lib.dptr(realph), i32(pid), F, K, i32(st), i32(ln),
-                             len(st), float(sr), int(nfft), int(hop_a), int(hop_s), float(edge), int(minframes),
-                             _lib.dptr(w), n), "pvx_synth")
+    _lib.check(lib.pvx_synth_flags(_lib.dptr(f), _lib.dptr(mag), _lib.dptr(realph), i32(pid), F, K, i32(st), i32(ln),
+                                   len(st), float(sr), int(nfft), int(hop_a), int(hop_s), float(edge), int(minframes),
+                                   _lib.dptr(w), n, int(flags)), "pvx_synth")
     return w
 
 
@@ -608,8 +748,39 @@ class SinSum(object):
         # device-side table (set by PV.toSinSum): analysis arrays + partial ids
         self._tab = None
         self._materialised = True
+        self._rpv = None            # the PV whose resident results (and resident partial table) this object reads
+        self._rP = 0
+        self._rmaxend = -1
 
     # ---- table built by the tracker kernels ------------------------------------------------
+    def _from_resident(self, pv, maxpitchjmp=0.5):
+        """PV.toSinSum on results that are still in HBM: the tracker runs there and its table stays there."""
+        import weakref
+        me = ctypes.c_int64(-1)
+        P = _lib.load().pvx_track_resident(pv._plan.handle, float(maxpitchjmp), ctypes.byref(me))
+        _lib.check(P, "pvx_track_resident")
+        self._rpv, self._rP, self._rmaxend = pv, int(P), int(me.value)
+        self._tab = None
+        self._materialised = False
+        pv._dependents.append(weakref.ref(self))
+
+    def _detach_resident(self):
+        """Copy the resident table (and, through the PV's attributes, the arrays) to the host."""
+        pv = self._rpv
+        if pv is None:
+            return
+        F, K, P = pv.nframes, pv.npeaks, self._rP
+        pid = np.empty((F, K), dtype=np.int32)
+        st = np.empty(max(P, 1), dtype=np.int32)
+        ln = np.empty(max(P, 1), dtype=np.int32)
+        i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        _lib.check(_lib.load().pvx_resident_fetch_table(pv._plan.handle, i32(pid), i32(st), i32(ln)), "pvx_resident_fetch_table")
+        self._rpv = None
+        self._tab = dict(f=np.ascontiguousarray(pv.f, dtype=np.float64), mag=np.ascontiguousarray(pv.mag, dtype=np.float64),
+                         ph=np.ascontiguousarray(pv.ph, dtype=np.float64), realph=np.ascontiguousarray(pv.realph, dtype=np.float64),
+                         pid=pid, st=st[:P].copy(), ln=ln[:P].copy())
+        self._materialised = False
+
     def _from_analysis(self, f, mag, ph, realph, maxpitchjmp=0.5):
         lib = _lib.load()
         _lib.init()
@@ -632,6 +803,7 @@ class SinSum(object):
         """Build the reference's Python objects (RegPartial lists, st, end) from the table."""
         if self._materialised:
             return
+        self._detach_resident()
         tab = self._tab
         pid, st, ln = tab['pid'], tab['st'], tab['ln']
         P = len(st)
@@ -717,35 +889,6 @@ class SinSum(object):
     def get_partials_at_frame(self, fr):
         return [self._partial[i] for i in self.get_partials_idx_at_frame(fr)]
 
-    def add_point(self, fr, f, mag, ph, maxpitchjmp=0.5):
-        '''
-        Add a point to the matching partial or create a new one (PVAnalysis.py:832-868).  The
-        reference's slow single-point path, kept on the host: nearest previous partial by
-        semitone distance + |dB difference|, accepted when the semitone distance alone is below
-        maxpitchjmp.  Use add_frame / toSinSum for whole frames (tracker kernels).
-        '''
-        self._materialise()
-        pidx = [int(i) for i in self.get_partials_idx_ending_at_frame(fr - 1)]
-        idx = -1
-        part = None
-        if len(pidx) > 0:
-            pmag = [self._partial[ii].get_mag_at_frame(fr - 1) for ii in pidx]
-            pmag, pidx = zip(*sorted(zip(pmag, pidx), reverse=True))
-            partials = [self._partial[ii] for ii in pidx]
-            prev_f = [pp.get_freq_at_frame(fr - 1) for pp in partials]
-            stonediff = np.array([abs(dpitch2st(ff, f)) for ff in prev_f])
-            with np.errstate(divide="ignore", invalid="ignore"):
-                dbdiff = 20 * np.log10(np.array(pmag) / mag)
-            nearest = np.argmin(stonediff + abs(dbdiff))
-            if stonediff[nearest] < maxpitchjmp:
-                idx = pidx[nearest]
-                part = partials[nearest]
-        if part is None:
-            part = self.add_empty_partial(fr)
-        part.append_point(f, mag, ph)
-        self._end[idx] = fr
-        self._tab_dirty = True
-
     def get_points_at_frame(self, fr):
         '''Placeholder in the reference too (PVAnalysis.py:996-1000).'''
         pass
@@ -828,6 +971,19 @@ class SinSum(object):
             # (np.ones(float)); mirror that instead of inventing behaviour.
             raise TypeError("'float' object cannot be interpreted as an integer")
         hop = int(hop)
+        pv = self._rpv
+        if pv is not None and not self._tab_dirty and pv._on_device():
+            # analysis arrays and partial table are in HBM: only the waveform comes back
+            lib = _lib.load()
+            if self._rP == 0:
+                raise ValueError("max() arg is an empty sequence")
+            n = lib.pvx_synth_len(self._rmaxend, int(self.nfft), int(self.hop), hop, float(edge))
+            _lib.check(n, "pvx_synth_len")
+            w = np.empty(n)
+            _lib.check(lib.pvx_synth_resident(pv._plan.handle, float(sr), hop, float(edge), int(minframes), _lib.dptr(w), n),
+                       "pvx_synth_resident")
+            return w
+        self._detach_resident()
         if self._tab is not None and not self._tab_dirty:
             tab = self._tab
             if len(tab['st']) == 0:
@@ -847,40 +1003,10 @@ class SinSum(object):
     def get_nframes(self):
         return max(self.end)
 
-    def get_summary(self, minlen=10):
-        psum = np.array([(ii, len(xx.f), np.mean(xx.f), np.mean(xx.mag))
-                         for ii, xx in enumerate(self.partial) if len(xx.f) > minlen],
-                        dtype=[('idx', 'i4'), ('n', 'i4'), ('f', 'f4'), ('mag', 'f4')])
-        psum.sort(order='mag')
-        return psum
-
-    def get_part_data_around_freq(self, fc, semitones=.5):
-        '''
-        Frame-indexed f, mag, ph of the partials whose mean frequency lies within `semitones` of fc
-        (PVAnalysis.py:1091-1112); where several overlap in time, the one with the larger mean
-        magnitude wins (partials are written in ascending-magnitude order).
-        '''
-        nframes = self.get_nframes() + 1
-        t = np.arange(nframes) / float(self.sr) * self.hop
-        f = np.zeros(nframes)
-        mag = np.zeros(nframes)
-        ph = np.zeros(nframes)
-        ss = self.get_summary(minlen=0)
-        ss.sort(order='mag')
-        with np.errstate(divide="ignore", invalid="ignore"):
-            idx = ss['idx'][(abs(12 * np.log2(abs(ss['f'] / fc))) < semitones).nonzero()]
-        for i in idx:
-            part = self.partial[i]
-            sti = part.start_idx
-            endi = sti + len(part.mag)
-            f[sti:endi] = part.f
-            mag[sti:endi] = part.mag
-            ph[sti:endi] = part.ph
-        return t, f, mag, ph
-
     # table access without building Python objects (large analyses)
     def partial_table(self):
         """(partial_id[F,K], part_start[P], part_len[P]) as produced by the tracker kernels."""
+        self._detach_resident()
         if self._tab is None or self._tab_dirty:
             self._materialise()
             _, _, _, pid, st, ln = self._pack_partials()

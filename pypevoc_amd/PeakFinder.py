@@ -136,66 +136,6 @@ class PeakFinder(object):
             prevb = nextb
         self._bounds = np.array(bounds)
 
-    # ---- sub-sample refinement (PeakFinder.py:304-406): host-side post-processing of the few peaks found
-    def refine(self, idx, fun=None, yvec=None):
-        """Parabola through the peak sample and its two neighbours -> (fine position on self.x, fine value)
-        (PeakFinder.py:331-372).  Not a strict local maximum: the sample itself is returned."""
-        y = self.y if yvec is None else yvec
-        pos = int(self._idx[idx])
-        lo, mid, hi = (y[pos - 1:pos + 2] if fun is None else fun(y[pos - 1:pos + 2]))
-        fpos, fval = float(pos), mid
-        if mid > lo and mid >= hi:
-            b = (hi - lo) / 2
-            a = (hi + lo) / 2 - mid
-            d = -b / 2 / a
-            fpos = pos + d
-            fval = a * d * d + b * d + mid
-            if fun is not None:
-                from scipy.optimize import broyden1
-                fval = broyden1(lambda v: fun(v) - fval, self.val[idx] / 2)
-        return np.interp(fpos, np.arange(len(self.x)), self.x), np.asarray(fval).tolist()
-
-    def refine_opt(self, idx, yvec=None, rad=2):
-        """Least-squares parabola over +-rad samples around the peak (PeakFinder.py:304-329)."""
-        y = self.y if yvec is None else yvec
-        pos = self.pos[idx]
-        imin = int(max(1, pos - rad))
-        imax = int(min(pos + rad + 1, len(y)))
-        pp = np.polyfit(np.arange(imin - pos, imax - pos), y[imin:imax], 2)
-        d = -pp[1] / 2.0 / pp[0]
-        return float(pos) + d, (pp[0] * d * d + pp[1] * d + pp[2]).tolist()
-
-    def refine_all(self, logarithmic=False, rad=1):
-        """Refine every peak found (PeakFinder.py:374-406): fills the arrays behind .pos / .val (also .fpos)."""
-        y = np.log10(self.y) if logarithmic else None
-        fine_pos = np.zeros(self._idx.shape)
-        fine_val = np.zeros(self._idx.shape)
-        for i in range(len(self._idx)):
-            if rad > 1:
-                fp, fv = self.refine_opt(i, yvec=y, rad=rad) if logarithmic else self.refine_opt(i, rad=rad)
-            else:
-                fp, fv = self.refine(i, yvec=y)
-            fine_pos[i] = fp
-            fine_val[i] = 10 ** fv if logarithmic else fv
-        self._fine_pos, self._fine_val = fine_pos, fine_val
-
-    @property
-    def fpos(self):
-        return self._fine_pos[self._keep]
-
-    def calc_individual_area(self, idx, funct=None, max_rad=None):
-        """Sum of y (or funct(y)) between the peak's boundaries (PeakFinder.py:408-413)."""
-        lims = self._bounds[idx]
-        seg = self.y[lims[0]:lims[-1]]
-        return sum(seg) if funct is None else sum(funct(seg))
-
-    def get_areas(self, funct=None, max_rad=None):
-        """(PeakFinder.py:415-426)"""
-        if not hasattr(self, '_bounds'):
-            self.find_boundaries()
-        self._areas = np.array([self.calc_individual_area(i, funct=funct) for i in range(len(self._idx))])
-        return self._areas[self._keep]
-
     def boundaries(self):
         try:
             self.find_boundaries(all=True)
@@ -206,5 +146,3 @@ class PeakFinder(object):
     def get_pos(self):
         return self.pos
 
-    def to_dict(self):
-        return {'pos': self.pos, 'val': self.val}

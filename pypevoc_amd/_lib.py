@@ -11,6 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVX_LIB") or os.path.join(_HERE, "libpvx_hip.so")   # PVX_LIB: A/B builds of the same library
 
+PVX_SYNTH_NO_PHCOR = 1
+PVX_ERR_SIZE = -6            # include/pvx.h
 PVX_F32, PVX_F64, PVX_I16 = 0, 1, 2
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -24,6 +26,7 @@ SIGNATURES = {
     "pvx_last_error": (ctypes.c_char_p, []),
     "pvx_version": (ctypes.c_int, []),
     "pvx_device_name": (ctypes.c_char_p, []),
+    "pvx_device": (ctypes.c_int, []),
     "pvx_nframes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "pvx_plan_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
@@ -56,6 +59,25 @@ SIGNATURES = {
                                  c_int32_p, c_int32_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p,
                                  ctypes.c_int64]),
+    "pvx_analyze_resident": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, c_double_p, c_double_p]),
+    "pvx_resident_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
+    "pvx_resident_ptr": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "pvx_track_resident": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_double, c_int64_p]),
+    "pvx_resident_fetch_table": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p, c_int32_p]),
+    "pvx_synth_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                          c_double_p, ctypes.c_int64]),
+    "pvx_f0_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_double_p, c_int32_p]),
+    "pvx_harmonic_power_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, c_double_p, c_double_p]),
+    "pvx_synth_flags": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.c_int64, ctypes.c_int,
+                                       c_int32_p, c_int32_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p,
+                                       ctypes.c_int64, ctypes.c_int]),
+    "pvx_synth_dev_flags": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
+                                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                   ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
     "pvx_synth_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
                                                              ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -147,7 +169,7 @@ def init(device=None):
     if _INIT_DEVICE is not None and (device is None or _INIT_DEVICE == dev):
         return _INIT_DEVICE
     check(lib.pvx_init(dev), "pvx_init")
-    _INIT_DEVICE = dev if dev >= 0 else 0
+    _INIT_DEVICE = int(lib.pvx_device())        # the device the library actually bound (the current one for None)
     return _INIT_DEVICE
 
 
@@ -208,7 +230,11 @@ def device_run(nbytes_out, launch):
     """Run `launch(out_ptr, stream_ptr)` with a float64 device output block of nbytes_out/8 elements
     on torch's current stream, return the block as a host numpy array."""
     import torch
-    out = torch.empty(nbytes_out // 8, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    bound = init()
+    if torch.cuda.current_device() != bound:
+        raise PvxError("torch's current device is cuda:%d but libpvx_hip is bound to device %d (pypevoc_amd._lib.init(device))"
+                       % (torch.cuda.current_device(), bound))
+    out = torch.empty(nbytes_out // 8, dtype=torch.float64, device=torch.device("cuda", bound))
     stream = torch.cuda.current_stream()
     launch(out.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
     stream.synchronize()

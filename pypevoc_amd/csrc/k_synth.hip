@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 // phase corrections, PVAnalysis.py:711-718
                 const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
                 const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
-                const double phcor = kPi * (fs1 - fs0) / fstep / 2.;
+                const double phcor = p.no_phcor ? 0.0 : kPi * (fs1 - fs0) / fstep / 2.;          // PVAnalysis.py:710-715
                 c.ph0 = pr[ii - j0] + phcor;                              // PVAnalysis.py:721
                 // fsig(nbase + q) = fa0 + fsa q for q < fmb, fb0 + fsb q beyond; msig likewise
                 const Piece2 qf = make_piece2(nbase, dh, offf, nfr, pf, j0);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                 } else if (ii < nfr - 1) {
                     // discontinuity ramp towards the next point, PVAnalysis.py:724-729
                     const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf, j0);
-                    const double phcornext = kPi * (fs2 - fs1) / fstep / 2.;
+                    const double phcornext = p.no_phcor ? 0.0 : kPi * (fs2 - fs1) / fstep / 2.;
                     const double phend = lastph + kPi2 * fs1 / p.sr;
                     const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
                     double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor

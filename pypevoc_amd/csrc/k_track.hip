@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
     int* used = porder + kp;
     int* ppid = used + kp;
     int* cpid = ppid + kp;
-    long long P = 0;
+    long long P = 0, lastfr = -1;
     for (int s = lane; s < K; s += 64) { pf[s] = 0.0; pm[s] = 0.0; ppid[s] = -1; }
     wave_sync_t();
     for (int64_t fr = 0; fr < p.F; fr++) {
@@ -218,9 +218,10 @@ __global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
             p.partial_id[fr * K + s] = cpid[s];
             pf[s] = cf[s]; pm[s] = cm[s]; ppid[s] = cpid[s];
         }
+        if (nc > 0) lastfr = (long long)fr;
         wave_sync_t();
     }
-    if (lane == 0) *p.npartials = P;
+    if (lane == 0) { *p.npartials = P; *p.maxend = lastfr; }
 }
 
 // exclusive scan of newcount[F] -> newbase[F+1] (single workgroup, 1024 threads, chunked)
@@ -290,6 +291,8 @@ __global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
         // one plain store per partial instead of one contended atomic per point
         if (!p.succ[i]) p.part_len[pid] = (int32_t)(i / p.K - rfr + 1);
     }
+    // max(SinSum.end): one atomic per partial (its last point)
+    if (!p.succ[i]) atomicMax((long long*)p.maxend, (long long)(i / p.K));
 }
 
 }  // namespace
@@ -305,6 +308,7 @@ int pvx_launch_track(const TrackParams& p, hipStream_t s) {
     if (per_wave * waves > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
     PVX_HIP_CHECK(hipMemsetAsync(p.succ, 0, (size_t)n, s));
     PVX_HIP_CHECK(hipMemsetAsync(p.ambiguous, 0, sizeof(int64_t), s));
+    PVX_HIP_CHECK(hipMemsetAsync(p.maxend, 0xff, sizeof(int64_t), s));          // -1
     hipLaunchKernelGGL(k_track_links, dim3((unsigned)((p.F + waves - 1) / waves)), dim3(64 * waves), per_wave * waves, s, p);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
     const unsigned nb = (unsigned)((n + 255) / 256);

@@ -64,6 +64,7 @@ extern "C" int pvx_init(int device) {
 }
 
 extern "C" const char* pvx_device_name(void) { return g_devname; }
+extern "C" int pvx_device(void) { return g_device; }
 
 int pvx_require_device() {
     if (g_device >= 0) {
@@ -111,6 +112,31 @@ struct pvx_plan {
     bool progress_live = false;   // inside a host entry point: chunk completions are reported
     int64_t fused_blocks = 0;    // PVX_FUSED_BLOCKS override
     int frames_per_wave = 2;     // k_phase_peaks: frames a wave handles one after the other (latency floor of a chunked launch; PVX_FPW)
+    // ---- host entry points: plan-owned, grow-only buffers (no hipMalloc / hipFree per call)
+    hipStream_t s_host = nullptr;          // non-blocking stream of the host entry points
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    void* d_in[2] = {nullptr, nullptr};    // input chunks (double-buffered: H2D of chunk i+1 under the kernels of chunk i)
+    size_t in_cap[2] = {0, 0};
+    double* d_out[2] = {nullptr, nullptr}; // result blocks of a chunk when the results stream back to the host
+    size_t out_cap[2] = {0, 0};
+    void* h_pin = nullptr;                 // pinned staging of small calls (input, then the result block)
+    size_t pin_cap = 0;
+    double* d_prev = nullptr;              // [N2][2] spectrum carried from one input chunk to the next (PV.py:209)
+    // resident results (pvx_analyze_resident): the reference's arrays stay in HBM for the tracker, the
+    // resynthesis and the frame descriptors; only what the caller fetches crosses PCIe
+    double* d_res = nullptr;
+    size_t res_cap = 0;
+    int64_t res_F = 0, res_nsig = 0;
+    bool res_valid = false;
+    int32_t *d_pid = nullptr, *d_pst = nullptr, *d_pln = nullptr;     // resident partial table
+    size_t trk_cap = 0;                    // entries of d_pid / d_pst / d_pln
+    void* d_tws = nullptr;                 // tracker workspace
+    size_t tws_cap = 0;
+    int64_t res_P = -1, res_maxend = -1;
+    double* d_w = nullptr;                 // resynthesised waveform
+    size_t w_cap = 0;
+    void* d_desc = nullptr;                // descriptor outputs (f0 / harmonic power)
+    size_t desc_cap = 0;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -135,6 +161,21 @@ static void plan_free(pvx_plan* p) {
     if (p->d_hf0) (void)hipFree(p->d_hf0);
     if (p->d_hprev) (void)hipFree(p->d_hprev);
     if (p->d_carry) (void)hipFree(p->d_carry);
+    for (int i = 0; i < 2; i++) {
+        if (p->d_in[i]) (void)hipFree(p->d_in[i]);
+        if (p->d_out[i]) (void)hipFree(p->d_out[i]);
+        if (p->ev_done[i]) (void)hipEventDestroy(p->ev_done[i]);
+    }
+    if (p->h_pin) (void)hipHostFree(p->h_pin);
+    if (p->d_prev) (void)hipFree(p->d_prev);
+    if (p->d_res) (void)hipFree(p->d_res);
+    if (p->d_pid) (void)hipFree(p->d_pid);
+    if (p->d_pst) (void)hipFree(p->d_pst);
+    if (p->d_pln) (void)hipFree(p->d_pln);
+    if (p->d_tws) (void)hipFree(p->d_tws);
+    if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_desc) (void)hipFree(p->d_desc);
+    if (p->s_host) (void)hipStreamDestroy(p->s_host);
     delete p;
 }
 
@@ -276,7 +317,9 @@ static int ensure_rocfft(pvx_plan* p) {
     const size_t fbytes = (size_t)ws_rows * p->ldi * rs, sbytes = (size_t)ws_rows * p->ldo * 2 * rs;
     if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(&p->d_spec, sbytes) != hipSuccess) {
         pvx_set_error("hipMalloc of %.1f MiB analysis workspace failed", (fbytes + sbytes) / 1048576.0);
-                return PVX_ERR_ALLOC;
+        if (p->d_frames) { (void)hipFree(p->d_frames); p->d_frames = nullptr; }
+        if (p->d_spec) { (void)hipFree(p->d_spec); p->d_spec = nullptr; }
+        return PVX_ERR_ALLOC;
     }
     // rocFFT: batched 1-D real -> hermitian, one transform per workspace row (PV.py:157)
     rocfft_plan_description desc = nullptr;
@@ -457,53 +500,237 @@ struct DevBuf {   // RAII for the host-buffer wrappers
 };
 }  // namespace
 
-extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
-                               double* f, double* mag, double* ph, double* realph, double* binno, double* t,
-                               double* totalmag, const double* prev0, double* last_spec) {
+// grow-only device / pinned buffers owned by the plan
+template <typename T> static int grow_dev(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return PVX_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = need + need / 4 + 256;
+    if (hipMalloc((void**)p, want) != hipSuccess) {
+        if (hipMalloc((void**)p, need ? need : 1) != hipSuccess) { pvx_set_error("hipMalloc(%zu) failed", need); *p = nullptr; return PVX_ERR_ALLOC; }
+        *cap = need;
+        return PVX_OK;
+    }
+    *cap = want;
+    return PVX_OK;
+}
+static int grow_pin(pvx_plan* p, size_t need) {
+    if (need <= p->pin_cap && p->h_pin) return PVX_OK;
+    if (p->h_pin) { (void)hipHostFree(p->h_pin); p->h_pin = nullptr; p->pin_cap = 0; }
+    if (hipHostMalloc(&p->h_pin, need, hipHostMallocDefault) != hipSuccess) { pvx_set_error("hipHostMalloc(%zu) failed", need); return PVX_ERR_ALLOC; }
+    p->pin_cap = need;
+    return PVX_OK;
+}
+static int host_stream(pvx_plan* p) {
+    if (!p->s_host) PVX_HIP_CHECK(hipStreamCreateWithFlags(&p->s_host, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++)
+        if (!p->ev_done[i]) PVX_HIP_CHECK(hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming));
+    return PVX_OK;
+}
+
+struct HostOut { double *f, *mag, *ph, *realph, *binno, *t, *totalmag; };
+
+// pointers into a packed result block of `rows` frames: f | mag | ph | realph | binno | t | totalmag
+static HostOut block_ptrs(double* base, int64_t rows, int K) {
+    const size_t n = (size_t)rows * K;
+    HostOut o;
+    o.f = base; o.mag = base + n; o.ph = base + 2 * n; o.realph = base + 3 * n; o.binno = base + 4 * n;
+    o.t = base + 5 * n; o.totalmag = base + 5 * n + rows;
+    return o;
+}
+
+static const size_t kSmallCall = (size_t)4 << 20;     // calls up to this size go through pinned staging, one sync
+
+// spectrum of the last row of the launch that just ran on `s` -> p->d_prev (float64 [N2][2])
+static int carry_spectrum(pvx_plan* p, int64_t rows_in_call, hipStream_t s) {
+    if (!p->d_prev) PVX_HIP_CHECK(hipMalloc((void**)&p->d_prev, sizeof(double) * 2 * (size_t)(p->N2 > 0 ? p->N2 : 1)));
+    if (p->fft_mode != 0) return pvx_launch_spec_to_prev(p->d_prev, p->d_specrow, 2 * p->N2, 1, s);
+    const int64_t lastR0 = ((rows_in_call - 1) / p->max_rows) * p->max_rows;
+    const int64_t wsrow = (rows_in_call - 1) - lastR0 + 1;
+    const size_t rs = real_size(p->precision);
+    return pvx_launch_spec_to_prev(p->d_prev, (const char*)p->d_spec + (size_t)wsrow * p->ldo * 2 * rs, 2 * p->N2, p->precision == 32, s);
+}
+
+// The host entry point of run_pv (PV.py:213-264).
+//   keep = false: results stream back into the caller's arrays (`ho`);
+//   keep = true : results stay in the plan's resident block (pvx_analyze_resident), nothing comes back.
+// The input is taken in chunks of frames (one signal) or of whole signals (a batch) that fit
+// PVX_MAX_DEVICE_BYTES, double-buffered: while the kernels of chunk i run on the plan's stream the host
+// copies chunk i+1 in and chunk i-1's results out.  Between chunks of one signal the spectrum of the last
+// frame is carried on the device as the next chunk's `oldfft` (PV.py:209), so the result is the same,
+// bit for bit, as one launch over the whole signal -- and a signal larger than HBM runs.
+static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                            const HostOut* ho, const double* prev0, double* last_spec, bool keep) {
     int rc = pvx_require_device();
     if (rc != PVX_OK) return rc;
     rc = check_analyze_args(p, x, x_dtype, nsamp, nsig, sig_stride, prev0);
     if (rc != PVX_OK) return rc;
     const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if (keep) { p->res_valid = false; p->res_P = -1; }         // only a resident run replaces the resident block
     if (F == 0) return 0;
-    if (!f || !mag || !ph || !realph || !binno) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    if (!keep && (!ho->f || !ho->mag || !ho->ph || !ho->realph || !ho->binno)) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
     if (nsig == 1) sig_stride = nsamp;
-    const size_t xbytes = (size_t)((nsig - 1) * sig_stride + nsamp) * dtype_size(x_dtype);
-    const size_t fk = (size_t)nsig * F * p->npks * sizeof(double), f1 = (size_t)nsig * F * sizeof(double);
-    DevBuf dx, dout, dprev;
-    if ((rc = dx.alloc(xbytes)) != PVX_OK) return rc;
-    if ((rc = dout.alloc(5 * fk + 2 * f1)) != PVX_OK) return rc;
-    PVX_HIP_CHECK(hipMemcpy(dx.p, x, xbytes, hipMemcpyHostToDevice));
-    if (prev0) {
-        if ((rc = dprev.alloc(sizeof(double) * 2 * p->N2)) != PVX_OK) return rc;
-        PVX_HIP_CHECK(hipMemcpy(dprev.p, prev0, sizeof(double) * 2 * p->N2, hipMemcpyHostToDevice));
+    if ((rc = host_stream(p)) != PVX_OK) return rc;
+    hipStream_t s = p->s_host;
+    const int K = p->npks;
+    const size_t es = dtype_size(x_dtype);
+    const size_t per_frame_out = (size_t)(5 * K + 2) * sizeof(double);
+    size_t limit = (size_t)2 << 30;                                   // per buffer (input chunk + its result block)
+    if (const char* e = getenv("PVX_MAX_DEVICE_BYTES")) { const long long v = atoll(e); if (v > 0) limit = (size_t)v; }
+    if (keep) {
+        if ((rc = grow_dev(&p->d_res, &p->res_cap, (size_t)nsig * F * per_frame_out)) != PVX_OK) return rc;
     }
-    char* o = (char*)dout.p;
-    double *d_f = (double*)o, *d_mag = (double*)(o + fk), *d_ph = (double*)(o + 2 * fk), *d_realph = (double*)(o + 3 * fk),
-           *d_binno = (double*)(o + 4 * fk), *d_t = (double*)(o + 5 * fk), *d_tm = (double*)(o + 5 * fk + f1);
-    const int64_t all_rows = nsig * (F + 1);
+    {
+        if (!p->d_prev) PVX_HIP_CHECK(hipMalloc((void**)&p->d_prev, sizeof(double) * 2 * (size_t)(p->N2 > 0 ? p->N2 : 1)));
+    }
+    if (prev0) PVX_HIP_CHECK(hipMemcpyAsync(p->d_prev, prev0, sizeof(double) * 2 * p->N2, hipMemcpyHostToDevice, s));
+
+    // ---- chunking: units are frames of the one signal, or whole signals of a batch
+    const bool by_frames = nsig == 1;
+    const int64_t units = by_frames ? F : nsig;
+    int64_t per_chunk;
+    if (by_frames) {
+        const size_t fixed = (size_t)p->nfft * es;
+        const size_t per = (size_t)p->hop * es + (keep ? 0 : per_frame_out);
+        per_chunk = limit > fixed + per ? (int64_t)((limit - fixed) / per) : 1;
+    } else {
+        const size_t per = (size_t)sig_stride * es + (keep ? 0 : (size_t)F * per_frame_out);
+        per_chunk = (int64_t)(limit / per);
+        if (per_chunk < 1) {
+            // one signal of the batch does not fit: run the signals one by one through the frame chunking
+            if (last_spec || prev0) { pvx_set_error("prev0 / last_spec need nsig == 1"); return PVX_ERR_INVALID; }
+            for (int64_t b = 0; b < nsig; b++) {
+                HostOut hb;
+                const size_t o1 = (size_t)b * F, ok = o1 * K;
+                if (!keep) { hb.f = ho->f + ok; hb.mag = ho->mag + ok; hb.ph = ho->ph + ok; hb.realph = ho->realph + ok; hb.binno = ho->binno + ok;
+                             hb.t = ho->t ? ho->t + o1 : nullptr; hb.totalmag = ho->totalmag ? ho->totalmag + o1 : nullptr; }
+                if (keep) { pvx_set_error("a signal of this batch exceeds PVX_MAX_DEVICE_BYTES: resident results need nsig == 1 for it"); return PVX_ERR_UNSUPPORTED; }
+                const int64_t r = analyze_host(p, (const char*)x + (size_t)b * sig_stride * es, x_dtype, nsamp, 1, nsamp, &hb, nullptr, nullptr, false);
+                if (r < 0) return r;
+            }
+            return F;
+        }
+    }
+    if (per_chunk < 1) per_chunk = 1;
+    if (per_chunk > units) per_chunk = units;
+    const int64_t nchunks = (units + per_chunk - 1) / per_chunk;
+    const size_t total_in = (size_t)((nsig - 1) * sig_stride + nsamp) * es;
+    const size_t total_out = (size_t)nsig * F * per_frame_out;
+    const bool small = nchunks == 1 && total_in + (keep ? 0 : total_out) <= kSmallCall;
+
+    auto chunk_geom = [&](int64_t c, int64_t& u0, int64_t& u1, size_t& in_off, size_t& in_bytes, int64_t& c_nsamp, int64_t& c_nsig, int64_t& c_frames) {
+        u0 = c * per_chunk; u1 = u0 + per_chunk < units ? u0 + per_chunk : units;
+        if (by_frames) {
+            in_off = (size_t)u0 * p->hop * es;
+            // frames u0 .. u1-1 need samples [u0 hop, (u1-1) hop + nfft]: nframes() is strict (PV.py:224-225), one more sample
+            c_nsamp = (u1 - 1 - u0) * (int64_t)p->hop + p->nfft + 1;
+            if ((int64_t)u0 * p->hop + c_nsamp > nsamp) c_nsamp = nsamp - u0 * (int64_t)p->hop;
+            in_bytes = (size_t)c_nsamp * es;
+            c_nsig = 1; c_frames = u1 - u0;
+        } else {
+            in_off = (size_t)u0 * sig_stride * es;
+            c_nsig = u1 - u0; c_nsamp = nsamp; c_frames = (u1 - u0) * F;
+            in_bytes = (size_t)((c_nsig - 1) * sig_stride + nsamp) * es;
+        }
+    };
+    // results of chunk c (in d_out[c & 1]) -> the caller's arrays
+    auto fetch = [&](int64_t c) -> int {
+        int64_t u0, u1, c_nsamp, c_nsig, c_frames; size_t in_off, in_bytes;
+        chunk_geom(c, u0, u1, in_off, in_bytes, c_nsamp, c_nsig, c_frames);
+        PVX_HIP_CHECK(hipEventSynchronize(p->ev_done[c & 1]));
+        const HostOut d = block_ptrs(p->d_out[c & 1], c_frames, K);
+        const size_t r0 = by_frames ? (size_t)u0 : (size_t)u0 * F;
+        const size_t nk = (size_t)c_frames * K * sizeof(double), n1 = (size_t)c_frames * sizeof(double);
+        PVX_HIP_CHECK(hipMemcpy(ho->f + r0 * K, d.f, nk, hipMemcpyDeviceToHost));
+        PVX_HIP_CHECK(hipMemcpy(ho->mag + r0 * K, d.mag, nk, hipMemcpyDeviceToHost));
+        PVX_HIP_CHECK(hipMemcpy(ho->ph + r0 * K, d.ph, nk, hipMemcpyDeviceToHost));
+        PVX_HIP_CHECK(hipMemcpy(ho->realph + r0 * K, d.realph, nk, hipMemcpyDeviceToHost));
+        PVX_HIP_CHECK(hipMemcpy(ho->binno + r0 * K, d.binno, nk, hipMemcpyDeviceToHost));
+        if (ho->totalmag) PVX_HIP_CHECK(hipMemcpy(ho->totalmag + r0, d.totalmag, n1, hipMemcpyDeviceToHost));
+        return PVX_OK;
+    };
+
     p->progress_live = true;
-    rc = analyze_rows(p, dx.p, x_dtype, nsamp, nsig, sig_stride, F, d_f, d_mag, d_ph, d_realph, d_binno, d_t, d_tm,
-                      (const double*)dprev.p, nullptr, last_spec ? all_rows - 1 : -1);
+    int64_t last_rows = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const int b = (int)(c & 1);
+        int64_t u0, u1, c_nsamp, c_nsig, c_frames; size_t in_off, in_bytes;
+        chunk_geom(c, u0, u1, in_off, in_bytes, c_nsamp, c_nsig, c_frames);
+        if (c >= 2) {
+            // chunk c-2 used these buffers: its kernels are done (and its results fetched, below)
+            if ((rc = (int)hipEventSynchronize(p->ev_done[b])) != 0) { pvx_set_error("hipEventSynchronize failed"); p->progress_live = false; return PVX_ERR_HIP; }
+        }
+        if ((rc = grow_dev(&p->d_in[b], &p->in_cap[b], in_bytes)) != PVX_OK) { p->progress_live = false; return rc; }
+        double* ob = nullptr;
+        if (!keep) {
+            if ((rc = grow_dev(&p->d_out[b], &p->out_cap[b], (size_t)c_frames * per_frame_out)) != PVX_OK) { p->progress_live = false; return rc; }
+            ob = p->d_out[b];
+        }
+        if (small) {
+            if ((rc = grow_pin(p, total_in + total_out)) != PVX_OK) { p->progress_live = false; return rc; }
+            memcpy(p->h_pin, (const char*)x + in_off, in_bytes);
+            PVX_HIP_CHECK(hipMemcpyAsync(p->d_in[b], p->h_pin, in_bytes, hipMemcpyHostToDevice, s));
+        } else {
+            // pageable, synchronous for the host -- and concurrent with the kernels of chunk c-1 on the plan's stream
+            PVX_HIP_CHECK(hipMemcpy(p->d_in[b], (const char*)x + in_off, in_bytes, hipMemcpyHostToDevice));
+        }
+        HostOut d;
+        if (keep) {
+            const HostOut all = block_ptrs(p->d_res, nsig * F, K);
+            const size_t r0 = by_frames ? (size_t)u0 : (size_t)u0 * F;
+            d.f = all.f + r0 * K; d.mag = all.mag + r0 * K; d.ph = all.ph + r0 * K; d.realph = all.realph + r0 * K;
+            d.binno = all.binno + r0 * K; d.t = nullptr; d.totalmag = all.totalmag + r0;
+        } else {
+            d = block_ptrs(ob, c_frames, K);
+            d.t = nullptr;
+        }
+        const bool want_spec = (c + 1 < nchunks && by_frames) || (last_spec && c + 1 == nchunks);
+        const double* dprev = (c > 0 && by_frames) || prev0 ? p->d_prev : nullptr;
+        last_rows = c_nsig * (c_frames / c_nsig + 1);
+        rc = analyze_rows(p, p->d_in[b], x_dtype, c_nsamp, c_nsig, by_frames ? c_nsamp : sig_stride, c_frames / c_nsig,
+                          d.f, d.mag, d.ph, d.realph, d.binno, d.t, d.totalmag, dprev, s, want_spec ? last_rows - 1 : -1);
+        if (rc == PVX_OK && c + 1 < nchunks && by_frames) rc = carry_spectrum(p, last_rows, s);
+        if (rc != PVX_OK) { p->progress_live = false; return rc; }
+        PVX_HIP_CHECK(hipEventRecord(p->ev_done[b], s));
+        if (!keep && !small && c >= 1) {
+            if ((rc = fetch(c - 1)) != PVX_OK) { p->progress_live = false; return rc; }      // under the kernels of chunk c
+        }
+        if (p->progress_fn && nchunks > 1 && c + 1 < nchunks) {
+            const int64_t done = by_frames ? u1 : u1 * F;
+            p->progress_fn(done, nsig * F, p->progress_user);
+        }
+    }
     p->progress_live = false;
-    if (rc != PVX_OK) return rc;
-    PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
-    PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(mag, d_mag, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(ph, d_ph, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(realph, d_realph, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(binno, d_binno, fk, hipMemcpyDeviceToHost));
-    if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
-    if (totalmag) PVX_HIP_CHECK(hipMemcpy(totalmag, d_tm, f1, hipMemcpyDeviceToHost));
+    // ---- tail: last chunk's results, frame times, the last spectrum
+    if (keep) {
+        const HostOut all = block_ptrs(p->d_res, nsig * F, K);
+        if ((rc = pvx_launch_fill_t(all.t, F, nsig, p->hop, p->nfft, p->sr, s)) != PVX_OK) return rc;
+        p->res_F = F; p->res_nsig = nsig; p->res_valid = true;
+    } else if (small) {
+        // one D2H of the whole block into pinned memory, one synchronisation, then plain memcpys
+        double* hb = (double*)((char*)p->h_pin + total_in);
+        PVX_HIP_CHECK(hipMemcpyAsync(hb, p->d_out[0], total_out, hipMemcpyDeviceToHost, s));
+        PVX_HIP_CHECK(hipStreamSynchronize(s));
+        const HostOut h = block_ptrs(hb, nsig * F, K);
+        const size_t nk = (size_t)nsig * F * K * sizeof(double), n1 = (size_t)nsig * F * sizeof(double);
+        memcpy(ho->f, h.f, nk); memcpy(ho->mag, h.mag, nk); memcpy(ho->ph, h.ph, nk); memcpy(ho->realph, h.realph, nk);
+        memcpy(ho->binno, h.binno, nk);
+        if (ho->totalmag) memcpy(ho->totalmag, h.totalmag, n1);
+    } else {
+        if ((rc = fetch(nchunks - 1)) != PVX_OK) return rc;
+    }
+    if (!keep && ho->t) {
+        for (int64_t b = 0; b < nsig; b++)
+            for (int64_t fr = 0; fr < F; fr++) ho->t[b * F + fr] = ((double)(fr * (int64_t)p->hop) + p->nfft / 2.0) / p->sr;   // PV.py:247
+    }
+    PVX_HIP_CHECK(hipStreamSynchronize(s));
     if (last_spec && p->fft_mode != 0) {
         std::vector<float> tmp(2 * (size_t)p->N2);
         PVX_HIP_CHECK(hipMemcpy(tmp.data(), p->d_specrow, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = (double)tmp[i];
     } else if (last_spec) {
         // the last chunk's last row is still in the spectrum workspace
-        const int64_t total_rows = nsig * (F + 1);
-        const int64_t lastR0 = ((total_rows - 1) / p->max_rows) * p->max_rows;
-        const int64_t wsrow = (total_rows - 1) - lastR0 + 1;
+        const int64_t lastR0 = ((last_rows - 1) / p->max_rows) * p->max_rows;
+        const int64_t wsrow = (last_rows - 1) - lastR0 + 1;
         const size_t rs = real_size(p->precision);
         std::vector<unsigned char> tmp((size_t)p->N2 * 2 * rs);
         PVX_HIP_CHECK(hipMemcpy(tmp.data(), (char*)p->d_spec + (size_t)wsrow * p->ldo * 2 * rs, tmp.size(), hipMemcpyDeviceToHost));
@@ -512,6 +739,45 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
     }
     if (p->progress_fn) p->progress_fn(nsig * F, nsig * F, p->progress_user);
     return F;
+}
+
+extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                               double* f, double* mag, double* ph, double* realph, double* binno, double* t,
+                               double* totalmag, const double* prev0, double* last_spec) {
+    HostOut ho = {f, mag, ph, realph, binno, t, totalmag};
+    return analyze_host(p, x, x_dtype, nsamp, nsig, sig_stride, &ho, prev0, last_spec, false);
+}
+
+// ---- resident results ---------------------------------------------------------------------------
+extern "C" int64_t pvx_analyze_resident(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig,
+                                        int64_t sig_stride, const double* prev0, double* last_spec) {
+    return analyze_host(p, x, x_dtype, nsamp, nsig, sig_stride, nullptr, prev0, last_spec, true);
+}
+
+static int need_resident(pvx_plan* p) {
+    if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    if (!p->res_valid) { pvx_set_error("the plan holds no resident results (pvx_analyze_resident first)"); return PVX_ERR_INVALID; }
+    return pvx_require_device();
+}
+
+extern "C" int pvx_resident_fetch(pvx_plan* p, int which, double* host) {
+    int rc = need_resident(p);
+    if (rc != PVX_OK) return rc;
+    if (!host || which < 0 || which > 6) { pvx_set_error("bad fetch argument"); return PVX_ERR_INVALID; }
+    const int64_t rows = p->res_nsig * p->res_F;
+    const HostOut all = block_ptrs(p->d_res, rows, p->npks);
+    const double* src[7] = {all.f, all.mag, all.ph, all.realph, all.binno, all.t, all.totalmag};
+    const size_t bytes = (size_t)rows * (which < 5 ? p->npks : 1) * sizeof(double);
+    PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+    PVX_HIP_CHECK(hipMemcpy(host, src[which], bytes, hipMemcpyDeviceToHost));
+    return PVX_OK;
+}
+
+extern "C" const double* pvx_resident_ptr(pvx_plan* p, int which) {
+    if (!p || !p->res_valid || which < 0 || which > 6) return nullptr;
+    const HostOut all = block_ptrs(p->d_res, p->res_nsig * p->res_F, p->npks);
+    const double* src[7] = {all.f, all.mag, all.ph, all.realph, all.binno, all.t, all.totalmag};
+    return src[which];
 }
 
 extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const int64_t* pos, int64_t nfr,
@@ -586,6 +852,47 @@ extern "C" int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks,
 }
 
 // ---- tracker: PV.toSinSum (PV.py:299-322) ---------------------------------------------------
+static size_t track_ws_bytes(int64_t F, int K) {
+    const size_t n = (size_t)F * K;
+    // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials, ambiguous, maxend int64; succ [F*K]
+    size_t off = n * 4 * 3 + (size_t)F * 4;
+    off = (off + 7) & ~(size_t)7;
+    return off + ((size_t)F + 1) * 8 + 24 + n;
+}
+
+// the tracker on device arrays with a caller-provided workspace of track_ws_bytes(F, K); returns P
+static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K, double maxpitchjmp,
+                        int32_t* d_partial_id, int32_t* d_part_start, int32_t* d_part_len, int64_t cap, char* w,
+                        hipStream_t s, int64_t* maxend) {
+    const size_t n = (size_t)F * K;
+    const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
+    const size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
+    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 24;
+    TrackParams tp;
+    tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
+    tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
+    tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
+    tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
+    tp.npartials = (int64_t*)(w + off_np);
+    tp.ambiguous = tp.npartials + 1;
+    tp.maxend = tp.npartials + 2;
+    int rc = pvx_launch_track(tp, s);
+    if (rc != PVX_OK) return rc;
+    int64_t pa[3] = {0, 0, -1};
+    PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+    PVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
+        // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
+        // table with the sequential kernel, which has the partial indices at hand
+        if ((rc = pvx_launch_track_sequential(tp, s)) != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+        PVX_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (maxend) *maxend = pa[2];
+    if (pa[0] > cap) { pvx_set_error("%lld partials exceed the table capacity %lld", (long long)pa[0], (long long)cap); return PVX_ERR_SIZE; }
+    return pa[0];
+}
+
 extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t F, int K, double maxpitchjmp,
                                  int32_t* d_partial_id, int32_t* d_part_start, int32_t* d_part_len, int64_t cap,
                                  void* stream) {
@@ -594,37 +901,124 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     if (F < 0 || K <= 0 || cap < 0) { pvx_set_error("bad tracker argument"); return PVX_ERR_INVALID; }
     if (F == 0) return 0;
     if (!d_f || !d_mag || !d_partial_id || !d_part_start || !d_part_len) { pvx_set_error("null tracker array"); return PVX_ERR_INVALID; }
-    hipStream_t s = (hipStream_t)stream;
-    const size_t n = (size_t)F * K;
     DevBuf ws;
-    // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials int64
-    const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
-    size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
-    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 16, total = off_succ + n;
-    if ((rc = ws.alloc(total)) != PVX_OK) return rc;
-    char* w = (char*)ws.p;
-    TrackParams tp;
-    tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
-    tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
-    tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
-    tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
-    tp.npartials = (int64_t*)(w + off_np);
-    tp.ambiguous = tp.npartials + 1;
-    rc = pvx_launch_track(tp, s);
+    if ((rc = ws.alloc(track_ws_bytes(F, K))) != PVX_OK) return rc;
+    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, (char*)ws.p, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
+                             int64_t F, int K, const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
+                             double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                             double* d_w, int64_t wlen, void* stream, int flags);
+extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge);
+
+// ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
+extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
+    int rc = need_resident(p);
     if (rc != PVX_OK) return rc;
-    int64_t pa[2] = {0, 0};
-    PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 16, hipMemcpyDeviceToHost, s));
-    PVX_HIP_CHECK(hipStreamSynchronize(s));
-    if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
-        // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
-        // table with the sequential kernel, which has the partial indices at hand
-        if ((rc = pvx_launch_track_sequential(tp, s)) != PVX_OK) return rc;
-        PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 8, hipMemcpyDeviceToHost, s));
-        PVX_HIP_CHECK(hipStreamSynchronize(s));
+    if (p->res_nsig != 1) { pvx_set_error("the tracker works on one signal (resident results hold %lld)", (long long)p->res_nsig); return PVX_ERR_INVALID; }
+    const int64_t F = p->res_F;
+    const int K = p->npks;
+    const size_t n = (size_t)F * K;
+    if (n > p->trk_cap) {
+        if (p->d_pid) (void)hipFree(p->d_pid);
+        if (p->d_pst) (void)hipFree(p->d_pst);
+        if (p->d_pln) (void)hipFree(p->d_pln);
+        p->d_pid = p->d_pst = p->d_pln = nullptr; p->trk_cap = 0;
+        if (hipMalloc((void**)&p->d_pid, n * 4) != hipSuccess || hipMalloc((void**)&p->d_pst, n * 4) != hipSuccess ||
+            hipMalloc((void**)&p->d_pln, n * 4) != hipSuccess) { pvx_set_error("hipMalloc of the partial table failed"); return PVX_ERR_ALLOC; }
+        p->trk_cap = n;
     }
-    int64_t P = pa[0];
-    if (P > cap) { pvx_set_error("%lld partials exceed the table capacity %lld", (long long)P, (long long)cap); return PVX_ERR_SIZE; }
+    if ((rc = grow_dev(&p->d_tws, &p->tws_cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
+    const HostOut all = block_ptrs(p->d_res, F, K);
+    int64_t maxend = -1;
+    const int64_t P = track_on(all.f, all.mag, F, K, maxpitchjmp, p->d_pid, p->d_pst, p->d_pln, (int64_t)n, (char*)p->d_tws, p->s_host, &maxend);
+    if (P < 0) return P;
+    p->res_P = P; p->res_maxend = maxend;
+    if (max_end_frame) *max_end_frame = maxend;
     return P;
+}
+
+extern "C" int pvx_resident_fetch_table(pvx_plan* p, int32_t* partial_id, int32_t* part_start, int32_t* part_len) {
+    int rc = need_resident(p);
+    if (rc != PVX_OK) return rc;
+    if (p->res_P < 0) { pvx_set_error("no resident partial table (pvx_track_resident first)"); return PVX_ERR_INVALID; }
+    PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+    if (partial_id) PVX_HIP_CHECK(hipMemcpy(partial_id, p->d_pid, (size_t)p->res_F * p->npks * 4, hipMemcpyDeviceToHost));
+    if (part_start && p->res_P) PVX_HIP_CHECK(hipMemcpy(part_start, p->d_pst, (size_t)p->res_P * 4, hipMemcpyDeviceToHost));
+    if (part_len && p->res_P) PVX_HIP_CHECK(hipMemcpy(part_len, p->d_pln, (size_t)p->res_P * 4, hipMemcpyDeviceToHost));
+    return PVX_OK;
+}
+
+extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double edge, int minframes, double* w, int64_t wlen) {
+    int rc = need_resident(p);
+    if (rc != PVX_OK) return rc;
+    if (p->res_P < 0) { pvx_set_error("no resident partial table (pvx_track_resident first)"); return PVX_ERR_INVALID; }
+    if (!w || hop_synth <= 0 || !(sr > 0)) { pvx_set_error("bad resynthesis argument"); return PVX_ERR_INVALID; }
+    if (p->res_P == 0) { pvx_set_error("max() arg is an empty sequence"); return PVX_ERR_INVALID; }          // PV.py:1059
+    const int64_t need = pvx_synth_len(p->res_maxend, p->nfft, p->hop, hop_synth, edge);
+    if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
+    if ((rc = grow_dev(&p->d_w, &p->w_cap, (size_t)wlen * 8)) != PVX_OK) return rc;
+    const HostOut all = block_ptrs(p->d_res, p->res_F, p->npks);
+    rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
+                             p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0);
+    if (rc != PVX_OK) return rc;
+    const size_t bytes = (size_t)wlen * 8;
+    if (bytes <= kSmallCall) {
+        if ((rc = grow_pin(p, bytes)) != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_w, bytes, hipMemcpyDeviceToHost, p->s_host));
+        PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+        memcpy(w, p->h_pin, bytes);
+    } else {
+        PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+        PVX_HIP_CHECK(hipMemcpy(w, p->d_w, bytes, hipMemcpyDeviceToHost));
+    }
+    return PVX_OK;
+}
+
+// PV.calc_f0 (PV.py:371-391) on the resident arrays: fm float64 [F], idx int32 [F] come back, nothing else moves
+extern "C" int pvx_f0_resident(pvx_plan* p, double fmin, double fmax, double thr, double* fm, int32_t* idx) {
+    int rc = need_resident(p);
+    if (rc != PVX_OK) return rc;
+    if (!fm || !idx) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    const int64_t rows = p->res_nsig * p->res_F;
+    if ((rc = grow_dev(&p->d_desc, &p->desc_cap, (size_t)rows * 12)) != PVX_OK) return rc;
+    const HostOut all = block_ptrs(p->d_res, rows, p->npks);
+    double* d_fm = (double*)p->d_desc;
+    int32_t* d_im = (int32_t*)(d_fm + rows);
+    if ((rc = pvx_launch_f0(all.f, all.mag, rows, p->npks, fmin, fmax, thr, d_fm, d_im, p->s_host)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+    PVX_HIP_CHECK(hipMemcpy(fm, d_fm, (size_t)rows * 8, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(idx, d_im, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    return PVX_OK;
+}
+
+// PV.calc_harmonic_power (PV.py:266-297) on the resident arrays: hpower, nharmonics float64 [F, K].
+// Returns PVX_ERR_SIZE where the reference raises IndexError (a valid peak slot >= number of frames, PV.py:278).
+extern "C" int pvx_harmonic_power_resident(pvx_plan* p, double f_threshold, double* hpower, double* nharm) {
+    int rc = need_resident(p);
+    if (rc != PVX_OK) return rc;
+    if (!hpower || !nharm) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
+    if (p->res_nsig != 1) { pvx_set_error("calc_harmonic_power works on one signal"); return PVX_ERR_INVALID; }
+    const int64_t F = p->res_F;
+    const int K = p->npks;
+    const size_t n = (size_t)F * K;
+    if ((rc = grow_dev(&p->d_desc, &p->desc_cap, n * 16 + (size_t)K * 8 + 16)) != PVX_OK) return rc;
+    const HostOut all = block_ptrs(p->d_res, F, K);
+    double* d_hp = (double*)p->d_desc;
+    double* d_nh = d_hp + n;
+    double* d_rp = d_nh + n;
+    int32_t* d_top = (int32_t*)(d_rp + K);
+    if ((rc = pvx_launch_hpower_rows(all.f, all.mag, F, K, d_rp, d_top, p->s_host)) != PVX_OK) return rc;
+    int32_t top = -1;
+    PVX_HIP_CHECK(hipMemcpyAsync(&top, d_top, 4, hipMemcpyDeviceToHost, p->s_host));
+    PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+    if (top >= F) { pvx_set_error("index %d is out of bounds for axis 0 with size %lld", (int)top, (long long)F); return PVX_ERR_SIZE; }
+    if ((rc = pvx_launch_hpower(all.f, F, K, f_threshold, d_rp, d_hp, d_nh, p->s_host)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+    PVX_HIP_CHECK(hipMemcpy(hpower, d_hp, n * 8, hipMemcpyDeviceToHost));
+    PVX_HIP_CHECK(hipMemcpy(nharm, d_nh, n * 8, hipMemcpyDeviceToHost));
+    return PVX_OK;
 }
 
 extern "C" int64_t pvx_track(const double* f, const double* mag, int64_t F, int K, double maxpitchjmp,
@@ -930,10 +1324,10 @@ extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analys
     return (max_end_frame + 2) * (int64_t)hop_synth + 2 * edgsamp - edgsamp;   // len(w[edgsamp:]), PV.py:1059, 1070
 }
 
-extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
+extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
                              int64_t F, int K, const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
                              double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
-                             double* d_w, int64_t wlen, void* stream) {
+                             double* d_w, int64_t wlen, void* stream, int flags) {
     int rc = pvx_require_device();
     if (rc != PVX_OK) return rc;
     if (F <= 0 || K <= 0 || P <= 0 || nfft <= 0 || hop_analysis <= 0 || hop_synth <= 0 || !(sr > 0) || wlen <= 0 || !(edge >= 0)) {
@@ -945,13 +1339,21 @@ extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const doubl
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
-    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr;
+    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr; sp.no_phcor = (flags & PVX_SYNTH_NO_PHCOR) ? 1 : 0;
     return pvx_launch_synth(sp, (hipStream_t)stream);
 }
 
-extern "C" int pvx_synth(const double* f, const double* mag, const double* realph, const int32_t* partial_id, int64_t F,
+extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
+                             int64_t F, int K, const int32_t* d_part_start, const int32_t* d_part_len, int64_t P,
+                             double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
+                             double* d_w, int64_t wlen, void* stream) {
+    return pvx_synth_dev_flags(d_f, d_mag, d_realph, d_partial_id, F, K, d_part_start, d_part_len, P, sr, nfft, hop_analysis,
+                               hop_synth, edge, minframes, d_w, wlen, stream, 0);
+}
+
+extern "C" int pvx_synth_flags(const double* f, const double* mag, const double* realph, const int32_t* partial_id, int64_t F,
                          int K, const int32_t* part_start, const int32_t* part_len, int64_t P, double sr, int nfft,
-                         int hop_analysis, int hop_synth, double edge, int minframes, double* w, int64_t wlen) {
+                         int hop_analysis, int hop_synth, double edge, int minframes, double* w, int64_t wlen, int flags) {
     int rc = pvx_require_device();
     if (rc != PVX_OK) return rc;
     if (F <= 0 || K <= 0 || P <= 0 || !f || !mag || !realph || !partial_id || !part_start || !part_len || !w) {
@@ -974,11 +1376,18 @@ extern "C" int pvx_synth(const double* f, const double* mag, const double* realp
     PVX_HIP_CHECK(hipMemcpy(dpid.p, partial_id, n * 4, hipMemcpyHostToDevice));
     PVX_HIP_CHECK(hipMemcpy(dst.p, part_start, (size_t)P * 4, hipMemcpyHostToDevice));
     PVX_HIP_CHECK(hipMemcpy(dln.p, part_len, (size_t)P * 4, hipMemcpyHostToDevice));
-    rc = pvx_synth_dev((const double*)df.p, (const double*)dm.p, (const double*)dr.p, (const int32_t*)dpid.p, F, K,
-                       (const int32_t*)dst.p, (const int32_t*)dln.p, P, sr, nfft, hop_analysis, hop_synth, edge, minframes,
-                       (double*)dw.p, wlen, nullptr);
+    rc = pvx_synth_dev_flags((const double*)df.p, (const double*)dm.p, (const double*)dr.p, (const int32_t*)dpid.p, F, K,
+                             (const int32_t*)dst.p, (const int32_t*)dln.p, P, sr, nfft, hop_analysis, hop_synth, edge, minframes,
+                             (double*)dw.p, wlen, nullptr, flags);
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
     PVX_HIP_CHECK(hipMemcpy(w, dw.p, (size_t)wlen * 8, hipMemcpyDeviceToHost));
     return PVX_OK;
+}
+
+extern "C" int pvx_synth(const double* f, const double* mag, const double* realph, const int32_t* partial_id, int64_t F,
+                         int K, const int32_t* part_start, const int32_t* part_len, int64_t P, double sr, int nfft,
+                         int hop_analysis, int hop_synth, double edge, int minframes, double* w, int64_t wlen) {
+    return pvx_synth_flags(f, mag, realph, partial_id, F, K, part_start, part_len, P, sr, nfft, hop_analysis, hop_synth, edge,
+                           minframes, w, wlen, 0);
 }

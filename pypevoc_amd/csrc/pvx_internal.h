@@ -120,6 +120,7 @@ struct TrackParams {
     int32_t* root;        // [F][K]  flattened index of the first point of the slot's partial
     unsigned char* succ;  // [F][K]  1 if a peak of the next frame continues this one
     int64_t* npartials;   // [1]
+    int64_t* maxend;      // [1]  last frame that holds a point of any partial = max(SinSum.end) (PV.py:1059)
     int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
                           //      the previous partials would decide an assignment (k_track.hip header)
 };
@@ -137,6 +138,7 @@ struct SynthParams {
     double* w;
     int64_t wlen;
     int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
+    int no_phcor;         // PVX_SYNTH_NO_PHCOR: fstep=None partials (PV.py:710-713)
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
 
@@ -182,3 +184,12 @@ struct WireParams {
 };
 size_t pvx_wire_block_bytes(int64_t rows, int K, int precision);
 int pvx_launch_wire(const WireParams& p, bool pack, hipStream_t s);
+
+// frame descriptors and helpers on the result arrays (k_desc.hip)
+int pvx_launch_f0(const double* f, const double* mag, int64_t F, int K, double fmin, double fmax, double thr, double* fm,
+                  int32_t* im, hipStream_t s);
+int pvx_launch_hpower_rows(const double* f, const double* mag, int64_t F, int K, double* rowpow, int32_t* top, hipStream_t s);
+int pvx_launch_hpower(const double* f, int64_t F, int K, double f_threshold, const double* rowpow, double* hpower,
+                      double* nharm, hipStream_t s);
+int pvx_launch_fill_t(double* t, int64_t F, int64_t nsig, int hop, int nfft, double sr, hipStream_t s);
+int pvx_launch_spec_to_prev(double* dst, const void* src, int n, int src_is_float, hipStream_t s);

@@ -14,6 +14,10 @@
         kind="stable", and prints how often the two sorts disagree on this host.
     With e = 2**-6 and c a multiple of 64: a new peak at (1 - e*e) c is exactly 17.312 * e semitones from
     partials at (1 - e) c and (1 + e) c (both quotients are exact in float64).
+
+  R1_regpartial_nofstep   RegPartial(istart, overlap=0.25, fstep=None).synth(sr, hop, edge) on the longest
+                    partial of fixture G4 and with a time-stretching hop: the branch without frequency-slope
+                    phase correction (PVAnalysis.py:710-713), which SinSum never takes (it always sets fstep).
 """
 import os
 import sys
@@ -87,6 +91,28 @@ def main():
     np.savez_compressed(path, f=f, mag=mag, ph=ph, realph=realph, sr=np.float64(sr), nfft=np.int64(nfft), hop=np.int64(hop),
                         part_start=start, part_len=plen, part_slot=slots)
     print("T1_tracker_ties: F=%d K=%d partials=%d; start=%s len=%s" % (f.shape[0], f.shape[1], len(start), start.tolist(), plen.tolist()))
+
+    # ---- R1: RegPartial without fstep
+    g = np.load(os.path.join(HERE, "G4_harm8_vibrato.npz"))
+    p = PV(np.zeros(int(g["nfft"]) + int(g["hop"]) * g["f"].shape[0] + 1), float(g["sr"]), nfft=int(g["nfft"]), hop=int(g["hop"]),
+           npks=g["f"].shape[1], progress=False)
+    p.f, p.mag, p.ph, p.realph, p.nframes = g["f"], g["mag"], g["ph"], g["realph"], g["f"].shape[0]
+    ss = p.toSinSum()
+    src = max(ss.partial, key=lambda pp: len(pp.f))
+    npt = 40                                                     # the first 40 points keep the fixture small
+    out = dict(sr=g["sr"], overlap=np.float64(src.overlap), start_idx=np.int64(src.start_idx),
+               f=np.array(src.f[:npt]), mag=np.array(src.mag[:npt]), ph=np.array(src.ph[:npt]), realph=np.array(src.realph[:npt]))
+    for hop_s, edge in ((512, 0.5), (700, 1.0)):
+        part = PVA.RegPartial(src.start_idx, overlap=src.overlap, fstep=None)
+        for a, b, c, d in zip(out["f"], out["mag"], out["ph"], out["realph"]):
+            part.append_point(a, b, c, realph=d)
+        sig, first = part.synth(float(g["sr"]), hop_s, edge=edge)
+        out["sig_hop%d" % hop_s] = sig
+        out["first_hop%d" % hop_s] = np.int64(first)
+        out["edge_hop%d" % hop_s] = np.float64(edge)
+    path = os.path.join(HERE, "R1_regpartial_nofstep.npz")
+    np.savez_compressed(path, **out)
+    print("R1_regpartial_nofstep: %d points -> %.0f KB" % (npt, os.path.getsize(path) / 1024.0))
 
 
 if __name__ == "__main__":

@@ -117,32 +117,6 @@ def test_frame_descriptors_match_reference():
     assert np.allclose(p.hpower, g["hpower_b"], rtol=1e-13, atol=0)
 
 
-def test_sinsum_host_bookkeeping_matches_reference():
-    """SinSum.add_point (single-point slow path), get_part_data_around_freq and RegPartial.prepend_point
-    are host bookkeeping in the reference and here; pinned by values captured from the reference (D2)."""
-    import pypevoc_amd
-    g4 = load_golden("G4_harm8_vibrato")
-    d = np.load(os.path.join(ROOT, "tests", "golden", "D2_bookkeeping.npz"))
-    ss = pypevoc_amd.SinSum(44100.0, nfft=2048, hop=512)
-    for fr in range(30):
-        for k in range(g4["f"].shape[1]):
-            if g4["f"][fr, k] > 0:
-                ss.add_point(fr, float(g4["f"][fr, k]), float(g4["mag"][fr, k]), float(g4["ph"][fr, k]))
-    assert np.array_equal(np.array(ss.st), d["st"]) and np.array_equal(np.array(ss.end), d["end"])
-    assert np.array_equal([p.start_idx for p in ss.partial], d["start_idx"])
-    assert np.array_equal([len(p.f) for p in ss.partial], d["plen"])
-    for k in ("f", "mag", "ph"):
-        assert np.array_equal(np.concatenate([getattr(p, k) for p in ss.partial]), d[k])
-    for fc in (220, 440, 1000):
-        got = ss.get_part_data_around_freq(float(fc))
-        for name, a in zip(("t", "f", "mag", "ph"), got):
-            assert np.array_equal(a, d["around%d_%s" % (fc, name)]), (fc, name)
-    p0 = ss.partial[0]
-    s0, f0 = p0.start_idx, list(p0.f)
-    p0.prepend_point(1.0, 2.0, 3.0)
-    assert p0.start_idx == s0 - 1 and p0.f == [1.0] + f0 and p0.mag[0] == 2.0 and p0.ph[0] == 3.0
-
-
 def test_generated_isa_has_no_asm_to_dpp_hazard():
     """The packed complex primitives of pvx_cplx.h are inline asm; the compiler's hazard recogniser does
     not see inside them, so a DPP move reading one of their results too early would silently read a stale

@@ -482,6 +482,20 @@ def test_regpartial_synth(amd, oracle):
     assert np.abs(sig - exp).max() <= 1e-10
 
 
+def test_regpartial_synth_without_fstep_matches_reference(amd):
+    """Fixture R1 (reference-generated): RegPartial(..., fstep=None).synth -- no frequency-slope phase correction
+    (PVAnalysis.py:710-713) -- at the analysis hop and with a time-stretching hop."""
+    g = dict(np.load(os.path.join(GOLDEN, "R1_regpartial_nofstep.npz")))
+    for hop_s in (512, 700):
+        part = amd.RegPartial(int(g["start_idx"]), overlap=float(g["overlap"]), fstep=None)
+        for a, b, c, d in zip(g["f"], g["mag"], g["ph"], g["realph"]):
+            part.append_point(a, b, c, realph=d)
+        sig, first = part.synth(float(g["sr"]), hop_s, edge=float(g["edge_hop%d" % hop_s]))
+        ref = g["sig_hop%d" % hop_s]
+        assert first == int(g["first_hop%d" % hop_s]) and sig.shape == ref.shape
+        assert np.abs(sig - ref).max() <= 1e-10
+
+
 # ------------------------------------------------------------------ (c) full-size properties
 def _c2_signal(seconds=600, sr=44100):
     """G4 generator, float32."""
@@ -928,33 +942,101 @@ def test_library_first_then_torch_in_a_fresh_process():
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-# ------------------------------------------------------------------ the reference's own PeakFinder unit tests
-def _parabolic_peak(max_pos=1.0, max_val=1.0, n=3, a=-1.):
-    x = np.arange(n)
-    b = -max_pos * 2 * a
-    c = max_val - a * max_pos * (b + max_pos)
-    return a * x * x + b * x + c
+# ------------------------------------------------------------------ host path: chunked input, resident chain, descriptors
+@pytest.mark.parametrize("nfft,hop,K,precision,mode", [(2048, 512, 8, 32, None), (2048, 333, 8, 32, 1), (4096, 1024, 12, 32, None),
+                                                        (1024, 256, 8, 64, None), (1000, 250, 6, 32, None)])
+def test_chunked_host_input_is_bitwise_the_single_shot_result(amd, monkeypatch, nfft, hop, K, precision, mode):
+    """pvx_analyze / pvx_analyze_resident take the input in chunks that fit PVX_MAX_DEVICE_BYTES and carry the
+    last spectrum from chunk to chunk on the device (PV.py:209): forced down to a handful of frames per chunk
+    (>= 3 chunks, also through an exactly silent stretch) the result is bit-identical to one launch -- for
+    every analysis kernel, both precisions, float32 / float64 / int16 input, and for a batch split by signals."""
+    rng = np.random.default_rng(31)
+    n = 60000
+    t = np.arange(n) / 44100.0
+    x = 0.3 * np.sin(2 * np.pi * 700.0 * t * (1 + 0.1 * t)) + 0.05 * rng.standard_normal(n)
+    x[20000:20000 + 3 * nfft] = 0.0
+    if mode is not None:
+        monkeypatch.setenv("PVX_FFT_MODE", str(mode))
+    for xin in (x.astype(np.float32), x, np.round(x * 20000).astype(np.int16)):
+        ref = run_pv(amd, xin, 44100.0, nfft, hop, K, precision=precision)
+        ref_arrays = {k: np.array(getattr(ref, k)) for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag")}
+        es = xin.dtype.itemsize
+        for frames_per_chunk in (7, 40):
+            monkeypatch.setenv("PVX_MAX_DEVICE_BYTES", str(nfft * es + frames_per_chunk * (hop * es + (5 * K + 2) * 8) + 8))
+            q = run_pv(amd, xin, 44100.0, nfft, hop, K, precision=precision)                  # resident results
+            for k, v in ref_arrays.items():
+                assert np.array_equal(np.array(getattr(q, k)), v), (xin.dtype, frames_per_chunk, k)
+            assert np.array_equal(q.oldfft, ref.oldfft)
+            # the streaming-back variant of the same entry point (PVBatch with one signal uses pvx_analyze)
+            b = amd.PVBatch(xin[None, :], 44100.0, nfft=nfft, hop=hop, npks=K, precision=precision).run_pv()
+            for k in ("f", "mag", "ph", "realph", "binno"):
+                assert np.array_equal(getattr(b, k)[0], ref_arrays[k]), ("stream", xin.dtype, frames_per_chunk, k)
+            monkeypatch.delenv("PVX_MAX_DEVICE_BYTES")
+    # a batch split into groups of whole signals
+    xb = np.stack([x[i * 9000:i * 9000 + 15000] for i in range(5)]).astype(np.float32)
+    full = amd.PVBatch(xb, 44100.0, nfft=nfft, hop=hop, npks=K, precision=precision).run_pv()
+    monkeypatch.setenv("PVX_MAX_DEVICE_BYTES", str(2 * (15000 * 4 + full.f.shape[1] * (5 * K + 2) * 8) + 64))
+    part = amd.PVBatch(xb, 44100.0, nfft=nfft, hop=hop, npks=K, precision=precision).run_pv()
+    for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+        assert np.array_equal(np.asarray(getattr(part, k)), np.asarray(getattr(full, k))), k
 
 
-def test_reference_peak_finder_unit_tests(amd):
-    """tests/test_peak_finder.py of the reference, case by case (findpos runs in the HIP kernel, the
-    parabolic refinement is host numpy as in the reference)."""
-    pf = amd.PeakFinder
+def test_resident_chain_equals_host_chain(amd, oracle):
+    """PV.run_pv keeps its results in HBM; toSinSum, SinSum.synth, calc_f0 and calc_harmonic_power run there
+    (pvx_track_resident / pvx_synth_resident / pvx_f0_resident / pvx_harmonic_power_resident).  The same chain
+    through host arrays (attributes assigned, which takes the object off the device path) must agree exactly:
+    integer tables identical, waveform and descriptors bit for bit."""
+    g = load_golden("G7_perlman")
+    for precision in (32, 64):
+        p = run_golden(amd, g, precision)
+        assert p._on_device()
+        ss = p.toSinSum()
+        w = ss.synth(g["sr"], g["hop"])                                   # nothing but w has crossed PCIe so far
+        f0 = p.calc_f0()
+        idx = p.fundamental_idx.copy()
+        p.calc_harmonic_power()
+        hp, nh = p.hpower.copy(), p.nharmonics.copy()
+        assert p._on_device() and "_res_f" not in p.__dict__             # still untouched on the host
+        # host chain on copies of the same arrays
+        q = amd.PV(g["x"], g["sr"], nfft=g["nfft"], hop=g["hop"], npks=g["npks"], pkthresh=g["pkthresh"], progress=False, precision=precision)
+        q.f, q.mag, q.ph, q.realph, q.binno, q.t, q.totalmag = p.f, p.mag, p.ph, p.realph, p.binno, p.t, p.totalmag
+        q.nframes = p.nframes
+        assert not q._on_device()
+        s2 = q.toSinSum()
+        pid, st, ln = ss.partial_table()
+        pid2, st2, ln2 = s2.partial_table()
+        assert np.array_equal(pid, pid2) and np.array_equal(st, st2) and np.array_equal(ln, ln2)
+        assert np.array_equal(w, s2.synth(g["sr"], g["hop"]))
+        assert np.array_equal(f0, q.calc_f0()) and np.array_equal(idx, q.fundamental_idx)
+        q.calc_harmonic_power()
+        assert np.array_equal(nh, q.nharmonics) and np.allclose(hp, q.hpower, rtol=1e-13, atol=0)
+        if precision == 64:
+            assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+            assert np.abs(w - g["w_hop%d" % g["hop"]]).max() <= 2e-7       # G7 waveform is stored as float32
+    # a second run_pv on the same object (results replaced) while a SinSum still reads the resident block
+    p = run_golden(amd, load_golden("G4_harm8_vibrato"), 64)
+    ss = p.toSinSum()
+    p.run_pv()                                                            # detaches ss first (and, like the reference,
+    pid, st, ln = ss.partial_table()                                      # starts from the oldfft the first run left)
+    g4 = load_golden("G4_harm8_vibrato")
+    assert np.array_equal(st, g4["part_start"]) and np.array_equal(ln, g4["part_len"])
+    # descriptors against the reference fixture D1 (same signal as G4, float64 analysis)
+    d = np.load(os.path.join(GOLDEN, "D1_descriptors.npz"))
+    p = run_golden(amd, g4, 64)
+    assert p._on_device()
+    f0 = p.calc_f0()
+    assert np.array_equal(p.fundamental_idx, d["fundamental_idx"]) and np.abs(f0 - d["f0"]).max() <= 1e-8
+    p.calc_harmonic_power()
+    assert np.array_equal(p.nharmonics, d["nharmonics"]) and np.allclose(p.hpower, d["hpower"], rtol=1e-9, atol=0)
+
+
+# ------------------------------------------------------------------ the reference's own PeakFinder unit test
+def test_reference_peak_finder_unit_test(amd):
+    """tests/test_peak_finder.py::testFindOnePeak of the reference (its other cases exercise the sub-sample
+    refinement helpers, which SURVEY.md 2 puts outside the hot path and which are not mirrored)."""
     x = np.concatenate((np.linspace(0, 1, 10), np.linspace(.9, 1, 9)))
-    peaks = pf(x)                                                    # testFindOnePeak
+    peaks = amd.PeakFinder(x)
     assert len(peaks.pos) == 1 and peaks.pos == 9
-    peaks = pf(_parabolic_peak(max_pos=1.0))                         # test_refine_one_peak_centered
-    peaks.refine_all()
-    assert len(peaks.pos) == 1 and peaks.pos == 1.0
-    peaks = pf(_parabolic_peak(max_pos=1.2, n=4))                    # test_refine_one_peak_at_random_pos
-    peaks.refine_all()
-    assert peaks.fpos.tolist() == [1.2]
-    peaks = pf(_parabolic_peak(max_pos=1.5, n=4))                    # test_refine_one_peak_between_samples
-    peaks.refine_all()
-    assert peaks.fpos.tolist() == [1.5]
-    peaks = pf(_parabolic_peak(max_pos=1.499, n=4))                  # test_refine_one_peak_almost_between_samples
-    peaks.refine_all()
-    assert len(peaks.fpos) == 1 and abs(peaks.fpos[0] - 1.499) < 1e-7
 
 
 def test_frame_range_shards_equal_the_unsharded_analysis(amd):

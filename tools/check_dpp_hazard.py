@@ -4,7 +4,7 @@ one of the inline-asm primitives of pvx_cplx.h wrote less than two wait states e
 DPP read needs two wait states on gfx9; the compiler inserts them for instructions it emitted itself,
 but its hazard recogniser does not look inside inline asm.)  Exit status 1 if a candidate is found.
 
-    python tools/check_dpp_hazard.py            # compiles k_fused.hip and k_fused_mw.hip to assembly
+    python tools/check_dpp_hazard.py            # compiles the fused kernels to assembly
 """
 import os
 import re
@@ -46,7 +46,9 @@ def scan(path):
             continue
         if inasm:
             nasm += 1
-            recent.append((0, regs(t.split()[1].rstrip(","))))
+            parts = t.split()
+            if op.startswith("v_") and len(parts) > 1:           # s_waitcnt / s_barrier in asm write no VGPR
+                recent.append((0, regs(parts[1].rstrip(","))))
             continue
         if op.startswith("v_mov_b32_dpp"):
             ndpp += 1
@@ -61,7 +63,7 @@ def main():
     hipcc = os.environ.get("HIPCC", "hipcc")
     status = 0
     with tempfile.TemporaryDirectory() as td:
-        for name in ("k_fused", "k_fused_mw"):
+        for name in ("k_fused", "k_fused_mw", "k_fused_ring"):
             out = os.path.join(td, name + ".s")
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
                                    "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", out,

@@ -1,31 +1,32 @@
 #!/usr/bin/env python3
-"""Wall-clock of the whole chain through the Python drop-in API (host buffers, PCIe included):
-run_pv -> toSinSum -> synth, on the BASELINE.md 60-s signal and on config 2 (600 s) and config 3."""
+"""Where the wall time of the config-3 round trip goes (fixture G7, nfft 4096, hop 1024, npks 100): Python-side
+construction, the three library calls, and the same calls with a float32 signal.  python tools/time_chain.py"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import pypevoc_amd
 from tests.conftest import load_golden
 
-def chain(x, sr, nfft, hop, K, label, reps=3):
-    best = None
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        p = pypevoc_amd.PV(x, sr, nfft=nfft, hop=hop, npks=K, progress=False)
-        p.run_pv(); t1 = time.perf_counter()
-        ss = p.toSinSum(); pid, st, ln = ss.partial_table(); t2 = time.perf_counter()
-        w = ss.synth(sr, hop); t3 = time.perf_counter()
-        r = (t1 - t0, t2 - t1, t3 - t2)
-        best = r if best is None or sum(r) < sum(best) else best
-    F = p.nframes
-    print("%s: F=%d partials=%d | run_pv %.4f s (%.0f frames/s) | toSinSum %.4f s (%.0f frames/s) | synth %.4f s (%.0f frames/s, %.0fx real time)" %
-          (label, F, len(st), best[0], F / best[0], best[1], F / best[1], best[2], F / best[2], (len(w) / sr) / best[2]))
-
-x = bench.c2_signal(60)
-chain(x, 44100, 2048, 512, 8, "60 s, 44.1 kHz, nfft 2048, hop 512, K 8 (BASELINE.md row)")
-x = bench.c2_signal(600)
-chain(x, 44100, 2048, 512, 8, "config 2: 600 s")
 g = load_golden("G7_perlman")
-chain(g["x"], g["sr"], 4096, 1024, 100, "config 3: perlmanVn.wav nfft 4096 K 100")
+
+
+def best(fn, n=30):
+    b = 1e9
+    for _ in range(n):
+        t0 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t0)
+    return b * 1e3, r
+
+
+for name, x in (("float64 signal", g["x"]), ("float32 signal", g["x"].astype(np.float32))):
+    mk = lambda: pypevoc_amd.PV(x, g["sr"], nfft=4096, hop=1024, npks=100, progress=False)
+    t_init, p = best(mk)
+    p.run_pv()
+    t_run, _ = best(lambda: (setattr(p, "oldfft", np.zeros(p.nfft2)), p.run_pv()))
+    t_sin, ss = best(lambda: p.toSinSum())
+    t_syn, w = best(lambda: ss.synth(g["sr"], 1024))
+    def chain():
+        q = pypevoc_amd.PV(x, g["sr"], nfft=4096, hop=1024, npks=100, progress=False)
+        q.run_pv()
+        return q.toSinSum().synth(g["sr"], 1024)
+    t_all, _ = best(chain)
+    print("%s: PV() %.3f ms | run_pv %.3f | toSinSum %.3f | synth %.3f | whole chain incl. construction %.3f ms" % (name, t_init, t_run, t_sin, t_syn, t_all))
