@@ -482,19 +482,22 @@ def main():
             n64 = (ctypes.c_int64 * 4)()
             _lib.check(lib.pvx_plan_get_timing(p64, m64, n64), "pvx_plan_get_timing")
             ab64 = alg_bytes(s=8, c=16)
-            # input samples are float32 in HBM: the framing kernel reads hop*4 and writes nfft*8
-            ab64k = [HOP * 4 + NFFT * 8, ab64["fft"], ab64["peaks"], ab64["fused"]]
+            stft = n64[0] > 0 and n64[1] == 0                      # k_stft.hip wrote the spectra: no frame buffer, no rocFFT
+            # input samples are float32 in HBM.  k_stft: hop*4 in, (nfft/2)*16 out; framing kernel: hop*4 in, nfft*8 out
+            ab64k = [HOP * 4 + (NFFT // 2) * 16 if stft else HOP * 4 + NFFT * 8, ab64["fft"], (NFFT // 2) * 16 + NPKS * 40 + 16, ab64["fused"]]
+            n64names = ["k_stft" if stft else "k_frames", "rocfft_r2c", "k_phase_peaks", "fused"]
             k64 = []
             for i in range(4):
                 if n64[i]:
                     dur = m64[i] * 1e-3 / n64[i]
                     fpl = F64 * 5.0 / n64[i]                       # 2 warm-up + 3 timed passes were recorded
-                    k64.append(dict(kernel=names[i] if i < 3 else "fused", ms_per_launch=round(dur * 1e3, 4), launches=int(n64[i]),
+                    k64.append(dict(kernel=n64names[i], ms_per_launch=round(dur * 1e3, 4), launches=int(n64[i]),
                                     alg_bytes_per_frame=ab64k[i], achieved_GBps=round(ab64k[i] * fpl / dur / 1e9, 1),
                                     frac=round(ab64k[i] * fpl / dur / HBM_PEAK, 4)))
-            stage64 = ab64["contract"] - HOP * 4                   # float32 input: hop*4, not hop*8
+            stage64 = sum(ab64k[i] for i in range(4) if n64[i])    # what the kernels of this path have to move per frame
             f64 = dict(value=round(F64 / ms64 * 1e3, 1), unit="frames/s", ms_per_step=round(ms64, 4), dtype="f64",
                        fft_mode=int(lib.pvx_plan_get_fft_mode(p64)),
+                       contract_bytes_per_frame=ab64["contract"] - HOP * 4,
                        roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64,
                                      achieved=round(stage64 * F64 / (ms64 * 1e-3) / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                      frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4), kernels=k64))

@@ -1,0 +1,330 @@
+// k_stft.hip -- windowed real FFT of every frame in ONE kernel, at the reference's own precision (float64):
+//
+//   PV.calc_fft_frame   pypevoc/PVAnalysis.py:150-158   fft(x[pos:pos+nfft] * win) / wfact, np.fft on float64
+//
+// for nfft = 128 R, R in {4, 8, 16} (nfft 512, 1024, 2048).  It writes the half spectrum rows (bins 0 .. nfft/2-1,
+// complex T) into the general path's workspace, where k_phase_peaks (k_peaks.hip) and k_harmonic_rows
+// (k_harmonic.hip) read them -- replacing k_frames + rocFFT's two kernels: one launch instead of three per
+// workspace chunk, hop*4 B in and nfft/2 * 16 B out per frame instead of ~5x that through HBM / Infinity Cache,
+// and no windowed-frame buffer at all.
+//
+// Same factorisation as the float32 kernels (k_fused.hip): the real FFT of nfft samples is a complex FFT of
+// M = nfft/2 = 64 R points on z[j] = xw[2j] + i xw[2j+1] plus the untangle; M = R (registers) x R (registers,
+// after one LDS exchange) x P (P = 64/R lanes, DPP / swizzle steps).  One wave64 per frame, plain float64
+// arithmetic (no packed instructions exist for it), explicit fma in the complex multiplies so that a frame's
+// spectrum does not depend on which wave computes it.  The untangle writes straight to global memory (bins k
+// and M-k: two coalesced 1 KiB stores per step), so a wave needs ONE LDS buffer; window and twiddles are LDS
+// tables shared by the workgroup, which keeps the kernel under 256 registers: 6 waves per CU.
+// Rows are dealt to waves round-robin (consecutive waves = consecutive frames: their 75 % input overlap is served
+// by L1/L2); the samples of a wave's next row are prefetched in four groups spread over the transform.
+#include "pvx_fft.h"
+
+using namespace pvxw;
+using namespace pvxf;
+
+namespace {
+
+template <typename T> struct cx { T x, y; };
+template <typename T> __device__ __forceinline__ cx<T> mkc(T a, T b) { cx<T> r; r.x = a; r.y = b; return r; }
+template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mkc<T>(a.x + b.x, a.y + b.y); }
+template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mkc<T>(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ __attribute__((unused)) float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// z * w with explicit fused multiply-adds (the rounding of pvxf::cmul)
+template <typename T> __device__ __forceinline__ cx<T> cmulT(cx<T> z, cx<T> w) {
+    return mkc<T>(fmaT(z.x, w.x, -(z.y * w.y)), fmaT(z.x, w.y, z.y * w.x));
+}
+template <typename T> __device__ __forceinline__ cx<T> mniT(cx<T> z) { return mkc<T>(z.y, -z.x); }          // -i z
+template <typename T> __device__ __forceinline__ cx<T> addmni(cx<T> b, cx<T> d) { return mkc<T>(b.x + d.y, b.y - d.x); }   // b - i d
+template <typename T> __device__ __forceinline__ cx<T> addpi(cx<T> b, cx<T> d) { return mkc<T>(b.x - d.y, b.y + d.x); }    // b + i d
+
+// radix-R DFT in registers, natural order in and out (pvx_fft.h's dft16 / radix-2 network in type T)
+template <int R, typename T> __device__ __forceinline__ void dftT(cx<T> (&x)[R]) {
+    constexpr T C1 = (T)0.92387953251128673848, S1 = (T)0.38268343236508978178, H = (T)0.70710678118654752440;
+    if constexpr (R == 16) {
+        const T cr[10] = {(T)1, C1, H, S1, (T)0, (T)0, -H, (T)0, (T)0, -C1};
+        const T ci[10] = {(T)0, -S1, -H, -C1, (T)-1, (T)0, -H, (T)0, (T)0, S1};
+        cx<T> t[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 4; n1++) {
+            const cx<T> a = x[n1], b = x[n1 + 4], c = x[n1 + 8], d = x[n1 + 12];
+            const cx<T> A = a + c, B = a - c, C = b + d, D = b - d;
+            cx<T> y[4];
+            y[0] = A + C; y[2] = A - C; y[1] = addmni(B, D); y[3] = addpi(B, D);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const int m = n1 * k2;
+                if (m == 0) t[n1 * 4 + k2] = y[k2];
+                else if (m == 4) t[n1 * 4 + k2] = mniT(y[k2]);
+                else t[n1 * 4 + k2] = cmulT(y[k2], mkc<T>(cr[m], ci[m]));
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const cx<T> a = t[k2], b = t[4 + k2], c = t[8 + k2], d = t[12 + k2];
+            const cx<T> A = a + c, B = a - c, C = b + d, D = b - d;
+            x[k2] = A + C; x[k2 + 8] = A - C; x[k2 + 4] = addmni(B, D); x[k2 + 12] = addpi(B, D);
+        }
+    } else {
+        // radix-2 decimation in frequency, R in {4, 8}: the only non-trivial twiddles are W_8^1 and W_8^3
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+                for (int i = 0; i < h; i++) {
+                    const int a = blk + i, b = blk + i + h;
+                    const cx<T> s = x[a] + x[b];
+                    cx<T> d = x[a] - x[b];
+                    const int tw = i * (8 / (2 * h)) % 8;              // W_2h^i = W_8^(i * 8/(2h)), 2h in {2, 4, 8}
+                    if (tw == 1) d = cmulT(d, mkc<T>(H, -H));
+                    else if (tw == 2) d = mniT(d);
+                    else if (tw == 3) d = cmulT(d, mkc<T>(-H, -H));
+                    x[a] = s; x[b] = d;
+                }
+            }
+        }
+        constexpr int bits = ilog2(R);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int j = bitrev_c(i, bits);
+            if (i < j) { const cx<T> t = x[i]; x[i] = x[j]; x[j] = t; }
+        }
+    }
+}
+
+// value of lane (l ^ H)
+template <int H> __device__ __forceinline__ double lane_xorT(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const float lo = lane_xor<H>(__builtin_bit_cast(float, (int)b));
+    const float hi = lane_xor<H>(__builtin_bit_cast(float, (int)(b >> 32)));
+    return __builtin_bit_cast(double, ((long long)__builtin_bit_cast(int, hi) << 32) | (unsigned)__builtin_bit_cast(int, lo));
+}
+template <int H> __device__ __forceinline__ float lane_xorT(float v) { return lane_xor<H>(v); }
+
+// one decimation-in-frequency step of the cross-lane DFT: a' = sg a + partner, then the lane's twiddle
+template <int H, bool TW, typename T> __device__ __forceinline__ cx<T> xstepT(cx<T> a, T sg, cx<T> w) {
+    const cx<T> q = mkc<T>(lane_xorT<H>(a.x), lane_xorT<H>(a.y));
+    cx<T> r = mkc<T>(fmaT(sg, a.x, q.x), fmaT(sg, a.y, q.y));
+    if constexpr (TW) r = cmulT(r, w);
+    return r;
+}
+
+template <int R, typename T> struct StftGeo {
+    static constexpr int M = 64 * R, N = 128 * R, P = 64 / R, LOGP = ilog2(P), LOGR = ilog2(R), R2 = R * R, HALF = M / 2;
+    static constexpr int PITCH = 64 + P;                              // exchange row pitch (complex)
+    // padding of the natural-order spectrum per R^2 bins so that the P lanes of a group (which write bins R^2 apart)
+    // land in different banks: 16-byte elements -> 16 bank groups
+    static constexpr int EPB = 64 / (int)(2 * sizeof(T) / 4);        // complex elements per 256-byte bank sweep
+    static constexpr int ZP = (EPB / P > 0 ? EPB / P : 1);
+    static constexpr int ZLEN = M + ZP * (P - 1);
+    static constexpr int BUFRAW = (R * PITCH > ZLEN) ? R * PITCH : ZLEN;
+    static constexpr int BUFC = ((BUFRAW + 63) / 64) * 64;
+    static constexpr int TW3N = (HALF + 8) & ~7;
+    static constexpr size_t OFF_WIN = 0;                                                     // T [N]  window / wfact
+    static constexpr size_t OFF_T1 = OFF_WIN + (size_t)N * sizeof(T);                        // cx [R][64]  W_M^(l q)
+    static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 2 * sizeof(T);                // cx [R][P]   W_64^(l1 t2)
+    static constexpr size_t OFF_TW3 = OFF_T2 + 64 * 2 * sizeof(T);                           // cx [TW3N]   W_nfft^k
+    static constexpr size_t OFF_BUF = OFF_TW3 + (size_t)TW3N * 2 * sizeof(T);                // cx [NW][BUFC]
+    __host__ __device__ static size_t total(int nw) { return OFF_BUF + (size_t)nw * BUFC * 2 * sizeof(T); }
+};
+template <int R, typename T> __device__ __forceinline__ int zpadT(int k) { return k + StftGeo<R, T>::ZP * (k >> (2 * StftGeo<R, T>::LOGR)); }
+
+struct StftParams {
+    const void* x;            // input samples
+    int64_t nsamp, sig_stride, F, R0, ws_rows, total_rows;
+    int hop;
+    const void* win;          // T [nfft]  window / wfact
+    const void* twiddle;      // cx<T> [nfft]  W_nfft^j
+    void* spec;               // cx<T> [ws_rows][ldo]
+    int64_t ldo;
+};
+
+template <int R, typename T, typename InT>
+__global__ __launch_bounds__(384) void k_stft(StftParams p) {
+    using G = StftGeo<R, T>;
+    constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    T* const winL = (T*)(smem + G::OFF_WIN);
+    cx<T>* const t1L = (cx<T>*)(smem + G::OFF_T1);
+    cx<T>* const t2L = (cx<T>*)(smem + G::OFF_T2);
+    cx<T>* const tw3 = (cx<T>*)(smem + G::OFF_TW3);
+    cx<T>* const dz = (cx<T>*)(smem + G::OFF_BUF) + (size_t)wid * G::BUFC;
+    {
+        const cx<T>* tab = (const cx<T>*)p.twiddle;
+        constexpr int NMASK = G::N - 1;
+        for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = ((const T*)p.win)[i];
+        for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * (i & 63) * (i >> 6)) & NMASK];
+        for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
+        for (int i = threadIdx.x; i <= G::HALF; i += blockDim.x) tw3[i] = tab[i];
+    }
+    __syncthreads();
+    const int Q = lane / P, L1 = lane % P;
+    T csg[G::LOGP > 0 ? G::LOGP : 1];
+    cx<T> cw[G::LOGP > 0 ? G::LOGP : 1];
+    {
+        const cx<T>* tab = (const cx<T>*)p.twiddle;
+        constexpr int NMASK = G::N - 1;
+#pragma unroll
+        for (int s = 0; s < G::LOGP; s++) {
+            const int h = P >> (s + 1);
+            const bool up = (L1 & h) != 0;
+            csg[s] = up ? (T)-1 : (T)1;
+            const cx<T> wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+            cw[s] = up ? wv : mkc<T>((T)1, (T)0);
+        }
+    }
+    int t1v = 0;
+#pragma unroll
+    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
+
+    // workspace row j holds global row R0 - 1 + j (pvx_internal.h): rows are dealt round-robin to the waves
+    const int64_t W = (int64_t)gridDim.x * nw;
+    const int64_t w = (int64_t)blockIdx.x * nw + wid;
+    const int64_t rows1 = p.F + 1;
+    auto row_src = [&](int64_t j) -> const InT* {                     // samples of workspace row j; nullptr: zero row
+        if (j >= p.ws_rows) return nullptr;
+        const int64_t g = p.R0 - 1 + j;
+        if (g < 0 || g >= p.total_rows) return nullptr;
+        const int64_t b = g / rows1, q = g - b * rows1;
+        if (q == 0) return nullptr;
+        return (const InT*)p.x + b * p.sig_stride + (q - 1) * (int64_t)p.hop;
+    };
+    T raw[2 * R];                                                     // samples (2l + 128 r, + 1) of the next row
+    auto prefetch_part = [&](const InT* src, int part) {
+        if (src == nullptr) return;
+        constexpr int PR = R / 4;
+#pragma unroll
+        for (int r = part * PR; r < (part + 1) * PR; r++) {
+            const InT* q = src + 2 * lane + 128 * r;
+            raw[2 * r] = (T)q[0]; raw[2 * r + 1] = (T)q[1];
+        }
+    };
+    {
+        const InT* s0 = row_src(w);
+        prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3);
+    }
+    for (int64_t j = w; j < p.ws_rows; j += W) {
+        cx<T>* out = (cx<T>*)p.spec + (size_t)j * p.ldo;
+        const bool zero_row = row_src(j) == nullptr;
+        const InT* nsrc = row_src(j + W);
+        cx<T> z[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            z[r] = mkc<T>(raw[2 * r] * winL[2 * lane + 128 * r], raw[2 * r + 1] * winL[2 * lane + 128 * r + 1]);
+            asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 0);
+        if (zero_row) {
+            prefetch_part(nsrc, 1); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3);
+            for (int k = lane; k < M; k += 64) out[k] = mkc<T>((T)0, (T)0);
+            continue;
+        }
+        dftT<R, T>(z);                                                // stage 1
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 1);
+#pragma unroll
+        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        wave_sync();
+#pragma unroll
+        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
+        prefetch_part(nsrc, 2);
+        wave_sync();
+        dftT<R, T>(z);                                                // stage 2
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 3);
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            // twiddle W_64^(l1 t2), then stage 3: P-point DFT across the P lanes of a group (decimation in frequency)
+            cx<T> a = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+            if constexpr (G::LOGP >= 1) {
+                if constexpr (P >= 16) a = xstepT<8, true, T>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
+                if constexpr (P >= 8) a = xstepT<4, true, T>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
+                if constexpr (P >= 4) a = xstepT<2, true, T>(a, csg[G::LOGP - 2], cw[G::LOGP - 2]);
+                a = xstepT<1, false, T>(a, csg[G::LOGP - 1], cw[G::LOGP - 1]);
+            }
+            dz[zpadT<R, T>(Q + R * t + G::R2 * t1v)] = a;
+        }
+        wave_sync();
+        // ---- untangle straight to global memory: pairs (k, M-k), k = lane + 64 j2
+        //   S = Za + conj Zb, D = Za - conj Zb;  E = S/2, O = -i D/2, Pk = W^k O;  X[k] = E + Pk, X[M-k] = conj(E - Pk)
+        constexpr int NPAIR = R / 2;
+        cx<T> za[NPAIR], zb[NPAIR];
+#pragma unroll
+        for (int j2 = 0; j2 < NPAIR; j2++) {
+            const int k = lane + 64 * j2;
+            za[j2] = dz[zpadT<R, T>(k)];
+            zb[j2] = dz[zpadT<R, T>((M - k) & (M - 1))];
+        }
+        const cx<T> zc = dz[zpadT<R, T>(G::HALF)];
+#pragma unroll
+        for (int j2 = 0; j2 < NPAIR; j2++) {
+            const int k = lane + 64 * j2;
+            const int km = (M - k) & (M - 1);
+            const cx<T> S = mkc<T>(za[j2].x + zb[j2].x, za[j2].y - zb[j2].y);
+            const cx<T> D = mkc<T>(za[j2].x - zb[j2].x, za[j2].y + zb[j2].y);
+            const cx<T> O = mkc<T>((T)0.5 * D.y, (T)-0.5 * D.x);
+            const cx<T> Pk = cmulT(O, tw3[k]);
+            const cx<T> x0 = mkc<T>(fmaT((T)0.5, S.x, Pk.x), fmaT((T)0.5, S.y, Pk.y));
+            cx<T> x1 = mkc<T>(fmaT((T)0.5, S.x, -Pk.x), -fmaT((T)0.5, S.y, -Pk.y));
+            int kk = km;
+            if (j2 == 0 && lane == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = G::HALF; }      // bin 0 pairs with itself; its slot takes bin M/2
+            out[k] = x0;
+            out[kk] = x1;
+        }
+        wave_sync();                                                  // dz is free again
+    }
+}
+
+template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype, hipStream_t s) {
+    using G = StftGeo<R, T>;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    int nw = 6;
+    while (nw > 1 && G::total(nw) > 160 * 1024) nw--;
+    const size_t lds = G::total(nw);
+    const void* fn = nullptr;
+    switch (x_dtype) {
+        case PVX_F32: fn = (const void*)k_stft<R, T, float>; break;
+        case PVX_F64: fn = (const void*)k_stft<R, T, double>; break;
+        case PVX_I16: fn = (const void*)k_stft<R, T, int16_t>; break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t nblocks = ncu;
+    const int64_t maxb = (p.ws_rows + nw - 1) / nw;
+    if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
+    dim3 grid((unsigned)nblocks), block(64 * nw);
+    switch (x_dtype) {
+        case PVX_F32: hipLaunchKernelGGL((k_stft<R, T, float>), grid, block, lds, s, p); break;
+        case PVX_F64: hipLaunchKernelGGL((k_stft<R, T, double>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((k_stft<R, T, int16_t>), grid, block, lds, s, p); break;
+    }
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}
+
+}  // namespace
+
+int pvx_stft_supported(int nfft, int precision) { return precision == 64 && (nfft == 512 || nfft == 1024 || nfft == 2048); }
+
+// spectra of workspace rows [0, ws_rows) (global rows R0-1 ..) -> spec [ws_rows][ldo] complex double
+int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, hipStream_t s) {
+    if (fp.ws_rows <= 0) return PVX_OK;
+    StftParams p;
+    p.x = fp.x; p.nsamp = fp.nsamp; p.sig_stride = fp.sig_stride; p.F = fp.F; p.R0 = fp.R0; p.ws_rows = fp.ws_rows;
+    p.total_rows = fp.total_rows; p.hop = fp.hop; p.win = fp.win; p.twiddle = twiddle; p.spec = spec; p.ldo = ldo;
+    switch (fp.nfft) {
+        case 512: return launch_stft_r<4, double>(p, x_dtype, s);
+        case 1024: return launch_stft_r<8, double>(p, x_dtype, s);
+        case 2048: return launch_stft_r<16, double>(p, x_dtype, s);
+        default: pvx_set_error("the fused STFT kernel does not handle nfft=%d", fp.nfft); return PVX_ERR_UNSUPPORTED;
+    }
+}

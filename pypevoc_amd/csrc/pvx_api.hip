@@ -99,6 +99,10 @@ struct pvx_plan {
     rocfft_plan fft = nullptr;
     rocfft_execution_info info = nullptr;
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
+    bool use_stft = false;       // float64, nfft 512..2048: k_stft writes the spectrum rows (no frame buffer, no rocFFT)
+    int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (use_stft: 2, for pvx_stft_frames only)
+    void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
+    void* d_twiddle64 = nullptr; // double2[nfft] W_nfft^j for k_stft
     void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
     float* d_specrow = nullptr;  // 1024 complex: spectrum of one requested row (fused mode)
     // PVHarmonic: per-frame f0 / previous-row tables and the carried spectrum of the last valid frame
@@ -156,6 +160,8 @@ static void plan_free(pvx_plan* p) {
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_spec) (void)hipFree(p->d_spec);
     if (p->d_work) (void)hipFree(p->d_work);
+    if (p->d_rspec) (void)hipFree(p->d_rspec);
+    if (p->d_twiddle64) (void)hipFree(p->d_twiddle64);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_specrow) (void)hipFree(p->d_specrow);
     if (p->d_hf0) (void)hipFree(p->d_hf0);
@@ -217,6 +223,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         pvx_set_error("invalid analysis parameters (sr=%g nfft=%d hop=%d npks=%d precision=%d)", sr, nfft, hop, npks, precision);
         return PVX_ERR_INVALID;
     }
+    const int64_t rows_hint = max_rows;
     pvx_plan* p = new pvx_plan();
     p->sr = sr; p->nfft = nfft; p->hop = hop; p->npks = npks; p->pkthresh = pkthresh;
     p->precision = precision;
@@ -285,6 +292,23 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (e != hipSuccess) { pvx_set_error("hipMemcpy(win) failed"); plan_free(p); return PVX_ERR_HIP; }
     }
 
+    // float64 fused STFT kernel (k_stft.hip): its own twiddle table; the spectrum workspace is the only intermediate
+    // array left, so a launch may cover far more rows than the Infinity-Cache-sized chunks of the three-kernel path
+    if (pvx_stft_supported(nfft, precision) && !getenv("PVX_NO_STFT")) {
+        std::vector<double> tw(2 * (size_t)nfft);
+        const double pi = 3.141592653589793238462643383279502884;
+        for (int j = 0; j < nfft; j++) { tw[2 * j] = cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = -sin(2.0 * pi * j / (double)nfft); }
+        if (hipMalloc(&p->d_twiddle64, tw.size() * 8) != hipSuccess) { pvx_set_error("hipMalloc(twiddle64) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        if (hipMemcpy(p->d_twiddle64, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle64) failed"); plan_free(p); return PVX_ERR_HIP; }
+        p->use_stft = true;
+        if (!getenv("PVX_MAX_ROWS")) {
+            int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 16));
+            if (big > 262144) big = 262144;
+            const int64_t want = (rows_hint > 0 && rows_hint < big) ? rows_hint : big;
+            p->max_rows = want < 2 ? 2 : want;
+        }
+    }
+
     // fused kernel tables
     const bool can1 = pvx_fused_supported(nfft, precision, npks) != 0, can2 = pvx_fused_mw_supported(nfft, precision, npks) != 0;
     const bool can3 = pvx_fused_ring_supported(nfft, precision, npks) != 0;
@@ -308,17 +332,30 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
 }
 
 // frames + spectrum workspace and the rocFFT plan (fft mode 0, calc_fft_frame): created on first use
+// spectrum workspace of the k_stft path: [max_rows+1][ldo] complex
+static int ensure_spec_ws(pvx_plan* p) {
+    if (p->d_spec) return PVX_OK;
+    const size_t sbytes = (size_t)(p->max_rows + 1) * p->ldo * 2 * real_size(p->precision);
+    if (hipMalloc(&p->d_spec, sbytes) != hipSuccess) { pvx_set_error("hipMalloc of %.1f MiB spectrum workspace failed", sbytes / 1048576.0); p->d_spec = nullptr; return PVX_ERR_ALLOC; }
+    p->ws_bytes += (int64_t)sbytes;
+    return PVX_OK;
+}
+
+// frames + spectrum workspace and the rocFFT plan (fft mode 0, calc_fft_frame): created on first use.
+// With k_stft in charge of the analysis the rocFFT side only serves pvx_stft_frames: two rows, its own output.
 static int ensure_rocfft(pvx_plan* p) {
     if (p->rocfft_ready) return PVX_OK;
     const int nfft = p->nfft, precision = p->precision;
     const size_t rs = real_size(precision);
-    const int64_t max_rows = p->max_rows;
+    const int64_t max_rows = p->use_stft ? 2 : p->max_rows;
     const int64_t ws_rows = max_rows + 1;
+    p->rocfft_rows = max_rows;
     const size_t fbytes = (size_t)ws_rows * p->ldi * rs, sbytes = (size_t)ws_rows * p->ldo * 2 * rs;
-    if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(&p->d_spec, sbytes) != hipSuccess) {
+    void** specp = p->use_stft ? &p->d_rspec : &p->d_spec;
+    if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(specp, sbytes) != hipSuccess) {
         pvx_set_error("hipMalloc of %.1f MiB analysis workspace failed", (fbytes + sbytes) / 1048576.0);
         if (p->d_frames) { (void)hipFree(p->d_frames); p->d_frames = nullptr; }
-        if (p->d_spec) { (void)hipFree(p->d_spec); p->d_spec = nullptr; }
+        if (*specp) { (void)hipFree(*specp); *specp = nullptr; }
         return PVX_ERR_ALLOC;
     }
     // rocFFT: batched 1-D real -> hermitian, one transform per workspace row (PV.py:157)
@@ -345,7 +382,7 @@ static int ensure_rocfft(pvx_plan* p) {
         st = rocfft_execution_info_set_work_buffer(p->info, p->d_work, p->work_bytes);
         if (st != rocfft_status_success) { pvx_set_error("rocfft set_work_buffer failed: %d", (int)st); return PVX_ERR_HIP; }
     }
-    p->ws_bytes = (int64_t)(fbytes + sbytes + p->work_bytes);
+    p->ws_bytes += (int64_t)(fbytes + sbytes + p->work_bytes);
     p->rocfft_ready = true;
     return PVX_OK;
 }
@@ -431,8 +468,11 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }
-    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
-    PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
+    if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
+    else {
+        if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+        PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
+    }
     for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
         const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
         FrameParams fp;
@@ -440,11 +480,16 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
         fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
         if ((rc = plan_event(p, s, 0)) != PVX_OK) return rc;
-        if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
-        if ((rc = plan_event(p, s, 1)) != PVX_OK) return rc;
-        void* in[1] = {p->d_frames};
-        void* out[1] = {p->d_spec};
-        PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        if (p->use_stft) {
+            // window + FFT + untangle of every workspace row in one kernel (k_stft.hip)
+            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, s)) != PVX_OK) return rc;
+        } else {
+            if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
+            if ((rc = plan_event(p, s, 1)) != PVX_OK) return rc;
+            void* in[1] = {p->d_frames};
+            void* out[1] = {p->d_spec};
+            PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        }
         if ((rc = plan_event(p, s, 2)) != PVX_OK) return rc;
         PeaksParams pp;
         pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
@@ -804,15 +849,16 @@ extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t 
         FrameParams fp;
         fp.x = dx.p; fp.nsamp = p->nfft + 1; fp.sig_stride = p->nfft + 1; fp.F = 1; fp.R0 = 0; fp.ws_rows = 3;
         fp.total_rows = 2; fp.nfft = p->nfft; fp.hop = p->hop; fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
-        if (p->max_rows < 2) { pvx_set_error("plan workspace too small"); return PVX_ERR_SIZE; }
+        if (p->rocfft_rows < 2) { pvx_set_error("plan workspace too small"); return PVX_ERR_SIZE; }
         rc = pvx_launch_frames(fp, x_dtype, p->precision, nullptr);
         if (rc != PVX_OK) return rc;
+        void* rspec = p->use_stft ? p->d_rspec : p->d_spec;
         void* in[1] = {p->d_frames};
-        void* out[1] = {p->d_spec};
+        void* out[1] = {rspec};
         PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
         PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
         // global row 1 (frame 0) sits in workspace row 2
-        PVX_HIP_CHECK(hipMemcpy(row.data(), (char*)p->d_spec + (size_t)2 * p->ldo * 2 * rs, row.size(), hipMemcpyDeviceToHost));
+        PVX_HIP_CHECK(hipMemcpy(row.data(), (char*)rspec + (size_t)2 * p->ldo * 2 * rs, row.size(), hipMemcpyDeviceToHost));
         double* o = spec + (size_t)i * nb * 2;
         for (int k = 0; k < 2 * nb; k++)
             o[k] = p->precision == 32 ? (double)((float*)row.data())[k] : ((double*)row.data())[k];
@@ -1051,7 +1097,8 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
                          double fmin, double* d_f, double* d_mag, double* d_ph, double* d_res, double* d_t,
                          const double* d_prev0, hipStream_t s, bool* any_valid) {
     int rc;
-    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+    if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
+    else if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
     const size_t rs = real_size(p->precision);
     // previous-valid-frame table (PV.py:509, 491: oldfft only moves on analysed frames)
     std::vector<int32_t> prow((size_t)F);
@@ -1084,7 +1131,7 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
     PVX_HIP_CHECK(hipMemcpyAsync(p->d_hf0, f0, (size_t)F * 8, hipMemcpyHostToDevice, s));
     PVX_HIP_CHECK(hipMemcpyAsync(p->d_hprev, prow.data(), (size_t)F * 4, hipMemcpyHostToDevice, s));
     PVX_HIP_CHECK(hipStreamSynchronize(s));                              // prow is a local
-    PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
+    if (!p->use_stft) PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
     const int64_t total_rows = F + 1;
     for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
         const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
@@ -1092,10 +1139,14 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
         fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = nsamp; fp.F = F; fp.R0 = R0;
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
         fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
-        if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
-        void* in[1] = {p->d_frames};
-        void* out[1] = {p->d_spec};
-        PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        if (p->use_stft) {
+            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, s)) != PVX_OK) return rc;
+        } else {
+            if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
+            void* in[1] = {p->d_frames};
+            void* out[1] = {p->d_spec};
+            PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
+        }
         HarmParams hp;
         hp.spec = p->d_spec; hp.ldo = p->ldo;
         hp.fr_begin = (R0 > 1 ? R0 : 1) - 1;

@@ -96,8 +96,13 @@ int pvx_launch_fused_mw(const FusedParams& p, int nfft, int x_dtype, hipStream_t
 int pvx_fused_ring_supported(int nfft, int precision, int K);   // k_fused_ring.hip: workgroup-shared spectrum ring
 int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 
+// k_stft.hip: fused float64 STFT into the spectrum workspace
+int pvx_stft_supported(int nfft, int precision);
+struct FrameParams;
+
 // launchers (defined in the .hip files)
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);
+int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, hipStream_t s);
 int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
