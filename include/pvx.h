@@ -81,9 +81,9 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
  *      intermediate arrays in HBM (nfft in {512, 1024, 2048}, precision = 32)
  *   2  fused kernel with several waves per frame (nfft in {2048, 4096, 8192}, precision = 32)
- *   3  mode 1's arithmetic (bit-identical results) with a workgroup of 8 waves walking 8 consecutive
- *      frames over a shared ring of spectra in LDS: two waves per SIMD at nfft 2048 (precision = 32,
- *      npks <= 120: the staging has to fit the LDS next to the ring)
+ *   3  mode 1's arithmetic (bit-identical results) with a workgroup of 8 (nfft 2048) or 12 (nfft 512, 1024)
+ *      waves walking as many consecutive frames over a shared ring of spectra in LDS: two / three waves per
+ *      SIMD (precision = 32; npks <= 120 at nfft 2048: the staging has to fit the LDS next to the ring)
  * A new plan uses 3 where it is supported, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);

@@ -479,7 +479,7 @@ template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipS
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = (int)((160 * 1024) / lds);
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    if (blocks_per_cu * NW > 8) blocks_per_cu = (8 / NW) > 0 ? 8 / NW : 1;
+    if (blocks_per_cu * NW > 16) blocks_per_cu = (16 / NW) > 0 ? 16 / NW : 1;
     int64_t nblocks = (int64_t)ncu * blocks_per_cu;
     if (p.blocks_override > 0) nblocks = p.blocks_override;
     // a workgroup handles NW rows per iteration plus one halo row: at least two iterations' worth each
@@ -504,6 +504,8 @@ int pvx_fused_ring_supported(int nfft, int precision, int K) {
     if (precision != 32) return 0;
     switch (nfft) {
         case 2048: return RingGeo<16, 8>::total(K) <= 160 * 1024;
+        case 1024: return RingGeo<8, 12>::total(K) <= 160 * 1024;
+        case 512: return RingGeo<4, 12>::total(K) <= 160 * 1024;
         default: return 0;
     }
 }
@@ -512,6 +514,8 @@ int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
         case 2048: return launch_ring<16, 8>(p, x_dtype, s);
+        case 1024: return launch_ring<8, 12>(p, x_dtype, s);
+        case 512: return launch_ring<4, 12>(p, x_dtype, s);
         default: pvx_set_error("the ring kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

@@ -196,7 +196,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     if (mode < 0 || mode > 3) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
     if (mode == 3 && !pvx_fused_ring_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the ring kernel handles nfft = 2048 at precision=32 with npks <= 120 (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
+        pvx_set_error("the ring kernel handles nfft in {512, 1024, 2048} at precision=32 while npks leaves it enough LDS (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 2 && !pvx_fused_mw_supported(plan->nfft, plan->precision, plan->npks)) {

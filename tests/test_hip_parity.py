@@ -354,12 +354,20 @@ def test_fused_kernel_variants(amd, oracle):
     r1 = run_pv(amd, x.astype(np.float32), sr, nfft, 512, K, precision=32)
     assert np.array_equal(r0.binno, r1.binno)
     assert np.abs(r0.f - r1.f).max() <= 1e-3 and np.abs(r0.mag - r1.mag).max() <= 1e-6 * r0.mag.max()
-    # the other fused sizes (nfft 512 and 1024: 2 waves per SIMD, 16- and 8-lane cross-lane DFTs)
+    # the other fused sizes (nfft 512 and 1024: 16- and 8-lane cross-lane DFTs; ring of 12 waves by default,
+    # independent waves on request)
     for nf, hp in ((512, 128), (512, 77), (1024, 256), (1024, 512)):
         o = oracle.analyze(x, sr, nf, hp, K)
+        for mode in (3, 1):
+            os.environ["PVX_FFT_MODE"] = str(mode)
+            try:
+                p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
+            finally:
+                del os.environ["PVX_FFT_MODE"]
+            assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == mode
+            assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
         p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
-        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1
-        assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
+        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 3
     # nfft 4096 / 8192: the multi-wave-per-frame fused kernel (fft mode 2); nfft 2048 can run it too
     xl = _rand_signal(22, 70000)
     for nf, hp, mode in ((4096, 1024, None), (4096, 999, None), (8192, 2048, None), (2048, 512, 2), (2048, 333, 2)):
@@ -388,7 +396,8 @@ def test_fused_kernel_variants(amd, oracle):
         assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
 
 
-def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch):
+@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
     of spectra, hand-off through progress counters in LDS) does the arithmetic of mode 1 (k_fused.hip, which the
     other tests pin to the reference and the oracle): every output must be bit-identical, whatever the signal
@@ -396,12 +405,12 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch):
     npks, hop, input type, number of signals in the call (zero rows between signals; F = 1) or grid."""
     from pypevoc_amd import _lib
     rng = np.random.default_rng(77)
-    sr, nfft = 44100.0, 2048
-    n = 60000
+    sr = 44100.0
+    n = 60000 * nfft // 2048
     t = np.arange(n) / sr
     noise = 0.1 * rng.standard_normal(n)
     harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
-    gaps = harm.copy(); gaps[9000:9000 + 3 * nfft] = 0.0; gaps[30000:30000 + nfft + 100] = 0.0
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
     quant = np.round(harm * 50) / 50
 
     def both(make):
@@ -417,32 +426,34 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch):
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
 
     for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant)):
-        for K, thr, hop in ((8, 0.005, 512), (1, 0.005, 333), (3, 0.0, 512), (20, 0.3, 2047), (24, 0.005, 256)):
+        for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (24, 0.005, nfft // 8)):
             a, b = both(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
             assert _lib.load().pvx_plan_get_fft_mode(b._plan.handle) == 3
             assert _lib.load().pvx_plan_get_fft_mode(a._plan.handle) == 1
             same(a, b, (name, K, thr, hop))
     for xin in (noise.astype(np.float32), np.round(harm * 20000).astype(np.int16)):
-        a, b = both(lambda: run_pv(amd, xin, sr, nfft, 512, 8, precision=32))
+        a, b = both(lambda: run_pv(amd, xin, sr, nfft, nfft // 4, 8, precision=32))
         same(a, b, xin.dtype)
     # several signals per call (a zero row in front of each), down to one frame per signal
-    for ns in (nfft + 1, nfft + 513, nfft + 512 * 9 + 5):
-        xb = np.stack([noise[:ns], harm[:ns], gaps[8000:8000 + ns], quant[:ns], noise[100:100 + ns]]).astype(np.float32)
-        a, b = both(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=512, npks=8).run_pv())
+    for ns in (nfft + 1, nfft + nfft // 4 + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 40):
+        g0 = n // 7 - 1000
+        xb = np.stack([noise[:ns], harm[:ns], gaps[g0:g0 + ns], quant[:ns], noise[100:100 + ns]]).astype(np.float32)
+        a, b = both(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=8).run_pv())
         for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
     # other grids: one workgroup; more workgroups than fit the rows two iterations each
-    ref = run_pv(amd, harm, sr, nfft, 512, 8, precision=32)
+    monkeypatch.setenv("PVX_FFT_MODE", "3")
+    ref = run_pv(amd, harm, sr, nfft, nfft // 4, 8, precision=32)
     for nb in ("1", "3", "1000"):
         monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
-        q = run_pv(amd, harm, sr, nfft, 512, 8, precision=32)
+        q = run_pv(amd, harm, sr, nfft, nfft // 4, 8, precision=32)
         monkeypatch.delenv("PVX_FUSED_BLOCKS")
         same(ref, q, ("blocks", nb))
     # streaming entry points: previous spectrum handed in, frame by frame
-    q = amd.PV(gaps, sr, nfft=nfft, hop=512, npks=8, progress=False, precision=32)
-    full = run_pv(amd, gaps, sr, nfft, 512, 8, precision=32)
+    q = amd.PV(gaps, sr, nfft=nfft, hop=nfft // 4, npks=8, progress=False, precision=32)
+    full = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=32)
     for fr in range(20):
-        f, mag, ph, realph, binno, tm = q.calc_pv_frame(fr * 512)
+        f, mag, ph, realph, binno, tm = q.calc_pv_frame(fr * (nfft // 4))
         nv = len(f)
         assert nv == int((full.f[fr] > 0).sum()) and binno == [int(v) for v in full.binno[fr, :nv]]
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
