@@ -81,16 +81,18 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     float2* const ring = (float2*)(smem + RG::OFF_RING);
     int* const Pfft = (int*)(smem + RG::OFF_PROG);                  // [w]: iterations whose spectrum wave w has completed
     int* const Ppk = Pfft + NW;                                     // [w]: iterations whose ring reads wave w has completed
+    // per-wave region: everything whose size is known at compile time first, so that those arrays are one base
+    // register plus immediate offsets (each runtime offset costs a scalar register across the whole frame loop)
     unsigned char* wb = smem + RG::OFF_WAVE + RG::per_wave(K) * wid;
     long long* const Lorow = (long long*)wb;
     double* const Ltot = (double*)(Lorow + GFR);
     float* const Ly = (float*)(Ltot + GFR);
-    float* const Lsval = Ly + M + 4 * R;
-    int* const Lsel = (int*)(Lsval + gs * kpad * 5);
-    int* const Lsbin = Lsel + kpad;
-    int* const Lcnt = Lsbin + gs * kpad;
+    int* const Lcnt = (int*)(Ly + M + 4 * R);
     int* const Lfrm = Lcnt + GFR;
     u16* const Lci = (u16*)(Lfrm + GFR);
+    int* const Lsel = (int*)(Lci + G::CAP + 64);
+    int* const Lsbin = Lsel + kpad;
+    float* const Lsval = (float*)(Lsbin + gs * kpad);
 
     // ---- block-shared tables
     {
@@ -134,23 +136,28 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
 
     // ---- rows of this workgroup: [r0, r1) plus the halo row r0 - 1 (spectrum only)
-    const int64_t NB = gridDim.x;
-    const int64_t r0 = p.total_rows * (int64_t)blockIdx.x / NB, r1 = p.total_rows * ((int64_t)blockIdx.x + 1) / NB;
+    // row indices fit 32 bits (the launcher checks): 64-bit scalar arithmetic in the frame loop costs SGPR pairs
+    const int NB = (int)gridDim.x;
+    const int r0 = (int)(p.total_rows * (int64_t)blockIdx.x / NB), r1 = (int)(p.total_rows * ((int64_t)blockIdx.x + 1) / NB);
     if (r0 >= r1) return;                                           // block-uniform
-    const int64_t first = r0 - 1;
-    const int nit = (int)((r1 - first + NW - 1) / NW);
-    const int64_t rows1 = p.F + 1;                                  // rows per signal
+    const int first = r0 - 1;
+    const int nit = (r1 - first + NW - 1) / NW;
+    const int Fi = (int)p.F;
+    const int rows1 = Fi + 1;                                       // rows per signal
 
-    PeakConst pc;
-    pc.fstep = p.fstep; pc.dt = p.dt; pc.nfft = G::N; pc.hop = p.hop; pc.wfbin = p.wfbin;
+    // The output pointers and the constants of the per-peak arithmetic are only needed once per staging buffer
+    // (every 8th frame): kept in scalar registers across the frame loop they are ~30 of the ~100 SGPRs the
+    // compiler has, and what does not fit is spilled to VGPR lanes (v_writelane / v_readlane in the loop).
+    // flush() re-reads them from the kernel argument segment instead.
+    const FusedParams* const kargs = (const FusedParams*)__builtin_amdgcn_kernarg_segment_ptr();
 
     v2f raw[R];
 #pragma unroll
     for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
     // samples of global row gn = (bn, qn): nullptr when there is nothing to load
-    auto row_src = [&](int64_t gn, int64_t bn, int64_t qn) -> const InT* {
+    auto row_src = [&](int gn, int bn, int qn) -> const InT* {
         if (gn < 0 || gn >= r1 || qn == 0) return nullptr;
-        return (const InT*)p.x + bn * p.sig_stride + (qn - 1) * (int64_t)p.hop;
+        return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
     };
     // The 16 loads of the next row are issued in four groups spread over the transform: issued together they
     // block the wave for ~1500 cycles (all waves of the workgroup queue 64 KB at the texture addresser at once)
@@ -260,15 +267,19 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
+        const FusedParams* q = kargs;
+        asm volatile("" : "+s"(q));                                  // loads through q stay here
+        PeakConst pc;
+        pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
         const int g = gl;
         const bool gvalid = g < ng;
         const int cnt = gvalid ? Lcnt[g] : -1;
         const int64_t orow = gvalid ? (int64_t)Lorow[g] : 0;
-        double* of = p.f + orow * K;
-        double* om = p.mag + orow * K;
-        double* op = p.ph + orow * K;
-        double* orp = p.realph + orow * K;
-        double* ob = p.binno + orow * K;
+        double* of = q->f + orow * K;
+        double* om = q->mag + orow * K;
+        double* op = q->ph + orow * K;
+        double* orp = q->realph + orow * K;
+        double* ob = q->binno + orow * K;
         int nout = 0;
         for (int eb = 0; eb < K; eb += LPF) {
             const int e = eb + e0;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
                 of[oi] = o.freq;
                 om[oi] = o.mag;
                 op[oi] = o.thisph;
-                orp[oi] = o.thisph + kPi * o.dfb / p.fstep;           // PV.py:207
+                orp[oi] = o.thisph + kPi * o.dfb / pc.fstep;          // PV.py:207
             }
             nout += __popcll(bal);
         }
@@ -299,20 +310,20 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
             }
             if (e0 == 0) {
                 const int64_t fr = Lfrm[g];
-                if (p.totalmag) p.totalmag[orow] = sqrt(Ltot[g]);                                     // PV.py:210
-                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + G::N / 2.0) / p.sr;             // PV.py:247
+                if (q->totalmag) q->totalmag[orow] = sqrt(Ltot[g]);                                   // PV.py:210
+                if (q->t) q->t[orow] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;         // PV.py:247
             }
         }
         wave_sync();
     };
 
     // ---- (signal b, row-in-signal q) of this wave's first row g = first + wid; rows advance by NW
-    int64_t g = first + wid, gb, gq;
+    int g = first + wid, gb, gq;
     if (g >= 0) { gb = g / rows1; gq = g - gb * rows1; }           // the only division
-    else { gb = -1; gq = p.F; }                                     // "row -1": a zero row
-    auto advance = [&](int64_t& b, int64_t& q) {
+    else { gb = -1; gq = Fi; }                                      // "row -1": a zero row
+    auto advance = [&](int& b, int& q) {
         q += NW;
-        while (q > p.F) { q -= rows1; b += 1; }
+        while (q > Fi) { q -= rows1; b += 1; }
     };
     if (g < r1) { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
     int slot = wid;                                                 // (g - first) mod NS
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     };
     const int wprev = (wid == 0) ? NW - 1 : wid - 1;
     for (int it = 0; it < nit; ++it) {
-        int64_t bn = gb, qn = gq;
+        int bn = gb, qn = gq;
         advance(bn, qn);
         const bool active = g < r1;                                 // wave-uniform
         float2* cur = ring + (size_t)slot * G::BUFC;
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
         if (active && !zero_row && g >= r0) {
             // the previous row's spectrum: wave w-1, this iteration (wave 0: wave NW-1, iteration it-1)
             wait_ge(Pfft + wprev, wid == 0 ? it : it + 1);
-            const int64_t orow = gb * p.F + (gq - 1);
+            const int64_t orow = (int64_t)gb * Fi + (gq - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
             const float maxy = __builtin_amdgcn_sqrtf(maxe);
             const double minamp = (double)maxy * p.thr;             // PF.py:60
@@ -415,7 +426,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
                 }
                 nk = __popcll(bal);
             } else {
-            const int nsel = peak_pick_regs<R / 2, 1, u16>(Ly, Lci, Lsel, M, K, C, th, mine, lane);
+            // radix select inlined: the call of the out-of-line version saves / restores ~100 scalar registers per frame
+            const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, C, th, mine, lane);
             for (int eb = 0; eb < nsel; eb += 64) {
                 const int e = eb + lane;
                 int pb = 0;
@@ -466,6 +478,7 @@ template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipS
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
+    if (p.total_rows >= 0x7fffff00LL) { pvx_set_error("the ring kernel indexes rows in 32 bits (%lld rows)", (long long)p.total_rows); return PVX_ERR_UNSUPPORTED; }
     const size_t lds = RG::total(p.K);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the ring kernel", Geo<R>::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);

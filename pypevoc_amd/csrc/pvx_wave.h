@@ -437,10 +437,10 @@ __device__ __attribute__((noinline)) int peak_radix_out(const float* y, const CI
 }
 // out of line only where the arrays are big (NCH > 4: nfft >= 2048); the small kernels inline it -- a
 // call makes them reserve stack / callee registers, which costs the 2-waves-per-SIMD variants ~4 %
-template <int NCH, int YP, typename CI>
+template <int NCH, int YP, typename CI, bool INL = false>
 __device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int* out, int npeaks, int C,
                                                float miny, int lane) {
-    if constexpr (NCH <= 4) return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
+    if constexpr (NCH <= 4 || INL) return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
     else return peak_radix_out<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
 }
 
@@ -449,7 +449,7 @@ __device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int
 // (noise-like frames: hundreds of maxima above the threshold) is a radix select on register keys --
 // 31 rounds of NCH compares + scalar popcounts, no LDS in the loop -- where the LDS-resident version
 // paid a memory round trip per bit.
-template <int NCH, int YP, typename CI>
+template <int NCH, int YP, typename CI, bool INL = false>
 __device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int* out, int n, int npeaks, int C,
                                               double th, float miny, int lane) {
     if (C <= npeaks) {
@@ -499,7 +499,7 @@ __device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int*
         wave_sync();
         return __popcll(bk);
     }
-    return peak_radix_regs<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
+    return peak_radix_regs<NCH, YP, CI, INL>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // `th`: a bin qualifies when y - miny > th (the caller derives it from PF.py:60, 69-70; y may be any
