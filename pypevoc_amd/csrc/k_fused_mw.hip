@@ -66,7 +66,7 @@ template <int R, int W> __host__ __device__ inline size_t mw_lds_bytes(int K) {
              + (size_t)(G::CAP * 2 + G::T) * 4                  // cs | ci | trash
              + kpad * 4                                         // sel
              + (size_t)staged_frames(K, GFM) * kpad * 4 * 6        // sbin | sval
-             + GFM * 4 * 2 + W * 4 + W * 4 * 2;                 // cnt | frm | Cw | pmax | pmin
+             + GFM * 4 * 2 + W * 4 * 2 + W * 4 * 2;             // cnt | frm | Cw | Nw | pmax | pmin
     b = (b + 7) & ~(size_t)7;
     b += GFM * 8 * 2 + W * 8;                                   // orow | tot | psum
     return (b + 15) & ~(size_t)15;
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     int* cntv = (int*)(sval + gs * kpad * 5);
     int* frmv = cntv + GFM;
     int* Cw = frmv + GFM;
-    float* pmax = (float*)(Cw + W);
+    int* Nw = Cw + W;                                             // survivors of each wave's local selection
+    float* pmax = (float*)(Nw + W);
     float* pmin = pmax + W;
     long long* orowv = (long long*)(((uintptr_t)(pmin + W) + 7) & ~(uintptr_t)7);
     double* totv = (double*)(orowv + GFM);
@@ -176,8 +177,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     const int64_t r0 = p.total_rows * (int64_t)blockIdx.x / NB, r1 = p.total_rows * ((int64_t)blockIdx.x + 1) / NB;
     if (r0 >= r1) return;                                         // block-uniform
 
-    PeakConst pc;
-    pc.fstep = p.fstep; pc.dt = p.dt; pc.nfft = G::N; pc.hop = p.hop; pc.wfbin = p.wfbin;
+    // output pointers and per-peak constants are re-read from the kernel argument segment inside flush() (every
+    // 8th frame) instead of occupying ~30 scalar registers across the frame loop (see k_fused_ring.hip)
+    const FusedParams* const kargs = (const FusedParams*)__builtin_amdgcn_kernarg_segment_ptr();
 
     float2* cur = bufA;
     float2* prv = bufB;
@@ -301,15 +303,19 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
+        const FusedParams* q = kargs;
+        asm volatile("" : "+s"(q));                                  // loads through q stay here
+        PeakConst pc;
+        pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
         const int g = gl;
         const bool gvalid = g < ng;
         const int cnt = gvalid ? cntv[g] : -1;
         const int64_t orow = gvalid ? (int64_t)orowv[g] : 0;
-        double* of = p.f + orow * K;
-        double* om = p.mag + orow * K;
-        double* op = p.ph + orow * K;
-        double* orp = p.realph + orow * K;
-        double* ob = p.binno + orow * K;
+        double* of = q->f + orow * K;
+        double* om = q->mag + orow * K;
+        double* op = q->ph + orow * K;
+        double* orp = q->realph + orow * K;
+        double* ob = q->binno + orow * K;
         int nout = 0;
         for (int eb = 0; eb < K; eb += LPF) {
             const int e = eb + e0;
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
                 of[oi] = o.freq;
                 om[oi] = o.mag;
                 op[oi] = o.thisph;
-                orp[oi] = o.thisph + kPi * o.dfb / p.fstep;       // PV.py:207
+                orp[oi] = o.thisph + kPi * o.dfb / pc.fstep;      // PV.py:207
             }
             nout += __popcll(bal);
         }
@@ -340,8 +346,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             }
             if (e0 == 0) {
                 const int64_t fr = frmv[g];
-                if (p.totalmag) p.totalmag[orow] = sqrt(totv[g]);                                    // PV.py:210
-                if (p.t) p.t[orow] = ((double)(fr * (int64_t)p.hop) + G::N / 2.0) / p.sr;            // PV.py:247
+                if (q->totalmag) q->totalmag[orow] = sqrt(totv[g]);                                  // PV.py:210
+                if (q->t) q->t[orow] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;        // PV.py:247
             }
         }
         wave_sync();
@@ -383,10 +389,39 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
 #pragma unroll
             for (int w = 0; w < W; w++) { const int c = Cw[w]; cbase += (w < wid) ? c : 0; C += c; }
             peak_block_write<R, int>(ci, wid * G::SCAN, lane, cm, cbase + cpos, G::CAP + tid);
-            block_sync_lds();
+            // Dense frames (noise-like: hundreds of candidates): every wave first reduces ITS segment of the list to
+            // its npks best -- the npks best of the whole row are among them, and ties are broken the same way
+            // (score, then bin) -- and wave 0 only selects among the W * npks survivors.  Before, wave 0 ran the
+            // radix select over the whole list alone while the others waited at the barrier.
+            int Csel = C;                                             // length of the list wave 0 selects from
+            const int* lsel = ci;
+            if (C > 64 && C > K) {                                    // block-uniform
+                wave_sync();                                          // a wave reads its own segment only
+                int* mine_out = (int*)cs + wid * G::CAPW;
+                int n_w = C_w;
+                if (C_w > K) n_w = peak_radix_regs<(G::CAPW + 63) / 64, 0, int, (W <= 4)>(y, ci + cbase, mine_out, K, C_w, mine, lane);
+                else { for (int c = lane; c < C_w; c += 64) mine_out[c] = ci[cbase + c]; }
+                if (lane == 0) Nw[wid] = n_w;
+                block_sync_lds();
+                if (wid == 0) {
+                    // survivors, segment after segment (= ascending bins), back into ci
+                    int off = 0;
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        const int n = Nw[w];
+                        const int* src = (const int*)cs + w * G::CAPW;
+                        for (int c = lane; c < n; c += 64) ci[off + c] = src[c];
+                        off += n;
+                    }
+                    Csel = off;
+                    wave_sync();
+                }
+            } else {
+                block_sync_lds();
+            }
             if (wid == 0) {
                 // at most M/2 candidates: M/128 list entries per lane, ranked / radix-selected in registers
-                const int nsel = peak_pick_regs<M / 128, 0, int>(y, ci, sel, M, K, C, th, mine, lane);
+                const int nsel = peak_pick_regs<M / 128, 0, int>(y, lsel, sel, M, K, Csel, th, mine, lane);
                 const bool use_prev0 = (p.prev0 != nullptr) && (orow == 0);
                 int nk = 0;
                 for (int eb = 0; eb < nsel; eb += 64) {
