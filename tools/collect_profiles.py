@@ -8,6 +8,7 @@ DESIGN.md cite):   python tools/collect_profiles.py r02
   profiles/<tag>_bench*.json          the bench lines of that pass"""
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -38,7 +39,7 @@ detail = {}
 for k, v in run.items():
     if "k_fused" not in k or "FETCH_SIZE" not in v:
         continue
-    short = k.split("::")[-1].split("<")[0]
+    short = re.search(r"(k_[a-z_0-9]+)", k).group(1)
     rd = v["FETCH_SIZE"]["mean"] * 1024.0 * factor
     wr = v["WRITE_SIZE"]["mean"] * 1024.0 * wfactor
     out[short] = int(rd + wr)
@@ -68,4 +69,23 @@ for src, dst in (("bench_%sa.json" % tag, "%s_bench.json" % tag), ("bench_c4.jso
         lines = [ln for ln in open(s).read().splitlines() if ln.startswith("{")]
         if lines:
             open(os.path.join(P, dst), "w").write(lines[-1] + "\n")
+for src, dst in (("configs_%s.jsonl" % tag, "%s_configs_3_4.jsonl" % tag), ("sweep5_%s.jsonl" % tag, "%s_config5_sweep.jsonl" % tag),
+                 ("sweep5_%s_f64.jsonl" % tag, "%s_config5_sweep_f64.jsonl" % tag), ("ab_nfft_%s.jsonl" % tag, "%s_nfft_harmonic_vs_noise.jsonl" % tag)):
+    s = os.path.join(G, src)
+    if os.path.exists(s) and os.path.getsize(s):
+        shutil.copy(s, os.path.join(P, dst))
+t64 = os.path.join(G, "traffic_%s_f64" % tag, "run.json")
+if os.path.exists(t64):
+    r64 = json.load(open(t64))
+    o64 = {}
+    for k, v in r64.items():
+        if ("k_stft" in k or "k_phase_peaks" in k) and "FETCH_SIZE" in v:
+            short = re.search(r"(k_[a-z_0-9]+)", k).group(1)
+            rd = v["FETCH_SIZE"]["mean"] * 1024.0 * factor
+            wr = v["WRITE_SIZE"]["mean"] * 1024.0 * wfactor
+            o64[short] = dict(kernel=k, read_bytes=int(rd), write_bytes=int(wr), bytes_per_frame=round((rd + wr) / FRAMES, 1),
+                              FETCH_SIZE_KB_mean=v["FETCH_SIZE"]["mean"], WRITE_SIZE_KB_mean=v["WRITE_SIZE"]["mean"])
+    json.dump(dict(kernels=o64, frames_per_launch=FRAMES, method="tools/prof_traffic.sh OUT -1 harmonic 8 64 (float64 plan), same calibration as traffic_latest.json"),
+              open(os.path.join(P, "%s_traffic_f64.json" % tag), "w"), indent=1)
+    print(json.dumps({k: v["bytes_per_frame"] for k, v in o64.items()}))
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))

@@ -6,3 +6,8 @@ python bench.py --workload c4 --steps 5 --warmup 1 > gpurun_out/bench_c4.json 2>
 bash tools/prof_sq.sh gpurun_out/sq_r02 -1; rm -rf gpurun_out/sq_r02/g*/
 bash tools/prof_traffic.sh gpurun_out/traffic_r02; rm -rf gpurun_out/traffic_r02/*_SIZE/
 cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/stats_r02 -o r --output-format csv -- python3 /root/repo/bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > /root/repo/gpurun_out/stats_r02.log 2>&1; cd /root/repo; ls gpurun_out/stats_r02
+bash tools/prof_traffic.sh gpurun_out/traffic_r02_f64 -1 harmonic 8 64; rm -rf gpurun_out/traffic_r02_f64/*_SIZE/
+python tools/bench_configs.py > gpurun_out/configs_r02.jsonl 2> gpurun_out/configs_r02.err
+python tools/sweep_config5.py > gpurun_out/sweep5_r02.jsonl 2> gpurun_out/sweep5_r02.err
+python tools/sweep_config5.py 3600 64 > gpurun_out/sweep5_r02_f64.jsonl 2>> gpurun_out/sweep5_r02.err
+python tools/ab_nfft.py 512,1024,2048,4096,8192 > gpurun_out/ab_nfft_r02.jsonl 2>/dev/null

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE config 5: nfft in {512..8192} x hop in {nfft/4, nfft/2} on a 60-min 96 kHz signal
-(345.6 M samples, 1.38 GB float32, resident in HBM), npks=8.  Prints one JSON line per point:
-frames/s and the fraction of the 8 TB/s HBM roofline at SURVEY.md 8(d)'s algorithmic bytes."""
+(345.6 M samples, 1.38 GB float32, resident in HBM), npks=8.  Prints one JSON line per point: frames/s, the fraction
+of the 8 TB/s HBM roofline at the fused kernels' own algorithmic bytes (hop*4 in + (5 npks + 2)*8 out), and the
+throughput against north_star's target (60 % of the roofline at SURVEY.md 8(d)'s three-kernel bytes).
+   python tools/sweep_config5.py [seconds] [precision]"""
 import ctypes, json, os, sys
 import numpy as np
 import torch
@@ -28,6 +30,7 @@ def signal(n, sr):
 
 def main():
     sr, secs, K = 96000, int(sys.argv[1]) if len(sys.argv) > 1 else 3600, 8
+    prec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     lib = _lib.load(); _lib.init(0)
     dev = torch.device("cuda", 0)
     n = sr * secs
@@ -41,7 +44,7 @@ def main():
             ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
             plan = ctypes.c_void_p()
             win = np.hanning(nfft)
-            _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(sr), nfft, hop, K, 0.005, _lib.dptr(win), 32, 0), "plan")
+            _lib.check(lib.pvx_plan_create(ctypes.byref(plan), float(sr), nfft, hop, K, 0.005, _lib.dptr(win), prec, 0), "plan")
             def step():
                 _lib.check(lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, ctypes.c_void_p(stream.cuda_stream)), "analyze")
             step(); torch.cuda.synchronize()
@@ -51,12 +54,17 @@ def main():
             for _ in range(reps): step()
             e1.record(stream); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            balg = hop * 4 + 2 * nfft * 4 + 2 * (nfft // 2 + 1) * 8 + (K * 5 * 8 + 16)
+            s_ = 4 if prec == 32 else 8
+            contract = hop * 4 + 2 * nfft * s_ + 2 * (nfft // 2 + 1) * 2 * s_ + (K * 5 * 8 + 16)
+            mode = int(lib.pvx_plan_get_fft_mode(plan))
+            own = hop * 4 + (K * 5 * 8 + 16) if mode != 0 else contract
+            if mode == 0 and prec == 64 and nfft in (512, 1024, 2048):      # k_stft + k_phase_peaks: spectrum rows written once, read once
+                own = hop * 4 + 2 * (nfft // 2) * 16 + (K * 5 * 8 + 16)
             fps = F / (ms * 1e-3)
-            print(json.dumps(dict(nfft=nfft, hop=hop, frames=F, ms=round(ms, 3), frames_per_s=round(fps, 1),
-                                  alg_bytes_per_frame=balg, achieved_GBps=round(fps * balg / 1e9, 1),
-                                  frac_of_8TBps=round(fps * balg / 8e12, 4),
-                                  fft_mode=int(lib.pvx_plan_get_fft_mode(plan)))))
+            print(json.dumps(dict(nfft=nfft, hop=hop, precision=prec, frames=F, ms=round(ms, 3), frames_per_s=round(fps, 1),
+                                  fft_mode=mode, alg_bytes_per_frame=own, achieved_GBps=round(fps * own / 1e9, 1),
+                                  frac_of_8TBps=round(fps * own / 8e12, 4), contract_bytes_per_frame=contract,
+                                  throughput_vs_60pct_target=round(fps * contract / (0.6 * 8e12), 3))))
             sys.stdout.flush()
             lib.pvx_plan_destroy(plan)
             del out
