@@ -100,7 +100,8 @@ struct pvx_plan {
     rocfft_execution_info info = nullptr;
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
     bool use_stft = false;       // float64, nfft 512..2048: k_stft writes the spectrum rows (no frame buffer, no rocFFT)
-    int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (use_stft: 2, for pvx_stft_frames only)
+    int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
+    bool rocfft_small = false;   // ... and its output then goes to d_rspec, not to the analysis' d_spec
     void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
     void* d_twiddle64 = nullptr; // double2[nfft] W_nfft^j for k_stft
     void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
@@ -343,15 +344,30 @@ static int ensure_spec_ws(pvx_plan* p) {
 
 // frames + spectrum workspace and the rocFFT plan (fft mode 0, calc_fft_frame): created on first use.
 // With k_stft in charge of the analysis the rocFFT side only serves pvx_stft_frames: two rows, its own output.
-static int ensure_rocfft(pvx_plan* p) {
-    if (p->rocfft_ready) return PVX_OK;
+static void release_rocfft(pvx_plan* p) {
+    if (p->info) { rocfft_execution_info_destroy(p->info); p->info = nullptr; }
+    if (p->fft) { rocfft_plan_destroy(p->fft); p->fft = nullptr; }
+    if (p->d_frames) { (void)hipFree(p->d_frames); p->d_frames = nullptr; }
+    if (p->d_rspec) { (void)hipFree(p->d_rspec); p->d_rspec = nullptr; }
+    if (p->d_work) { (void)hipFree(p->d_work); p->d_work = nullptr; }
+    if (!p->rocfft_small && !p->use_stft && p->d_spec) { (void)hipFree(p->d_spec); p->d_spec = nullptr; }
+    p->rocfft_ready = false; p->rocfft_small = false; p->work_bytes = 0;
+}
+
+// full = the analysis itself goes through rocFFT (fft mode 0 without k_stft, PVHarmonic at float32): workspace of
+// max_rows + 1 rows; otherwise only pvx_stft_frames uses it, one frame at a time: 3 rows, output of its own
+static int ensure_rocfft(pvx_plan* p, bool full) {
+    if (p->rocfft_ready && (!full || !p->rocfft_small)) return PVX_OK;
+    if (p->rocfft_ready) release_rocfft(p);
     const int nfft = p->nfft, precision = p->precision;
     const size_t rs = real_size(precision);
-    const int64_t max_rows = p->use_stft ? 2 : p->max_rows;
+    const bool small = !full || p->use_stft;
+    const int64_t max_rows = small ? 2 : p->max_rows;
     const int64_t ws_rows = max_rows + 1;
     p->rocfft_rows = max_rows;
     const size_t fbytes = (size_t)ws_rows * p->ldi * rs, sbytes = (size_t)ws_rows * p->ldo * 2 * rs;
-    void** specp = p->use_stft ? &p->d_rspec : &p->d_spec;
+    void** specp = small ? &p->d_rspec : &p->d_spec;
+    p->rocfft_small = small;
     if (hipMalloc(&p->d_frames, fbytes) != hipSuccess || hipMalloc(specp, sbytes) != hipSuccess) {
         pvx_set_error("hipMalloc of %.1f MiB analysis workspace failed", (fbytes + sbytes) / 1048576.0);
         if (p->d_frames) { (void)hipFree(p->d_frames); p->d_frames = nullptr; }
@@ -470,7 +486,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
     }
     if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
     else {
-        if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+        if ((rc = ensure_rocfft(p, true)) != PVX_OK) return rc;
         PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
     }
     for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
@@ -831,7 +847,7 @@ extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t 
     if (rc != PVX_OK) return rc;
     if (!p || !x || !pos || !spec || nfr < 0) { pvx_set_error("bad argument"); return PVX_ERR_INVALID; }
     if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID; }
-    if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+    if ((rc = ensure_rocfft(p, false)) != PVX_OK) return rc;
     const size_t es = dtype_size(x_dtype), rs = real_size(p->precision);
     for (int64_t i = 0; i < nfr; i++)
         if (pos[i] < 0 || pos[i] + p->nfft > nsamp) { pvx_set_error("frame %lld at %lld leaves the signal", (long long)i, (long long)pos[i]); return PVX_ERR_INVALID; }
@@ -852,7 +868,7 @@ extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t 
         if (p->rocfft_rows < 2) { pvx_set_error("plan workspace too small"); return PVX_ERR_SIZE; }
         rc = pvx_launch_frames(fp, x_dtype, p->precision, nullptr);
         if (rc != PVX_OK) return rc;
-        void* rspec = p->use_stft ? p->d_rspec : p->d_spec;
+        void* rspec = p->rocfft_small ? p->d_rspec : p->d_spec;
         void* in[1] = {p->d_frames};
         void* out[1] = {rspec};
         PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
@@ -1098,7 +1114,7 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
                          const double* d_prev0, hipStream_t s, bool* any_valid) {
     int rc;
     if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
-    else if ((rc = ensure_rocfft(p)) != PVX_OK) return rc;
+    else if ((rc = ensure_rocfft(p, true)) != PVX_OK) return rc;
     const size_t rs = real_size(p->precision);
     // previous-valid-frame table (PV.py:509, 491: oldfft only moves on analysed frames)
     std::vector<int32_t> prow((size_t)F);
