@@ -379,7 +379,8 @@ def main():
         frames_total = FT * world * args.steps
         value = frames_total / elapsed
         kname = {1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring"}.get(fft_mode, "k_fused_pv")
-        names = ["k_frames", "rocfft_r2c", "k_phase_peaks", kname]
+        # general path: k_stft.hip writes the spectrum rows when it can (no frame buffer, no rocFFT launches)
+        names = ["k_stft" if (nl[0] > 0 and nl[1] == 0) else "k_frames", "rocfft_r2c", "k_phase_peaks", kname]
         s_in = 4 if args.precision == 32 else 8
         abp = alg_bytes(s=s_in, c=2 * s_in)
         abk = [abp["frames"], abp["fft"], abp["peaks"], ab["fused"]]

@@ -29,7 +29,7 @@ template <typename T> __device__ __forceinline__ cx<T> mkc(T a, T b) { cx<T> r; 
 template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mkc<T>(a.x + b.x, a.y + b.y); }
 template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mkc<T>(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ __attribute__((unused)) float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // z * w with explicit fused multiply-adds (the rounding of pvxf::cmul)
 template <typename T> __device__ __forceinline__ cx<T> cmulT(cx<T> z, cx<T> w) {
     return mkc<T>(fmaT(z.x, w.x, -(z.y * w.y)), fmaT(z.x, w.y, z.y * w.x));
@@ -298,7 +298,10 @@ template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype,
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t nblocks = ncu;
+    int per_cu = (int)((160 * 1024) / lds);                            // workgroups that fit a CU's LDS side by side
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nw > 16) per_cu = 16 / nw > 0 ? 16 / nw : 1;
+    int64_t nblocks = (int64_t)ncu * per_cu;
     const int64_t maxb = (p.ws_rows + nw - 1) / nw;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * nw);
@@ -313,18 +316,32 @@ template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype,
 
 }  // namespace
 
-int pvx_stft_supported(int nfft, int precision) { return precision == 64 && (nfft == 512 || nfft == 1024 || nfft == 2048); }
+int pvx_stft_supported(int nfft, int precision) { return (precision == 64 || precision == 32) && (nfft == 512 || nfft == 1024 || nfft == 2048); }
 
-// spectra of workspace rows [0, ws_rows) (global rows R0-1 ..) -> spec [ws_rows][ldo] complex double
-int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, hipStream_t s) {
+// spectra of workspace rows [0, ws_rows) (global rows R0-1 ..) -> spec [ws_rows][ldo] complex T (T by `precision`;
+// window and twiddle table in T)
+int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, int precision, hipStream_t s) {
     if (fp.ws_rows <= 0) return PVX_OK;
     StftParams p;
     p.x = fp.x; p.nsamp = fp.nsamp; p.sig_stride = fp.sig_stride; p.F = fp.F; p.R0 = fp.R0; p.ws_rows = fp.ws_rows;
     p.total_rows = fp.total_rows; p.hop = fp.hop; p.win = fp.win; p.twiddle = twiddle; p.spec = spec; p.ldo = ldo;
-    switch (fp.nfft) {
-        case 512: return launch_stft_r<4, double>(p, x_dtype, s);
-        case 1024: return launch_stft_r<8, double>(p, x_dtype, s);
-        case 2048: return launch_stft_r<16, double>(p, x_dtype, s);
-        default: pvx_set_error("the fused STFT kernel does not handle nfft=%d", fp.nfft); return PVX_ERR_UNSUPPORTED;
+    if (precision == 64) {
+        switch (fp.nfft) {
+            case 512: return launch_stft_r<4, double>(p, x_dtype, s);
+            case 1024: return launch_stft_r<8, double>(p, x_dtype, s);
+            case 2048: return launch_stft_r<16, double>(p, x_dtype, s);
+            default: break;
+        }
+    } else {
+        // float32: the fall-back front end when the fused kernels cannot take the plan (npks beyond their LDS) and for
+        // PVHarmonic -- plain (unpacked) arithmetic, still one launch and no frame buffer
+        switch (fp.nfft) {
+            case 512: return launch_stft_r<4, float>(p, x_dtype, s);
+            case 1024: return launch_stft_r<8, float>(p, x_dtype, s);
+            case 2048: return launch_stft_r<16, float>(p, x_dtype, s);
+            default: break;
+        }
     }
+    pvx_set_error("the fused STFT kernel does not handle nfft=%d", fp.nfft);
+    return PVX_ERR_UNSUPPORTED;
 }

@@ -103,7 +103,7 @@ struct pvx_plan {
     int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
     bool rocfft_small = false;   // ... and its output then goes to d_rspec, not to the analysis' d_spec
     void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
-    void* d_twiddle64 = nullptr; // double2[nfft] W_nfft^j for k_stft
+    void* d_twiddle64 = nullptr; // complex<T>[nfft] W_nfft^j for k_stft (T = the plan's precision)
     void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
     float* d_specrow = nullptr;  // 1024 complex: spectrum of one requested row (fused mode)
     // PVHarmonic: per-frame f0 / previous-row tables and the carried spectrum of the last valid frame
@@ -299,11 +299,13 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         std::vector<double> tw(2 * (size_t)nfft);
         const double pi = 3.141592653589793238462643383279502884;
         for (int j = 0; j < nfft; j++) { tw[2 * j] = cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = -sin(2.0 * pi * j / (double)nfft); }
-        if (hipMalloc(&p->d_twiddle64, tw.size() * 8) != hipSuccess) { pvx_set_error("hipMalloc(twiddle64) failed"); plan_free(p); return PVX_ERR_ALLOC; }
-        if (hipMemcpy(p->d_twiddle64, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle64) failed"); plan_free(p); return PVX_ERR_HIP; }
+        std::vector<float> twf(tw.begin(), tw.end());
+        const void* src = precision == 64 ? (const void*)tw.data() : (const void*)twf.data();
+        if (hipMalloc(&p->d_twiddle64, tw.size() * rs) != hipSuccess) { pvx_set_error("hipMalloc(stft twiddle) failed"); plan_free(p); return PVX_ERR_ALLOC; }
+        if (hipMemcpy(p->d_twiddle64, src, tw.size() * rs, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(stft twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         p->use_stft = true;
         if (!getenv("PVX_MAX_ROWS")) {
-            int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 16));
+            int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 2 * rs));
             if (big > 262144) big = 262144;
             const int64_t want = (rows_hint > 0 && rows_hint < big) ? rows_hint : big;
             p->max_rows = want < 2 ? 2 : want;
@@ -498,7 +500,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         if ((rc = plan_event(p, s, 0)) != PVX_OK) return rc;
         if (p->use_stft) {
             // window + FFT + untangle of every workspace row in one kernel (k_stft.hip)
-            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, s)) != PVX_OK) return rc;
+            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, p->precision, s)) != PVX_OK) return rc;
         } else {
             if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
             if ((rc = plan_event(p, s, 1)) != PVX_OK) return rc;
@@ -1156,7 +1158,7 @@ static int harmonic_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsam
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
         fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
         if (p->use_stft) {
-            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, s)) != PVX_OK) return rc;
+            if ((rc = pvx_launch_stft(fp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, p->precision, s)) != PVX_OK) return rc;
         } else {
             if ((rc = pvx_launch_frames(fp, x_dtype, p->precision, s)) != PVX_OK) return rc;
             void* in[1] = {p->d_frames};

@@ -102,7 +102,7 @@ struct FrameParams;
 
 // launchers (defined in the .hip files)
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);
-int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, hipStream_t s);
+int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, int precision, hipStream_t s);
 int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
