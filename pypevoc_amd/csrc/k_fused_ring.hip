@@ -27,6 +27,8 @@
 // The arithmetic of a frame is the instruction sequence of k_fused.hip (same FFT factorisation, same
 // fmaf placement, same peak search), so results are bit-identical to it and independent of the launch
 // geometry.
+#include <stdlib.h>
+
 #include "pvx_fft.h"
 
 using namespace pvxw;
@@ -38,9 +40,10 @@ constexpr int GFR = 8;              // frames staged before the per-peak pass
 
 typedef unsigned short u16;
 
-template <int R, int NW> struct RingGeo {
+template <int R, int NW, int NG = 1> struct RingGeo {
     using G = Geo<R>;
-    static constexpr int NS = NW + 1;                                // ring slots
+    static constexpr int GW = NW / NG;                               // waves per ring (NG independent rings per workgroup)
+    static constexpr int NS = NG * (GW + 1);                         // ring slots of the workgroup
     static constexpr int TW3N = (G::HALF + 8) & ~7;
     // block-shared tables (bytes)
     static constexpr size_t OFF_T1 = 0;                              // v2f [R][64]   W_M^(l q)
@@ -63,11 +66,11 @@ template <int R, int NW> struct RingGeo {
     __host__ __device__ static size_t total(int K) { return OFF_WAVE + per_wave(K) * NW; }
 };
 
-template <int R, int NW, typename InT, bool AL2>
+template <int R, int NW, int NG, typename InT, bool AL2>
 __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     using G = Geo<R>;
-    using RG = RingGeo<R, NW>;
-    constexpr int M = G::M, P = G::P, PITCH = G::PITCH, NS = RG::NS;
+    using RG = RingGeo<R, NW, NG>;
+    constexpr int M = G::M, P = G::P, PITCH = G::PITCH, GW = RG::GW, NS = GW + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -137,11 +140,18 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
 
     // ---- rows of this workgroup: [r0, r1) plus the halo row r0 - 1 (spectrum only)
     // row indices fit 32 bits (the launcher checks): 64-bit scalar arithmetic in the frame loop costs SGPR pairs
+    // NG independent rings per workgroup: waves [grp GW, (grp + 1) GW) walk their own contiguous share of the
+    // workgroup's rows over their own GW + 1 slots.  Shorter hand-off chains: a wave that meets a slow frame
+    // (dense candidates) holds up three followers instead of seven (+5 % on noise; nothing on the bench signal --
+    // nor does running the SIMD partners, which then belong to different rings, deliberately out of step).
+    const int grp = wid / GW, wl = wid - grp * GW;
     const int NB = (int)gridDim.x;
-    const int r0 = (int)(p.total_rows * (int64_t)blockIdx.x / NB), r1 = (int)(p.total_rows * ((int64_t)blockIdx.x + 1) / NB);
-    if (r0 >= r1) return;                                           // block-uniform
+    const int R0 = (int)(p.total_rows * (int64_t)blockIdx.x / NB), R1 = (int)(p.total_rows * ((int64_t)blockIdx.x + 1) / NB);
+    const int r0 = R0 + (int)((int64_t)(R1 - R0) * grp / NG), r1 = R0 + (int)((int64_t)(R1 - R0) * (grp + 1) / NG);
+    if (r0 >= r1) return;                                           // uniform over the ring's waves
+    float2* const ringg = ring + (size_t)grp * NS * G::BUFC;
     const int first = r0 - 1;
-    const int nit = (r1 - first + NW - 1) / NW;
+    const int nit = (r1 - first + GW - 1) / GW;
     const int Fi = (int)p.F;
     const int rows1 = Fi + 1;                                       // rows per signal
 
@@ -318,15 +328,15 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
     };
 
     // ---- (signal b, row-in-signal q) of this wave's first row g = first + wid; rows advance by NW
-    int g = first + wid, gb, gq;
+    int g = first + wl, gb, gq;
     if (g >= 0) { gb = g / rows1; gq = g - gb * rows1; }           // the only division
     else { gb = -1; gq = Fi; }                                      // "row -1": a zero row
     auto advance = [&](int& b, int& q) {
-        q += NW;
+        q += GW;
         while (q > Fi) { q -= rows1; b += 1; }
     };
     if (g < r1) { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
-    int slot = wid;                                                 // (g - first) mod NS
+    int slot = wl;                                                  // (g - first) mod NS
     int ng = 0;
     // Pairwise hand-off: wave w only ever depends on wave w-1 (wave 0: on wave NW-1 one iteration back),
     // through two monotone counters per wave in LDS.  LDS operations of one wave execute in order, so "data
@@ -344,23 +354,23 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) *(volatile int*)f = v;
     };
-    const int wprev = (wid == 0) ? NW - 1 : wid - 1;
+    const int wprev = grp * GW + ((wl == 0) ? GW - 1 : wl - 1);
     for (int it = 0; it < nit; ++it) {
         int bn = gb, qn = gq;
         advance(bn, qn);
         const bool active = g < r1;                                 // wave-uniform
-        float2* cur = ring + (size_t)slot * G::BUFC;
-        float2* prv = ring + (size_t)(slot == 0 ? NS - 1 : slot - 1) * G::BUFC;
+        float2* cur = ringg + (size_t)slot * G::BUFC;
+        float2* prv = ringg + (size_t)(slot == 0 ? NS - 1 : slot - 1) * G::BUFC;
         const bool zero_row = (g < 0) || (gq == 0);
         float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
         // this wave's slot was read by wave w-1 (its own spectrum, iteration it-1; wave 0: wave NW-1, it-2)
-        if (it > 0) wait_ge(Ppk + wprev, wid == 0 ? it - 1 : it);
-        if (active) spectrum(zero_row, cur, row_src(g + NW, bn, qn), maxe, mine, tot);
+        if (it > 0) wait_ge(Ppk + wprev, wl == 0 ? it - 1 : it);
+        if (active) spectrum(zero_row, cur, row_src(g + GW, bn, qn), maxe, mine, tot);
         post(Pfft + wid, it + 1);
         if (active && !zero_row && g >= r0) {
             // the previous row's spectrum: wave w-1, this iteration (wave 0: wave NW-1, iteration it-1)
-            wait_ge(Pfft + wprev, wid == 0 ? it : it + 1);
+            wait_ge(Pfft + wprev, wl == 0 ? it : it + 1);
             const int64_t orow = (int64_t)gb * Fi + (gq - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
             const float maxy = __builtin_amdgcn_sqrtf(maxe);
@@ -465,14 +475,14 @@ __global__ __launch_bounds__(64 * NW) void k_fused_ring(FusedParams p) {
             }
         }
         post(Ppk + wid, it + 1);                                    // this wave's reads of the ring slots are over
-        g += NW; gb = bn; gq = qn;
+        g += GW; gb = bn; gq = qn;
         slot = (slot == 0) ? NS - 1 : slot - 1;                     // (slot + NW) mod (NW + 1)
     }
     if (ng > 0) flush(ng);
 }
 
-template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipStream_t s) {
-    using RG = RingGeo<R, NW>;
+template <int R, int NW, int NG> int launch_ring(const FusedParams& p, int x_dtype, hipStream_t s) {
+    using RG = RingGeo<R, NW, NG>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -484,9 +494,9 @@ template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipS
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     const void* fn = nullptr;
     switch (x_dtype) {
-        case PVX_F32: fn = al2 ? (const void*)k_fused_ring<R, NW, float, true> : (const void*)k_fused_ring<R, NW, float, false>; break;
-        case PVX_F64: fn = (const void*)k_fused_ring<R, NW, double, false>; break;
-        case PVX_I16: fn = (const void*)k_fused_ring<R, NW, int16_t, false>; break;
+        case PVX_F32: fn = al2 ? (const void*)k_fused_ring<R, NW, NG, float, true> : (const void*)k_fused_ring<R, NW, NG, float, false>; break;
+        case PVX_F64: fn = (const void*)k_fused_ring<R, NW, NG, double, false>; break;
+        case PVX_I16: fn = (const void*)k_fused_ring<R, NW, NG, int16_t, false>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -501,11 +511,11 @@ template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipS
     dim3 grid((unsigned)nblocks), block(64 * NW);
     switch (x_dtype) {
         case PVX_F32:
-            if (al2) hipLaunchKernelGGL((k_fused_ring<R, NW, float, true>), grid, block, lds, s, p);
-            else hipLaunchKernelGGL((k_fused_ring<R, NW, float, false>), grid, block, lds, s, p);
+            if (al2) hipLaunchKernelGGL((k_fused_ring<R, NW, NG, float, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((k_fused_ring<R, NW, NG, float, false>), grid, block, lds, s, p);
             break;
-        case PVX_F64: hipLaunchKernelGGL((k_fused_ring<R, NW, double, false>), grid, block, lds, s, p); break;
-        default: hipLaunchKernelGGL((k_fused_ring<R, NW, int16_t, false>), grid, block, lds, s, p); break;
+        case PVX_F64: hipLaunchKernelGGL((k_fused_ring<R, NW, NG, double, false>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((k_fused_ring<R, NW, NG, int16_t, false>), grid, block, lds, s, p); break;
     }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
@@ -516,7 +526,7 @@ template <int R, int NW> int launch_ring(const FusedParams& p, int x_dtype, hipS
 int pvx_fused_ring_supported(int nfft, int precision, int K) {
     if (precision != 32) return 0;
     switch (nfft) {
-        case 2048: return RingGeo<16, 8>::total(K) <= 160 * 1024;
+        case 2048: return RingGeo<16, 8, 1>::total(K) <= 160 * 1024;
         case 1024: return RingGeo<8, 12>::total(K) <= 160 * 1024;
         case 512: return RingGeo<4, 12>::total(K) <= 160 * 1024;
         default: return 0;
@@ -525,10 +535,14 @@ int pvx_fused_ring_supported(int nfft, int precision, int K) {
 
 int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
+    // nfft 2048: two rings of four waves per workgroup where the LDS holds the tenth slot next to the staging
+    // (npks <= 64); PVX_RING_GROUPS=1 forces the single ring (A/B; same results)
+    static const int groups = [] { const char* e = getenv("PVX_RING_GROUPS"); return e ? atoi(e) : 2; }();
     switch (nfft) {
-        case 2048: return launch_ring<16, 8>(p, x_dtype, s);
-        case 1024: return launch_ring<8, 12>(p, x_dtype, s);
-        case 512: return launch_ring<4, 12>(p, x_dtype, s);
+        case 2048: return (groups == 2 && RingGeo<16, 8, 2>::total(p.K) <= 160 * 1024) ? launch_ring<16, 8, 2>(p, x_dtype, s)
+                                                                                      : launch_ring<16, 8, 1>(p, x_dtype, s);
+        case 1024: return launch_ring<8, 12, 1>(p, x_dtype, s);
+        case 512: return launch_ring<4, 12, 1>(p, x_dtype, s);
         default: pvx_set_error("the ring kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }
