@@ -729,7 +729,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
             ob = p->d_out[b];
         }
         if (small) {
-            if ((rc = grow_pin(p, total_in + total_out)) != PVX_OK) { p->progress_live = false; return rc; }
+            if ((rc = grow_pin(p, ((total_in + 255) & ~(size_t)255) + total_out)) != PVX_OK) { p->progress_live = false; return rc; }
             memcpy(p->h_pin, (const char*)x + in_off, in_bytes);
             PVX_HIP_CHECK(hipMemcpyAsync(p->d_in[b], p->h_pin, in_bytes, hipMemcpyHostToDevice, s));
         } else {
@@ -770,7 +770,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
         p->res_F = F; p->res_nsig = nsig; p->res_valid = true;
     } else if (small) {
         // one D2H of the whole block into pinned memory, one synchronisation, then plain memcpys
-        double* hb = (double*)((char*)p->h_pin + total_in);
+        double* hb = (double*)((char*)p->h_pin + ((total_in + 255) & ~(size_t)255));
         PVX_HIP_CHECK(hipMemcpyAsync(hb, p->d_out[0], total_out, hipMemcpyDeviceToHost, s));
         PVX_HIP_CHECK(hipStreamSynchronize(s));
         const HostOut h = block_ptrs(hb, nsig * F, K);
