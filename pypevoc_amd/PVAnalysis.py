@@ -56,6 +56,10 @@ class _Result(object):
         obj.__dict__["_results_edited"] = True
 
 
+_NP_WINDOWS = (np.hanning, np.hamming, np.blackman, np.bartlett)
+_WIN_CACHE = {}
+
+
 class _Plan(object):
     """Owner of a pvx_plan handle (constants, tables and every device / pinned buffer of the host entry points).
 
@@ -173,12 +177,26 @@ class PV(object):
         self.nframes = 0
         self.precision = precision
 
-        self.win = wind(nfft)
-        # PVAnalysis.py:98-99 use Python's sum(): left-to-right float64 additions, which is what a cumulative
-        # sum does too (np.sum would add pairwise and round differently)
-        w = np.asarray(self.win, dtype=np.float64)
-        self.wsum = np.cumsum(w)[-1] if len(w) else 0
-        self.wsum2 = np.cumsum(w ** 2)[-1] if len(w) else 0
+        # numpy's own windows are functions of nfft alone: their array and the sums below are kept per (function, nfft);
+        # every PV still gets its own copy of the window (callers may edit pv.win)
+        ck = (wind, nfft) if wind in _NP_WINDOWS else None
+        cached = _WIN_CACHE.get(ck) if ck is not None else None
+        if cached is None:
+            win = wind(nfft)
+            # PVAnalysis.py:98-99 use Python's sum(): left-to-right float64 additions, which is what a cumulative
+            # sum does too (np.sum would add pairwise and round differently)
+            w = np.asarray(win, dtype=np.float64)
+            wsum = np.cumsum(w)[-1] if len(w) else 0
+            wsum2 = np.cumsum(w ** 2)[-1] if len(w) else 0
+            cached = (win, wsum, wsum2)
+            if ck is not None:
+                if len(_WIN_CACHE) > 32:
+                    _WIN_CACHE.clear()
+                _WIN_CACHE[ck] = cached
+            self.win = win if ck is None else win.copy()
+        else:
+            self.win = cached[0].copy()
+        self.wsum, self.wsum2 = cached[1], cached[2]
         self.wfact = np.sqrt(self.wsum2 * self.nfft) / 2.0     # PVAnalysis.py:102
         self.fstep = float(self.sr) / float(self.nfft)
         self.dt = float(self.hop) / float(self.sr)
@@ -979,7 +997,7 @@ class SinSum(object):
                 raise ValueError("max() arg is an empty sequence")
             n = lib.pvx_synth_len(self._rmaxend, int(self.nfft), int(self.hop), hop, float(edge))
             _lib.check(n, "pvx_synth_len")
-            w = np.empty(n)
+            w = _lib.result_empty(n)                          # page-locked: the waveform is DMA'd into the array itself
             _lib.check(lib.pvx_synth_resident(pv._plan.handle, float(sr), hop, float(edge), int(minframes), _lib.dptr(w), n),
                        "pvx_synth_resident")
             return w

@@ -27,6 +27,8 @@ SIGNATURES = {
     "pvx_version": (ctypes.c_int, []),
     "pvx_device_name": (ctypes.c_char_p, []),
     "pvx_device": (ctypes.c_int, []),
+    "pvx_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
+    "pvx_host_free": (None, [ctypes.c_void_p]),
     "pvx_nframes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "pvx_plan_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
@@ -239,3 +241,60 @@ def device_run(nbytes_out, launch):
     launch(out.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
     stream.synchronize()
     return out.cpu().numpy()
+
+
+# ---- result arrays in page-locked memory ------------------------------------------------------------
+class _HostPool(object):
+    """numpy arrays whose memory the DMA engine can write directly (pvx_host_alloc).  A buffer goes back to the
+    pool when the last array / view on it is collected; sizes are bucketed to powers of two, the pool keeps at
+    most _CAP bytes of idle buffers and hands out at most _LIVE_CAP bytes in all (beyond that: np.empty)."""
+    _CAP = 64 << 20
+    _LIVE_CAP = 1 << 30
+    _MIN = 64 << 10
+
+    def __init__(self):
+        self.free = {}
+        self.idle = 0
+        self.live = 0
+
+    def _release(self, ptr, size):
+        self.live -= size
+        if self.idle + size <= self._CAP:
+            self.free.setdefault(size, []).append(ptr)
+            self.idle += size
+        else:
+            try:
+                load().pvx_host_free(ctypes.c_void_p(ptr))
+            except Exception:
+                pass
+
+    def empty(self, n, dtype=np.float64):
+        import weakref
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        if nbytes < self._MIN:
+            return np.empty(n, dtype=dtype)
+        size = self._MIN
+        while size < nbytes:
+            size <<= 1
+        lst = self.free.get(size)
+        if lst:
+            ptr = lst.pop()
+            self.idle -= size
+        else:
+            if self.live + size > self._LIVE_CAP:
+                return np.empty(n, dtype=dtype)
+            ptr = load().pvx_host_alloc(size)
+            if not ptr:
+                return np.empty(n, dtype=dtype)
+        self.live += size
+        buf = (ctypes.c_char * size).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, size).atexit = False
+        return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+
+_HOST_POOL = _HostPool()
+
+
+def result_empty(n, dtype=np.float64):
+    """An uninitialised 1-D result array, page-locked when that pays (see _HostPool)."""
+    return _HOST_POOL.empty(n, dtype)

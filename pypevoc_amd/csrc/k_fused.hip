@@ -420,8 +420,8 @@ template <int R> int launch_fused_r(const FusedParams& p, int x_dtype, hipStream
     if (blocks_per_cu * waves > 8) blocks_per_cu = 8 / waves;
     int64_t nblocks = (int64_t)ncu * blocks_per_cu;
     if (p.blocks_override > 0) nblocks = p.blocks_override;
-    // never more waves than rows (each wave needs a few rows to be worth its halo FFT)
-    const int64_t min_rows_per_wave = 4;
+    // never more waves than rows; a short signal spreads one row per wave (plus its halo FFT): latency counts there
+    const int64_t min_rows_per_wave = 1;
     const int64_t maxb = (p.total_rows / min_rows_per_wave + waves - 1) / waves;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * waves);

@@ -490,7 +490,9 @@ template <int R, int W> int launch_mw(const FusedParams& p, int x_dtype, hipStre
     if (blocks_per_cu * W > 8) blocks_per_cu = (8 / W) > 0 ? 8 / W : 1;     // 2 waves per SIMD
     int64_t nblocks = (int64_t)ncu * blocks_per_cu;
     if (p.blocks_override > 0) nblocks = p.blocks_override;
-    const int64_t min_rows = 4;
+    // a short signal spreads over the chip one row per workgroup (each then transforms two rows: its own and the
+    // one before it): what counts there is the latency of the launch, not the redundant transform
+    const int64_t min_rows = 1;
     const int64_t maxb = p.total_rows / min_rows;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * W);

@@ -20,6 +20,9 @@
 // a few hundred bytes of table reads.
 // All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
 #include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "pvx_internal.h"
 
@@ -27,14 +30,37 @@ namespace {
 
 constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kPi2 = 2.0 * kPi;
-constexpr int NT = 256;
-constexpr int WMAX = 40;   // window of partial points kept in LDS (needs ceil(dfr + .5) + 6 <= WMAX)
-constexpr int NBATCH = 12; // contributions whose windows are gathered together
+constexpr int WMAX = 40;   // longest window of partial points (needs ceil(dfr + .5) + 6 <= WMAX)
+constexpr int NBMAX = 128; // contributions whose windows are gathered together (fewer if LDS is short)
 
-struct Win {               // a window of one partial's points, j in [j0, j0 + n)
-    double f[WMAX], m[WMAX], r[WMAX];
-    int j0, n;
-};
+// cos for the phase arguments of this kernel (1e3 .. 1e5 rad, sometimes far more): x = n pi + r by a two-term
+// Cody-Waite reduction with fused multiply-adds (n * pi is exact inside the fma, so r carries < 1 ulp of error for
+// |n| < 2^30), then cos r = 1 - 2 sin^2(r/2) with the fdlibm sine polynomial on |r/2| <= pi/4.  Absolute error
+// < 4e-16 in a fifth of the instructions of the library routine, which stays for arguments beyond the reduction's
+// range (kept out of line: its Payne-Hanek tables would otherwise set the kernel's register count).
+__device__ __attribute__((noinline)) double cos_far(double x) { return cos(x); }
+constexpr double kNear = 5.0e8;       // |x| below this: the two-term reduction holds (n < 2^28)
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    // a*b + c with c left in place: the compiler's two-address v_fmac form copies every polynomial constant first
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <bool FAR> __device__ __forceinline__ double fcos(double x) {
+    if constexpr (FAR) return cos_far(x);
+    const double n = rint(x * 3.18309886183790691216e-01);                 // 1/pi
+    double r = __builtin_fma(-n, 3.14159265358979311600e+00, x);
+    r = __builtin_fma(-n, 1.22464679914735320717e-16, r);
+    const double hr = 0.5 * r, z = hr * hr;
+    double ps = fma3(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma3(z, ps, 2.75573137070700676789e-06);
+    ps = fma3(z, ps, -1.98412698298579493134e-04);
+    ps = fma3(z, ps, 8.33333333332248946124e-03);
+    ps = fma3(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(hr * z, ps, hr);                       // sin(r/2)
+    const double v = __builtin_fma(-2.0 * sn, sn, 1.0);
+    return ((int)n & 1) ? -v : v;
+}
 
 // np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); fp through the window
 __device__ inline double interp_w(double x, double h, double off, int nfr, const double* fp, int j0) {
@@ -92,7 +118,7 @@ __device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, c
 
 // closed-form parameters of one contribution (see step 5 of the kernel)
 struct CParam {
-    int kind, fmb, mmb, pad_;
+    int kind, fmb, mmb, far;                 // far: some phase argument may leave the fast cosine's range
     long long o0;
     double ph0, step, amp, cfr;
     double fa0, fsa, fb0, fsb, smb, tmb;     // fsig pieces and the sum / triangular number at the break
@@ -105,18 +131,40 @@ __device__ inline double prefix_sum(const CParam& c, int m) {
     if (m <= c.fmb) return c.fa0 * (double)m + c.fsa * tm;
     return c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
 }
+// the same sum without a divergent branch (per-sample form): operands selected, then one expression whose
+// roundings are those of the two returns above (0 + x is exact)
+__device__ __forceinline__ double prefix_sum_sel(const CParam& c, int m, double tm) {
+    const bool a = m <= c.fmb;
+    const double base = a ? 0.0 : c.smb, f0 = a ? c.fa0 : c.fb0, fs = a ? c.fsa : c.fsb;
+    const double x = (double)(a ? m : m - c.fmb), t = a ? tm : tm - c.tmb;
+    return (base + f0 * x) + fs * t;
+}
 
+// tools/ubench/synth_phases.hip builds this file with PVX_SYNTH_STAMPS: s_memtime stamps of one workgroup in slot_of[]
+#ifdef PVX_SYNTH_STAMPS
+#define PVX_STAMP(slot) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ((long long*)p.slot_of)[slot] = (long long)clock64(); } while (0)
+#else
+#define PVX_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int HT = 512;    // pid -> contribution hash table of a batch (>= 4 * NBMAX: short probe chains)
+constexpr int TS = 256;    // threads across the samples of a segment; NT / TS groups share the contributions
+
+// LDS (dynamic): acc [G][h] | wf wm wr [NB][WL] doubles | prm [NB] | wslots [NB][WL] | cb_* 7 x [NB] | hkey hval [HT] ints
+__host__ __device__ inline size_t synth_lds_bytes(int h, int nb, int wl, int groups) {
+    return (size_t)h * 8 * groups + (size_t)nb * wl * 8 * 3 + (size_t)nb * sizeof(CParam) + (size_t)nb * wl * 4 + (size_t)nb * 4 * 7 + (size_t)HT * 8;
+}
+
+template <int NT>
 __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* acc = (double*)smem;                       // [h] output accumulators
-    __shared__ Win wins[NBATCH];
-    __shared__ int wslots[NBATCH][WMAX];
-    __shared__ int cb_pid[NBATCH], cb_st[NBATCH], cb_nfr[NBATCH], cb_ii[NBATCH], cb_kind[NBATCH], cb_j0[NBATCH], cb_wn[NBATCH];
     __shared__ int wcnt[NT / 64];
     __shared__ int qnext;
-    __shared__ CParam prm[NBATCH];
 
+    constexpr int SP = 4;            // samples per thread held in registers while a batch is added
+    constexpr int G = NT / TS;       // groups: group g adds contributions g, g + G, ... to its own accumulators
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
+    const int NB = p.nbatch;
     const int64_t seg = blockIdx.x;                    // output samples [seg*h, seg*h + h)
     const double dh = (double)h;
     const double overlap = p.hop_a / (double)p.nfft;   // PVAnalysis.py:824
@@ -127,18 +175,35 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     const int64_t edgsamp = (int64_t)(p.edge * h * dfr_s);           // PVAnalysis.py:1056 (integer, Python 2)
     const int EF = edgsam > 0 ? (edgsam + h - 1) / h : 0;            // frames an edge can reach
     const int WB = (int)ceil(dfr + 0.5) + 2;                         // points needed behind the node
+    const int WL = WB + 4;                                           // window length (<= WMAX, host-checked)
 
-    for (int m = tid; m < h; m += NT) acc[m] = 0.0;
+    double* acc = (double*)smem;                       // [G][h] accumulators; row 0 is the output
+    double* wf = acc + (size_t)G * h;                  // windows of partial points, j in [j0, j0 + wn)
+    double* wm = wf + (size_t)NB * WL;
+    double* wr = wm + (size_t)NB * WL;
+    CParam* prm = (CParam*)(wr + (size_t)NB * WL);
+    int* wslots = (int*)(prm + NB);
+    int* cb_pid = wslots + (size_t)NB * WL;
+    int* cb_st = cb_pid + NB;
+    int* cb_nfr = cb_st + NB;
+    int* cb_ii = cb_nfr + NB;
+    int* cb_kind = cb_ii + NB;
+    int* cb_j0 = cb_kind + NB;
+    int* cb_wn = cb_j0 + NB;
+    int* hkey = cb_wn + NB;
+    int* hval = hkey + HT;
+
+    PVX_STAMP(0);
+    for (int m = tid; m < G * h; m += NT) acc[m] = 0.0;
 
     // contributions: kind 0 = body of a peak of frame seg; 1 = attack of a partial starting at
     // frame seg+1 .. seg+EF; 2 = release of a partial whose last frame is seg-EF .. seg-1.
-    // Candidates q = (frame - fr_lo) * K + slot are examined 256 at a time; the valid ones are taken
-    // in order, NBATCH per round, and the windows of partial points of a whole batch are gathered
-    // together: four global round trips per batch instead of four per contribution (this kernel is
-    // bound by those dependent loads, not by arithmetic).
+    // Candidates q = (frame - fr_lo) * K + slot are examined NT at a time; the valid ones are taken
+    // in order, NB per round, and the windows of partial points of a whole batch are gathered
+    // together: four global round trips per batch instead of four per contribution (on a short signal
+    // this kernel is bound by those dependent loads, so a batch is as large as LDS allows).
     const int64_t fr_lo = seg - EF;
     const int NC = (2 * EF + 1) * K;
-    const int WL = WB + 4;                                            // window length (<= WMAX, host-checked)
     for (int qbase = 0; qbase < NC;) {
         // ---- round step 1: examine candidates qbase + [0, NT)
         __syncthreads();
@@ -172,47 +237,71 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
         const int pos = woff + __popcll(bal & ((1ull << lane_) - 1ull));
         if (tid == 0) qnext = qbase + NT;
         __syncthreads();
-        if (valid && pos < NBATCH) {
+        if (valid && pos < NB) {
             cb_pid[pos] = c_pid_; cb_st[pos] = c_st_; cb_nfr[pos] = c_nfr_; cb_ii[pos] = c_ii_; cb_kind[pos] = c_kind_;
             const int j0 = (c_ii_ - WB > 0) ? c_ii_ - WB : 0;
             int j1 = c_ii_ + 3;
             if (j1 > c_nfr_ - 1) j1 = c_nfr_ - 1;
-            cb_j0[pos] = j0; cb_wn[pos] = j1 - j0 + 1;                // <= WB + 4 <= WMAX (checked on the host)
-            if (pos == NBATCH - 1) qnext = q + 1;                     // the rest is re-examined next round
+            cb_j0[pos] = j0; cb_wn[pos] = j1 - j0 + 1;                // <= WB + 4 = WL
+            if (pos == NB - 1) qnext = q + 1;                         // the rest is re-examined next round
         }
         __syncthreads();
-        const int nb = total < NBATCH ? total : NBATCH;
-        // ---- step 3: slots of the window points of the whole batch
-        for (int idx = tid; idx < nb * WL * K; idx += NT) {
-            const int bb = idx / (WL * K), rem = idx - bb * (WL * K);
-            const int d = rem / K, s2 = rem - d * K;
-            if (d < cb_wn[bb]) {
-                const int64_t f2 = (int64_t)cb_st[bb] + cb_j0[bb] + d;
-                if (p.partial_id[f2 * K + s2] == cb_pid[bb]) wslots[bb][d] = s2;
+        const int nb = total < NB ? total : NB;
+        PVX_STAMP(1);
+        // ---- step 3: slots of the window points of the whole batch.  A partial sits in one slot per frame, somewhere
+        // among K: instead of searching K slots per window point, the rows of partial_id the windows can reach
+        // (frames seg-EF-WB .. seg+EF+3) are read once and every entry looks its partial up in a hash table of the batch
+        for (int i = tid; i < HT; i += NT) hkey[i] = -1;
+        __syncthreads();
+        for (int bb = tid; bb < nb; bb += NT) {
+            const int pid = cb_pid[bb];                               // unique within a segment's candidates
+            unsigned hh = ((unsigned)pid * 2654435761u) >> 23;        // 9 bits
+            while (atomicCAS(&hkey[hh], -1, pid) != -1) hh = (hh + 1) & (HT - 1);
+            hval[hh] = bb;
+        }
+        __syncthreads();
+        {
+            const int64_t fr_min = seg - EF - WB;
+            const int nrows = 2 * EF + WB + 4;
+            for (int idx = tid; idx < nrows * K; idx += NT) {
+                const int row = idx / K, s2 = idx - row * K;
+                const int64_t f2 = fr_min + row;
+                if (f2 < 0 || f2 >= p.F) continue;
+                const int pid = p.partial_id[f2 * K + s2];
+                if (pid < 0) continue;
+                unsigned hh = ((unsigned)pid * 2654435761u) >> 23;
+                int k;
+                while ((k = hkey[hh]) != -1 && k != pid) hh = (hh + 1) & (HT - 1);
+                if (k == pid) {
+                    const int bb = hval[hh];
+                    const int64_t d = f2 - ((int64_t)cb_st[bb] + cb_j0[bb]);
+                    if (d >= 0 && d < cb_wn[bb]) wslots[bb * WL + (int)d] = s2;
+                }
             }
         }
         __syncthreads();
+        PVX_STAMP(2);
         // ---- step 4: their values
         for (int idx = tid; idx < nb * WL; idx += NT) {
             const int bb = idx / WL, d = idx - bb * WL;
             if (d < cb_wn[bb]) {
-                const int64_t node = ((int64_t)cb_st[bb] + cb_j0[bb] + d) * K + wslots[bb][d];
-                wins[bb].f[d] = p.f[node];
-                wins[bb].m[d] = p.mag[node];
-                wins[bb].r[d] = p.realph[node];
+                const int64_t node = ((int64_t)cb_st[bb] + cb_j0[bb] + d) * K + wslots[idx];
+                wf[idx] = p.f[node];
+                wm[idx] = p.mag[node];
+                wr[idx] = p.realph[node];
             }
         }
         __syncthreads();
+        PVX_STAMP(3);
         const int qn = qnext;
         // ---- step 5: thread b derives the closed-form parameters of contribution b.  fsig and msig
         // are piecewise linear (two pieces per hop), so the phase prefix sum of PVAnalysis.py:705-708 is
         // a quadratic in the sample index: no scan, no barrier, every sample independent.
-        if (tid < nb) {
-            const int bb = tid;
+        for (int bb = tid; bb < nb; bb += NT) {
             const int st = cb_st[bb], nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
-            const double* pf = wins[bb].f;
-            const double* pm = wins[bb].m;
-            const double* pr = wins[bb].r;
+            const double* pf = wf + (size_t)bb * WL;
+            const double* pm = wm + (size_t)bb * WL;
+            const double* pr = wr + (size_t)bb * WL;
             const double offf = dfr + .5, offm = dfr;                     // PVAnalysis.py:701-702
             CParam c;
             c.kind = kind;
@@ -263,46 +352,84 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                     c.step = (md - kPi) / dh;                             // np.linspace(0, dph, h+1)[:-1]
                 }
             }
+            // can a phase argument of this contribution leave the fast cosine's range?  (a bound, not the maximum)
+            double bound;
+            if (kind == 1 || kind == 2) bound = fabs(c.ph0) + kPi2 * ((double)edgsam + 1.0) * fabs(c.cfr);
+            else bound = fabs(c.ph0) + dh * fabs(c.step)
+                         + (kPi2 / p.sr) * (fabs(c.smb) + dh * (fabs(c.fa0) + fabs(c.fb0) + dh * (fabs(c.fsa) + fabs(c.fsb))));
+            c.far = !(bound < kNear);
             prm[bb] = c;
         }
         __syncthreads();
-        // ---- step 6: every thread adds the batch's contributions to its own samples, in candidate order
-        for (int m = tid; m < h; m += NT) {
-            double a_ = acc[m];
-            const long long osamp = seg * (long long)h + m;
-            for (int bb = 0; bb < nb; ++bb) {
-                const CParam& c = prm[bb];
-                if (c.kind == 0) {
-                    const double ph_m = kPi2 * (prefix_sum(c, m) / p.sr) + c.ph0 + ((double)m * c.step + 0.0);
-                    const double ms = (m < c.mmb) ? (c.ma0 + c.msa * (double)m) : (c.mb0 + c.msb * (double)m);
-                    a_ += ms * cos(ph_m);                                 // PVAnalysis.py:734-736
-                } else {
-                    const long long j = osamp - c.o0;
-                    if (j >= 0 && j < edgsam) {
-                        const double cw = cos(kPi * (double)j / (double)edgsam);
-                        if (c.kind == 1) {
-                            // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
-                            a_ += (c.amp * (1 - cw) / 2.) * cos(c.ph0 - kPi2 * ((double)(edgsam - j) * c.cfr));
+        PVX_STAMP(4);
+        // ---- step 6: the samples.  Thread (g, tl) adds contributions g, g + G, ... (in candidate order) to samples
+        // tl, tl + TS, ... held in registers: the parameters of a contribution are read once for SP samples
+        {
+            const int g = tid / TS, tl = tid - g * TS;
+            double* accg = acc + (size_t)g * h;
+            const double rsr = 1.0 / p.sr;
+            for (int m0 = tl; m0 < h; m0 += TS * SP) {
+                double a_[SP];
+#pragma unroll
+                for (int u = 0; u < SP; u++) a_[u] = (m0 + u * TS < h) ? accg[m0 + u * TS] : 0.0;
+                auto add = [&](const CParam& c, auto far_tag) {
+                    constexpr bool FAR = decltype(far_tag)::value;
+#pragma unroll
+                    for (int u = 0; u < SP; u++) {
+                        const int m = m0 + u * TS;
+                        if (m >= h) continue;
+                        const double dm = (double)m;
+                        if (c.kind == 0) {
+                            // prefix / sr: reciprocal + one fma correction (within an ulp of the quotient; the phase
+                            // itself carries 1e-12 rad of rounding) instead of a 15-instruction division per sample
+                            const double pre = prefix_sum_sel(c, m, 0.5 * dm * (double)(m - 1));
+                            double qd = pre * rsr;
+                            qd = __builtin_fma(__builtin_fma(-qd, p.sr, pre), rsr, qd);
+                            const double ph_m = kPi2 * qd + c.ph0 + (dm * c.step + 0.0);
+                            const bool ma = m < c.mmb;
+                            const double ms = (ma ? c.ma0 : c.mb0) + (ma ? c.msa : c.msb) * dm;
+                            a_[u] += ms * fcos<FAR>(ph_m);                // PVAnalysis.py:734-736
                         } else {
-                            a_ += (c.amp * (1 + cw) / 2.) * cos(c.ph0 + kPi2 * ((double)(j + 1) * c.cfr));
+                            const long long j = seg * (long long)h + m - c.o0;
+                            if (j >= 0 && j < edgsam) {
+                                const double cw = fcos<false>(kPi * (double)j / (double)edgsam);
+                                if (c.kind == 1) {
+                                    // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
+                                    a_[u] += (c.amp * (1 - cw) / 2.) * fcos<FAR>(c.ph0 - kPi2 * ((double)(edgsam - j) * c.cfr));
+                                } else {
+                                    a_[u] += (c.amp * (1 + cw) / 2.) * fcos<FAR>(c.ph0 + kPi2 * ((double)(j + 1) * c.cfr));
+                                }
+                            }
                         }
                     }
+                };
+                for (int bb = g; bb < nb; bb += G) {
+                    const CParam c = prm[bb];
+                    if (c.far) add(c, std::true_type{});
+                    else add(c, std::false_type{});
                 }
+#pragma unroll
+                for (int u = 0; u < SP; u++) if (m0 + u * TS < h) accg[m0 + u * TS] = a_[u];
             }
-            acc[m] = a_;
         }
         qbase = qn;
+        PVX_STAMP(5);
     }
     __syncthreads();
     for (int m = tid; m < h; m += NT) {
         const int64_t o = seg * (int64_t)h + m;
-        if (o < p.wlen) p.w[o] = acc[m];
+        double v = acc[m];
+#pragma unroll
+        for (int g = 1; g < G; g++) v += acc[(size_t)g * h + m];          // fixed order: reproducible run to run
+        if (o < p.wlen) p.w[o] = v;
     }
+    PVX_STAMP(6);
 }
 
 }  // namespace
 
-int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
+int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
+    SynthParams p = p_in;
     if (p.wlen <= 0) return PVX_OK;
     const int h = p.hop_s;
     const double dfr = 1. / (p.hop_a / (double)p.nfft) / 2.;
@@ -310,13 +437,38 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         pvx_set_error("nfft/hop = %g is too large for the resynthesis window (dfr=%g)", (double)p.nfft / p.hop_a, dfr);
         return PVX_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)h * sizeof(double);
-    if (lds > 128 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
+    if ((size_t)h * sizeof(double) > 120 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
     const int64_t nseg = (p.wlen + h - 1) / h;
     if (nseg > 0x7fffffffLL) { pvx_set_error("too many output segments"); return PVX_ERR_INVALID; }
-    if (lds > 48 * 1024)
-        PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_synth_ola, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_synth_ola, dim3((unsigned)nseg), dim3(NT), lds, s, p);
+    // batch: every candidate of a segment in one round if LDS allows (two workgroups per CU when the grid is long)
+    const int WL = (int)ceil(dfr + 0.5) + 6;
+    const int edgsam = (int)(dfr * h * p.edge);
+    const int EF = edgsam > 0 ? (edgsam + h - 1) / h : 0;
+    const int64_t NC = (int64_t)(2 * EF + 1) * p.K;
+    int nb = NC < NBMAX ? (int)NC : NBMAX;
+    // a short signal leaves most of the chip idle at 256 threads per segment: more waves share a segment's contributions
+    int nt = 256;
+    // (512 = two groups: f64 issue is already saturated by two waves per SIMD, and 1024 threads would cap the kernel
+    // at 128 registers, which the four-sample loop body does not fit)
+    if (nseg < 1024 && NC >= 16) nt = 512;
+    if (const char* e = getenv("PVX_SYNTH_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) nt = v; }
+    while (nt > 256 && synth_lds_bytes(h, 4, WL, nt / TS) > 150 * 1024) nt >>= 1;
+    const int groups = nt / TS;
+    const size_t budget = (nseg > 512 ? 72 : 150) * 1024;
+    while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
+    if (nb < 1) nb = 1;
+    p.nbatch = nb;
+    const size_t lds = synth_lds_bytes(h, nb, WL, groups);
+    if (lds > 158 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
+#define PVX_SYNTH(NT_)                                                                                                      \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_synth_ola<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_synth_ola<NT_>, dim3((unsigned)nseg), dim3(NT_), lds, s, p);                                   \
+    } while (0)
+    if (nt == 512) PVX_SYNTH(512);
+    else PVX_SYNTH(256);
+#undef PVX_SYNTH
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
 }

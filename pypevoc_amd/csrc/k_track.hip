@@ -6,11 +6,17 @@
 // ended at frame fr-1" -- and that set is exactly the set of valid peaks (f > 0 and mag > 0) of
 // frame fr-1.  So the greedy assignment of frame fr depends on rows fr-1 and fr only and all
 // frames are linked in parallel:
-//   k_track_links  one wave64 per frame: greedy nearest-in-semitones assignment, new peaks in
-//                  descending magnitude against previous peaks in descending magnitude
-//   k_scan_counts  exclusive scan of "partials created per frame" -> creation-order numbering
-//   k_root_*       pointer jumping along the links: every peak learns the first point of its partial
-//   k_assign_ids   partial_id / part_start / part_len (length written by the partial's last point)
+//   k_track_links       one wave64 per frame: greedy nearest-in-semitones assignment, new peaks in descending
+//                       magnitude against previous peaks in descending magnitude; a workgroup holds a CHUNK of
+//                       consecutive frames and leaves every peak's root (the first point of its partial) as far
+//                       as the chunk knows it: final, or the peak of the chunk before that it continues
+//   k_track_boundaries  one workgroup: exclusive scan of "partials created per frame" (creation-order numbering)
+//                       and pointer jumping over the chunks' last frames only -- log2(#chunks) rounds in LDS
+//   k_assign_chunked    every peak: at most one more hop to its root, then partial_id / part_start / part_len
+//                       (length written by the partial's last point)
+// Three launches whatever F is (the first version chained 3 + log2 F launches; for a 240-frame signal their launch
+// gaps were most of the tracker's time).  k_scan_counts / k_root_* / k_assign_ids remain for tables whose chunk
+// boundaries do not fit one workgroup's LDS.
 // Tiny, latency-bound integer work (<= K^2 compares per frame); no roofline claim.
 //
 // Exact ties.
@@ -28,15 +34,14 @@
 //    elsewhere; on the AVX-512 host of this build 57 % of 8-element rows with ties come out differently from
 //    kind="stable").  Here, as in the oracle: the stable order reversed, i.e. higher slot first.
 #include <math.h>
+#include <stdlib.h>
 
 #include "pvx_internal.h"
+#include "pvx_wave.h"
 
 namespace {
 
-__device__ inline void wave_sync_t() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
+__device__ inline void wave_sync_t() { pvxw::wave_sync(); }     // LDS hand-off inside one wave (pvx_wave.h)
 
 // arg-min with first-index ties (np.argmin, PVAnalysis.py:920)
 __device__ inline void wave_argmin(double& v, int& i) {
@@ -48,35 +53,46 @@ __device__ inline void wave_argmin(double& v, int& i) {
     }
 }
 
-// LDS per wave: cm[K] cf[K] pm[K] pf[K] doubles | corder[K] porder[K] used[K] ints
-__global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// tools/ubench/track_phases.hip builds this file with PVX_TRACK_STAMPS: phase boundaries as s_memtime stamps behind
+// newbase[F] (the microbenchmark allocates 16 more entries)
+#ifdef PVX_TRACK_STAMPS
+#define PVX_STAMP(cond, slot) do { if (cond) p.newbase[p.F + 1 + (slot)] = (int64_t)clock64(); } while (0)
+#else
+#define PVX_STAMP(cond, slot) do { } while (0)
+#endif
+
+constexpr int kAmbBit = 1 << 30;   // newcount[fr] carries the frame's "exact double tie" flag in this bit
+
+// LDS of one wave (= one frame): 4 double rows and 7 int rows of kp = K rounded up to even.  Rows 4..6 of the ints are
+// the frame's result, read by the chunk step: linkL (slot in frame fr-1 | -1 new partial | -2 empty), nrkL (rank
+// among the frame's new partials), succL (by slot of frame fr-1: continued); row 7 is the chunk step's root row.
+struct WaveLds {
+    double* d[4];
+    int *a, *b, *linkL, *nrkL, *succL, *used, *rootL;
+    static __host__ __device__ size_t bytes(int kp) { return (size_t)kp * 8 * 4 + (size_t)kp * 4 * 7; }
+    __device__ WaveLds(unsigned char* smem, int kp, int w) {
+        unsigned char* base = smem + bytes(kp) * w;
+        d[0] = (double*)base; d[1] = d[0] + kp; d[2] = d[1] + kp; d[3] = d[2] + kp;
+        a = (int*)(d[3] + kp); b = a + kp; linkL = b + kp; nrkL = linkL + kp; succL = nrkL + kp; used = succL + kp; rootL = used + kp;
+    }
+};
+
+// ---- one frame, any K: the assignment loop (PVAnalysis.py:903-957) through LDS ---------------------------------
+__device__ void links_frame_lds(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out) {
     const int K = p.K;
-    const int kp = (K + 1) & ~1;
-    const size_t per_wave = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 3;
-    unsigned char* base = smem + per_wave * wid;
-    double* cm = (double*)base;
-    double* cf = cm + kp;
-    double* pm = cf + kp;
-    double* pf = pm + kp;
-    int* corder = (int*)(pf + kp);   // corder[r] = slot of the r-th new peak (descending mag)
-    int* porder = corder + kp;       // porder[r] = slot (in frame fr-1) of the r-th previous peak
-    int* used = porder + kp;
-    const int64_t fr = (int64_t)blockIdx.x * nw + wid;
-    if (fr >= p.F) return;
+    double *cm = L.d[0], *cf = L.d[1], *pm = L.d[2], *pf = L.d[3];
+    int *corder = L.a, *porder = L.b, *linkL = L.linkL, *nrkL = L.nrkL, *succL = L.succL, *used = L.used;
     const double* fc = p.f + fr * K;
     const double* mc = p.mag + fr * K;
-    int32_t* link = p.link + fr * K;
-    int32_t* nrk = p.newrank + fr * K;
     for (int s = lane; s < K; s += 64) {
         cf[s] = fc[s]; cm[s] = mc[s];
         if (fr > 0) { pf[s] = p.f[(fr - 1) * K + s]; pm[s] = p.mag[(fr - 1) * K + s]; }
         else { pf[s] = 0.0; pm[s] = 0.0; }
-        link[s] = -2;
-        nrk[s] = -1;
+        linkL[s] = -2;
+        nrkL[s] = -1;
+        succL[s] = 0;
     }
-    wave_sync_t();
+    pvxw::wave_sync();
     // descending-magnitude ranks of the valid entries (PVAnalysis.py:874-876, 891-893)
     int nc = 0, np = 0;
     for (int s0 = 0; s0 < K; s0 += 64) {
@@ -96,48 +112,256 @@ __global__ __launch_bounds__(256) void k_track_links(TrackParams p) {
                 for (int j = 0; j < K; j++)
                     if (pf[j] > 0.0 && pm[j] > 0.0 && (pm[j] > pm[s] || (pm[j] == pm[s] && j > s))) r++;
                 porder[r] = s;
-                used[r] = 0;
             }
         }
         nc += __popcll(__ballot(vc));
         np += __popcll(__ballot(vp));
     }
-    wave_sync_t();
+    pvxw::wave_sync();
+    const int npl = (np + 63) / 64;                                  // previous peaks per lane: i = lane*npl + j
+    for (int j = 0; j < npl; j++) { const int i = lane * npl + j; if (i < np) used[i] = 0; }
+    pvxw::wave_sync();
     int nnew = 0;
+    bool amb_any = false;
     for (int c = 0; c < nc; c++) {                                   // PVAnalysis.py:903
         const int s = corder[c];
         const double fcur = cf[s];
         double best = INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = lane; i < np; i += 64) {
-            if (!used[i]) {
-                double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));  // dpitch2st, PVAnalysis.py:62-68, 914
-                if (st < best) { best = st; bi = i; }
+        int bj = -1;
+        for (int j = 0; j < npl; j++) {
+            const int i = lane * npl + j;
+            if (i < np && !used[i]) {
+                const double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));   // dpitch2st, PVAnalysis.py:62-68, 914
+                if (st < best) { best = st; bj = j; }
             }
         }
-        wave_argmin(best, bi);
-        const bool hit = (bi != 0x7fffffff) && (best < p.maxjmp);    // PVAnalysis.py:923
-        // another unused previous partial exactly as near AND exactly as strong as the winner: the reference
-        // would let the partial index decide (see the header)
+        const double m = pvxw::wave_min(best);
+        // lanes hold ascending index ranges and keep their first minimum: the lowest lane at the minimum has the
+        // first index (np.argmin, PVAnalysis.py:920)
+        const unsigned long long bal = __ballot(bj >= 0 && best == m);
+        const bool hit = bal != 0ull && m < p.maxjmp;                // PVAnalysis.py:923
         if (hit) {
+            const int wl = __ffsll((long long)bal) - 1;
+            const int wj = __builtin_amdgcn_readlane(bj, wl);
+            const int myo = bj >= 0 ? porder[lane * npl + bj] : 0;
+            const double wm = pvxw::rl_d(pm[myo], wl);
+            const int wo = __builtin_amdgcn_readlane(myo, wl);
+            // another unused previous partial exactly as near AND exactly as strong as the winner: the reference
+            // would let the partial index decide (see the header)
             bool amb = false;
-            const double wm = pm[porder[bi]];
-            for (int i = lane; i < np; i += 64) {
-                if (!used[i] && i != bi) {
-                    const double st = fabs(17.312 * (fcur / pf[porder[i]] - 1.0));
-                    amb = amb || (st == best && pm[porder[i]] == wm);
+            for (int j = 0; j < npl; j++) {
+                const int i = lane * npl + j;
+                if (i < np && !used[i] && !(lane == wl && j == wj)) {
+                    const int o = porder[i];
+                    const double st = fabs(17.312 * (fcur / pf[o] - 1.0));
+                    amb = amb || (st == m && pm[o] == wm);
                 }
             }
-            if (__ballot(amb) != 0ull && lane == 0) *p.ambiguous = 1;
+            amb_any = amb_any || (__ballot(amb) != 0ull);
+            if (lane == wl) used[lane * npl + wj] = 1;
+            if (lane == 0) { linkL[s] = wo; succL[wo] = 1; }
+        } else {
+            if (lane == 0) { linkL[s] = -1; nrkL[s] = nnew; }        // add_empty_partial
+            nnew++;
         }
-        if (lane == 0) {
-            if (hit) { link[s] = porder[bi]; used[bi] = 1; p.succ[(fr - 1) * K + porder[bi]] = 1; }
-            else { link[s] = -1; nrk[s] = nnew; }                    // add_empty_partial
-        }
-        if (!hit) nnew++;
-        wave_sync_t();
+        pvxw::wave_sync();
     }
-    if (lane == 0) p.newcount[fr] = nnew;
+    nnew_out = nnew; amb_out = amb_any;
+}
+
+// ---- one frame, K <= 64 NPL, with nothing but registers inside the loops ---------------------------------------
+// One wave alone on its SIMD issues an instruction every ~4.5 cycles, so a K = 100 frame costs what its instruction
+// count says: a first version spent 135 k cycles ranking through dependent LDS reads, 1 100 cycles per assignment
+// step, and waited for a global store acknowledgement in every step (82 us per frame).  Here: ranks by readlane
+// broadcast, the previous peaks of a lane (NPL consecutive ranks), the frame's new peaks (rank = lane + 64 q) and the
+// "unused" flags in registers, the minimum by v_min_f64 over DPP with row broadcasts, the first index by ballots;
+// the exact-tie test only runs when two distances are bit-equal; results reach global memory once, after the loop.
+template <int CTRL, int ROWS> __device__ __forceinline__ double dpp_keep(double v) {   // rows not in ROWS keep v
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, ROWS, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double min_nn(double a, double b) {     // neither is a NaN: no canonicalising v_max first
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double wave_min_pos(double v) {         // v >= 0 or +inf everywhere; uniform result
+    v = min_nn(v, pvxw::dpp_d<0xB1>(v));
+    v = min_nn(v, pvxw::dpp_d<0x4E>(v));
+    v = min_nn(v, pvxw::dpp_d<0x141>(v));
+    v = min_nn(v, pvxw::dpp_d<0x140>(v));
+    v = min_nn(v, dpp_keep<0x142, 0xa>(v));                        // row_bcast:15 -> rows 1, 3
+    v = min_nn(v, dpp_keep<0x143, 0xc>(v));                        // row_bcast:31 -> rows 2, 3
+    return pvxw::rl_d(v, 63);
+}
+
+template <int NPL>
+__device__ __forceinline__ void links_frame_reg(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out) {
+    const int K = p.K;
+    double *sf = L.d[0], *pfs = L.d[1], *pms = L.d[2];               // by rank: new peaks' frequency; previous f, mag
+    int *sslot = L.a, *pslot = L.b, *linkL = L.linkL, *nrkL = L.nrkL, *succL = L.succL;   // rank -> slot
+    // lane holds slots lane + 64 q
+    double cfv[NPL], pfv[NPL], kc[NPL], kpv[NPL], pmv[NPL];
+    bool vc[NPL], vp[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; q++) {
+        const int s = lane + 64 * q;
+        double cm = 0.0;
+        cfv[q] = 0.0; pfv[q] = 0.0; pmv[q] = 0.0;
+        if (s < K) {
+            cfv[q] = p.f[fr * K + s]; cm = p.mag[fr * K + s];
+            if (fr > 0) { pfv[q] = p.f[(fr - 1) * K + s]; pmv[q] = p.mag[(fr - 1) * K + s]; }
+            linkL[s] = -2; nrkL[s] = -1; succL[s] = 0;
+        }
+        vc[q] = cfv[q] > 0.0 && cm > 0.0;
+        vp[q] = pfv[q] > 0.0 && pmv[q] > 0.0;
+        kc[q] = vc[q] ? cm : -1.0;                                       // invalid entries rank below every valid one
+        kpv[q] = vp[q] ? pmv[q] : -1.0;
+    }
+    // descending-magnitude ranks of the valid entries, ties: higher slot first (PVAnalysis.py:874-876, 891-893)
+    int rc[NPL], rp[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; q++) { rc[q] = 0; rp[q] = 0; }
+#pragma unroll
+    for (int qj = 0; qj < NPL; qj++) {
+        const int jn = K - 64 * qj < 64 ? K - 64 * qj : 64;
+        for (int j = 0; j < jn; j++) {
+            const double a = pvxw::rl_d(kc[qj], j), b = pvxw::rl_d(kpv[qj], j);
+#pragma unroll
+            for (int q = 0; q < NPL; q++) {
+                // slot j + 64 qj against this lane's slot lane + 64 q: "greater, or equal and a higher slot"
+                if (qj > q) { rc[q] += a >= kc[q]; rp[q] += b >= kpv[q]; }
+                else if (qj < q) { rc[q] += a > kc[q]; rp[q] += b > kpv[q]; }
+                else { rc[q] += (a > kc[q]) | ((a == kc[q]) & (j > lane)); rp[q] += (b > kpv[q]) | ((b == kpv[q]) & (j > lane)); }
+            }
+        }
+    }
+    int nc = 0, np = 0;
+#pragma unroll
+    for (int q = 0; q < NPL; q++) {
+        const int s = lane + 64 * q;
+        if (vc[q]) { sf[rc[q]] = cfv[q]; sslot[rc[q]] = s; }
+        if (vp[q]) { pfs[rp[q]] = pfv[q]; pms[rp[q]] = pmv[q]; pslot[rp[q]] = s; }
+        nc += __popcll(__ballot(vc[q]));
+        np += __popcll(__ballot(vp[q]));
+    }
+    pvxw::wave_sync();
+    PVX_STAMP(fr == 1 && lane == 0, 1);
+    // previous peaks of this lane: ranks lane*NPL + j (ascending index ranges per lane: the lowest lane at the minimum
+    // holds the first index, np.argmin, PVAnalysis.py:920); new peaks: rank lane + 64 q, broadcast by readlane
+    double pfr[NPL], pmr[NPL], cfr[NPL];
+    int por[NPL], csr[NPL];
+    bool un[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int i = lane * NPL + j;
+        un[j] = i < np;
+        pfr[j] = un[j] ? pfs[i] : 1.0;
+        pmr[j] = un[j] ? pms[i] : 0.0;
+        por[j] = un[j] ? pslot[i] : 0;
+        const int c = lane + 64 * j;
+        cfr[j] = c < nc ? sf[c] : 0.0;
+        csr[j] = c < nc ? sslot[c] : 0;
+    }
+    int nnew = 0;
+    bool amb_any = false;
+#pragma unroll
+    for (int q = 0; q < NPL; q++) {
+        const int cn = nc - 64 * q < 64 ? nc - 64 * q : 64;
+        for (int cc = 0; cc < cn; cc++) {                             // PVAnalysis.py:903
+            const double fcur = pvxw::rl_d(cfr[q], cc);
+            const int s = __builtin_amdgcn_readlane(csr[q], cc);
+            double sm[NPL];
+            double best = INFINITY;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const double st = fabs(17.312 * (fcur / pfr[j] - 1.0));      // dpitch2st, PVAnalysis.py:62-68, 914
+                sm[j] = un[j] ? st : INFINITY;
+                best = min_nn(best, sm[j]);
+            }
+            const double m = wave_min_pos(best);
+            if (m < p.maxjmp) {                                       // PVAnalysis.py:923 (m finite: some unused peak has it)
+                unsigned long long e[NPL], any = 0ull;
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < NPL; j++) { e[j] = __ballot(sm[j] == m); any |= e[j]; cnt += __popcll(e[j]); }
+                const int wl = __ffsll((long long)any) - 1;
+                int wj = NPL - 1;
+#pragma unroll
+                for (int j = NPL - 2; j >= 0; j--) wj = ((e[j] >> wl) & 1ull) ? j : wj;
+                int wo = __builtin_amdgcn_readlane(por[NPL - 1], wl);
+#pragma unroll
+                for (int j = NPL - 2; j >= 0; j--) { const int o = __builtin_amdgcn_readlane(por[j], wl); wo = (wj == j) ? o : wo; }
+                if (cnt > 1) {
+                    // two unused previous peaks exactly as near: if they are also exactly as strong as the winner
+                    // the reference lets the partial index decide (see the header)
+                    double wm = pvxw::rl_d(pmr[NPL - 1], wl);
+#pragma unroll
+                    for (int j = NPL - 2; j >= 0; j--) { const double o = pvxw::rl_d(pmr[j], wl); wm = (wj == j) ? o : wm; }
+                    int same = 0;
+#pragma unroll
+                    for (int j = 0; j < NPL; j++) same += __popcll(e[j] & __ballot(pmr[j] == wm));
+                    amb_any = amb_any || same > 1;
+                }
+#pragma unroll
+                for (int j = 0; j < NPL; j++) un[j] = un[j] && !(lane == wl && wj == j);
+                if (lane == 0) { linkL[s] = wo; succL[wo] = 1; }
+            } else {
+                if (lane == 0) { linkL[s] = -1; nrkL[s] = nnew; }     // add_empty_partial
+                nnew++;
+            }
+        }
+    }
+    nnew_out = nnew; amb_out = amb_any;
+}
+
+// One wave per frame, a workgroup per chunk of blockDim/64 consecutive frames.  NPL > 0: K <= 64 NPL.
+template <int NPL>
+__global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = p.K;
+    const int kp = (K + 1) & ~1;
+    const WaveLds L(smem, kp, wid);
+    const int64_t fb = (int64_t)blockIdx.x * nw, fr = fb + wid;
+    const bool live = fr < p.F;
+    int nnew = 0;
+    bool amb_any = false;
+    PVX_STAMP(fr == 1 && lane == 0, 0);
+    if (live) {
+        if constexpr (NPL > 0) links_frame_reg<NPL>(p, L, fr, lane, nnew, amb_any);
+        else links_frame_lds(p, L, fr, lane, nnew, amb_any);
+    }
+    __syncthreads();
+    PVX_STAMP(fr == 1 && lane == 0, 2);
+    // the chunk's roots, frame after frame (one wave: the steps are dependent): a new partial's root is its own
+    // node, a continued peak takes its predecessor's -- the chunk's first frame points into the frame before it
+    if (wid == 0) {
+        for (int t = 0; t < nw && fb + t < p.F; t++) {
+            const WaveLds Lt(smem, kp, t);
+            const int* rprev = t > 0 ? WaveLds(smem, kp, t - 1).rootL : nullptr;
+            const int64_t base = (fb + t) * K;
+            for (int s = lane; s < K; s += 64) {
+                const int l = Lt.linkL[s];
+                Lt.rootL[s] = l == -2 ? -1 : (l == -1 ? (int)(base + s) : (t == 0 ? (int)(base - K + l) : rprev[l]));
+            }
+            pvxw::wave_sync();
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // every frame defines its own link and root rows and the succ row of the frame before it (no memset)
+    for (int s = lane; s < K; s += 64) {
+        const int l = L.linkL[s];                                    // slot in frame fr-1 | -1 new partial | -2 empty
+        p.link[fr * K + s] = l >= 0 ? l : (l == -2 ? -1 : -(L.nrkL[s] + 2));   // the table's code (pvx_internal.h)
+        p.root[fr * K + s] = L.rootL[s];
+        if (fr > 0) p.succ[(fr - 1) * K + s] = (unsigned char)L.succL[s];
+        if (fr == p.F - 1) p.succ[fr * K + s] = 0;
+    }
+    if (lane == 0) p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0);
+    PVX_STAMP(fr == 1 && lane == 0, 3);
 }
 
 // The reference's loop as it stands (PVAnalysis.py:871-957), one wave, frames in order, partial indices at
@@ -224,16 +448,17 @@ __global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
     if (lane == 0) { *p.npartials = P; *p.maxend = lastfr; }
 }
 
-// exclusive scan of newcount[F] -> newbase[F+1] (single workgroup, 1024 threads, chunked)
-__global__ __launch_bounds__(1024) void k_scan_counts(TrackParams p) {
-    __shared__ long long wsum[16];
-    __shared__ long long carry_s;
+// exclusive scan of newcount[F] (ambiguity flags masked and OR-ed) with a 1024-thread workgroup; out(i, value)
+template <typename Out>
+__device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsum, long long* carry_s, int* amb_s, Out out) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) { *carry_s = 0; *amb_s = 0; }
     __syncthreads();
     for (int64_t base = 0; base < p.F; base += 1024) {
         const int64_t i = base + tid;
-        long long v = (i < p.F) ? (long long)p.newcount[i] : 0;
+        const int raw = (i < p.F) ? p.newcount[i] : 0;
+        if (raw & kAmbBit) *amb_s = 1;
+        long long v = (long long)(raw & (kAmbBit - 1));
         long long inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -244,13 +469,90 @@ __global__ __launch_bounds__(1024) void k_scan_counts(TrackParams p) {
         __syncthreads();
         long long woff = 0;
         for (int w = 0; w < wid; w++) woff += wsum[w];
-        const long long carry = carry_s;
-        if (i < p.F) p.newbase[i] = carry + woff + inc - v;
+        const long long carry = *carry_s;
+        if (i < p.F) out(i, carry + woff + inc - v);
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + inc;
+        if (tid == 1023) *carry_s = carry + woff + inc;
         __syncthreads();
     }
-    if (tid == 0) { p.newbase[p.F] = carry_s; *p.npartials = carry_s; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_counts(TrackParams p) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    __shared__ int amb_s;
+    scan_counts(p, wsum, &carry_s, &amb_s, [&](int64_t i, long long v) { p.newbase[i] = v; });
+    if (threadIdx.x == 0) { p.newbase[p.F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = -1; }
+}
+
+// The scan, and the roots of the chunks' LAST frames: rb[c][s] starts as k_track_links left it -- final, or a node of
+// the last frame of chunk c-1.  Pointer jumping between those rows only (in LDS, log2(#chunks) rounds; in place is
+// safe: any value read is an ancestor), then back to p.root: every other node is now at most one hop from its root.
+__global__ __launch_bounds__(1024) void k_track_boundaries(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    __shared__ int amb_s;
+    int32_t* rb = (int32_t*)smem;                                // [NCH][K]
+    const int tid = threadIdx.x;
+    const int K = p.K, CL = p.chunk;
+    const int64_t F = p.F;
+    const int NCH = (int)((F + CL - 1) / CL);
+    const int items = NCH * K;
+    PVX_STAMP(tid == 0, 8);
+    // 16 waves share this CU's issue slots (an instruction of a wave every ~18 cycles): no integer division below.
+    // v / K through a float reciprocal (exact after one fix for v < 2^24, else the division); CL is a power of two.
+    const float invK = 1.0f / (float)K;
+    const bool small = F * (int64_t)K < (1 << 24);
+    auto div_k = [&](int v) {
+        if (!small) return v / K;
+        int q = (int)((float)v * invK);
+        if (q * K > v) q--; else if ((q + 1) * K <= v) q++;
+        return q;
+    };
+    const int lg = 31 - __builtin_clz((unsigned)CL);
+    auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) << lg; return (e < F ? e : F) - 1; };
+    for (int w = tid; w < items; w += 1024) { const int c = div_k(w); rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
+    scan_counts(p, wsum, &carry_s, &amb_s, [&](int64_t i, long long v) { p.newbase[i] = v; });     // (barriers inside)
+    if (tid == 0) { p.newbase[F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = -1; }
+    PVX_STAMP(tid == 0, 9);
+    for (int r = 0; (1 << r) < NCH; r++) {
+        int moved = 0;
+        for (int w = tid; w < items; w += 1024) {
+            const int v = rb[w];
+            if (v < 0) continue;                                  // empty slot
+            const int fv = div_k(v), cv = fv >> lg;               // the frame and chunk v names
+            if (cv >= div_k(w)) continue;                         // a root inside this item's own chunk: final
+            if (((fv + 1) & (CL - 1)) != 0) continue;             // a root that is not on a chunk's last frame: final
+            const int wv = cv * K + (v - fv * K);                 // that last-frame node's item
+            const int nv = rb[wv];
+            if (nv != v) { rb[w] = nv; moved = 1; }
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    for (int w = tid; w < items; w += 1024) { const int c = div_k(w); p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+    PVX_STAMP(tid == 0, 10);
+}
+
+__global__ __launch_bounds__(256) void k_assign_chunked(TrackParams p) {
+    const int64_t n = p.F * (int64_t)p.K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t r = p.root[i];
+    if (r < 0) { p.partial_id[i] = -1; return; }
+    const int64_t ifr = i / p.K;
+    if ((int64_t)r < (ifr / p.chunk) * p.chunk * p.K) r = p.root[r];     // before the chunk: a last-frame node, final by now
+    const int64_t rfr = r / p.K;
+    const int64_t pid = p.newbase[rfr] + (-(p.link[r] + 2));         // creation order, PVAnalysis.py:826
+    p.partial_id[i] = (int32_t)pid;
+    const bool last = !p.succ[i];
+    if (pid < p.cap) {
+        if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
+        // the last point of a partial (no peak of the next frame continues it) knows the length:
+        // one plain store per partial instead of one contended atomic per point
+        if (last) p.part_len[pid] = (int32_t)(ifr - rfr + 1);
+    }
+    if (last) atomicMax((long long*)p.maxend, (long long)ifr);       // max(SinSum.end): one atomic per partial
 }
 
 __global__ __launch_bounds__(256) void k_root_init(TrackParams p) {
@@ -259,8 +561,8 @@ __global__ __launch_bounds__(256) void k_root_init(TrackParams p) {
     if (i >= n) return;
     const int l = p.link[i];
     int32_t r;
-    if (l == -2) r = -1;
-    else if (l == -1) r = (int32_t)i;
+    if (l == -1) r = -1;
+    else if (l <= -2) r = (int32_t)i;
     else r = (int32_t)(i - (i % p.K) - p.K + l);                     // (fr-1)*K + slot
     p.root[i] = r;
 }
@@ -283,7 +585,7 @@ __global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
     const int32_t r = p.root[i];
     if (r < 0) { p.partial_id[i] = -1; return; }
     const int64_t rfr = r / p.K;
-    const int64_t pid = p.newbase[rfr] + p.newrank[r];               // creation order, PVAnalysis.py:826
+    const int64_t pid = p.newbase[rfr] + (-(p.link[r] + 2));         // creation order, PVAnalysis.py:826
     p.partial_id[i] = (int32_t)pid;
     if (pid < p.cap) {
         if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
@@ -297,21 +599,48 @@ __global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
 
 }  // namespace
 
-int pvx_launch_track(const TrackParams& p, hipStream_t s) {
+int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
+    TrackParams p = p_in;
     if (p.F <= 0) return PVX_OK;
     const int64_t n = p.F * (int64_t)p.K;
     if (n >= 0x7fffffffLL) { pvx_set_error("F*K = %lld does not fit the 32-bit node index", (long long)n); return PVX_ERR_UNSUPPORTED; }
     const int kp = (p.K + 1) & ~1;
-    int waves = 4;
-    size_t per_wave = (size_t)kp * 8 * 4 + (size_t)kp * 4 * 3;
+    const size_t per_wave = WaveLds::bytes(kp);
+    if (per_wave > 160 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
+    // frames per workgroup = chunk of the root step.  A frame with many peaks is a long serial chain that wants its
+    // SIMD to itself (4 waves per workgroup: measured 74 k cycles per K = 100 frame against 98 k at 8); short chains
+    // pack 16 to keep the number of chunk boundaries down.  Always within 64 KB of LDS, never below 1.
+    int waves = p.K > 32 ? 4 : 16;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
-    if (per_wave * waves > 64 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
-    PVX_HIP_CHECK(hipMemsetAsync(p.succ, 0, (size_t)n, s));
-    PVX_HIP_CHECK(hipMemsetAsync(p.ambiguous, 0, sizeof(int64_t), s));
-    PVX_HIP_CHECK(hipMemsetAsync(p.maxend, 0xff, sizeof(int64_t), s));          // -1
-    hipLaunchKernelGGL(k_track_links, dim3((unsigned)((p.F + waves - 1) / waves)), dim3(64 * waves), per_wave * waves, s, p);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
+    if (const char* e = getenv("PVX_TRACK_CHUNK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) waves = v < waves ? v : waves; }
+    p.chunk = waves;
+    const dim3 grid((unsigned)((p.F + waves - 1) / waves)), block(64 * waves);
+    const size_t lds = per_wave * waves;
+#define PVX_LINKS(NPL)                                                                                                     \
+    do {                                                                                                                   \
+        if (lds > 48 * 1024)                                                                                               \
+            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_links<NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_track_links<NPL>, grid, block, lds, s, p);                                                    \
+    } while (0)
+    const bool generic = p.K > 256 || getenv("PVX_TRACK_GENERIC");
+    if (generic) PVX_LINKS(0);
+    else if (p.K <= 64) PVX_LINKS(1);
+    else if (p.K <= 128) PVX_LINKS(2);
+    else PVX_LINKS(4);
+#undef PVX_LINKS
     const unsigned nb = (unsigned)((n + 255) / 256);
+    const int64_t nch = (p.F + waves - 1) / waves;
+    const size_t blds = (size_t)nch * p.K * 4;
+    if (blds <= 150 * 1024 && !getenv("PVX_TRACK_LARGE")) {
+        if (blds > 48 * 1024)
+            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+        hipLaunchKernelGGL(k_track_boundaries, dim3(1), dim3(1024), blds, s, p);
+        hipLaunchKernelGGL(k_assign_chunked, dim3(nb), dim3(256), 0, s, p);
+        PVX_HIP_CHECK(hipGetLastError());
+        return PVX_OK;
+    }
+    // the chunk boundaries do not fit one workgroup: roots by pointer jumping over all nodes, one launch per round
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(k_root_init, dim3(nb), dim3(256), 0, s, p);
     int rounds = 1;
     while ((1LL << rounds) < p.F) rounds++;

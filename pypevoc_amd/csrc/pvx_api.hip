@@ -13,7 +13,41 @@
 #include <string>
 #include <vector>
 
+#include <time.h>
+
 #include "pvx_internal.h"
+
+// float64 -> float32 while staging (RNE, what v_cvt_f32_f64 does on the device): AVX2 where the host has it
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void narrow_avx2(const double* src, float* dst, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m128 a = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)), b = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4));
+        _mm256_storeu_ps(dst + i, _mm256_set_m128(b, a));
+    }
+    for (; i < n; i++) dst[i] = (float)src[i];
+}
+#endif
+static void narrow_f64_f32(const double* src, float* dst, size_t n) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { narrow_avx2(src, dst, n); return; }
+#endif
+    for (size_t i = 0; i < n; i++) dst[i] = (float)src[i];
+}
+
+// PVX_TRACE=1: host-side time stamps of the small-call paths on stderr (where a sub-millisecond round trip goes)
+namespace {
+struct HostTrace {
+    bool on;
+    const char* what;
+    double t0, last;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+    explicit HostTrace(const char* w) : on(getenv("PVX_TRACE") != nullptr), what(w), t0(0), last(0) { if (on) { t0 = last = now(); } }
+    void mark(const char* label) { if (on) { const double t = now(); fprintf(stderr, "[pvx %s] %-28s +%7.1f us (%7.1f)\n", what, label, t - last, t - t0); last = t; } }
+};
+}  // namespace
 
 // ---- errors ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -623,6 +657,7 @@ static int carry_spectrum(pvx_plan* p, int64_t rows_in_call, hipStream_t s) {
 // bit for bit, as one launch over the whole signal -- and a signal larger than HBM runs.
 static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                             const HostOut* ho, const double* prev0, double* last_spec, bool keep) {
+    HostTrace tr("analyze");
     int rc = pvx_require_device();
     if (rc != PVX_OK) return rc;
     rc = check_analyze_args(p, x, x_dtype, nsamp, nsig, sig_stride, prev0);
@@ -679,6 +714,12 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     const size_t total_in = (size_t)((nsig - 1) * sig_stride + nsamp) * es;
     const size_t total_out = (size_t)nsig * F * per_frame_out;
     const bool small = nchunks == 1 && total_in + (keep ? 0 : total_out) <= kSmallCall;
+    // a float64 signal analysed at precision 32: every kernel's first step is (float)x[n], so the small-call path
+    // narrows while it stages (same rounding, half the bytes over PCIe, the aligned float loads on the device)
+    const size_t spec_pin = (size_t)(p->N2 > 0 ? p->N2 : 1) * 16 + 256;       // the last spectrum lands behind the staged data
+    const bool narrow = small && p->precision == 32 && x_dtype == PVX_F64;
+    const int dev_dtype = narrow ? PVX_F32 : x_dtype;
+    const size_t des = narrow ? 4 : es;
 
     auto chunk_geom = [&](int64_t c, int64_t& u0, int64_t& u1, size_t& in_off, size_t& in_bytes, int64_t& c_nsamp, int64_t& c_nsig, int64_t& c_frames) {
         u0 = c * per_chunk; u1 = u0 + per_chunk < units ? u0 + per_chunk : units;
@@ -714,6 +755,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
 
     p->progress_live = true;
     int64_t last_rows = 0;
+    tr.mark("setup");
     for (int64_t c = 0; c < nchunks; c++) {
         const int b = (int)(c & 1);
         int64_t u0, u1, c_nsamp, c_nsig, c_frames; size_t in_off, in_bytes;
@@ -729,19 +771,30 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
             ob = p->d_out[b];
         }
         if (small) {
-            if ((rc = grow_pin(p, ((total_in + 255) & ~(size_t)255) + total_out)) != PVX_OK) { p->progress_live = false; return rc; }
-            memcpy(p->h_pin, (const char*)x + in_off, in_bytes);
-            PVX_HIP_CHECK(hipMemcpyAsync(p->d_in[b], p->h_pin, in_bytes, hipMemcpyHostToDevice, s));
+            if ((rc = grow_pin(p, ((total_in + 255) & ~(size_t)255) + (keep ? 0 : total_out) + spec_pin)) != PVX_OK) { p->progress_live = false; return rc; }
+            // staged in pieces: the DMA of piece i runs under the host copy of piece i+1
+            const size_t nel = in_bytes / es, piece = (size_t)64 << 10;
+            for (size_t e0 = 0; e0 < nel; e0 += piece) {
+                const size_t cnt = nel - e0 < piece ? nel - e0 : piece;
+                if (narrow) {
+                    narrow_f64_f32((const double*)x + e0, (float*)p->h_pin + e0, cnt);
+                    tr.mark("  piece narrowed");
+                } else {
+                    memcpy((char*)p->h_pin + e0 * es, (const char*)x + e0 * es, cnt * es);
+                }
+                PVX_HIP_CHECK(hipMemcpyAsync((char*)p->d_in[b] + e0 * des, (char*)p->h_pin + e0 * des, cnt * des, hipMemcpyHostToDevice, s));
+            }
         } else {
             // pageable, synchronous for the host -- and concurrent with the kernels of chunk c-1 on the plan's stream
             PVX_HIP_CHECK(hipMemcpy(p->d_in[b], (const char*)x + in_off, in_bytes, hipMemcpyHostToDevice));
         }
+        tr.mark("staged + H2D issued");
         HostOut d;
         if (keep) {
             const HostOut all = block_ptrs(p->d_res, nsig * F, K);
             const size_t r0 = by_frames ? (size_t)u0 : (size_t)u0 * F;
             d.f = all.f + r0 * K; d.mag = all.mag + r0 * K; d.ph = all.ph + r0 * K; d.realph = all.realph + r0 * K;
-            d.binno = all.binno + r0 * K; d.t = nullptr; d.totalmag = all.totalmag + r0;
+            d.binno = all.binno + r0 * K; d.t = nchunks == 1 ? all.t : nullptr; d.totalmag = all.totalmag + r0;
         } else {
             d = block_ptrs(ob, c_frames, K);
             d.t = nullptr;
@@ -749,8 +802,9 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
         const bool want_spec = (c + 1 < nchunks && by_frames) || (last_spec && c + 1 == nchunks);
         const double* dprev = (c > 0 && by_frames) || prev0 ? p->d_prev : nullptr;
         last_rows = c_nsig * (c_frames / c_nsig + 1);
-        rc = analyze_rows(p, p->d_in[b], x_dtype, c_nsamp, c_nsig, by_frames ? c_nsamp : sig_stride, c_frames / c_nsig,
+        rc = analyze_rows(p, p->d_in[b], dev_dtype, c_nsamp, c_nsig, by_frames ? c_nsamp : sig_stride, c_frames / c_nsig,
                           d.f, d.mag, d.ph, d.realph, d.binno, d.t, d.totalmag, dprev, s, want_spec ? last_rows - 1 : -1);
+        tr.mark("kernels issued");
         if (rc == PVX_OK && c + 1 < nchunks && by_frames) rc = carry_spectrum(p, last_rows, s);
         if (rc != PVX_OK) { p->progress_live = false; return rc; }
         PVX_HIP_CHECK(hipEventRecord(p->ev_done[b], s));
@@ -766,7 +820,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     // ---- tail: last chunk's results, frame times, the last spectrum
     if (keep) {
         const HostOut all = block_ptrs(p->d_res, nsig * F, K);
-        if ((rc = pvx_launch_fill_t(all.t, F, nsig, p->hop, p->nfft, p->sr, s)) != PVX_OK) return rc;
+        if (nchunks > 1 && (rc = pvx_launch_fill_t(all.t, F, nsig, p->hop, p->nfft, p->sr, s)) != PVX_OK) return rc;   // else the kernels wrote it
         p->res_F = F; p->res_nsig = nsig; p->res_valid = true;
     } else if (small) {
         // one D2H of the whole block into pinned memory, one synchronisation, then plain memcpys
@@ -785,20 +839,35 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
         for (int64_t b = 0; b < nsig; b++)
             for (int64_t fr = 0; fr < F; fr++) ho->t[b * F + fr] = ((double)(fr * (int64_t)p->hop) + p->nfft / 2.0) / p->sr;   // PV.py:247
     }
-    PVX_HIP_CHECK(hipStreamSynchronize(s));
-    if (last_spec && p->fft_mode != 0) {
-        std::vector<float> tmp(2 * (size_t)p->N2);
-        PVX_HIP_CHECK(hipMemcpy(tmp.data(), p->d_specrow, tmp.size() * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 2 * p->N2; i++) last_spec[i] = (double)tmp[i];
-    } else if (last_spec) {
-        // the last chunk's last row is still in the spectrum workspace
+    // the spectrum of the last frame (PV.oldfft after the loop, PV.py:209): float [N2][2] from the fused kernels,
+    // or the last chunk's last row of the general path's workspace
+    const size_t rs = real_size(p->fft_mode != 0 ? 32 : p->precision);
+    const void* d_last = nullptr;
+    if (last_spec && p->fft_mode != 0) d_last = p->d_specrow;
+    else if (last_spec) {
         const int64_t lastR0 = ((last_rows - 1) / p->max_rows) * p->max_rows;
         const int64_t wsrow = (last_rows - 1) - lastR0 + 1;
-        const size_t rs = real_size(p->precision);
-        std::vector<unsigned char> tmp((size_t)p->N2 * 2 * rs);
-        PVX_HIP_CHECK(hipMemcpy(tmp.data(), (char*)p->d_spec + (size_t)wsrow * p->ldo * 2 * rs, tmp.size(), hipMemcpyDeviceToHost));
+        d_last = (const char*)p->d_spec + (size_t)wsrow * p->ldo * 2 * rs;
+    }
+    std::vector<unsigned char> tmp;
+    unsigned char* h_last = nullptr;
+    if (d_last && small) {
+        // small call: into the pinned block behind the staged data, under the one synchronisation below
+        h_last = (unsigned char*)p->h_pin + ((((total_in + 255) & ~(size_t)255) + (keep ? 0 : total_out) + 255) & ~(size_t)255);
+        if ((size_t)(h_last - (unsigned char*)p->h_pin) + (size_t)p->N2 * 2 * rs > p->pin_cap) h_last = nullptr;
+    }
+    if (h_last) PVX_HIP_CHECK(hipMemcpyAsync(h_last, d_last, (size_t)p->N2 * 2 * rs, hipMemcpyDeviceToHost, s));
+    tr.mark("tail issued");
+    PVX_HIP_CHECK(hipStreamSynchronize(s));
+    tr.mark("synchronised");
+    if (d_last) {
+        if (!h_last) {
+            tmp.resize((size_t)p->N2 * 2 * rs);
+            h_last = tmp.data();
+            PVX_HIP_CHECK(hipMemcpy(h_last, d_last, tmp.size(), hipMemcpyDeviceToHost));
+        }
         for (int i = 0; i < 2 * p->N2; i++)
-            last_spec[i] = p->precision == 32 ? (double)((float*)tmp.data())[i] : ((double*)tmp.data())[i];
+            last_spec[i] = rs == 4 ? (double)((const float*)h_last)[i] : ((const double*)h_last)[i];
     }
     if (p->progress_fn) p->progress_fn(nsig * F, nsig * F, p->progress_user);
     return F;
@@ -809,6 +878,17 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
                                double* totalmag, const double* prev0, double* last_spec) {
     HostOut ho = {f, mag, ph, realph, binno, t, totalmag};
     return analyze_host(p, x, x_dtype, nsamp, nsig, sig_stride, &ho, prev0, last_spec, false);
+}
+
+// ---- page-locked host arrays for results (the DMA engine writes them directly) ------------------------
+extern "C" void* pvx_host_alloc(size_t bytes) {
+    if (pvx_require_device() != PVX_OK) return nullptr;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pvx_set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return q;
+}
+extern "C" void pvx_host_free(void* q) {
+    if (q) (void)hipHostFree(q);
 }
 
 // ---- resident results ---------------------------------------------------------------------------
@@ -918,8 +998,8 @@ extern "C" int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks,
 // ---- tracker: PV.toSinSum (PV.py:299-322) ---------------------------------------------------
 static size_t track_ws_bytes(int64_t F, int K) {
     const size_t n = (size_t)F * K;
-    // link, newrank, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials, ambiguous, maxend int64; succ [F*K]
-    size_t off = n * 4 * 3 + (size_t)F * 4;
+    // link, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials, ambiguous, maxend int64; succ [F*K]
+    size_t off = n * 4 * 2 + (size_t)F * 4;
     off = (off + 7) & ~(size_t)7;
     return off + ((size_t)F + 1) * 8 + 24 + n;
 }
@@ -927,22 +1007,23 @@ static size_t track_ws_bytes(int64_t F, int K) {
 // the tracker on device arrays with a caller-provided workspace of track_ws_bytes(F, K); returns P
 static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K, double maxpitchjmp,
                         int32_t* d_partial_id, int32_t* d_part_start, int32_t* d_part_len, int64_t cap, char* w,
-                        hipStream_t s, int64_t* maxend) {
+                        hipStream_t s, int64_t* maxend, int64_t* pinned3 = nullptr) {
     const size_t n = (size_t)F * K;
-    const size_t off_link = 0, off_rank = off_link + n * 4, off_root = off_rank + n * 4, off_cnt = off_root + n * 4;
+    const size_t off_link = 0, off_root = off_link + n * 4, off_cnt = off_root + n * 4;
     const size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
     const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 24;
     TrackParams tp;
     tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
     tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
-    tp.link = (int32_t*)(w + off_link); tp.newrank = (int32_t*)(w + off_rank); tp.root = (int32_t*)(w + off_root);
+    tp.link = (int32_t*)(w + off_link); tp.root = (int32_t*)(w + off_root);
     tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
     tp.npartials = (int64_t*)(w + off_np);
     tp.ambiguous = tp.npartials + 1;
     tp.maxend = tp.npartials + 2;
     int rc = pvx_launch_track(tp, s);
     if (rc != PVX_OK) return rc;
-    int64_t pa[3] = {0, 0, -1};
+    int64_t pa_[3] = {0, 0, -1};
+    int64_t* pa = pinned3 ? pinned3 : pa_;                 // { partials, exact double tie met, last frame with a point }
     PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 24, hipMemcpyDeviceToHost, s));
     PVX_HIP_CHECK(hipStreamSynchronize(s));
     if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
@@ -996,7 +1077,11 @@ extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* 
     if ((rc = grow_dev(&p->d_tws, &p->tws_cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
     const HostOut all = block_ptrs(p->d_res, F, K);
     int64_t maxend = -1;
-    const int64_t P = track_on(all.f, all.mag, F, K, maxpitchjmp, p->d_pid, p->d_pst, p->d_pln, (int64_t)n, (char*)p->d_tws, p->s_host, &maxend);
+    if ((rc = grow_pin(p, 64)) != PVX_OK) return rc;
+    HostTrace tr("track");
+    const int64_t P = track_on(all.f, all.mag, F, K, maxpitchjmp, p->d_pid, p->d_pst, p->d_pln, (int64_t)n, (char*)p->d_tws, p->s_host, &maxend,
+                               (int64_t*)p->h_pin);
+    tr.mark("launched + synchronised");
     if (P < 0) return P;
     p->res_P = P; p->res_maxend = maxend;
     if (max_end_frame) *max_end_frame = maxend;
@@ -1022,17 +1107,44 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
     if (p->res_P == 0) { pvx_set_error("max() arg is an empty sequence"); return PVX_ERR_INVALID; }          // PV.py:1059
     const int64_t need = pvx_synth_len(p->res_maxend, p->nfft, p->hop, hop_synth, edge);
     if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
+    HostTrace tr("synth");
     if ((rc = grow_dev(&p->d_w, &p->w_cap, (size_t)wlen * 8)) != PVX_OK) return rc;
     const HostOut all = block_ptrs(p->d_res, p->res_F, p->npks);
     rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
                              p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0);
     if (rc != PVX_OK) return rc;
     const size_t bytes = (size_t)wlen * 8;
-    if (bytes <= kSmallCall) {
-        if ((rc = grow_pin(p, bytes)) != PVX_OK) return rc;
-        PVX_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_w, bytes, hipMemcpyDeviceToHost, p->s_host));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, w) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        // the caller's array is page-locked (pvx_host_alloc): the DMA lands in it, nothing to stage or copy
+        PVX_HIP_CHECK(hipMemcpyAsync(w, p->d_w, bytes, hipMemcpyDeviceToHost, p->s_host));
+        tr.mark("kernel + copy issued");
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-        memcpy(w, p->h_pin, bytes);
+        tr.mark("here");
+        return PVX_OK;
+    }
+    (void)hipGetLastError();                                     // an ordinary pointer is reported as an error
+    if (bytes <= kSmallCall) {
+        // through pinned memory in pieces: the host copy of piece i runs under the DMA of piece i+1 (two events in turn)
+        if ((rc = grow_pin(p, bytes)) != PVX_OK) return rc;
+        const size_t piece = bytes > ((size_t)256 << 10) ? ((bytes + 3) / 4 + 255) & ~(size_t)255 : bytes;
+        const int np_ = (int)((bytes + piece - 1) / piece);
+        auto issue = [&](int i) -> int {
+            const size_t o = (size_t)i * piece, c = bytes - o < piece ? bytes - o : piece;
+            PVX_HIP_CHECK(hipMemcpyAsync((char*)p->h_pin + o, (const char*)p->d_w + o, c, hipMemcpyDeviceToHost, p->s_host));
+            PVX_HIP_CHECK(hipEventRecord(p->ev_done[i & 1], p->s_host));
+            return PVX_OK;
+        };
+        if ((rc = issue(0)) != PVX_OK) return rc;
+        if (np_ > 1 && (rc = issue(1)) != PVX_OK) return rc;
+        tr.mark("kernel + copies issued");
+        for (int i = 0; i < np_; i++) {
+            const size_t o = (size_t)i * piece, c = bytes - o < piece ? bytes - o : piece;
+            PVX_HIP_CHECK(hipEventSynchronize(p->ev_done[i & 1]));
+            if (i + 2 < np_ && (rc = issue(i + 2)) != PVX_OK) return rc;       // its event is free again
+            memcpy((char*)w + o, (const char*)p->h_pin + o, c);
+        }
+        tr.mark("copied out");
     } else {
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
         PVX_HIP_CHECK(hipMemcpy(w, p->d_w, bytes, hipMemcpyDeviceToHost));

@@ -118,14 +118,15 @@ struct TrackParams {
     int32_t* part_len;    // [cap]
     int64_t cap;
     // workspace
-    int32_t* link;        // [F][K]  slot in frame-1, -1 = starts a partial, -2 = empty slot
-    int32_t* newrank;     // [F][K]  rank among the new partials of its frame (creation order)
+    int32_t* link;        // [F][K]  >= 0: continues that slot of frame-1; -1: empty slot; <= -2: starts a partial,
+                          //         -(link + 2) = its rank among the new partials of its frame (creation order)
     int32_t* newcount;    // [F]     partials created at each frame
     int64_t* newbase;     // [F+1]   exclusive scan of newcount
     int32_t* root;        // [F][K]  flattened index of the first point of the slot's partial
     unsigned char* succ;  // [F][K]  1 if a peak of the next frame continues this one
     int64_t* npartials;   // [1]
     int64_t* maxend;      // [1]  last frame that holds a point of any partial = max(SinSum.end) (PV.py:1059)
+    int chunk;            // frames per k_track_links workgroup = chunk length of the root step (set by pvx_launch_track)
     int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
                           //      the previous partials would decide an assignment (k_track.hip header)
 };
@@ -144,6 +145,7 @@ struct SynthParams {
     int64_t wlen;
     int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
     int no_phcor;         // PVX_SYNTH_NO_PHCOR: fstep=None partials (PV.py:710-713)
+    int nbatch;           // contributions gathered per round (set by pvx_launch_synth from the LDS budget)
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
 

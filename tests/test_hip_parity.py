@@ -145,6 +145,44 @@ def test_sequential_tracker_kernel_equals_parallel(amd, name, monkeypatch):
     assert np.array_equal(pid, pid2) and np.array_equal(st, st2) and np.array_equal(ln, ln2)
 
 
+@pytest.mark.parametrize("env", [{"PVX_TRACK_CHUNK": "1"}, {"PVX_TRACK_CHUNK": "2"}, {"PVX_TRACK_CHUNK": "16"},
+                                 {"PVX_TRACK_GENERIC": "1"}, {"PVX_TRACK_LARGE": "1"},
+                                 {"PVX_TRACK_GENERIC": "1", "PVX_TRACK_CHUNK": "1", "PVX_TRACK_LARGE": "1"}])
+@pytest.mark.parametrize("name", ["G1_two_sines", "G5a_noise_n1024_k20", "G6_silence_gaps", "G7_perlman"])
+def test_tracker_variants_give_the_reference_table(amd, name, env, monkeypatch):
+    """The tracker's launch shapes -- chunk length of the root step (frames per k_track_links workgroup), the any-K
+    link loop through LDS, the pointer-jumping kernels for tables whose chunk boundaries do not fit one workgroup --
+    all build the reference's table (PVAnalysis.py:299-322)."""
+    g = load_golden(name)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    pid, st, ln = ss.partial_table()
+    assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+    for k in env:
+        monkeypatch.delenv(k)
+    s2 = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    s2._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    assert np.array_equal(pid, s2.partial_table()[0])
+
+
+def test_tracker_wide_rows(amd, oracle):
+    """npks beyond the register kernels (K > 256: the LDS link loop) and at their edges (64, 65, 128, 129, 256)."""
+    rng = np.random.default_rng(11)
+    for K in (64, 65, 128, 129, 256, 300):
+        F = 37
+        f = np.sort(rng.uniform(50.0, 8000.0, (F, K)), axis=1) * (1.0 + 0.01 * rng.standard_normal((F, K)))
+        mag = rng.uniform(0.0, 1.0, (F, K))
+        mag[rng.uniform(size=(F, K)) < 0.2] = 0.0
+        f[rng.uniform(size=(F, K)) < 0.05] = 0.0
+        ss = amd.SinSum(44100.0, nfft=2048, hop=512)
+        ss._from_analysis(f, mag, np.zeros((F, K)), np.zeros((F, K)))
+        pid, st, ln = ss.partial_table()
+        opid, ost, oln = oracle.track(f, mag)
+        assert np.array_equal(pid, opid) and np.array_equal(st, ost) and np.array_equal(ln, oln), K
+
+
 @pytest.mark.parametrize("name", TRACKED)
 def test_synth_matches_reference(amd, name):
     g = load_golden(name)
@@ -166,6 +204,45 @@ def test_synth_matches_reference(amd, name):
         w32 = s32.synth(g["sr"], h)
         assert w32.shape == ref.shape
         assert np.abs(w32 - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_synth_workgroup_shapes_and_result_arrays(amd, monkeypatch):
+    """k_synth_ola with one and two groups of contributions per segment (256 / 512 threads; the sums associate
+    differently, float64 round-off apart) and the page-locked result arrays of the resident chain: writable,
+    and a later result does not touch an earlier one that is still alive."""
+    g = load_golden("G7_perlman")
+    h = int(g["hop"])
+    ref = g["w_hop%d" % h].astype(np.float64)
+    p = run_golden(amd, g, 32)
+    ss = p.toSinSum()
+    ws = {}
+    for nt in ("256", "512"):
+        monkeypatch.setenv("PVX_SYNTH_THREADS", nt)
+        ws[nt] = ss.synth(g["sr"], h)
+        assert np.abs(ws[nt] - ref).max() <= 1e-4 * np.abs(ref).max()
+    monkeypatch.delenv("PVX_SYNTH_THREADS")
+    assert np.abs(ws["256"] - ws["512"]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    keep = ws["512"].copy()
+    w3 = ss.synth(g["sr"], h)                      # a third buffer of the same size while two are alive
+    assert ws["512"].flags.writeable and np.array_equal(ws["512"], keep)
+    w3 += 1.0
+    assert np.array_equal(ws["512"], keep)
+    del ws, w3
+    w4 = ss.synth(g["sr"], h)                      # reuses a returned buffer
+    assert np.array_equal(w4, keep)
+
+
+def test_float64_signal_is_narrowed_like_the_kernels_do(amd):
+    """precision=32 takes a float64 signal through float32 staging on the small-call path: the same numbers as
+    handing over the float32 cast, and as the device-resident float64 signal."""
+    g = load_golden("G7_perlman")
+    x = np.asarray(g["x"], dtype=np.float64)
+    a = run_pv(amd, x, g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], precision=32)
+    b = run_pv(amd, x.astype(np.float32), g["sr"], g["nfft"], g["hop"], g["npks"], g["pkthresh"], precision=32)
+    for name in ("f", "mag", "ph", "realph", "binno", "t"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.array_equal(np.asarray(a.totalmag), np.asarray(b.totalmag))
+    assert np.array_equal(a.oldfft, b.oldfft)
 
 
 def test_g1_known_answer(amd):

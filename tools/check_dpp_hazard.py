@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check on the generated gfx950 ISA of the fused kernels: no DPP move may read a register that
+"""Static check on the generated gfx950 ISA of the fused kernels and the tracker: no DPP move may read a register that
 one of the inline-asm primitives of pvx_cplx.h wrote less than two wait states earlier.  (VALU write ->
 DPP read needs two wait states on gfx9; the compiler inserts them for instructions it emitted itself,
 but its hazard recogniser does not look inside inline asm.)  Exit status 1 if a candidate is found.
@@ -63,7 +63,7 @@ def main():
     hipcc = os.environ.get("HIPCC", "hipcc")
     status = 0
     with tempfile.TemporaryDirectory() as td:
-        for name in ("k_fused", "k_fused_mw", "k_fused_ring"):
+        for name in ("k_fused", "k_fused_mw", "k_fused_ring", "k_track"):
             out = os.path.join(td, name + ".s")
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
                                    "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", out,

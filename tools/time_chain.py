@@ -30,3 +30,12 @@ for name, x in (("float64 signal", g["x"]), ("float32 signal", g["x"].astype(np.
         return q.toSinSum().synth(g["sr"], 1024)
     t_all, _ = best(chain)
     print("%s: PV() %.3f ms | run_pv %.3f | toSinSum %.3f | synth %.3f | whole chain incl. construction %.3f ms" % (name, t_init, t_run, t_sin, t_syn, t_all))
+
+# the resynthesis kernel's workgroup size on this short signal (default: 512 threads per segment below 1024 segments)
+x = g["x"]
+q = pypevoc_amd.PV(x, g["sr"], nfft=4096, hop=1024, npks=100, progress=False); q.run_pv(); ss = q.toSinSum()
+for nt in ("256", "512"):
+    os.environ["PVX_SYNTH_THREADS"] = nt
+    t, _ = best(lambda: ss.synth(g["sr"], 1024))
+    print("synth with %s threads per segment: %.3f ms" % (nt, t))
+os.environ.pop("PVX_SYNTH_THREADS", None)
