@@ -62,6 +62,7 @@ __device__ inline void wave_argmin(double& v, int& i) {
 #endif
 
 constexpr int kAmbBit = 1 << 30;   // newcount[fr] carries the frame's "exact double tie" flag in this bit
+constexpr int kHasBit = 1 << 29;   // ... and "the frame has a valid peak" (max(SinSum.end), PV.py:1059) in this one
 
 // LDS of one wave (= one frame): 4 double rows and 7 int rows of kp = K rounded up to even.  Rows 4..6 of the ints are
 // the frame's result, read by the chunk step: linkL (slot in frame fr-1 | -1 new partial | -2 empty), nrkL (rank
@@ -78,7 +79,7 @@ struct WaveLds {
 };
 
 // ---- one frame, any K: the assignment loop (PVAnalysis.py:903-957) through LDS ---------------------------------
-__device__ void links_frame_lds(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out) {
+__device__ void links_frame_lds(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out, bool& has_out) {
     const int K = p.K;
     double *cm = L.d[0], *cf = L.d[1], *pm = L.d[2], *pf = L.d[3];
     int *corder = L.a, *porder = L.b, *linkL = L.linkL, *nrkL = L.nrkL, *succL = L.succL, *used = L.used;
@@ -166,7 +167,7 @@ __device__ void links_frame_lds(const TrackParams& p, const WaveLds& L, int64_t 
         }
         pvxw::wave_sync();
     }
-    nnew_out = nnew; amb_out = amb_any;
+    nnew_out = nnew; amb_out = amb_any; has_out = nc > 0;
 }
 
 // ---- one frame, K <= 64 NPL, with nothing but registers inside the loops ---------------------------------------
@@ -198,7 +199,7 @@ __device__ __forceinline__ double wave_min_pos(double v) {         // v >= 0 or 
 }
 
 template <int NPL>
-__device__ __forceinline__ void links_frame_reg(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out) {
+__device__ __forceinline__ void links_frame_reg(const TrackParams& p, const WaveLds& L, int64_t fr, int lane, int& nnew_out, bool& amb_out, bool& has_out) {
     const int K = p.K;
     double *sf = L.d[0], *pfs = L.d[1], *pms = L.d[2];               // by rank: new peaks' frequency; previous f, mag
     int *sslot = L.a, *pslot = L.b, *linkL = L.linkL, *nrkL = L.nrkL, *succL = L.succL;   // rank -> slot
@@ -314,7 +315,7 @@ __device__ __forceinline__ void links_frame_reg(const TrackParams& p, const Wave
             }
         }
     }
-    nnew_out = nnew; amb_out = amb_any;
+    nnew_out = nnew; amb_out = amb_any; has_out = nc > 0;
 }
 
 // One wave per frame, a workgroup per chunk of blockDim/64 consecutive frames.  NPL > 0: K <= 64 NPL.
@@ -328,11 +329,11 @@ __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
     const int64_t fb = (int64_t)blockIdx.x * nw, fr = fb + wid;
     const bool live = fr < p.F;
     int nnew = 0;
-    bool amb_any = false;
+    bool amb_any = false, has = false;
     PVX_STAMP(fr == 1 && lane == 0, 0);
     if (live) {
-        if constexpr (NPL > 0) links_frame_reg<NPL>(p, L, fr, lane, nnew, amb_any);
-        else links_frame_lds(p, L, fr, lane, nnew, amb_any);
+        if constexpr (NPL > 0) links_frame_reg<NPL>(p, L, fr, lane, nnew, amb_any, has);
+        else links_frame_lds(p, L, fr, lane, nnew, amb_any, has);
     }
     __syncthreads();
     PVX_STAMP(fr == 1 && lane == 0, 2);
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
         if (fr > 0) p.succ[(fr - 1) * K + s] = (unsigned char)L.succL[s];
         if (fr == p.F - 1) p.succ[fr * K + s] = 0;
     }
-    if (lane == 0) p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0);
+    if (lane == 0) p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0) | (has ? kHasBit : 0);
     PVX_STAMP(fr == 1 && lane == 0, 3);
 }
 
@@ -450,15 +451,17 @@ __global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
 
 // exclusive scan of newcount[F] (ambiguity flags masked and OR-ed) with a 1024-thread workgroup; out(i, value)
 template <typename Out>
-__device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsum, long long* carry_s, int* amb_s, Out out) {
+__device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsum, long long* carry_s, int* amb_s, int* last_s, Out out) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { *carry_s = 0; *amb_s = 0; }
+    if (tid == 0) { *carry_s = 0; *amb_s = 0; *last_s = -1; }
     __syncthreads();
+    int last = -1;                                                   // last frame with a valid peak seen by this thread
     for (int64_t base = 0; base < p.F; base += 1024) {
         const int64_t i = base + tid;
         const int raw = (i < p.F) ? p.newcount[i] : 0;
         if (raw & kAmbBit) *amb_s = 1;
-        long long v = (long long)(raw & (kAmbBit - 1));
+        if (raw & kHasBit) last = (int)i;
+        long long v = (long long)(raw & (kHasBit - 1));
         long long inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -475,14 +478,16 @@ __device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsu
         if (tid == 1023) *carry_s = carry + woff + inc;
         __syncthreads();
     }
+    if (last >= 0) atomicMax(last_s, last);
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void k_scan_counts(TrackParams p) {
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
-    __shared__ int amb_s;
-    scan_counts(p, wsum, &carry_s, &amb_s, [&](int64_t i, long long v) { p.newbase[i] = v; });
-    if (threadIdx.x == 0) { p.newbase[p.F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = -1; }
+    __shared__ int amb_s, last_s;
+    scan_counts(p, wsum, &carry_s, &amb_s, &last_s, [&](int64_t i, long long v) { p.newbase[i] = v; });
+    if (threadIdx.x == 0) { p.newbase[p.F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
 }
 
 // The scan, and the roots of the chunks' LAST frames: rb[c][s] starts as k_track_links left it -- final, or a node of
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_track_boundaries(TrackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
-    __shared__ int amb_s;
+    __shared__ int amb_s, last_s;
     int32_t* rb = (int32_t*)smem;                                // [NCH][K]
     const int tid = threadIdx.x;
     const int K = p.K, CL = p.chunk;
@@ -513,8 +518,10 @@ __global__ __launch_bounds__(1024) void k_track_boundaries(TrackParams p) {
     const int lg = 31 - __builtin_clz((unsigned)CL);
     auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) << lg; return (e < F ? e : F) - 1; };
     for (int w = tid; w < items; w += 1024) { const int c = div_k(w); rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
-    scan_counts(p, wsum, &carry_s, &amb_s, [&](int64_t i, long long v) { p.newbase[i] = v; });     // (barriers inside)
-    if (tid == 0) { p.newbase[F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = -1; }
+    scan_counts(p, wsum, &carry_s, &amb_s, &last_s, [&](int64_t i, long long v) { p.newbase[i] = v; });     // (barriers inside)
+    // the three words the host waits for (they may live in page-locked host memory: single plain stores).  maxend =
+    // max(SinSum.end) (PV.py:1059) = the last frame that holds a valid peak: every valid peak is a point of a partial
+    if (tid == 0) { p.newbase[F] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
     PVX_STAMP(tid == 0, 9);
     for (int r = 0; (1 << r) < NCH; r++) {
         int moved = 0;
@@ -552,7 +559,6 @@ __global__ __launch_bounds__(256) void k_assign_chunked(TrackParams p) {
         // one plain store per partial instead of one contended atomic per point
         if (last) p.part_len[pid] = (int32_t)(ifr - rfr + 1);
     }
-    if (last) atomicMax((long long*)p.maxend, (long long)ifr);       // max(SinSum.end): one atomic per partial
 }
 
 __global__ __launch_bounds__(256) void k_root_init(TrackParams p) {
@@ -593,8 +599,6 @@ __global__ __launch_bounds__(256) void k_assign_ids(TrackParams p) {
         // one plain store per partial instead of one contended atomic per point
         if (!p.succ[i]) p.part_len[pid] = (int32_t)(i / p.K - rfr + 1);
     }
-    // max(SinSum.end): one atomic per partial (its last point)
-    if (!p.succ[i]) atomicMax((long long*)p.maxend, (long long)(i / p.K));
 }
 
 }  // namespace

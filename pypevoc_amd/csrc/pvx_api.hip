@@ -140,6 +140,7 @@ struct pvx_plan {
     void* d_twiddle64 = nullptr; // complex<T>[nfft] W_nfft^j for k_stft (T = the plan's precision)
     void* d_twiddle = nullptr;   // float2[2048] W_2048^j for the fused kernel
     float* d_specrow = nullptr;  // 1024 complex: spectrum of one requested row (fused mode)
+    float* spec_host = nullptr;  // when set: the fused kernels write that row straight into this page-locked host block
     // PVHarmonic: per-frame f0 / previous-row tables and the carried spectrum of the last valid frame
     double* d_hf0 = nullptr;
     int32_t* d_hprev = nullptr;
@@ -512,7 +513,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.wfbin = p->d_wfbin; fp.prev0 = d_prev0;
         fp.f = d_f; fp.mag = d_mag; fp.ph = d_ph; fp.realph = d_realph; fp.binno = d_binno;
         fp.t = d_t; fp.totalmag = d_totalmag; fp.win = p->d_win; fp.twiddle = p->d_twiddle;
-        fp.spec_out = spec_row >= 0 ? p->d_specrow : nullptr; fp.spec_row = spec_row;
+        fp.spec_out = spec_row >= 0 ? (p->spec_host ? p->spec_host : p->d_specrow) : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
         if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
         rc = (p->fft_mode == 1) ? pvx_launch_fused(fp, p->nfft, x_dtype, s)
@@ -800,10 +801,19 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
             d.t = nullptr;
         }
         const bool want_spec = (c + 1 < nchunks && by_frames) || (last_spec && c + 1 == nchunks);
+        // small call, fused kernels: the last spectrum is written by the kernel itself into the pinned block (one
+        // 16 KB burst over PCIe instead of a separate copy operation behind the kernel)
+        float* spec_host = nullptr;
+        if (small && last_spec && p->fft_mode != 0) {
+            spec_host = (float*)((unsigned char*)p->h_pin + ((((total_in + 255) & ~(size_t)255) + (keep ? 0 : total_out) + 255) & ~(size_t)255));
+            if ((size_t)((unsigned char*)spec_host - (unsigned char*)p->h_pin) + (size_t)p->N2 * 8 > p->pin_cap) spec_host = nullptr;
+        }
+        p->spec_host = spec_host;
         const double* dprev = (c > 0 && by_frames) || prev0 ? p->d_prev : nullptr;
         last_rows = c_nsig * (c_frames / c_nsig + 1);
         rc = analyze_rows(p, p->d_in[b], dev_dtype, c_nsamp, c_nsig, by_frames ? c_nsamp : sig_stride, c_frames / c_nsig,
                           d.f, d.mag, d.ph, d.realph, d.binno, d.t, d.totalmag, dprev, s, want_spec ? last_rows - 1 : -1);
+        p->spec_host = nullptr;
         tr.mark("kernels issued");
         if (rc == PVX_OK && c + 1 < nchunks && by_frames) rc = carry_spectrum(p, last_rows, s);
         if (rc != PVX_OK) { p->progress_live = false; return rc; }
@@ -851,12 +861,17 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     }
     std::vector<unsigned char> tmp;
     unsigned char* h_last = nullptr;
-    if (d_last && small) {
+    bool by_kernel = false;
+    if (d_last && small && p->fft_mode != 0) {
+        unsigned char* q = (unsigned char*)p->h_pin + ((((total_in + 255) & ~(size_t)255) + (keep ? 0 : total_out) + 255) & ~(size_t)255);
+        if ((size_t)(q - (unsigned char*)p->h_pin) + (size_t)p->N2 * 8 <= p->pin_cap) { h_last = q; by_kernel = true; }   // as decided before the launch
+    }
+    if (d_last && small && !by_kernel) {
         // small call: into the pinned block behind the staged data, under the one synchronisation below
         h_last = (unsigned char*)p->h_pin + ((((total_in + 255) & ~(size_t)255) + (keep ? 0 : total_out) + 255) & ~(size_t)255);
         if ((size_t)(h_last - (unsigned char*)p->h_pin) + (size_t)p->N2 * 2 * rs > p->pin_cap) h_last = nullptr;
     }
-    if (h_last) PVX_HIP_CHECK(hipMemcpyAsync(h_last, d_last, (size_t)p->N2 * 2 * rs, hipMemcpyDeviceToHost, s));
+    if (h_last && !by_kernel) PVX_HIP_CHECK(hipMemcpyAsync(h_last, d_last, (size_t)p->N2 * 2 * rs, hipMemcpyDeviceToHost, s));
     tr.mark("tail issued");
     PVX_HIP_CHECK(hipStreamSynchronize(s));
     tr.mark("synchronised");
@@ -1017,20 +1032,23 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
     tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
     tp.link = (int32_t*)(w + off_link); tp.root = (int32_t*)(w + off_root);
     tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
-    tp.npartials = (int64_t*)(w + off_np);
+    // { partials, exact double tie met, last frame with a point }: three single stores by the kernels.  In page-locked
+    // host memory when the caller has some (the resident chain): the host reads them after the one synchronisation,
+    // no copy operation behind the kernels.
+    int64_t pa_[3] = {0, 0, -1};
+    volatile int64_t* pa = pinned3 ? pinned3 : pa_;
+    tp.npartials = pinned3 ? pinned3 : (int64_t*)(w + off_np);
     tp.ambiguous = tp.npartials + 1;
     tp.maxend = tp.npartials + 2;
     int rc = pvx_launch_track(tp, s);
     if (rc != PVX_OK) return rc;
-    int64_t pa_[3] = {0, 0, -1};
-    int64_t* pa = pinned3 ? pinned3 : pa_;                 // { partials, exact double tie met, last frame with a point }
-    PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+    if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 24, hipMemcpyDeviceToHost, s));
     PVX_HIP_CHECK(hipStreamSynchronize(s));
     if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
         // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
         // table with the sequential kernel, which has the partial indices at hand
         if ((rc = pvx_launch_track_sequential(tp, s)) != PVX_OK) return rc;
-        PVX_HIP_CHECK(hipMemcpyAsync(pa, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+        if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 24, hipMemcpyDeviceToHost, s));
         PVX_HIP_CHECK(hipStreamSynchronize(s));
     }
     if (maxend) *maxend = pa[2];
