@@ -318,29 +318,33 @@ __device__ __forceinline__ void links_frame_reg(const TrackParams& p, const Wave
     nnew_out = nnew; amb_out = amb_any; has_out = nc > 0;
 }
 
-// One wave per frame, a workgroup per chunk of blockDim/64 consecutive frames.  NPL > 0: K <= 64 NPL.
+// One wave per frame (p.fpw frames one after the other when rows are short), a workgroup per chunk of
+// p.chunk = waves * fpw consecutive frames, one LDS block (WaveLds) per frame of the chunk.  NPL > 0: K <= 64 NPL.
 template <int NPL>
 __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int K = p.K;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int K = p.K, CL = p.chunk, fpw = p.fpw;
     const int kp = (K + 1) & ~1;
-    const WaveLds L(smem, kp, wid);
-    const int64_t fb = (int64_t)blockIdx.x * nw, fr = fb + wid;
-    const bool live = fr < p.F;
-    int nnew = 0;
-    bool amb_any = false, has = false;
-    PVX_STAMP(fr == 1 && lane == 0, 0);
-    if (live) {
+    const int64_t fb = (int64_t)blockIdx.x * CL;
+    PVX_STAMP(fb + wid == 1 && lane == 0, 0);
+    for (int j = 0; j < fpw; j++) {
+        const int t = wid * fpw + j;
+        const int64_t fr = fb + t;
+        if (fr >= p.F) break;
+        const WaveLds L(smem, kp, t);
+        int nnew = 0;
+        bool amb_any = false, has = false;
         if constexpr (NPL > 0) links_frame_reg<NPL>(p, L, fr, lane, nnew, amb_any, has);
         else links_frame_lds(p, L, fr, lane, nnew, amb_any, has);
+        if (lane == 0) p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0) | (has ? kHasBit : 0);
     }
     __syncthreads();
-    PVX_STAMP(fr == 1 && lane == 0, 2);
+    PVX_STAMP(fb + wid == 1 && lane == 0, 2);
     // the chunk's roots, frame after frame (one wave: the steps are dependent): a new partial's root is its own
     // node, a continued peak takes its predecessor's -- the chunk's first frame points into the frame before it
     if (wid == 0) {
-        for (int t = 0; t < nw && fb + t < p.F; t++) {
+        for (int t = 0; t < CL && fb + t < p.F; t++) {
             const WaveLds Lt(smem, kp, t);
             const int* rprev = t > 0 ? WaveLds(smem, kp, t - 1).rootL : nullptr;
             const int64_t base = (fb + t) * K;
@@ -352,17 +356,21 @@ __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
         }
     }
     __syncthreads();
-    if (!live) return;
     // every frame defines its own link and root rows and the succ row of the frame before it (no memset)
-    for (int s = lane; s < K; s += 64) {
-        const int l = L.linkL[s];                                    // slot in frame fr-1 | -1 new partial | -2 empty
-        p.link[fr * K + s] = l >= 0 ? l : (l == -2 ? -1 : -(L.nrkL[s] + 2));   // the table's code (pvx_internal.h)
-        p.root[fr * K + s] = L.rootL[s];
-        if (fr > 0) p.succ[(fr - 1) * K + s] = (unsigned char)L.succL[s];
-        if (fr == p.F - 1) p.succ[fr * K + s] = 0;
+    for (int j = 0; j < fpw; j++) {
+        const int t = wid * fpw + j;
+        const int64_t fr = fb + t;
+        if (fr >= p.F) break;
+        const WaveLds L(smem, kp, t);
+        for (int s = lane; s < K; s += 64) {
+            const int l = L.linkL[s];                                // slot in frame fr-1 | -1 new partial | -2 empty
+            p.link[fr * K + s] = l >= 0 ? l : (l == -2 ? -1 : -(L.nrkL[s] + 2));   // the table's code (pvx_internal.h)
+            p.root[fr * K + s] = L.rootL[s];
+            if (fr > 0) p.succ[(fr - 1) * K + s] = (unsigned char)L.succL[s];
+            if (fr == p.F - 1) p.succ[fr * K + s] = 0;
+        }
     }
-    if (lane == 0) p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0) | (has ? kHasBit : 0);
-    PVX_STAMP(fr == 1 && lane == 0, 3);
+    PVX_STAMP(fb + wid == 1 && lane == 0, 3);
 }
 
 // The reference's loop as it stands (PVAnalysis.py:871-957), one wave, frames in order, partial indices at
@@ -449,20 +457,27 @@ __global__ __launch_bounds__(64) void k_track_sequential(TrackParams p) {
     if (lane == 0) { *p.npartials = P; *p.maxend = lastfr; }
 }
 
-// exclusive scan of newcount[F] (ambiguity flags masked and OR-ed) with a 1024-thread workgroup; out(i, value)
+// exclusive scan of newcount[F] (flags masked; "exact tie" OR-ed, "has a peak" -> last such frame) with a 1024-thread
+// workgroup, 4 consecutive frames per thread and tile (one coalesced pass per 4096 frames).  out(i, value)
 template <typename Out>
 __device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsum, long long* carry_s, int* amb_s, int* last_s, Out out) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) { *carry_s = 0; *amb_s = 0; *last_s = -1; }
     __syncthreads();
-    int last = -1;                                                   // last frame with a valid peak seen by this thread
-    for (int64_t base = 0; base < p.F; base += 1024) {
-        const int64_t i = base + tid;
-        const int raw = (i < p.F) ? p.newcount[i] : 0;
-        if (raw & kAmbBit) *amb_s = 1;
-        if (raw & kHasBit) last = (int)i;
-        long long v = (long long)(raw & (kHasBit - 1));
-        long long inc = v;
+    int last = -1;
+    bool amb = false;
+    for (int64_t base = 0; base < p.F; base += 4096) {
+        const int64_t i0 = base + 4 * tid;
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int raw = (i0 + u < p.F) ? p.newcount[i0 + u] : 0;
+            amb = amb || (raw & kAmbBit);
+            if (raw & kHasBit) last = (int)(i0 + u);
+            c[u] = raw & (kHasBit - 1);
+        }
+        const long long sum = (long long)c[0] + c[1] + c[2] + c[3];
+        long long inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             long long u = __shfl_up(inc, o);
@@ -470,14 +485,15 @@ __device__ __forceinline__ void scan_counts(const TrackParams& p, long long* wsu
         }
         if (lane == 63) wsum[wid] = inc;
         __syncthreads();
-        long long woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        const long long carry = *carry_s;
-        if (i < p.F) out(i, carry + woff + inc - v);
+        long long run = *carry_s + inc - sum;
+        for (int w = 0; w < wid; w++) run += wsum[w];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { if (i0 + u < p.F) out(i0 + u, run); run += c[u]; }
         __syncthreads();
-        if (tid == 1023) *carry_s = carry + woff + inc;
+        if (tid == 1023) *carry_s = run;
         __syncthreads();
     }
+    if (amb) *amb_s = 1;
     if (last >= 0) atomicMax(last_s, last);
     __syncthreads();
 }
@@ -617,9 +633,14 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     int waves = p.K > 32 ? 4 : 16;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
     if (const char* e = getenv("PVX_TRACK_CHUNK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) waves = v < waves ? v : waves; }
-    p.chunk = waves;
-    const dim3 grid((unsigned)((p.F + waves - 1) / waves)), block(64 * waves);
-    const size_t lds = per_wave * waves;
+    // short rows on a long table: a wave takes 4 frames in turn, so a chunk is 64 frames and there are 4 x fewer
+    // boundary rows for k_track_boundaries' single workgroup to jump over
+    int fpw = (p.K <= 16 && p.F >= 4096 && waves == 16 && per_wave * 64 <= 64 * 1024) ? 4 : 1;
+    if (const char* e = getenv("PVX_TRACK_FPW")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && per_wave * waves * v <= 64 * 1024) fpw = v; }
+    p.fpw = fpw;
+    p.chunk = waves * fpw;
+    const dim3 grid((unsigned)((p.F + p.chunk - 1) / p.chunk)), block(64 * waves);
+    const size_t lds = per_wave * p.chunk;
 #define PVX_LINKS(NPL)                                                                                                     \
     do {                                                                                                                   \
         if (lds > 48 * 1024)                                                                                               \
@@ -633,7 +654,7 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     else PVX_LINKS(4);
 #undef PVX_LINKS
     const unsigned nb = (unsigned)((n + 255) / 256);
-    const int64_t nch = (p.F + waves - 1) / waves;
+    const int64_t nch = (p.F + p.chunk - 1) / p.chunk;
     const size_t blds = (size_t)nch * p.K * 4;
     if (blds <= 150 * 1024 && !getenv("PVX_TRACK_LARGE")) {
         if (blds > 48 * 1024)

@@ -126,7 +126,8 @@ struct TrackParams {
     unsigned char* succ;  // [F][K]  1 if a peak of the next frame continues this one
     int64_t* npartials;   // [1]
     int64_t* maxend;      // [1]  last frame that holds a point of any partial = max(SinSum.end) (PV.py:1059)
-    int chunk;            // frames per k_track_links workgroup = chunk length of the root step (set by pvx_launch_track)
+    int chunk, fpw;       // frames per k_track_links workgroup = chunk length of the root step (a power of two), and
+                          // frames a wave takes in turn (set by pvx_launch_track)
     int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
                           //      the previous partials would decide an assignment (k_track.hip header)
 };
