@@ -444,7 +444,7 @@ __device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int
     // the entries exist or not): a recording's frames have 80-200 candidates, white noise ~280 of the 512 the list
     // can hold at nfft 2048 -- take the narrowest instantiation that covers C
     if constexpr (NCH > 2) { if (C <= 128) return peak_radix_body<2, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
-    if constexpr (NCH > 4) { if (C <= 192) return peak_radix_body<3, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
+    if constexpr (NCH > 3) { if (C <= 192) return peak_radix_body<3, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
     if constexpr (NCH > 5) { if (C <= 320) return peak_radix_body<5, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
     if constexpr (NCH <= 4 || INL) return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
     else return peak_radix_out<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
