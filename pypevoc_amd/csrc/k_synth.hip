@@ -131,15 +131,6 @@ __device__ inline double prefix_sum(const CParam& c, int m) {
     if (m <= c.fmb) return c.fa0 * (double)m + c.fsa * tm;
     return c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
 }
-// the same sum without a divergent branch (per-sample form): operands selected, then one expression whose
-// roundings are those of the two returns above (0 + x is exact)
-__device__ __forceinline__ double prefix_sum_sel(const CParam& c, int m, double tm) {
-    const bool a = m <= c.fmb;
-    const double base = a ? 0.0 : c.smb, f0 = a ? c.fa0 : c.fb0, fs = a ? c.fsa : c.fsb;
-    const double x = (double)(a ? m : m - c.fmb), t = a ? tm : tm - c.tmb;
-    return (base + f0 * x) + fs * t;
-}
-
 // tools/ubench/synth_phases.hip builds this file with PVX_SYNTH_STAMPS: s_memtime stamps of one workgroup in slot_of[]
 #ifdef PVX_SYNTH_STAMPS
 #define PVX_STAMP(slot) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ((long long*)p.slot_of)[slot] = (long long)clock64(); } while (0)
@@ -358,6 +349,12 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
             else bound = fabs(c.ph0) + dh * fabs(c.step)
                          + (kPi2 / p.sr) * (fabs(c.smb) + dh * (fabs(c.fa0) + fabs(c.fb0) + dh * (fabs(c.fsa) + fabs(c.fsb))));
             c.far = !(bound < kNear);
+            if (kind == 0) {
+                // the per-sample form: 2 pi / sr folded into the two-piece phase polynomial (the sample loop is this
+                // kernel's bound; the folding moves the phase by a few ulp of ~1e4 rad, 1e-12 of the waveform)
+                const double sc = kPi2 / p.sr;
+                c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
+            }
             prm[bb] = c;
         }
         __syncthreads();
@@ -367,7 +364,6 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
         {
             const int g = tid / TS, tl = tid - g * TS;
             double* accg = acc + (size_t)g * h;
-            const double rsr = 1.0 / p.sr;
             for (int m0 = tl; m0 < h; m0 += TS * SP) {
                 double a_[SP];
 #pragma unroll
@@ -380,15 +376,15 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
                         if (m >= h) continue;
                         const double dm = (double)m;
                         if (c.kind == 0) {
-                            // prefix / sr: reciprocal + one fma correction (within an ulp of the quotient; the phase
-                            // itself carries 1e-12 rad of rounding) instead of a 15-instruction division per sample
-                            const double pre = prefix_sum_sel(c, m, 0.5 * dm * (double)(m - 1));
-                            double qd = pre * rsr;
-                            qd = __builtin_fma(__builtin_fma(-qd, p.sr, pre), rsr, qd);
-                            const double ph_m = kPi2 * qd + c.ph0 + (dm * c.step + 0.0);
+                            // phase = ph0 + step m + [m <= fmb: fa0 m + fsa T(m) | smb + fb0 (m - fmb) + fsb (T(m) - T(fmb))],
+                            // T(m) = m (m - 1) / 2, coefficients pre-scaled by 2 pi / sr; both pieces, then one select
+                            const double tm = 0.5 * dm * (double)(m - 1);
+                            const double pa = __builtin_fma(c.fsa, tm, c.fa0 * dm);
+                            const double pb = __builtin_fma(c.fsb, tm - c.tmb, __builtin_fma(c.fb0, (double)(m - c.fmb), c.smb));
+                            const double ph_m = (m <= c.fmb ? pa : pb) + __builtin_fma(c.step, dm, c.ph0);
                             const bool ma = m < c.mmb;
-                            const double ms = (ma ? c.ma0 : c.mb0) + (ma ? c.msa : c.msb) * dm;
-                            a_[u] += ms * fcos<FAR>(ph_m);                // PVAnalysis.py:734-736
+                            const double ms = __builtin_fma(ma ? c.msa : c.msb, dm, ma ? c.ma0 : c.mb0);
+                            a_[u] = __builtin_fma(ms, fcos<FAR>(ph_m), a_[u]);    // PVAnalysis.py:734-736
                         } else {
                             const long long j = seg * (long long)h + m - c.o0;
                             if (j >= 0 && j < edgsam) {
