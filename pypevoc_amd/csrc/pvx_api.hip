@@ -1126,22 +1126,36 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
     const int64_t need = pvx_synth_len(p->res_maxend, p->nfft, p->hop, hop_synth, edge);
     if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
     HostTrace tr("synth");
-    if ((rc = grow_dev(&p->d_w, &p->w_cap, (size_t)wlen * 8)) != PVX_OK) return rc;
     const HostOut all = block_ptrs(p->d_res, p->res_F, p->npks);
+    const size_t bytes = (size_t)wlen * 8;
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, w) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();                        // an ordinary pointer is reported as an error
+    static const bool zero_copy = getenv("PVX_SYNTH_NO_ZEROCOPY") == nullptr;
+    if (pinned && zero_copy && bytes <= kSmallCall) {
+        // the caller's array is page-locked (pvx_host_alloc) and small: the kernel stores its segments straight into
+        // it (posted writes over PCIe, spread over the kernel's run time as workgroups finish) -- no copy operation
+        // behind the kernel at all
+        rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
+                                 p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0);
+        if (rc != PVX_OK) return rc;
+        tr.mark("kernel issued");
+        PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+        tr.mark("here");
+        return PVX_OK;
+    }
+    if ((rc = grow_dev(&p->d_w, &p->w_cap, (size_t)wlen * 8)) != PVX_OK) return rc;
     rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
                              p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0);
     if (rc != PVX_OK) return rc;
-    const size_t bytes = (size_t)wlen * 8;
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, w) == hipSuccess && attr.type == hipMemoryTypeHost) {
-        // the caller's array is page-locked (pvx_host_alloc): the DMA lands in it, nothing to stage or copy
+    if (pinned) {
+        // the caller's array is page-locked: the DMA lands in it, nothing to stage or copy
         PVX_HIP_CHECK(hipMemcpyAsync(w, p->d_w, bytes, hipMemcpyDeviceToHost, p->s_host));
         tr.mark("kernel + copy issued");
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
         tr.mark("here");
         return PVX_OK;
     }
-    (void)hipGetLastError();                                     // an ordinary pointer is reported as an error
     if (bytes <= kSmallCall) {
         // through pinned memory in pieces: the host copy of piece i runs under the DMA of piece i+1 (two events in turn)
         if ((rc = grow_pin(p, bytes)) != PVX_OK) return rc;
