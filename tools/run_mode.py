@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run the analysis stage a few times in one fft mode on the bench workload (for rocprofv3 --pmc runs).
-   python3 tools/run_mode.py MODE [harmonic|noise] [K] [reps] [precision]"""
+   python3 tools/run_mode.py MODE [harmonic|noise] [K] [reps] [precision]      (PVX_RUN_NFFT=4096: that nfft, hop = nfft/4)"""
 import ctypes
 import os
 import sys
@@ -27,7 +27,7 @@ if kind == "noise":
     x = 0.1 * torch.randn(44100 * 600, device=dev, generator=g)
 else:
     x = torch.from_numpy(c2_signal(600)).to(dev)
-nfft, hop = 2048, 512
+nfft = int(os.environ.get("PVX_RUN_NFFT", "2048")); hop = nfft // 4      # PVX_RUN_NFFT: another point of config 5's sweep
 nsamp = x.numel()
 F = int(lib.pvx_nframes(nsamp, nfft, hop))
 out = torch.zeros(5 * F * K + 2 * F, dtype=torch.float64, device=dev); b = out.data_ptr()
