@@ -246,11 +246,12 @@ def device_run(nbytes_out, launch):
 # ---- result arrays in page-locked memory ------------------------------------------------------------
 class _HostPool(object):
     """numpy arrays whose memory the DMA engine can write directly (pvx_host_alloc).  A buffer goes back to the
-    pool when the last array / view on it is collected; sizes are bucketed to powers of two, the pool keeps at
-    most _CAP bytes of idle buffers and hands out at most _LIVE_CAP bytes in all (beyond that: np.empty)."""
+    pool when the last array / view on it is collected; sizes (64 KB .. 16 MB) are bucketed to powers of two, the pool
+    keeps at most _CAP bytes of idle buffers and hands out at most _LIVE_CAP bytes in all (beyond that: np.empty)."""
     _CAP = 64 << 20
     _LIVE_CAP = 1 << 30
     _MIN = 64 << 10
+    _MAX = 16 << 20            # beyond this a result pays for its copy anyway and page-locking it costs more than it saves
 
     def __init__(self):
         self.free = {}
@@ -271,7 +272,7 @@ class _HostPool(object):
     def empty(self, n, dtype=np.float64):
         import weakref
         nbytes = int(n) * np.dtype(dtype).itemsize
-        if nbytes < self._MIN:
+        if nbytes < self._MIN or nbytes > self._MAX:
             return np.empty(n, dtype=dtype)
         size = self._MIN
         while size < nbytes:

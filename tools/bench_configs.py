@@ -19,13 +19,13 @@ from pypevoc_amd.batch import ResultWire
 from tests.conftest import load_golden
 
 
-def config3():
+def config3(precision=32):
     g = load_golden("G7_perlman")
     best = None
     for _ in range(8):
         # the reference's usage: a new PV object per signal, then run_pv -> toSinSum -> synth (examples/WavResynth.py)
         t0 = time.perf_counter()
-        p = pypevoc_amd.PV(g["x"], g["sr"], nfft=4096, hop=1024, npks=100, progress=False)
+        p = pypevoc_amd.PV(g["x"], g["sr"], nfft=4096, hop=1024, npks=100, progress=False, precision=precision)
         p.run_pv(); t1 = time.perf_counter()
         ss = p.toSinSum(); t2 = time.perf_counter()
         w = ss.synth(g["sr"], p.hop / 1); t3 = time.perf_counter()
@@ -43,7 +43,9 @@ def config3():
                 round_trip_ms=round(sum(best) * 1e3, 3), fetch_table_and_arrays_ms=round((t5 - t4) * 1e3, 3),
                 audio_seconds=round(len(g["x"]) / g["sr"], 3), realtime_factor=round(len(g["x"]) / g["sr"] / sum(best), 1),
                 waveform_max_abs_err_vs_reference=err, waveform_peak=float(np.abs(ref).max()),
-                note="precision=32 analysis; stated waveform tolerance 1e-4*max|w| (tests/test_hip_parity.py)")
+                precision=precision,
+                note=("precision=32 analysis; stated waveform tolerance 1e-4*max|w| (tests/test_hip_parity.py)" if precision == 32 else
+                      "precision=64: the reference's own arithmetic end to end (general path: nfft 4096 has no fused float64 kernel); the fixture's waveform is stored as float32"))
 
 
 def config4(nsig=128, seconds=30, sr=48000, nfft=2048, hop=512, K=8, reps=10):
@@ -125,5 +127,6 @@ def config2_chain():
 
 if __name__ == "__main__":
     print(json.dumps(config3()))
+    print(json.dumps(config3(64)))
     print(json.dumps(config2_chain()))
     print(json.dumps(config4()))
