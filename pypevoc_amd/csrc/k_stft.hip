@@ -280,6 +280,225 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
     }
 }
 
+// ---- nfft = 128 R S: the M = 64 R S point transform as S interleaved M1 = 64 R point ones (decimation in time) ------
+// nfft 4096 (R = 16, S = 2) does not fit one wave's registers as a single R x R x P factorisation (R = 32 is 64
+// complex values per lane before any temporary).  Sub-transform s takes z[S j + s], j < M1, through exactly the
+// stages of k_stft above and leaves its natural-order result in its own LDS region; one in-place radix-S pass with
+// the twiddles W_M^(s k1) joins them (Z[k1 + M1 q] = sum_s W_S^(s q) W_M^(s k1) Z_s[k1]); the untangle reads the
+// joined buffer.  Window, join and untangle twiddles come from global memory (L2-resident tables; an LDS copy of a
+// float64 window of 4096 would cost a wave's buffer), the sub-transform tables stay in LDS.
+template <int R, int S, typename T> struct SplitGeo {
+    using G1 = StftGeo<R, T>;
+    static constexpr int M1 = G1::M, M = M1 * S, N = 2 * M, LOGM1 = ilog2(M1);
+    static constexpr int BUFC = G1::BUFC;                                                    // one region (complex)
+    static constexpr size_t OFF_T1 = 0;                                                      // cx [R][64]  W_M1^(l q)
+    static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 2 * sizeof(T);                // cx [R][P]   W_64^(l1 t2)
+    static constexpr size_t OFF_BUF = OFF_T2 + 64 * 2 * sizeof(T);                           // cx [NW][S][BUFC]
+    __host__ __device__ static size_t total(int nw) { return OFF_BUF + (size_t)nw * S * BUFC * 2 * sizeof(T); }
+};
+
+template <int R, int S, typename T, typename InT>
+__global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
+    using G = SplitGeo<R, S, T>;
+    using G1 = StftGeo<R, T>;
+    constexpr int M1 = G::M1, M = G::M, P = G1::P, PITCH = G1::PITCH;
+    constexpr int NMASK = G::N - 1;
+    static_assert(S == 2 || S == 4, "radix of the join");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    cx<T>* const t1L = (cx<T>*)(smem + G::OFF_T1);
+    cx<T>* const t2L = (cx<T>*)(smem + G::OFF_T2);
+    cx<T>* const buf = (cx<T>*)(smem + G::OFF_BUF) + (size_t)wid * S * G::BUFC;
+    const cx<T>* const tab = (const cx<T>*)p.twiddle;                 // W_N^j
+    const T* const winG = (const T*)p.win;
+    for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * S * (i & 63) * (i >> 6)) & NMASK];          // W_M1^(l q)
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];           // [t2][l1]
+    __syncthreads();
+    const int Q = lane / P, L1 = lane % P;
+    T csg[G1::LOGP > 0 ? G1::LOGP : 1];
+    cx<T> cw[G1::LOGP > 0 ? G1::LOGP : 1];
+#pragma unroll
+    for (int st = 0; st < G1::LOGP; st++) {
+        const int h = P >> (st + 1);
+        const bool up = (L1 & h) != 0;
+        csg[st] = up ? (T)-1 : (T)1;
+        const cx<T> wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+        cw[st] = up ? wv : mkc<T>((T)1, (T)0);
+    }
+    int t1v = 0;
+#pragma unroll
+    for (int b = 0; b < G1::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G1::LOGP - 1 - b);
+
+    const int64_t W = (int64_t)gridDim.x * nw;
+    const int64_t w = (int64_t)blockIdx.x * nw + wid;
+    const int64_t rows1 = p.F + 1;
+    auto row_src = [&](int64_t j) -> const InT* {                     // samples of workspace row j; nullptr: zero row
+        if (j >= p.ws_rows) return nullptr;
+        const int64_t g = p.R0 - 1 + j;
+        if (g < 0 || g >= p.total_rows) return nullptr;
+        const int64_t b = g / rows1, q = g - b * rows1;
+        if (q == 0) return nullptr;
+        return (const InT*)p.x + b * p.sig_stride + (q - 1) * (int64_t)p.hop;
+    };
+    // samples and window values of the next sub-transform: element j = l + 64 r of sub-sequence s is the sample pair
+    // at 2 (S j + s) = 2 S l + 128 S r + 2 s
+    T raw[2 * R], wn[2 * R];
+    auto prefetch_part = [&](const InT* src, int sub, int part) {
+        if (src == nullptr) return;
+        constexpr int PR = R / 4;
+#pragma unroll
+        for (int r = part * PR; r < (part + 1) * PR; r++) {
+            const int o = 2 * S * lane + 128 * S * r + 2 * sub;
+            raw[2 * r] = (T)src[o]; raw[2 * r + 1] = (T)src[o + 1];
+            wn[2 * r] = winG[o]; wn[2 * r + 1] = winG[o + 1];
+        }
+    };
+    {
+        const InT* s0 = row_src(w);
+        prefetch_part(s0, 0, 0); prefetch_part(s0, 0, 1); prefetch_part(s0, 0, 2); prefetch_part(s0, 0, 3);
+    }
+    for (int64_t j = w; j < p.ws_rows; j += W) {
+        cx<T>* out = (cx<T>*)p.spec + (size_t)j * p.ldo;
+        const InT* src = row_src(j);
+        const InT* nrow = row_src(j + W);
+        if (src == nullptr) {
+            // (nothing of this row was prefetched)
+            prefetch_part(nrow, 0, 0); prefetch_part(nrow, 0, 1); prefetch_part(nrow, 0, 2); prefetch_part(nrow, 0, 3);
+            for (int k = lane; k < M; k += 64) out[k] = mkc<T>((T)0, (T)0);
+            continue;
+        }
+#pragma unroll 1
+        for (int sub = 0; sub < S; sub++) {
+            cx<T>* dz = buf + (size_t)sub * G::BUFC;
+            const InT* nsrc = (sub + 1 < S) ? src : nrow;             // the next sub-transform's samples
+            const int nsub = (sub + 1 < S) ? sub + 1 : 0;
+            cx<T> z[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                z[r] = mkc<T>(raw[2 * r] * wn[2 * r], raw[2 * r + 1] * wn[2 * r + 1]);
+                asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));       // the multiplies stay above the next loads
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_part(nsrc, nsub, 0);
+            dftT<R, T>(z);                                            // stage 1
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_part(nsrc, nsub, 1);
+#pragma unroll
+            for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+            wave_sync();
+#pragma unroll
+            for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
+            prefetch_part(nsrc, nsub, 2);
+            wave_sync();
+            dftT<R, T>(z);                                            // stage 2
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_part(nsrc, nsub, 3);
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                cx<T> a = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+                if constexpr (G1::LOGP >= 1) {
+                    if constexpr (P >= 16) a = xstepT<8, true, T>(a, csg[G1::LOGP - 4], cw[G1::LOGP - 4]);
+                    if constexpr (P >= 8) a = xstepT<4, true, T>(a, csg[G1::LOGP - 3], cw[G1::LOGP - 3]);
+                    if constexpr (P >= 4) a = xstepT<2, true, T>(a, csg[G1::LOGP - 2], cw[G1::LOGP - 2]);
+                    a = xstepT<1, false, T>(a, csg[G1::LOGP - 1], cw[G1::LOGP - 1]);
+                }
+                dz[zpadT<R, T>(Q + R * t + G1::R2 * t1v)] = a;       // Z_sub[k1], natural order
+            }
+            wave_sync();
+        }
+        // ---- join, in place: slots k1 of the S regions hold Z_s[k1] and become Z[k1 + M1 q]
+#pragma unroll 4
+        for (int jj = 0; jj < R; jj++) {
+            const int k1 = lane + 64 * jj;
+            const int idx = zpadT<R, T>(k1);
+            cx<T> a[S];
+#pragma unroll
+            for (int sub = 0; sub < S; sub++) a[sub] = buf[(size_t)sub * G::BUFC + idx];
+#pragma unroll
+            for (int sub = 1; sub < S; sub++) a[sub] = cmulT(a[sub], tab[(2 * sub * k1) & NMASK]);        // W_M^(s k1)
+            if constexpr (S == 2) {
+                buf[idx] = a[0] + a[1];
+                buf[(size_t)G::BUFC + idx] = a[0] - a[1];
+            } else {
+                const cx<T> A = a[0] + a[2], B = a[0] - a[2], C = a[1] + a[3], D = a[1] - a[3];
+                buf[idx] = A + C;
+                buf[(size_t)G::BUFC + idx] = addmni(B, D);            // W_4^q: 1, -i, -1, i
+                buf[(size_t)2 * G::BUFC + idx] = A - C;
+                buf[(size_t)3 * G::BUFC + idx] = addpi(B, D);
+            }
+        }
+        wave_sync();
+        // ---- untangle straight to global memory: pairs (k, M-k), k = lane + 64 j2 (see k_stft)
+        auto zat = [&](int k) -> cx<T> { return buf[(size_t)(k >> G::LOGM1) * G::BUFC + zpadT<R, T>(k & (M1 - 1))]; };
+        const cx<T> zc = zat(M / 2);
+        constexpr int NPAIR = R / 2;
+#pragma unroll 1
+        for (int ch = 0; ch < S; ch++) {
+            cx<T> za[NPAIR], zb[NPAIR], tw[NPAIR];
+#pragma unroll
+            for (int j2 = 0; j2 < NPAIR; j2++) {
+                const int k = lane + 64 * (ch * NPAIR + j2);
+                za[j2] = zat(k);
+                zb[j2] = zat((M - k) & (M - 1));
+                tw[j2] = tab[k];                                      // W_N^k, k < M/2
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < NPAIR; j2++) {
+                const int k = lane + 64 * (ch * NPAIR + j2);
+                const int km = (M - k) & (M - 1);
+                const cx<T> Sm = mkc<T>(za[j2].x + zb[j2].x, za[j2].y - zb[j2].y);
+                const cx<T> D = mkc<T>(za[j2].x - zb[j2].x, za[j2].y + zb[j2].y);
+                const cx<T> O = mkc<T>((T)0.5 * D.y, (T)-0.5 * D.x);
+                const cx<T> Pk = cmulT(O, tw[j2]);
+                const cx<T> x0 = mkc<T>(fmaT((T)0.5, Sm.x, Pk.x), fmaT((T)0.5, Sm.y, Pk.y));
+                cx<T> x1 = mkc<T>(fmaT((T)0.5, Sm.x, -Pk.x), -fmaT((T)0.5, Sm.y, -Pk.y));
+                int kk = km;
+                if (ch == 0 && j2 == 0 && lane == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = M / 2; }      // bin 0 pairs with itself; its slot takes bin M/2
+                out[k] = x0;
+                out[kk] = x1;
+            }
+        }
+        wave_sync();                                                  // the regions are free again
+    }
+}
+
+template <int R, int S, typename T> int launch_stft_split(const StftParams& p, int x_dtype, hipStream_t s) {
+    using G = SplitGeo<R, S, T>;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    int nw = 4;
+    while (nw > 1 && G::total(nw) > 160 * 1024) nw--;
+    const size_t lds = G::total(nw);
+    if (lds > 160 * 1024) { pvx_set_error("nfft=%d needs %zu bytes of LDS in the split STFT kernel", G::N, lds); return PVX_ERR_UNSUPPORTED; }
+    const void* fn = nullptr;
+    switch (x_dtype) {
+        case PVX_F32: fn = (const void*)k_stft_split<R, S, T, float>; break;
+        case PVX_F64: fn = (const void*)k_stft_split<R, S, T, double>; break;
+        case PVX_I16: fn = (const void*)k_stft_split<R, S, T, int16_t>; break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nw > 8) per_cu = 8 / nw > 0 ? 8 / nw : 1;
+    int64_t nblocks = (int64_t)ncu * per_cu;
+    const int64_t maxb = (p.ws_rows + nw - 1) / nw;
+    if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
+    dim3 grid((unsigned)nblocks), block(64 * nw);
+    switch (x_dtype) {
+        case PVX_F32: hipLaunchKernelGGL((k_stft_split<R, S, T, float>), grid, block, lds, s, p); break;
+        case PVX_F64: hipLaunchKernelGGL((k_stft_split<R, S, T, double>), grid, block, lds, s, p); break;
+        default: hipLaunchKernelGGL((k_stft_split<R, S, T, int16_t>), grid, block, lds, s, p); break;
+    }
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}
+
 template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype, hipStream_t s) {
     using G = StftGeo<R, T>;
     int dev = 0, ncu = 256;
@@ -316,7 +535,9 @@ template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype,
 
 }  // namespace
 
-int pvx_stft_supported(int nfft, int precision) { return (precision == 64 || precision == 32) && (nfft == 512 || nfft == 1024 || nfft == 2048); }
+int pvx_stft_supported(int nfft, int precision) {
+    return (precision == 64 || precision == 32) && (nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096);
+}
 
 // spectra of workspace rows [0, ws_rows) (global rows R0-1 ..) -> spec [ws_rows][ldo] complex T (T by `precision`;
 // window and twiddle table in T)
@@ -330,6 +551,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
             case 512: return launch_stft_r<4, double>(p, x_dtype, s);
             case 1024: return launch_stft_r<8, double>(p, x_dtype, s);
             case 2048: return launch_stft_r<16, double>(p, x_dtype, s);
+            case 4096: return launch_stft_split<16, 2, double>(p, x_dtype, s);
             default: break;
         }
     } else {
@@ -339,6 +561,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
             case 512: return launch_stft_r<4, float>(p, x_dtype, s);
             case 1024: return launch_stft_r<8, float>(p, x_dtype, s);
             case 2048: return launch_stft_r<16, float>(p, x_dtype, s);
+            case 4096: return launch_stft_split<16, 2, float>(p, x_dtype, s);
             default: break;
         }
     }
