@@ -536,7 +536,7 @@ template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype,
 }  // namespace
 
 int pvx_stft_supported(int nfft, int precision) {
-    return (precision == 64 || precision == 32) && (nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096);
+    return (precision == 64 || precision == 32) && (nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096 || nfft == 8192);
 }
 
 // spectra of workspace rows [0, ws_rows) (global rows R0-1 ..) -> spec [ws_rows][ldo] complex T (T by `precision`;
@@ -552,6 +552,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
             case 1024: return launch_stft_r<8, double>(p, x_dtype, s);
             case 2048: return launch_stft_r<16, double>(p, x_dtype, s);
             case 4096: return launch_stft_split<16, 2, double>(p, x_dtype, s);
+            case 8192: return launch_stft_split<16, 4, double>(p, x_dtype, s);
             default: break;
         }
     } else {
@@ -562,6 +563,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
             case 1024: return launch_stft_r<8, float>(p, x_dtype, s);
             case 2048: return launch_stft_r<16, float>(p, x_dtype, s);
             case 4096: return launch_stft_split<16, 2, float>(p, x_dtype, s);
+            case 8192: return launch_stft_split<16, 4, float>(p, x_dtype, s);
             default: break;
         }
     }
