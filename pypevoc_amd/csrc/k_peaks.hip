@@ -22,7 +22,11 @@
 //
 // precision=32: angles are computed in float32 (the float32 FFT already limits them to ~1e-7 rad)
 // and assembled into float64 outputs around the exactly known bin centre; precision=64: the
-// reference's operation order in float64 throughout.
+// reference's operation order in float64 for the per-peak arithmetic.
+// The peak SEARCH runs on |X|^2 at both precisions (re*re + im*im, three instructions per bin where hypot() is
+// about fifty): every test it makes -- local maximum, threshold, ranking, salience -- is monotone in |X|, so it
+// selects the bins np.abs() would unless two compared magnitudes agree to the last bit or two, where the
+// reference's own outcome hangs on its libm's hypot() rounding (no two implementations agree there either).
 #include "pvx_wave.h"
 
 using namespace pvxw;
@@ -102,11 +106,11 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
                     lmin = fminf(lmin, fminf(e0, e1));
                     lsum += (double)e0 + (double)e1;
                 } else {
-                    const T m0 = hypot(v.x, v.y);                    // np.abs of complex128
+                    const T m0 = v.x * v.x + v.y * v.y;              // float64: |X|^2 too (see the header)
                     y[i] = m0;
                     lmax = m0 > lmax ? m0 : lmax;
                     lmin = m0 < lmin ? m0 : lmin;
-                    lsum += m0 * m0;
+                    lsum += m0;
                 }
             }
             for (int k = nvec * CPV + lane; k < N2; k += 64) {       // odd tail (CPV == 2, N2 odd)
@@ -123,17 +127,13 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
         const double tot = wave_sum(lsum);
         wave_sync();
         // ---- PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
-        int nsel;
-        if constexpr (sizeof(T) == 4) {
-            // the row holds |X|^2: |X| - miny > minamp - miny  <=>  |X|^2 - mine > minamp^2 - mine; minamp == 0
-            // means minamp = miny (PF.py:69-70) and the threshold is then exactly 0 (see k_fused.hip)
-            const double minamp = (double)sqrtf(maxv) * p.thr;       // PF.py:60
-            const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
-            nsel = peak_select_th<T>(y, cs, ci, sel, N2, K, th, minv, lane);
-        } else {
-            const double minamp = (double)maxv * p.thr;              // PF.py:60
-            nsel = peak_select<T>(y, cs, ci, sel, N2, K, minamp, true, minv, lane);
-        }
+        // the row holds |X|^2: |X| - miny > minamp - miny  <=>  |X|^2 - mine > minamp^2 - mine; minamp == 0
+        // means minamp = miny (PF.py:69-70) and the threshold is then exactly 0 (see k_fused.hip)
+        double minamp;
+        if constexpr (sizeof(T) == 4) minamp = (double)sqrtf(maxv) * p.thr;          // PF.py:60
+        else minamp = sqrt((double)maxv) * p.thr;
+        const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
+        const int nsel = peak_select_th<T>(y, cs, ci, sel, N2, K, th, minv, lane);
         int nk = 0;
         for (int e0 = 0; e0 < nsel; e0 += 64) {
             const int e = e0 + lane;

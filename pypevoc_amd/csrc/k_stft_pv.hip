@@ -1,0 +1,462 @@
+// k_stft_pv.hip -- the general path's analysis stage in ONE kernel: k_stft's windowed FFT (k_stft.hip) and
+// k_phase_peaks' peak search + phase-vocoder arithmetic (k_peaks.hip) on the same wave, at the reference's own
+// precision (float64) or in plain float32:
+//
+//   PV.calc_fft_frame   pypevoc/PVAnalysis.py:150-158
+//   PV.calc_pv_frame    pypevoc/PVAnalysis.py:160-211   (abs, PeakFinder + filter_by_salience, dphase2freq, 3-bin energy)
+//   PV.run_pv           pypevoc/PVAnalysis.py:213-264   (frame loop, zero-padded packing)
+//
+// Why: as two kernels the half spectra (nfft/2 complex per frame: 847 MB at BASELINE config 2 in float64) are written
+// by one kernel and streamed back by the next, and that second kernel is latency-bound (one wave per row: load, reduce,
+// search, in turn).  Here the magnitudes a frame's peak search needs are in the wave's registers when the untangle
+// produces the bins: they go to LDS, INTO the buffer the transform has just finished with (|X|^2 row + candidate lists
+// fit where the exchange matrix was), so the kernel needs no more LDS per wave than k_stft -- the same 6 waves per CU
+// at nfft 2048 -- and never reads a spectrum row back.  The spectrum rows are still written to the workspace
+// (PVHarmonic, calc_fft_frame and the chunk carry read them there); the per-peak arithmetic needs the current and
+// the PREVIOUS frame's spectrum at the <= K selected bins only, and fetches those few values from the workspace
+// rows this same wave wrote (a wave owns a contiguous range of rows and computes the row before its first one
+// itself: no wave ever reads what another wave wrote).  Results are bit-identical to k_stft + k_phase_peaks.
+//
+// Order of a frame: window * samples -> radix-R / LDS exchange / radix-R / P-lane DFT -> natural order in LDS ->
+// untangle (bins to the workspace row, |X|^2 of both bins of a pair) -> squared magnitudes to LDS ->
+// max / min / energy -> PeakFinder (pvx_wave.h: peak_select) -> salience -> selected bins staged.  Every GF staged
+// frames: all 64 lanes do the per-peak arithmetic on (frame, peak) pairs (peak_math) and write the result rows.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "pvx_stft.h"
+
+using namespace pvxw;
+using namespace pvxf;
+using namespace pvxs;
+
+namespace {
+
+constexpr int GF = 8;                 // frames staged before the per-peak pass
+
+struct StftPvParams {
+    StftParams s;                     // rows, input, tables, workspace
+    PeaksParams p;                    // peak parameters and result arrays (p.spec / p.ldo = s.spec / s.ldo)
+};
+
+// per-wave LDS behind the transform buffer: lst[GF][kpad] int | cnt[GF] int | rel[GF] int64 | tot[GF] double
+__host__ __device__ inline size_t pv_stage_bytes(int K) {
+    const size_t kpad = (size_t)((K + 3) & ~3);
+    size_t b = (size_t)GF * kpad * 4 + GF * 4;
+    b = (b + 7) & ~(size_t)7;
+    b += GF * 8 + GF * 8;
+    return (b + 15) & ~(size_t)15;
+}
+// what the peak search keeps in the transform buffer: y[M] T | cs[cap] T | ci[cap] int | sel[kpad] int
+template <int R, typename T> __host__ __device__ inline size_t pv_search_bytes(int K) {
+    constexpr size_t M = StftGeo<R, T>::M, cap = M / 2 + 4;
+    return M * sizeof(T) + cap * sizeof(T) + cap * 4 + (size_t)((K + 3) & ~3) * 4;
+}
+template <int R, typename T> __host__ __device__ inline size_t pv_total_lds(int nw, int K) {
+    return StftGeo<R, T>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
+}
+
+// a value this wave stored earlier in the kernel: read it where the store went (L2), not from a vector-L1 line that
+// may predate it
+__device__ __forceinline__ double ldw(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldw(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int R, typename T, typename InT>
+__global__ __launch_bounds__(384) void k_stft_pv(StftPvParams a) {
+    using G = StftGeo<R, T>;
+    constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
+    const StftParams& p = a.s;
+    const PeaksParams& pk = a.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    const int K = pk.K;
+    const int kpad = (K + 3) & ~3;
+    T* const winL = (T*)(smem + G::OFF_WIN);
+    cx<T>* const t1L = (cx<T>*)(smem + G::OFF_T1);
+    cx<T>* const t2L = (cx<T>*)(smem + G::OFF_T2);
+    cx<T>* const tw3 = (cx<T>*)(smem + G::OFF_TW3);
+    unsigned char* const wbase = smem + G::OFF_BUF + (size_t)wid * (G::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
+    cx<T>* const dz = (cx<T>*)wbase;
+    // the peak search's arrays live in dz between the untangle's reads and the next frame's exchange
+    constexpr int CAP = M / 2 + 4;
+    T* const y = (T*)wbase;
+    T* const cs = y + M;
+    int* const ci = (int*)(cs + CAP);
+    int* const sel = ci + CAP;
+    int* const lst = (int*)(wbase + G::BUFC * 2 * sizeof(T));            // [GF][kpad]
+    int* const cntv = lst + GF * kpad;                                    // [GF]
+    long long* const relv = (long long*)(((uintptr_t)(cntv + GF) + 7) & ~(uintptr_t)7);   // [GF]
+    double* const totv = (double*)(relv + GF);                            // [GF]
+    {
+        const cx<T>* tab = (const cx<T>*)p.twiddle;
+        constexpr int NMASK = G::N - 1;
+        for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = ((const T*)p.win)[i];
+        for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * (i & 63) * (i >> 6)) & NMASK];
+        for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
+        for (int i = threadIdx.x; i <= G::HALF; i += blockDim.x) tw3[i] = tab[i];
+    }
+    __syncthreads();
+    const int Q = lane / P, L1 = lane % P;
+    T csg[G::LOGP > 0 ? G::LOGP : 1];
+    cx<T> cw[G::LOGP > 0 ? G::LOGP : 1];
+    {
+        const cx<T>* tab = (const cx<T>*)p.twiddle;
+        constexpr int NMASK = G::N - 1;
+#pragma unroll
+        for (int s = 0; s < G::LOGP; s++) {
+            const int h = P >> (s + 1);
+            const bool up = (L1 & h) != 0;
+            csg[s] = up ? (T)-1 : (T)1;
+            const cx<T> wv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+            cw[s] = up ? wv : mkc<T>((T)1, (T)0);
+        }
+    }
+    int t1v = 0;
+#pragma unroll
+    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
+
+    // ---- rows of this wave: result rows rel in [rel0, rel1) = workspace rows rel0 + 1 .. rel1; workspace row rel0 is
+    // the predecessor of its first one and is computed here too (spectrum only)
+    const int64_t W = (int64_t)gridDim.x * nw;
+    const int64_t w = (int64_t)blockIdx.x * nw + wid;
+    const int64_t nrows = p.ws_rows - 1;
+    const int64_t rel0 = nrows * w / W, rel1 = nrows * (w + 1) / W;
+    if (rel0 >= rel1) return;
+    const int64_t rows1 = p.F + 1;
+    auto row_src = [&](int64_t j) -> const InT* {                     // samples of workspace row j; nullptr: zero row
+        if (j > rel1) return nullptr;
+        const int64_t g = p.R0 - 1 + j;
+        if (g < 0 || g >= p.total_rows) return nullptr;
+        const int64_t b = g / rows1, q = g - b * rows1;
+        if (q == 0) return nullptr;
+        return (const InT*)p.x + b * p.sig_stride + (q - 1) * (int64_t)p.hop;
+    };
+    // samples (2l + 128 r, + 1) of the next row, kept as float32 until the window multiply unless both the input and
+    // the arithmetic are float64 (int16 and float32 samples are exact in float32: half the registers across the frame)
+    using RawT = typename std::conditional<(sizeof(T) == 8 && sizeof(InT) == 8), double, float>::type;
+    RawT raw[2 * R];
+    auto prefetch_part = [&](const InT* src, int part) {
+        if (src == nullptr) return;
+        constexpr int PR = R / 4;
+#pragma unroll
+        for (int r = part * PR; r < (part + 1) * PR; r++) {
+            const InT* q = src + 2 * lane + 128 * r;
+            raw[2 * r] = (RawT)q[0]; raw[2 * r + 1] = (RawT)q[1];
+        }
+    };
+
+    PeakConst pc;
+    pc.fstep = pk.fstep; pc.dt = pk.dt; pc.nfft = pk.nfft; pc.hop = pk.hop; pc.wfbin = pk.wfbin;
+    int LPF = 1;
+    while (LPF < K && LPF < 64) LPF <<= 1;
+    const int fpp = 64 / LPF;
+
+    // per-peak phase vocoder arithmetic on the (frame, peak) pairs of the staged frames [0, ng) (k_peaks.hip, phase B)
+    auto flush = [&](int ng) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's spectrum rows are in L2
+        wave_sync();
+        // (the lane index goes through an opaque move here and in the peak search below: derived indices and addresses
+        // are then computed where they are used instead of being hoisted out of the frame loop, where they would
+        // occupy -- and spill -- registers across the transform)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int gl = ln / LPF, e0 = ln - gl * LPF;
+        const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
+        for (int gb = 0; gb < ng; gb += fpp) {
+            const int g = gb + gl;
+            const bool gvalid = g < ng;
+            const int cnt = gvalid ? cntv[g] : -1;
+            const int64_t rel = gvalid ? (int64_t)relv[g] : rel0;
+            const int64_t gr = p.R0 + rel;
+            const int64_t b = gr / rows1;
+            const int64_t fr = gr - b * rows1 - 1;
+            const int64_t orow = b * p.F + fr;
+            const T* cur = (const T*)p.spec + (size_t)(rel + 1) * p.ldo * 2;
+            const T* prv = (const T*)p.spec + (size_t)rel * p.ldo * 2;
+            const bool use_prev0 = (pk.prev0 != nullptr) && (orow == 0);
+            double* of = pk.f + orow * K;
+            double* om = pk.mag + orow * K;
+            double* op = pk.ph + orow * K;
+            double* orp = pk.realph + orow * K;
+            double* ob = pk.binno + orow * K;
+            int nout = 0;
+            for (int eb = 0; eb < K; eb += LPF) {                     // wave-uniform bound (ballots inside)
+                const int e = eb + e0;
+                bool valid = (cnt >= 0) && (e < cnt);
+                int nbin = 0;
+                double freq = 0.0, dfb = 0.0, thisph = 0.0, mg = 0.0;
+                if (valid) {
+                    nbin = lst[g * kpad + e];
+                    const T re = ldw(cur + 2 * nbin), im = ldw(cur + 2 * nbin + 1);
+                    T pr, pi;
+                    if (use_prev0) { pr = (T)pk.prev0[2 * nbin]; pi = (T)pk.prev0[2 * nbin + 1]; }
+                    else { pr = ldw(prv + 2 * nbin); pi = ldw(prv + 2 * nbin + 1); }
+                    // PV.py:197-199: 3-bin energy, bin 0 excluded
+                    const int imin = nbin - 1 > 1 ? nbin - 1 : 1;
+                    int imax = nbin + 1 < M ? nbin + 1 : M;
+                    if (imax > M - 1) imax = M - 1;
+                    T s3 = (T)0;
+                    for (int j = imin; j <= imax; j++) { const T ar = ldw(cur + 2 * j), c = ldw(cur + 2 * j + 1); s3 = s3 + (ar * ar + c * c); }
+                    const PeakOut o = peak_math<T>(nbin, re, im, pr, pi, s3, pc);
+                    freq = o.freq; dfb = o.dfb; thisph = o.thisph; mg = o.mag;
+                    valid = o.valid;
+                }
+                const unsigned long long bal = __ballot(valid) & gmask;
+                if (valid) {
+                    const int o = nout + __popcll(bal & ((1ull << ln) - 1ull));
+                    ob[o] = (double)nbin;
+                    of[o] = freq;
+                    om[o] = mg;
+                    op[o] = thisph;
+                    orp[o] = thisph + kPi * dfb / pk.fstep;           // PV.py:207
+                }
+                nout += __popcll(bal);
+            }
+            if (cnt >= 0) {
+                for (int j = nout + e0; j < K; j += LPF) {            // zero padding, PV.py:226-239
+                    ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
+                }
+                if (e0 == 0) {
+                    if (pk.totalmag) pk.totalmag[orow] = sqrt(totv[g]);                                  // PV.py:210
+                    if (pk.t) pk.t[orow] = ((double)(fr * (int64_t)pk.hop) + pk.nfft / 2.0) / pk.sr;     // PV.py:247
+                }
+            }
+        }
+        wave_sync();
+    };
+
+    {
+        const InT* s0 = row_src(rel0);
+        prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3);
+    }
+    int ng = 0;
+    for (int64_t j = rel0; j <= rel1; ++j) {
+        cx<T>* out = (cx<T>*)p.spec + (size_t)j * p.ldo;
+        const bool zero_row = row_src(j) == nullptr;
+        const bool with_peaks = j > rel0;
+        const InT* nsrc = row_src(j + 1);
+        cx<T> z[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            z[r] = mkc<T>((T)raw[2 * r] * winL[2 * lane + 128 * r], (T)raw[2 * r + 1] * winL[2 * lane + 128 * r + 1]);
+            asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 0);
+        if (zero_row) {
+            // the zero frame in front of every signal (PV.py:121): a spectrum row of zeros, no result row
+            prefetch_part(nsrc, 1); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3);
+            for (int k = lane; k < M; k += 64) out[k] = mkc<T>((T)0, (T)0);
+            continue;
+        }
+        dftT<R, T>(z);                                                // stage 1
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 1);
+#pragma unroll
+        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        wave_sync();
+#pragma unroll
+        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
+        // float64 samples: the second half of the next row is fetched after the transform (with all of it in flight
+        // through stages 2 and 3 the kernel needs more than 256 registers)
+        constexpr bool LATE = sizeof(RawT) == 8 && R == 16;
+        if constexpr (!LATE) prefetch_part(nsrc, 2);
+        wave_sync();
+        dftT<R, T>(z);                                                // stage 2
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LATE) prefetch_part(nsrc, 3);
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            // twiddle W_64^(l1 t2), then stage 3: P-point DFT across the P lanes of a group (decimation in frequency)
+            cx<T> v = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+            if constexpr (G::LOGP >= 1) {
+                if constexpr (P >= 16) v = xstepT<8, true, T>(v, csg[G::LOGP - 4], cw[G::LOGP - 4]);
+                if constexpr (P >= 8) v = xstepT<4, true, T>(v, csg[G::LOGP - 3], cw[G::LOGP - 3]);
+                if constexpr (P >= 4) v = xstepT<2, true, T>(v, csg[G::LOGP - 2], cw[G::LOGP - 2]);
+                v = xstepT<1, false, T>(v, csg[G::LOGP - 1], cw[G::LOGP - 1]);
+            }
+            dz[zpadT<R, T>(Q + R * t + G::R2 * t1v)] = v;
+        }
+        wave_sync();
+        // ---- untangle straight to the workspace row: pairs (k, M-k), k = lane + 64 j2 (k_stft.hip); the magnitudes
+        // of both bins stay in registers until every lane has read its part of dz
+        constexpr int NPAIR = R / 2;
+        int lu = lane;
+        asm volatile("" : "+v"(lu));                                 // (see flush: addresses derived here, not hoisted)
+        cx<T> za[NPAIR], zb[NPAIR];
+#pragma unroll
+        for (int j2 = 0; j2 < NPAIR; j2++) {
+            const int k = lu + 64 * j2;
+            za[j2] = dz[zpadT<R, T>(k)];
+            zb[j2] = dz[zpadT<R, T>((M - k) & (M - 1))];
+        }
+        const cx<T> zc = dz[zpadT<R, T>(G::HALF)];
+        wave_sync();                                                  // dz is free: the magnitude row goes there
+        if constexpr (LATE) { __builtin_amdgcn_sched_barrier(0); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int j2 = 0; j2 < NPAIR; j2++) {
+            const int k = lu + 64 * j2;
+            const int km = (M - k) & (M - 1);
+            const cx<T> S = mkc<T>(za[j2].x + zb[j2].x, za[j2].y - zb[j2].y);
+            const cx<T> D = mkc<T>(za[j2].x - zb[j2].x, za[j2].y + zb[j2].y);
+            const cx<T> O = mkc<T>((T)0.5 * D.y, (T)-0.5 * D.x);
+            const cx<T> Pk = cmulT(O, tw3[k]);
+            const cx<T> x0 = mkc<T>(fmaT((T)0.5, S.x, Pk.x), fmaT((T)0.5, S.y, Pk.y));
+            cx<T> x1 = mkc<T>(fmaT((T)0.5, S.x, -Pk.x), -fmaT((T)0.5, S.y, -Pk.y));
+            int kk = km;
+            if (j2 == 0 && lu == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = G::HALF; }      // bin 0 pairs with itself; its slot takes bin M/2
+            out[k] = x0;
+            out[kk] = x1;
+            if (with_peaks) {
+                // the peak search runs on |X|^2: every test it makes (local maximum, threshold, ranking, salience) is
+                // monotone in |X| (k_peaks.hip); plain products and one sum, the same value whichever kernel computes it
+                y[k] = x0.x * x0.x + x0.y * x0.y;
+                y[kk] = x1.x * x1.x + x1.y * x1.y;
+            }
+        }
+        wave_sync();
+        if (!with_peaks) continue;
+
+        // ---- extremes and energy of the row, in k_phase_peaks' order of summation (PV.py:173, 210; PF.py:60, 164)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        T lmax = (T)-INFINITY, lmin = (T)INFINITY;
+        double lsum = 0.0;
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int i = 0; i < M / 128; i++) {
+                const float2 v = *(const float2*)(y + 2 * (ln + 64 * i));
+                lmax = fmaxf(lmax, fmaxf(v.x, v.y));
+                lmin = fminf(lmin, fminf(v.x, v.y));
+                lsum += (double)v.x + (double)v.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M / 64; i++) {
+                const T m0 = y[ln + 64 * i];
+                lmax = m0 > lmax ? m0 : lmax;
+                lmin = m0 < lmin ? m0 : lmin;
+                lsum += m0;
+            }
+        }
+        const T maxv = wave_max(lmax);
+        const T minv = wave_min(lmin);
+        const double tot = wave_sum(lsum);
+        // ---- PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178)
+        // PF.py:69-70, 174 on the squared row: |X| - miny > minamp - miny  <=>  |X|^2 - mine > minamp^2 - mine; minamp == 0
+        // means minamp = miny there and the threshold is then exactly 0 (k_peaks.hip)
+        double minamp;
+        if constexpr (sizeof(T) == 4) minamp = (double)sqrtf(maxv) * pk.thr;        // PF.py:60
+        else minamp = sqrt((double)maxv) * pk.thr;
+        const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
+        // the candidate scan in pieces of at most 512 bins: all of a piece's LDS reads are in flight at once (peak_scan),
+        // and a piece's values fit beside the prefetched samples of the next row
+        constexpr int PIECE = M < 512 ? M : 512;
+        int C = 0;
+#pragma unroll 1
+        for (int kb = 0; kb < M; kb += PIECE) C += peak_scan<T, PIECE / 64>(y, kb, PIECE, M, minv, th, cs + C, ci + C, ln);
+        wave_sync();
+        const int nsel = peak_pick<T>(y, cs, ci, sel, M, K, C, th, ln);
+        int nk = 0;
+        int rad = pk.rad;
+        asm volatile("" : "+s"(rad));                                 // (like ln above: nothing derived from it is hoisted)
+        for (int eb = 0; eb < nsel; eb += 64) {
+            const int e = eb + ln;
+            int pb = 0;
+            bool keep = false;
+            if (e < nsel) { pb = sel[e]; keep = salient<T>(y, M, pb, rad); }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) lst[ng * kpad + nk + lane_prefix(bal)] = pb;
+            nk += __popcll(bal);
+        }
+        if (lane == 0) { cntv[ng] = nk; relv[ng] = j - 1; totv[ng] = tot; }
+        ng++;
+        if (ng == GF) { flush(ng); ng = 0; }
+        wave_sync();                                                  // y / cs / ci / sel are read: dz is free again
+    }
+    if (ng > 0) flush(ng);
+}
+
+template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_dtype, hipStream_t s) {
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    const int K = a.p.K;
+    int nw = 6;
+    if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 6) nw = v; }                 // tests: other workgroups
+    while (nw > 1 && pv_total_lds<R, T>(nw, K) > 160 * 1024) nw--;
+    const size_t lds = pv_total_lds<R, T>(nw, K);
+    const void* fn = nullptr;
+    switch (x_dtype) {
+        case PVX_F32: fn = (const void*)k_stft_pv<R, T, float>; break;
+        case PVX_F64: fn = (const void*)k_stft_pv<R, T, double>; break;
+        case PVX_I16: fn = (const void*)k_stft_pv<R, T, int16_t>; break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / lds);                            // workgroups that fit a CU's LDS side by side
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nw > 16) per_cu = 16 / nw > 0 ? 16 / nw : 1;
+    const int64_t nrows = a.s.ws_rows - 1;
+    int64_t nblocks = (int64_t)ncu * per_cu;
+    if (const char* e = getenv("PVX_STFT_PV_BLOCKS")) { const long long v = atoll(e); if (v >= 1) nblocks = v; }   // tests: other grids
+    const int64_t maxb = (nrows + nw - 1) / nw;                        // never more waves than rows
+    if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
+    dim3 grid((unsigned)nblocks), block(64 * nw);
+    switch (x_dtype) {
+        case PVX_F32: hipLaunchKernelGGL((k_stft_pv<R, T, float>), grid, block, lds, s, a); break;
+        case PVX_F64: hipLaunchKernelGGL((k_stft_pv<R, T, double>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((k_stft_pv<R, T, int16_t>), grid, block, lds, s, a); break;
+    }
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}
+
+template <int R, typename T> bool pv_fits(int K) {
+    return pv_search_bytes<R, T>(K) <= StftGeo<R, T>::BUFC * 2 * sizeof(T) && pv_total_lds<R, T>(1, K) <= 160 * 1024;
+}
+
+}  // namespace
+
+int pvx_stft_pv_supported(int nfft, int precision, int K) {
+    if (precision != 64 && precision != 32) return 0;
+    switch (nfft) {
+        case 512: return precision == 64 ? pv_fits<4, double>(K) : pv_fits<4, float>(K);
+        case 1024: return precision == 64 ? pv_fits<8, double>(K) : pv_fits<8, float>(K);
+        case 2048: return precision == 64 ? pv_fits<16, double>(K) : pv_fits<16, float>(K);
+        default: return 0;
+    }
+}
+
+// result rows [R0, R0 + nrows) of the general path in one launch: spectra into spec rows [0, nrows], peaks into the
+// result arrays of pp (pp.spec / pp.ldo are taken from the arguments)
+int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec, int64_t ldo, const void* twiddle, int x_dtype,
+                       int precision, hipStream_t s) {
+    if (fp.ws_rows <= 1) return PVX_OK;
+    StftPvParams a;
+    a.s.x = fp.x; a.s.nsamp = fp.nsamp; a.s.sig_stride = fp.sig_stride; a.s.F = fp.F; a.s.R0 = fp.R0; a.s.ws_rows = fp.ws_rows;
+    a.s.total_rows = fp.total_rows; a.s.hop = fp.hop; a.s.win = fp.win; a.s.twiddle = twiddle; a.s.spec = spec; a.s.ldo = ldo;
+    a.p = pp; a.p.spec = spec; a.p.ldo = ldo;
+    if (precision == 64) {
+        switch (fp.nfft) {
+            case 512: return launch_stft_pv_r<4, double>(a, x_dtype, s);
+            case 1024: return launch_stft_pv_r<8, double>(a, x_dtype, s);
+            case 2048: return launch_stft_pv_r<16, double>(a, x_dtype, s);
+            default: break;
+        }
+    } else {
+        switch (fp.nfft) {
+            case 512: return launch_stft_pv_r<4, float>(a, x_dtype, s);
+            case 1024: return launch_stft_pv_r<8, float>(a, x_dtype, s);
+            case 2048: return launch_stft_pv_r<16, float>(a, x_dtype, s);
+            default: break;
+        }
+    }
+    pvx_set_error("the fused STFT + peaks kernel does not handle nfft=%d", fp.nfft);
+    return PVX_ERR_UNSUPPORTED;
+}

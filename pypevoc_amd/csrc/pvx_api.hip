@@ -134,6 +134,7 @@ struct pvx_plan {
     rocfft_execution_info info = nullptr;
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
     bool use_stft = false;       // float64, nfft 512..2048: k_stft writes the spectrum rows (no frame buffer, no rocFFT)
+    bool use_stft_pv = false;    // ... and finds the peaks in the same launch (k_stft_pv.hip)
     int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
     bool rocfft_small = false;   // ... and its output then goes to d_rspec, not to the analysis' d_spec
     void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
@@ -339,6 +340,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (hipMalloc(&p->d_twiddle64, tw.size() * rs) != hipSuccess) { pvx_set_error("hipMalloc(stft twiddle) failed"); plan_free(p); return PVX_ERR_ALLOC; }
         if (hipMemcpy(p->d_twiddle64, src, tw.size() * rs, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(stft twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         p->use_stft = true;
+        p->use_stft_pv = pvx_stft_pv_supported(nfft, precision, npks) != 0 && !getenv("PVX_NO_STFT_PV");
         if (!getenv("PVX_MAX_ROWS")) {
             int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 2 * rs));
             if (big > 262144) big = 262144;
@@ -532,6 +534,22 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = sig_stride; fp.F = F; fp.R0 = R0;
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
         fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
+        PeaksParams pp;
+        pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
+        pp.nfft = p->nfft; pp.hop = p->hop; pp.N2 = p->N2; pp.K = p->npks; pp.rad = 5;   // PV.py:177
+        pp.thr = p->pkthresh; pp.sr = p->sr; pp.fstep = p->fstep; pp.dt = p->dt;
+        pp.wfbin = p->d_wfbin; pp.prev0 = d_prev0;
+        pp.f = d_f; pp.mag = d_mag; pp.ph = d_ph; pp.realph = d_realph; pp.binno = d_binno;
+        pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
+        if (p->use_stft && p->use_stft_pv) {
+            // window + FFT + untangle + peaks of every row in one kernel (k_stft_pv.hip); the spectrum rows still land in
+            // the workspace
+            if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
+            if ((rc = pvx_launch_stft_pv(fp, pp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, p->precision, s)) != PVX_OK) return rc;
+            if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
+            if ((rc = plan_progress(p, s, R0 + nrows, total_rows, nsig)) != PVX_OK) return rc;
+            continue;
+        }
         if ((rc = plan_event(p, s, 0)) != PVX_OK) return rc;
         if (p->use_stft) {
             // window + FFT + untangle of every workspace row in one kernel (k_stft.hip)
@@ -544,13 +562,6 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
             PVX_FFT_CHECK(rocfft_execute(p->fft, in, out, p->info));
         }
         if ((rc = plan_event(p, s, 2)) != PVX_OK) return rc;
-        PeaksParams pp;
-        pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
-        pp.nfft = p->nfft; pp.hop = p->hop; pp.N2 = p->N2; pp.K = p->npks; pp.rad = 5;   // PV.py:177
-        pp.thr = p->pkthresh; pp.sr = p->sr; pp.fstep = p->fstep; pp.dt = p->dt;
-        pp.wfbin = p->d_wfbin; pp.prev0 = d_prev0;
-        pp.f = d_f; pp.mag = d_mag; pp.ph = d_ph; pp.realph = d_realph; pp.binno = d_binno;
-        pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
         if ((rc = pvx_launch_phase_peaks(pp, p->precision, s)) != PVX_OK) return rc;
         if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
         if ((rc = plan_progress(p, s, R0 + nrows, total_rows, nsig)) != PVX_OK) return rc;

@@ -104,6 +104,10 @@ struct FrameParams;
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);
 int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, int precision, hipStream_t s);
 int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
+// k_stft_pv.hip: k_stft + k_phase_peaks in one launch (nfft 512..2048 while the peak search fits the transform buffer)
+int pvx_stft_pv_supported(int nfft, int precision, int K);
+int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec, int64_t ldo, const void* twiddle, int x_dtype,
+                       int precision, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
 

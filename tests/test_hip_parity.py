@@ -536,6 +536,59 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft):
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+def test_fused_general_kernel_is_bit_identical_to_two_kernels(amd, monkeypatch, nfft, precision):
+    """k_stft_pv.hip (window + FFT + peaks of the general path in one launch; the default at precision 64 for
+    nfft 512..2048) against k_stft + k_phase_peaks (PVX_NO_STFT_PV=1), which the other tests pin to the reference:
+    every output bit for bit -- noise (radix select), silence (zero rows, x/0 frames), threshold 0 (zero fill),
+    npks, hops, input types, several signals per call, other grids and workgroup sizes."""
+    rng = np.random.default_rng(78)
+    sr = 44100.0
+    n = 50000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    quant = np.round(harm * 50) / 50
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+
+    def both(make):
+        monkeypatch.setenv("PVX_NO_STFT_PV", "1")
+        a = make()
+        monkeypatch.delenv("PVX_NO_STFT_PV")
+        return a, make()
+
+    def same(a, b, what):
+        for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
+
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant)):
+        for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (70, 0.005, nfft // 8)):
+            a, b = both(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=precision))
+            same(a, b, (name, K, thr, hop))
+    for xin in (noise.astype(np.float32), np.round(harm * 20000).astype(np.int16)):
+        a, b = both(lambda: run_pv(amd, xin, sr, nfft, nfft // 4, 8, precision=precision))
+        same(a, b, xin.dtype)
+    for ns in (nfft + 1, nfft + nfft // 4 + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 40):
+        g0 = n // 7 - 1000
+        xb = np.stack([noise[:ns], harm[:ns], gaps[g0:g0 + ns], quant[:ns], noise[100:100 + ns]])
+        a, b = both(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=8, precision=precision).run_pv())
+        for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
+    ref = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=precision)
+    for var, val in (("PVX_STFT_PV_BLOCKS", "1"), ("PVX_STFT_PV_BLOCKS", "3"), ("PVX_STFT_PV_BLOCKS", "100000"), ("PVX_STFT_PV_NW", "1"), ("PVX_STFT_PV_NW", "4")):
+        monkeypatch.setenv(var, val)
+        q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=precision)
+        monkeypatch.delenv(var)
+        same(ref, q, (var, val))
+    # a workspace of a few rows: many launches, the previous spectrum handed over in workspace row 0
+    monkeypatch.setenv("PVX_MAX_ROWS", "37")
+    q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=precision)
+    monkeypatch.delenv("PVX_MAX_ROWS")
+    same(ref, q, "max_rows")
+
+
 def test_add_frame_incremental_equals_tosinsum(amd):
     g = load_golden("G5a_noise_n1024_k20")
     ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
