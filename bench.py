@@ -378,12 +378,14 @@ def main():
         ab = alg_bytes()
         frames_total = FT * world * args.steps
         value = frames_total / elapsed
-        kname = {1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring"}.get(fft_mode, "k_fused_pv")
+        # fft mode 0 with a stage-3 span: k_stft_pv.hip (general path, STFT + peaks in one launch, spectrum rows still written)
+        kname = {0: "k_stft_pv", 1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring"}.get(fft_mode, "k_fused_pv")
         # general path: k_stft.hip writes the spectrum rows when it can (no frame buffer, no rocFFT launches)
         names = ["k_stft" if (nl[0] > 0 and nl[1] == 0) else "k_frames", "rocfft_r2c", "k_phase_peaks", kname]
         s_in = 4 if args.precision == 32 else 8
         abp = alg_bytes(s=s_in, c=2 * s_in)
-        abk = [abp["frames"], abp["fft"], abp["peaks"], ab["fused"]]
+        abk = [abp["frames"], abp["fft"], abp["peaks"],
+               ab["fused"] if fft_mode else HOP * 4 + (NFFT // 2) * 2 * s_in + NPKS * 40 + 16]
         per = []
         for i in range(4):
             if nl[i]:
@@ -485,8 +487,10 @@ def main():
             ab64 = alg_bytes(s=8, c=16)
             stft = n64[0] > 0 and n64[1] == 0                      # k_stft.hip wrote the spectra: no frame buffer, no rocFFT
             # input samples are float32 in HBM.  k_stft: hop*4 in, (nfft/2)*16 out; framing kernel: hop*4 in, nfft*8 out
-            ab64k = [HOP * 4 + (NFFT // 2) * 16 if stft else HOP * 4 + NFFT * 8, ab64["fft"], (NFFT // 2) * 16 + NPKS * 40 + 16, ab64["fused"]]
-            n64names = ["k_stft" if stft else "k_frames", "rocfft_r2c", "k_phase_peaks", "fused"]
+            # k_stft_pv (one launch): hop*4 in, the spectrum row (nfft/2)*16 and the result row out
+            ab64k = [HOP * 4 + (NFFT // 2) * 16 if stft else HOP * 4 + NFFT * 8, ab64["fft"], (NFFT // 2) * 16 + NPKS * 40 + 16,
+                     HOP * 4 + (NFFT // 2) * 16 + NPKS * 40 + 16]
+            n64names = ["k_stft" if stft else "k_frames", "rocfft_r2c", "k_phase_peaks", "k_stft_pv"]
             k64 = []
             for i in range(4):
                 if n64[i]:
@@ -502,6 +506,10 @@ def main():
                        roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64,
                                      achieved=round(stage64 * F64 / (ms64 * 1e-3) / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                      frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4), kernels=k64))
+            g64 = torch.Generator(device=dev)
+            g64.manual_seed(1)
+            Fn64, msn64, _ = quick(p64, 0.1 * torch.randn(nsamp, device=dev, generator=g64), 5)
+            f64["white_noise"] = dict(value=round(Fn64 / msn64 * 1e3, 1), unit="frames/s", ms_per_step=round(msn64, 4))
             lib.pvx_plan_destroy(p64)
             # ---- the same geometry on other material (the headline signal has ~10 candidate maxima per frame)
             workloads = {}

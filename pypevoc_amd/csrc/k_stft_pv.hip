@@ -387,7 +387,8 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     const int K = a.p.K;
-    int nw = 6;
+    // float64: LDS admits 6 waves per CU at nfft 2048; float32 (<= 176 registers: two waves per SIMD): two workgroups of 4
+    int nw = sizeof(T) == 8 ? 6 : 4;
     if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 6) nw = v; }                 // tests: other workgroups
     while (nw > 1 && pv_total_lds<R, T>(nw, K) > 160 * 1024) nw--;
     const size_t lds = pv_total_lds<R, T>(nw, K);

@@ -157,6 +157,62 @@ __device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n
     return C;
 }
 
+// Exact radix select on a candidate list of at most 64 * NCH entries with the keys in REGISTERS (lane owns entries
+// lane + 64 j): two bits per round -- three trial values whose counts come from independent compares, ballots and
+// scalar popcounts -- and the loop stops as soon as exactly npeaks keys are at or above the prefix.  The list-resident
+// loop below (one bit per round, the entries beyond the first 128 re-read from LDS every round) is what remains for
+// longer lists; on a recording (80-300 candidates per frame at nfft 2048) it was most of a float64 frame's time.
+template <typename T, int NCH>
+__device__ __forceinline__ int peak_radix_list(const T* cs, const int* ci, int* out, int npeaks, int C, int lane) {
+    using K = Key<T>;
+    using KT = typename K::type;
+    KT key[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) { const int c = lane + 64 * j; key[j] = (c < C) ? K::of(cs[c < C ? c : 0]) : (KT)0; }
+    KT prefix = 0;
+    for (int bit = K::TOP; bit >= 0; bit -= 2) {                    // TOP is even: rounds take bits (bit, bit - 1); the last one bit 0 alone
+        const int lo = bit >= 1 ? bit - 1 : 0;
+        const KT t1 = prefix | ((KT)1 << lo);
+        const KT t2 = bit >= 1 ? (prefix | ((KT)2 << lo)) : ~(KT)0;
+        const KT t3 = bit >= 1 ? (prefix | ((KT)3 << lo)) : ~(KT)0;
+        int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            c1 += __popcll(__ballot(key[j] >= t1));
+            c2 += __popcll(__ballot(key[j] >= t2));
+            c3 += __popcll(__ballot(key[j] >= t3));
+        }
+        int cnt = -1;
+        if (c3 >= npeaks) { prefix = t3; cnt = c3; }
+        else if (c2 >= npeaks) { prefix = t2; cnt = c2; }
+        else if (c1 >= npeaks) { prefix = t1; cnt = c1; }
+        if (cnt == npeaks) break;                                    // exactly the keys >= prefix: nothing left to resolve
+    }
+    // prefix = key of the npeaks-th best (or a lower bound that exactly npeaks keys reach); strictly greater ones
+    // all go, ties in list (= bin) order
+    int ngt = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) ngt += __popcll(__ballot(key[j] > prefix));
+    // (after an early stop every key >= prefix is wanted: treat them all as "ties" of the prefix class)
+    int tc = 0, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int c = lane + 64 * j;
+        const bool valid = c < C;
+        const bool ge = valid && (key[j] >= prefix);
+        const bool gt = valid && (key[j] > prefix);
+        const bool tie = ge && !gt;
+        const unsigned long long bt = __ballot(tie);
+        const bool take = gt || (tie && (tc + lane_prefix(bt)) < npeaks - ngt);
+        const unsigned long long bk = __ballot(take);
+        if (take) out[cnt + lane_prefix(bk)] = ci[c];
+        tc += __popcll(bt);
+        cnt += __popcll(bk);
+    }
+    wave_sync();
+    return cnt;
+}
+
 // peak_pick: the npeaks best of the C candidates in cs/ci (list in ascending bin order) -> out[],
 // ascending bins; returns the count (wave-uniform).  th < 0 additionally admits the zeros of pkmskamp.
 // Optional padded layout of a magnitude row in LDS: YP = 1 keeps 4 spare floats after every 64 so that
@@ -213,6 +269,10 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
     }
     // ---- C > 64: exact radix select of the npeaks-th largest score (bits of a non-negative
     // float order like unsigned integers).  Ballot + popcount only.
+    if (C <= 128) return peak_radix_list<T, 2>(cs, ci, out, npeaks, C, lane);
+    if (C <= 192) return peak_radix_list<T, 3>(cs, ci, out, npeaks, C, lane);
+    if (C <= 320) return peak_radix_list<T, 5>(cs, ci, out, npeaks, C, lane);
+    if (C <= 512) return peak_radix_list<T, 8>(cs, ci, out, npeaks, C, lane);
     using K = Key<T>;
     using KT = typename K::type;
     const KT k0r = (lane < C) ? K::of(cs[lane]) : (KT)0;            // first two per lane live in registers
