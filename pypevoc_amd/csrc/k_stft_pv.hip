@@ -10,8 +10,8 @@
 // by one kernel and streamed back by the next, and that second kernel is latency-bound (one wave per row: load, reduce,
 // search, in turn).  Here the magnitudes a frame's peak search needs are in the wave's registers when the untangle
 // produces the bins: they go to LDS, INTO the buffer the transform has just finished with (|X|^2 row + candidate lists
-// fit where the exchange matrix was), so the kernel needs no more LDS per wave than k_stft -- the same 6 waves per CU
-// at nfft 2048 -- and never reads a spectrum row back.  The spectrum rows are still written to the workspace
+// fit where the exchange matrix was), so the kernel needs no more LDS per wave than k_stft -- 7 waves per CU at nfft
+// 2048 -- and never reads a spectrum row back.  The spectrum rows are still written to the workspace
 // (PVHarmonic, calc_fft_frame and the chunk carry read them there); the per-peak arithmetic needs the current and
 // the PREVIOUS frame's spectrum at the <= K selected bins only, and fetches those few values from the workspace
 // rows this same wave wrote (a wave owns a contiguous range of rows and computes the row before its first one
@@ -53,8 +53,15 @@ template <int R, typename T> __host__ __device__ inline size_t pv_search_bytes(i
     constexpr size_t M = StftGeo<R, T>::M, cap = M / 2 + 4;
     return M * sizeof(T) + cap * sizeof(T) + cap * 4 + (size_t)((K + 3) & ~3) * 4;
 }
+// the untangle's twiddles W_nfft^k, k < nfft/4, from the first octant of the table (k <= nfft/8) and its symmetry
+// W^(nfft/4 - k) = (-Im, -Re) W^k (exact in the host's table, pvx_plan_create): 4 KB of LDS instead of 8 at nfft 2048,
+// which is what lets a seventh wave's buffer in
+template <int R, typename T> struct PvGeo : StftGeo<R, T> {
+    static constexpr int TW8N = (StftGeo<R, T>::HALF / 2 + 1 + 7) & ~7;
+    static constexpr size_t OFF_BUF = StftGeo<R, T>::OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);          // cx [NW][BUFC]
+};
 template <int R, typename T> __host__ __device__ inline size_t pv_total_lds(int nw, int K) {
-    return StftGeo<R, T>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
+    return PvGeo<R, T>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
 }
 
 // a value this wave stored earlier in the kernel: read it where the store went (L2), not from a vector-L1 line that
@@ -63,8 +70,8 @@ __device__ __forceinline__ double ldw(const double* q) { return __hip_atomic_loa
 __device__ __forceinline__ float ldw(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int R, typename T, typename InT>
-__global__ __launch_bounds__(384) void k_stft_pv(StftPvParams a) {
-    using G = StftGeo<R, T>;
+__global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
+    using G = PvGeo<R, T>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
     const StftParams& p = a.s;
     const PeaksParams& pk = a.p;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(384) void k_stft_pv(StftPvParams a) {
         for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = ((const T*)p.win)[i];
         for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * (i & 63) * (i >> 6)) & NMASK];
         for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
-        for (int i = threadIdx.x; i <= G::HALF; i += blockDim.x) tw3[i] = tab[i];
+        for (int i = threadIdx.x; i <= G::HALF / 2; i += blockDim.x) tw3[i] = tab[i];
     }
     __syncthreads();
     const int Q = lane / P, L1 = lane % P;
@@ -303,7 +310,10 @@ __global__ __launch_bounds__(384) void k_stft_pv(StftPvParams a) {
             const cx<T> S = mkc<T>(za[j2].x + zb[j2].x, za[j2].y - zb[j2].y);
             const cx<T> D = mkc<T>(za[j2].x - zb[j2].x, za[j2].y + zb[j2].y);
             const cx<T> O = mkc<T>((T)0.5 * D.y, (T)-0.5 * D.x);
-            const cx<T> Pk = cmulT(O, tw3[k]);
+            cx<T> wk;
+            if (j2 < NPAIR / 2) wk = tw3[k];                         // k <= nfft/8
+            else { const cx<T> e = tw3[G::HALF - k]; wk = mkc<T>(-e.y, -e.x); }
+            const cx<T> Pk = cmulT(O, wk);
             const cx<T> x0 = mkc<T>(fmaT((T)0.5, S.x, Pk.x), fmaT((T)0.5, S.y, Pk.y));
             cx<T> x1 = mkc<T>(fmaT((T)0.5, S.x, -Pk.x), -fmaT((T)0.5, S.y, -Pk.y));
             int kk = km;
@@ -387,9 +397,9 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     const int K = a.p.K;
-    // float64: LDS admits 6 waves per CU at nfft 2048; float32 (<= 176 registers: two waves per SIMD): two workgroups of 4
-    int nw = sizeof(T) == 8 ? 6 : 4;
-    if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 6) nw = v; }                 // tests: other workgroups
+    // float64: LDS admits 7 waves per CU at nfft 2048 (npks <= 12); float32 (<= 176 registers: two waves per SIMD): two workgroups of 4
+    int nw = (sizeof(T) == 8 && R == 16) ? 7 : 4;                      // (the others hold two waves per SIMD by registers)
+    if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 7) nw = v; }                 // tests: other workgroups
     while (nw > 1 && pv_total_lds<R, T>(nw, K) > 160 * 1024) nw--;
     const size_t lds = pv_total_lds<R, T>(nw, K);
     const void* fn = nullptr;

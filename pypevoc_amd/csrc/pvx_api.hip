@@ -334,6 +334,16 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     if (pvx_stft_supported(nfft, precision) && !getenv("PVX_NO_STFT")) {
         std::vector<double> tw(2 * (size_t)nfft);
         const double pi = 3.141592653589793238462643383279502884;
+        if (nfft % 8 == 0) {
+            // W^j = cos - i sin from libm on the first octant only; the rest by the table's exact symmetries
+            // W^(N/4 - j) = (-Im, -Re) W^j and W^(j + N/4) = -i W^j, so that a kernel may keep an eighth of the table and
+            // derive the other entries (k_stft_pv.hip) and still use the very values the full-table kernels read
+            const int q = nfft / 4, o = nfft / 8;
+            for (int j = 0; j <= o; j++) { tw[2 * j] = cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = -sin(2.0 * pi * j / (double)nfft); }
+            tw[2 * o] = 0.70710678118654752440; tw[2 * o + 1] = -0.70710678118654752440;      // W^(N/8) is its own mirror image
+            for (int j = o + 1; j <= q; j++) { tw[2 * j] = -tw[2 * (q - j) + 1]; tw[2 * j + 1] = -tw[2 * (q - j)]; }
+            for (int j = q + 1; j < nfft; j++) { tw[2 * j] = tw[2 * (j - q) + 1]; tw[2 * j + 1] = -tw[2 * (j - q)]; }
+        } else
         for (int j = 0; j < nfft; j++) { tw[2 * j] = cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = -sin(2.0 * pi * j / (double)nfft); }
         std::vector<float> twf(tw.begin(), tw.end());
         const void* src = precision == 64 ? (const void*)tw.data() : (const void*)twf.data();
