@@ -69,7 +69,11 @@ template <int R, typename T> __host__ __device__ inline size_t pv_total_lds(int 
 __device__ __forceinline__ double ldw(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ldw(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int R, typename T, typename InT>
+// H > 0: hop = 128 H (nfft/4 or nfft/2).  A lane's samples of the next frame are then the ones it holds, moved up by H
+// register pairs (sample 2l + 128 r + hop = 2l + 128 (r + H)): only the last H pairs are loaded -- hop*4 bytes per
+// frame from HBM instead of nfft*4 (a wave walks its rows alone: by the time it comes back for the next frame the
+// spectrum rows streaming through L2 have evicted the samples it shared with this one).
+template <int R, typename T, typename InT, int H>
 __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
     using G = PvGeo<R, T>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         cx<T>* out = (cx<T>*)p.spec + (size_t)j * p.ldo;
         const bool zero_row = row_src(j) == nullptr;
         const bool with_peaks = j > rel0;
-        const InT* nsrc = row_src(j + 1);
+        const InT* nsrc = row_src(j + 1);                             // (nullptr once the window has been slid)
         cx<T> z[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -252,6 +256,20 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
             asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
         }
         __builtin_amdgcn_sched_barrier(0);
+        // rows j and j + 1 are consecutive frames of one signal: slide the window, fetch the hop's new samples
+        const bool slide = (H > 0) && !zero_row && (nsrc != nullptr);
+        if constexpr (H > 0) {
+            if (slide) {
+#pragma unroll
+                for (int r = 0; r < R - H; r++) { raw[2 * r] = raw[2 * (r + H)]; raw[2 * r + 1] = raw[2 * (r + H) + 1]; }
+#pragma unroll
+                for (int r = R - H; r < R; r++) {
+                    const InT* q = nsrc + 2 * lane + 128 * r;
+                    raw[2 * r] = (RawT)q[0]; raw[2 * r + 1] = (RawT)q[1];
+                }
+                nsrc = nullptr;                                       // nothing else to fetch for row j + 1
+            }
+        }
         prefetch_part(nsrc, 0);
         if (zero_row) {
             // the zero frame in front of every signal (PV.py:121): a spectrum row of zeros, no result row
@@ -402,11 +420,13 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 7) nw = v; }                 // tests: other workgroups
     while (nw > 1 && pv_total_lds<R, T>(nw, K) > 160 * 1024) nw--;
     const size_t lds = pv_total_lds<R, T>(nw, K);
+    // the sliding-window instantiations for the two usual hops
+    const int H = (a.s.hop == 32 * R) ? R / 4 : (a.s.hop == 64 * R) ? R / 2 : 0;
     const void* fn = nullptr;
     switch (x_dtype) {
-        case PVX_F32: fn = (const void*)k_stft_pv<R, T, float>; break;
-        case PVX_F64: fn = (const void*)k_stft_pv<R, T, double>; break;
-        case PVX_I16: fn = (const void*)k_stft_pv<R, T, int16_t>; break;
+        case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4> : H ? (const void*)k_stft_pv<R, T, float, R / 2> : (const void*)k_stft_pv<R, T, float, 0>; break;
+        case PVX_F64: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : H ? (const void*)k_stft_pv<R, T, double, R / 2> : (const void*)k_stft_pv<R, T, double, 0>; break;
+        case PVX_I16: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4> : H ? (const void*)k_stft_pv<R, T, int16_t, R / 2> : (const void*)k_stft_pv<R, T, int16_t, 0>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -419,11 +439,9 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     const int64_t maxb = (nrows + nw - 1) / nw;                        // never more waves than rows
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * nw);
-    switch (x_dtype) {
-        case PVX_F32: hipLaunchKernelGGL((k_stft_pv<R, T, float>), grid, block, lds, s, a); break;
-        case PVX_F64: hipLaunchKernelGGL((k_stft_pv<R, T, double>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((k_stft_pv<R, T, int16_t>), grid, block, lds, s, a); break;
-    }
+    StftPvParams arg = a;
+    void* args[] = {&arg};
+    PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
 }
