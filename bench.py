@@ -97,6 +97,15 @@ def alg_bytes(nfft=NFFT, hop=HOP, npks=NPKS, s=4, c=8):
                 fused=hop * s + out, contract=hop * s + 2 * nfft * s + 2 * (nfft // 2 + 1) * c + out)
 
 
+def f64_traffic():
+    """Measured HBM bytes per launch of k_stft_pv<16, double> on C2 (profiles/r02_traffic_f64.json; tools/prof_traffic.sh)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_f64.json")))["kernels"]["k_stft_pv"]
+        return int(d["read_bytes"] + d["write_bytes"])
+    except Exception:
+        return None
+
+
 def self_launch(args, argv):
     """--gpus N > 1 outside a torch.distributed environment: run N ranks as a child process."""
     import torch
@@ -402,6 +411,8 @@ def main():
                 traffic = json.load(open(tpath)).get(dom["kernel"])
             except Exception:
                 traffic = None
+        if dom and traffic is None and dom["kernel"] == "k_stft_pv" and args.precision == 64 and args.workload == "c2" and not args.seconds:
+            traffic = f64_traffic()
         roofline = None
         if dom:
             fpl = FT * args.steps / dom["launches"]
@@ -503,7 +514,7 @@ def main():
             f64 = dict(value=round(F64 / ms64 * 1e3, 1), unit="frames/s", ms_per_step=round(ms64, 4), dtype="f64",
                        fft_mode=int(lib.pvx_plan_get_fft_mode(p64)),
                        contract_bytes_per_frame=ab64["contract"] - HOP * 4,
-                       roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64,
+                       roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64, traffic=f64_traffic(),
                                      achieved=round(stage64 * F64 / (ms64 * 1e-3) / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                      frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4), kernels=k64))
             g64 = torch.Generator(device=dev)

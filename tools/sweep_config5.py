@@ -58,7 +58,9 @@ def main():
             contract = hop * 4 + 2 * nfft * s_ + 2 * (nfft // 2 + 1) * 2 * s_ + (K * 5 * 8 + 16)
             mode = int(lib.pvx_plan_get_fft_mode(plan))
             own = hop * 4 + (K * 5 * 8 + 16) if mode != 0 else contract
-            if mode == 0 and prec == 64 and nfft in (512, 1024, 2048):      # k_stft + k_phase_peaks: spectrum rows written once, read once
+            if mode == 0 and prec == 64 and nfft in (512, 1024, 2048):      # k_stft_pv: spectrum rows written once, never read back
+                own = hop * 4 + (nfft // 2) * 16 + (K * 5 * 8 + 16)
+            elif mode == 0 and prec == 64 and nfft in (4096, 8192):         # k_stft_split + k_phase_peaks: written once, read once
                 own = hop * 4 + 2 * (nfft // 2) * 16 + (K * 5 * 8 + 16)
             fps = F / (ms * 1e-3)
             print(json.dumps(dict(nfft=nfft, hop=hop, precision=prec, frames=F, ms=round(ms, 3), frames_per_s=round(fps, 1),
