@@ -43,10 +43,12 @@ constexpr int GMAX = 8;               // frames a wave batches before the per-pe
 // LDS per wave (bytes), shared with the host-side sizing below
 __host__ __device__ __forceinline__ size_t peaks_lds_per_wave(int N2, int K, size_t ts) {
     const size_t n2pad = (size_t)((N2 + 3) & ~3);
-    const size_t cap = n2pad / 2 + 4;
+    const size_t cap = (n2pad / 2 + 4 + 1) & ~(size_t)1;
     const size_t kpad = (size_t)((K + 3) & ~3);
-    // y[n2pad] T | cs[cap] T | ci[cap] int | sel[kpad] int | lst[GMAX][kpad] int | cnt[GMAX] int | tot[GMAX] double
-    size_t b = n2pad * ts + cap * ts + cap * 4 + kpad * 4 + (size_t)GMAX * kpad * 4 + GMAX * 4;
+    // y[n2pad] T | ci[cap] u16 | sel[kpad] int | lst[GMAX][kpad] int | cnt[GMAX] int | tot[GMAX] double
+    // (no score list and 16-bit bins: 10 bytes of LDS per bin at float64 instead of 14, i.e. 8 waves per CU instead of
+    // 4 at nfft 4096 -- what this latency-bound kernel's speed hangs on there)
+    size_t b = n2pad * ts + cap * 2 + kpad * 4 + (size_t)GMAX * kpad * 4 + GMAX * 4;
     b = (b + 7) & ~(size_t)7;
     b += GMAX * 8;
     return (b + 15) & ~(size_t)15;
@@ -60,13 +62,12 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     const int nwaves = blockDim.x >> 6;
     const int N2 = p.N2, K = p.K;
     const int n2pad = (N2 + 3) & ~3;
-    const int cap = n2pad / 2 + 4;
+    const int cap = (n2pad / 2 + 4 + 1) & ~1;
     const int kpad = (K + 3) & ~3;
     unsigned char* base = smem + peaks_lds_per_wave(N2, K, sizeof(T)) * wid;
     T* y = (T*)base;
-    T* cs = y + n2pad;
-    int* ci = (int*)(cs + cap);
-    int* sel = ci + cap;
+    unsigned short* ci = (unsigned short*)(y + n2pad);
+    int* sel = (int*)(ci + cap);
     int* lst = sel + kpad;                       // [GMAX][kpad]
     int* cntv = lst + GMAX * kpad;               // [GMAX]
     double* totv = (double*)(((uintptr_t)(cntv + GMAX) + 7) & ~(uintptr_t)7);   // [GMAX]
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
         if constexpr (sizeof(T) == 4) minamp = (double)sqrtf(maxv) * p.thr;          // PF.py:60
         else minamp = sqrt((double)maxv) * p.thr;
         const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
-        const int nsel = peak_select_th<T>(y, cs, ci, sel, N2, K, th, minv, lane);
+        int nsel = 0;
+        if (N2 >= 3) {
+            const int C = peak_scan<T, 0, false>((const T*)y, 0, N2, N2, minv, th, (T*)nullptr, ci, lane);
+            wave_sync();
+            nsel = peak_pick<T, 0, false, true>((const T*)y, (T*)nullptr, ci, sel, N2, K, C, th, lane, minv);
+        }
         int nk = 0;
         for (int e0 = 0; e0 < nsel; e0 += 64) {
             const int e = e0 + lane;

@@ -102,8 +102,12 @@ template <> struct Key<double> {
 //   NIT > 0: nscan == 64*NIT is known at compile time (fused kernels): the scan is unrolled and split
 //   into a read phase (all LDS loads in flight at once) and a compaction phase, one LDS round trip
 //   instead of one per 64 bins.
-template <typename T, int NIT = 0>
-__device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n, T miny, double th, T* cs, int* ci, int lane) {
+//   Y: the row -- a pointer, or any object whose operator[](bin) returns the value the search runs on; CI: the type of
+//   the list's bin entries (unsigned short halves the list); CS = false: no score list is kept (cs unused), the scores
+//   are re-derived from the row where they are needed -- together they cut a wave's LDS from 14 to 10 bytes per bin,
+//   which is what decides how many waves of k_phase_peaks a CU holds at nfft 4096 and up.
+template <typename T, int NIT = 0, bool CS = true, typename Y, typename CI>
+__device__ __forceinline__ int peak_scan(Y y, int kbase, int nscan, int n, T miny, double th, T* cs, CI* ci, int lane) {
     int C = 0;
     if constexpr (NIT > 0) {
         const float thf = __double2float_rd(th);
@@ -135,7 +139,7 @@ __device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n
         for (int i = 0; i < NIT; i++) {
             const unsigned long long bal = bals[i];
             if (bal != 0ull) {                                       // wave-uniform
-                if ((bal >> lane) & 1ull) { const int pos = C + lane_prefix(bal); cs[pos] = sv[i]; ci[pos] = kbase + i * 64 + lane; }
+                if ((bal >> lane) & 1ull) { const int pos = C + lane_prefix(bal); if constexpr (CS) cs[pos] = sv[i]; ci[pos] = (CI)(kbase + i * 64 + lane); }
                 C += __popcll(bal);
             }
         }
@@ -150,7 +154,7 @@ __device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n
                 cand = (a < b) && (b >= c) && ((double)s > th);
             }
             const unsigned long long bal = __ballot(cand);
-            if (cand) { const int pos = C + lane_prefix(bal); cs[pos] = s; ci[pos] = k; }
+            if (cand) { const int pos = C + lane_prefix(bal); if constexpr (CS) cs[pos] = s; ci[pos] = (CI)k; }
             C += __popcll(bal);
         }
     }
@@ -162,13 +166,18 @@ __device__ __forceinline__ int peak_scan(const T* y, int kbase, int nscan, int n
 // scalar popcounts -- and the loop stops as soon as exactly npeaks keys are at or above the prefix.  The list-resident
 // loop below (one bit per round, the entries beyond the first 128 re-read from LDS every round) is what remains for
 // longer lists; on a recording (80-300 candidates per frame at nfft 2048) it was most of a float64 frame's time.
-template <typename T, int NCH>
-__device__ __forceinline__ int peak_radix_list(const T* cs, const int* ci, int* out, int npeaks, int C, int lane) {
+template <typename T, int NCH, bool CS = true, typename Y, typename CI>
+__device__ __forceinline__ int peak_radix_list(Y y, const T* cs, const CI* ci, int* out, int npeaks, int C, int lane, T miny) {
     using K = Key<T>;
     using KT = typename K::type;
     KT key[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; j++) { const int c = lane + 64 * j; key[j] = (c < C) ? K::of(cs[c < C ? c : 0]) : (KT)0; }
+    for (int j = 0; j < NCH; j++) {
+        const int c = lane + 64 * j;
+        T sc;
+        if constexpr (CS) sc = cs[c < C ? c : 0]; else sc = (T)(y[(int)ci[c < C ? c : 0]] - miny);
+        key[j] = (c < C) ? K::of(sc) : (KT)0;
+    }
     KT prefix = 0;
     for (int bit = K::TOP; bit >= 0; bit -= 2) {                    // TOP is even: rounds take bits (bit, bit - 1); the last one bit 0 alone
         const int lo = bit >= 1 ? bit - 1 : 0;
@@ -205,7 +214,7 @@ __device__ __forceinline__ int peak_radix_list(const T* cs, const int* ci, int* 
         const unsigned long long bt = __ballot(tie);
         const bool take = gt || (tie && (tc + lane_prefix(bt)) < npeaks - ngt);
         const unsigned long long bk = __ballot(take);
-        if (take) out[cnt + lane_prefix(bk)] = ci[c];
+        if (take) out[cnt + lane_prefix(bk)] = (int)ci[c];
         tc += __popcll(bt);
         cnt += __popcll(bk);
     }
@@ -219,8 +228,10 @@ __device__ __forceinline__ int peak_radix_list(const T* cs, const int* ci, int* 
 // the per-lane block reads of peak_scan_block below are bank-conflict free.
 template <int YP> __device__ __forceinline__ int ymap(int k) { return YP ? k + ((k >> 6) << 2) : k; }
 
-template <typename T, int YP = 0>
-__device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, int n, int npeaks, int C, double th, int lane) {
+//   BIG: also instantiate the register-resident select for lists of up to 2048 entries (rows of nfft >= 4096)
+template <typename T, int YP = 0, bool CS = true, bool BIG = false, typename Y, typename CI>
+__device__ __forceinline__ int peak_pick(Y y, T* cs, CI* ci, int* out, int n, int npeaks, int C, double th, int lane, T miny = (T)0) {
+    auto score = [&](int c) -> T { if constexpr (CS) return cs[c]; else return (T)(y[ymap<YP>((int)ci[c])] - miny); };
     if (C <= npeaks) {
         if (th < 0.0 && C < npeaks) {
             // zeros of pkmskamp are above the (negative) threshold: all maxima, then the first
@@ -245,7 +256,7 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
             wave_sync();
             return cnt;
         }
-        for (int c = lane; c < C; c += 64) out[c] = ci[c];
+        for (int c = lane; c < C; c += 64) out[c] = (int)ci[c];
         wave_sync();
         return C;
     }
@@ -253,8 +264,8 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
         // ---- a few more candidates than wanted (the usual case): every lane owns one candidate and
         // counts the candidates that beat it, broadcast one by one with readlane (no LDS round trip).
         // "beats" = larger score, or equal score and lower bin (np.argmax takes the first maximum).
-        const T mys = (lane < C) ? cs[lane] : (T)0;
-        const int myi = (lane < C) ? ci[lane] : 0;
+        const T mys = (lane < C) ? score(lane) : (T)0;
+        const int myi = (lane < C) ? (int)ci[lane] : 0;
         int rank = 0;
         for (int j = 0; j < C; ++j) {
             T sj;
@@ -269,20 +280,25 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
     }
     // ---- C > 64: exact radix select of the npeaks-th largest score (bits of a non-negative
     // float order like unsigned integers).  Ballot + popcount only.
-    if (C <= 128) return peak_radix_list<T, 2>(cs, ci, out, npeaks, C, lane);
-    if (C <= 192) return peak_radix_list<T, 3>(cs, ci, out, npeaks, C, lane);
-    if (C <= 320) return peak_radix_list<T, 5>(cs, ci, out, npeaks, C, lane);
-    if (C <= 512) return peak_radix_list<T, 8>(cs, ci, out, npeaks, C, lane);
+    if (C <= 128) return peak_radix_list<T, 2, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+    if (C <= 192) return peak_radix_list<T, 3, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+    if (C <= 320) return peak_radix_list<T, 5, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+    if (C <= 512) return peak_radix_list<T, 8, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+    if constexpr (BIG) {
+        if (C <= 768) return peak_radix_list<T, 12, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+        if (C <= 1280) return peak_radix_list<T, 20, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+        if (C <= 2048) return peak_radix_list<T, 32, CS>(y, cs, ci, out, npeaks, C, lane, miny);
+    }
     using K = Key<T>;
     using KT = typename K::type;
-    const KT k0r = (lane < C) ? K::of(cs[lane]) : (KT)0;            // first two per lane live in registers
-    const KT k1r = (lane + 64 < C) ? K::of(cs[lane + 64]) : (KT)0;
+    const KT k0r = (lane < C) ? K::of(score(lane)) : (KT)0;            // first two per lane live in registers
+    const KT k1r = (lane + 64 < C) ? K::of(score(lane + 64)) : (KT)0;
     KT prefix = 0;
     for (int bit = K::TOP; bit >= 0; --bit) {
         const KT trial = prefix | ((KT)1 << bit);
         int cnt = __popcll(__ballot(k0r >= trial)) + __popcll(__ballot(k1r >= trial));
         for (int c = lane + 128; c - lane < C; c += 64) {           // wave-uniform trip count
-            const bool p = (c < C) && (K::of(cs[c]) >= trial);
+            const bool p = (c < C) && (K::of(score(c < C ? c : 0)) >= trial);
             cnt += __popcll(__ballot(p));
         }
         if (cnt >= npeaks) {
@@ -292,17 +308,17 @@ __device__ __forceinline__ int peak_pick(const T* y, T* cs, int* ci, int* out, i
     }
     // prefix = key of the npeaks-th best; strictly greater ones all go, ties in index order
     int ngt = __popcll(__ballot(k0r > prefix)) + __popcll(__ballot(k1r > prefix));
-    for (int c = lane + 128; c - lane < C; c += 64) ngt += __popcll(__ballot((c < C) && (K::of(cs[c]) > prefix)));
+    for (int c = lane + 128; c - lane < C; c += 64) ngt += __popcll(__ballot((c < C) && (K::of(score(c < C ? c : 0)) > prefix)));
     const int need = npeaks - ngt;
     int tc = 0, cnt = 0;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + lane;
-        const KT key = (c < C) ? K::of(cs[c]) : (KT)0;
+        const KT key = (c < C) ? K::of(score(c < C ? c : 0)) : (KT)0;
         const bool tie = (c < C) && (key == prefix);
         const unsigned long long bt = __ballot(tie);
         const bool take = (c < C) && ((key > prefix) || (tie && (tc + lane_prefix(bt)) < need));
         const unsigned long long bk = __ballot(take);
-        if (take) out[cnt + lane_prefix(bk)] = ci[c];
+        if (take) out[cnt + lane_prefix(bk)] = (int)ci[c];
         tc += __popcll(bt);
         cnt += __popcll(bk);
     }
@@ -581,7 +597,7 @@ __device__ __forceinline__ int peak_select_block(const float* y, CI* ci, int tra
 
 // filter_by_salience(rad), sal = 0 (PF.py:126-134): keep unless any y in
 // [max(p-rad,1), min(p+rad,n)] (clipped to the array) exceeds y[p]
-template <typename T, int YP = 0> __device__ __forceinline__ bool salient(const T* y, int n, int p, int rad) {
+template <typename T, int YP = 0, typename Y> __device__ __forceinline__ bool salient(Y y, int n, int p, int rad) {
     if (rad < 0) return true;
     const T v = y[ymap<YP>(p)];
     const int lo = p - rad > 1 ? p - rad : 1;
