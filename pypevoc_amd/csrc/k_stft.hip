@@ -17,6 +17,8 @@
 // tables shared by the workgroup, which keeps the kernel under 256 registers: 6 waves per CU.
 // Rows are dealt to waves round-robin (consecutive waves = consecutive frames: their 75 % input overlap is served
 // by L1/L2); the samples of a wave's next row are prefetched in four groups spread over the transform.
+#include <type_traits>
+
 #include "pvx_stft.h"
 
 using namespace pvxw;
@@ -167,23 +169,34 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
 
 // ---- nfft = 128 R S: the M = 64 R S point transform as S interleaved M1 = 64 R point ones (decimation in time) ------
 // nfft 4096 (R = 16, S = 2) does not fit one wave's registers as a single R x R x P factorisation (R = 32 is 64
-// complex values per lane before any temporary).  Sub-transform s takes z[S j + s], j < M1, through exactly the
-// stages of k_stft above and leaves its natural-order result in its own LDS region; one in-place radix-S pass with
-// the twiddles W_M^(s k1) joins them (Z[k1 + M1 q] = sum_s W_S^(s q) W_M^(s k1) Z_s[k1]); the untangle reads the
-// joined buffer.  Window, join and untangle twiddles come from global memory (L2-resident tables; an LDS copy of a
-// float64 window of 4096 would cost a wave's buffer), the sub-transform tables stay in LDS.
+// complex values per lane before any temporary).  A TEAM of S waves takes a frame: wave s runs sub-sequence z[S j + s],
+// j < M1, through exactly the stages of k_stft above and leaves its natural-order result in its own LDS region; after a
+// barrier one in-place radix-S pass with the twiddles W_M^(s k1) joins them (Z[k1 + M1 q] = sum_s W_S^(s q) W_M^(s k1)
+// Z_s[k1]; every wave a quarter or half of the k1), and after another each wave untangles its share of the bin pairs
+// straight to global memory.  nfft 4096: a workgroup of three teams (6 waves per CU, window table in LDS); nfft 8192: one
+// team (4 waves per CU).  One wave per frame with all S regions to itself held 4 / 2 waves per CU.  Window, join and untangle twiddles come
+// from global memory (L2-resident tables), the sub-transform tables stay in LDS.
 template <int R, int S, typename T> struct SplitGeo {
     using G1 = StftGeo<R, T>;
     static constexpr int M1 = G1::M, M = M1 * S, N = 2 * M, LOGM1 = ilog2(M1);
     static constexpr int BUFC = G1::BUFC;                                                    // one region (complex)
-    static constexpr size_t OFF_T1 = 0;                                                      // cx [R][64]  W_M1^(l q)
+    // S = 2: three teams (6 waves, 256 registers each) with the window in LDS; S = 4: one team (4 waves, up to 512
+    // registers each: the window values of the next row are prefetched with its samples)
+    static constexpr bool WL = (S == 2);
+    static constexpr int TEAMS = WL ? 3 : 1;
+    static constexpr size_t OFF_WIN = 0;                                                     // T [N]  window / wfact (WL)
+    static constexpr size_t OFF_T1 = OFF_WIN + (WL ? (size_t)N * sizeof(T) : 0);             // cx [R][64]  W_M1^(l q)
     static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 2 * sizeof(T);                // cx [R][P]   W_64^(l1 t2)
-    static constexpr size_t OFF_BUF = OFF_T2 + 64 * 2 * sizeof(T);                           // cx [NW][S][BUFC]
-    __host__ __device__ static size_t total(int nw) { return OFF_BUF + (size_t)nw * S * BUFC * 2 * sizeof(T); }
+    static constexpr size_t OFF_BUF = OFF_T2 + 64 * 2 * sizeof(T);                           // cx [teams][S][BUFC]
+    __host__ __device__ static size_t total(int teams) { return OFF_BUF + (size_t)teams * S * BUFC * 2 * sizeof(T); }
 };
 
+// workgroup barrier for LDS hand-offs: LDS traffic drained, then s_barrier -- not __syncthreads(), which would also
+// wait for the prefetched samples of the next row
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int R, int S, typename T, typename InT>
-__global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
+__global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p) {
     using G = SplitGeo<R, S, T>;
     using G1 = StftGeo<R, T>;
     constexpr int M1 = G::M1, M = G::M, P = G1::P, PITCH = G1::PITCH;
@@ -192,12 +205,16 @@ __global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nw = blockDim.x >> 6;
+    const int teams = (int)(blockDim.x >> 6) / S;                     // frames a workgroup has in flight
+    const int team = wid / S, sub = wid - team * S;                   // this wave: sub-sequence `sub` of its team's frame
     cx<T>* const t1L = (cx<T>*)(smem + G::OFF_T1);
     cx<T>* const t2L = (cx<T>*)(smem + G::OFF_T2);
-    cx<T>* const buf = (cx<T>*)(smem + G::OFF_BUF) + (size_t)wid * S * G::BUFC;
+    cx<T>* const buf = (cx<T>*)(smem + G::OFF_BUF) + (size_t)team * S * G::BUFC;     // the team's S regions
+    cx<T>* const dz = buf + (size_t)sub * G::BUFC;                                    // this wave's region
     const cx<T>* const tab = (const cx<T>*)p.twiddle;                 // W_N^j
     const T* const winG = (const T*)p.win;
+    T* const winL = (T*)(smem + G::OFF_WIN);
+    if constexpr (G::WL) for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = winG[i];
     for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * S * (i & 63) * (i >> 6)) & NMASK];          // W_M1^(l q)
     for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];           // [t2][l1]
     __syncthreads();
@@ -216,8 +233,10 @@ __global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
 #pragma unroll
     for (int b = 0; b < G1::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G1::LOGP - 1 - b);
 
-    const int64_t W = (int64_t)gridDim.x * nw;
-    const int64_t w = (int64_t)blockIdx.x * nw + wid;
+    // rows are dealt round-robin to the teams of the grid; every wave of a workgroup makes the same number of trips (the
+    // barriers below are workgroup barriers), a team without a row on its last trip just keeps step
+    const int64_t TT = (int64_t)gridDim.x * teams;
+    const int64_t t0 = (int64_t)blockIdx.x * teams + team;
     const int64_t rows1 = p.F + 1;
     auto row_src = [&](int64_t j) -> const InT* {                     // samples of workspace row j; nullptr: zero row
         if (j >= p.ws_rows) return nullptr;
@@ -227,59 +246,60 @@ __global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
         if (q == 0) return nullptr;
         return (const InT*)p.x + b * p.sig_stride + (q - 1) * (int64_t)p.hop;
     };
-    // samples and window values of the next sub-transform: element j = l + 64 r of sub-sequence s is the sample pair
-    // at 2 (S j + s) = 2 S l + 128 S r + 2 s
-    T raw[2 * R], wn[2 * R];
-    auto prefetch_part = [&](const InT* src, int sub, int part) {
+    // samples and window values of this wave's sub-sequence of the next row: element j = l + 64 r is the sample pair at
+    // 2 (S j + sub) = 2 S l + 128 S r + 2 sub
+    using RawT = typename std::conditional<(sizeof(T) == 8 && sizeof(InT) == 8), double, float>::type;   // (see k_stft_pv.hip)
+    RawT raw[2 * R];
+    T wn[G::WL ? 2 : 2 * R];
+    auto prefetch_part = [&](const InT* src, int part) {
         if (src == nullptr) return;
         constexpr int PR = R / 4;
 #pragma unroll
         for (int r = part * PR; r < (part + 1) * PR; r++) {
             const int o = 2 * S * lane + 128 * S * r + 2 * sub;
-            raw[2 * r] = (T)src[o]; raw[2 * r + 1] = (T)src[o + 1];
-            wn[2 * r] = winG[o]; wn[2 * r + 1] = winG[o + 1];
+            raw[2 * r] = (RawT)src[o]; raw[2 * r + 1] = (RawT)src[o + 1];
+            if constexpr (!G::WL) { wn[2 * r] = winG[o]; wn[2 * r + 1] = winG[o + 1]; }
         }
     };
     {
-        const InT* s0 = row_src(w);
-        prefetch_part(s0, 0, 0); prefetch_part(s0, 0, 1); prefetch_part(s0, 0, 2); prefetch_part(s0, 0, 3);
+        const InT* s0 = row_src(t0);
+        prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3);
     }
-    for (int64_t j = w; j < p.ws_rows; j += W) {
-        cx<T>* out = (cx<T>*)p.spec + (size_t)j * p.ldo;
-        const InT* src = row_src(j);
-        const InT* nrow = row_src(j + W);
-        if (src == nullptr) {
-            // (nothing of this row was prefetched)
-            prefetch_part(nrow, 0, 0); prefetch_part(nrow, 0, 1); prefetch_part(nrow, 0, 2); prefetch_part(nrow, 0, 3);
-            for (int k = lane; k < M; k += 64) out[k] = mkc<T>((T)0, (T)0);
-            continue;
-        }
-#pragma unroll 1
-        for (int sub = 0; sub < S; sub++) {
-            cx<T>* dz = buf + (size_t)sub * G::BUFC;
-            const InT* nsrc = (sub + 1 < S) ? src : nrow;             // the next sub-transform's samples
-            const int nsub = (sub + 1 < S) ? sub + 1 : 0;
+    const int64_t trips = (p.ws_rows - (int64_t)blockIdx.x * teams + TT - 1) / TT;      // of the workgroup's first team: the most
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t j = t0 + it * TT;
+        const bool have = j < p.ws_rows;
+        cx<T>* out = (cx<T>*)p.spec + (size_t)(have ? j : 0) * p.ldo;
+        const InT* src = have ? row_src(j) : nullptr;
+        const InT* nrow = row_src(j + TT);
+        const bool real = src != nullptr;
+        if (real) {
             cx<T> z[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                z[r] = mkc<T>(raw[2 * r] * wn[2 * r], raw[2 * r + 1] * wn[2 * r + 1]);
+                if constexpr (G::WL) {
+                    const int o = 2 * S * lane + 128 * S * r + 2 * sub;
+                    z[r] = mkc<T>((T)raw[2 * r] * winL[o], (T)raw[2 * r + 1] * winL[o + 1]);
+                } else {
+                    z[r] = mkc<T>((T)raw[2 * r] * wn[2 * r], (T)raw[2 * r + 1] * wn[2 * r + 1]);
+                }
                 asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));       // the multiplies stay above the next loads
             }
             __builtin_amdgcn_sched_barrier(0);
-            prefetch_part(nsrc, nsub, 0);
+            prefetch_part(nrow, 0);
             dftT<R, T>(z);                                            // stage 1
             __builtin_amdgcn_sched_barrier(0);
-            prefetch_part(nsrc, nsub, 1);
+            prefetch_part(nrow, 1);
 #pragma unroll
             for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
             wave_sync();
 #pragma unroll
             for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
-            prefetch_part(nsrc, nsub, 2);
+            prefetch_part(nrow, 2);
             wave_sync();
             dftT<R, T>(z);                                            // stage 2
             __builtin_amdgcn_sched_barrier(0);
-            prefetch_part(nsrc, nsub, 3);
+            prefetch_part(nrow, 3);
 #pragma unroll
             for (int t = 0; t < R; t++) {
                 cx<T> a = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
@@ -291,36 +311,45 @@ __global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
                 }
                 dz[zpadT<R, T>(Q + R * t + G1::R2 * t1v)] = a;       // Z_sub[k1], natural order
             }
-            wave_sync();
+        } else {
+            // a zero row (or no row on this trip): nothing of it was prefetched
+            prefetch_part(nrow, 0); prefetch_part(nrow, 1); prefetch_part(nrow, 2); prefetch_part(nrow, 3);
         }
-        // ---- join, in place: slots k1 of the S regions hold Z_s[k1] and become Z[k1 + M1 q]
+        lds_barrier();                                                // the team's S sub-transforms are in their regions
+        if (real) {
+            // ---- join, in place: slots k1 of the S regions hold Z_s[k1] and become Z[k1 + M1 q]; this wave's share of k1
+            constexpr int JW = R / S;
 #pragma unroll 4
-        for (int jj = 0; jj < R; jj++) {
-            const int k1 = lane + 64 * jj;
-            const int idx = zpadT<R, T>(k1);
-            cx<T> a[S];
+            for (int jj = sub * JW; jj < (sub + 1) * JW; jj++) {
+                const int k1 = lane + 64 * jj;
+                const int idx = zpadT<R, T>(k1);
+                cx<T> a[S];
 #pragma unroll
-            for (int sub = 0; sub < S; sub++) a[sub] = buf[(size_t)sub * G::BUFC + idx];
+                for (int s2 = 0; s2 < S; s2++) a[s2] = buf[(size_t)s2 * G::BUFC + idx];
 #pragma unroll
-            for (int sub = 1; sub < S; sub++) a[sub] = cmulT(a[sub], tab[(2 * sub * k1) & NMASK]);        // W_M^(s k1)
-            if constexpr (S == 2) {
-                buf[idx] = a[0] + a[1];
-                buf[(size_t)G::BUFC + idx] = a[0] - a[1];
-            } else {
-                const cx<T> A = a[0] + a[2], B = a[0] - a[2], C = a[1] + a[3], D = a[1] - a[3];
-                buf[idx] = A + C;
-                buf[(size_t)G::BUFC + idx] = addmni(B, D);            // W_4^q: 1, -i, -1, i
-                buf[(size_t)2 * G::BUFC + idx] = A - C;
-                buf[(size_t)3 * G::BUFC + idx] = addpi(B, D);
+                for (int s2 = 1; s2 < S; s2++) a[s2] = cmulT(a[s2], tab[(2 * s2 * k1) & NMASK]);          // W_M^(s k1)
+                if constexpr (S == 2) {
+                    buf[idx] = a[0] + a[1];
+                    buf[(size_t)G::BUFC + idx] = a[0] - a[1];
+                } else {
+                    const cx<T> A = a[0] + a[2], B = a[0] - a[2], C = a[1] + a[3], D = a[1] - a[3];
+                    buf[idx] = A + C;
+                    buf[(size_t)G::BUFC + idx] = addmni(B, D);        // W_4^q: 1, -i, -1, i
+                    buf[(size_t)2 * G::BUFC + idx] = A - C;
+                    buf[(size_t)3 * G::BUFC + idx] = addpi(B, D);
+                }
             }
         }
-        wave_sync();
-        // ---- untangle straight to global memory: pairs (k, M-k), k = lane + 64 j2 (see k_stft)
-        auto zat = [&](int k) -> cx<T> { return buf[(size_t)(k >> G::LOGM1) * G::BUFC + zpadT<R, T>(k & (M1 - 1))]; };
-        const cx<T> zc = zat(M / 2);
-        constexpr int NPAIR = R / 2;
-#pragma unroll 1
-        for (int ch = 0; ch < S; ch++) {
+        lds_barrier();                                                // Z is complete
+        if (have && !real) {
+            // the zero frame in front of every signal (PV.py:121): this wave's share of a row of zeros
+            for (int k = lane + 64 * sub; k < M; k += 64 * S) out[k] = mkc<T>((T)0, (T)0);
+        } else if (real) {
+            // ---- untangle straight to global memory: this wave's chunk of the pairs (k, M-k), k = lane + 64 j2 (see k_stft)
+            auto zat = [&](int k) -> cx<T> { return buf[(size_t)(k >> G::LOGM1) * G::BUFC + zpadT<R, T>(k & (M1 - 1))]; };
+            const cx<T> zc = zat(M / 2);
+            constexpr int NPAIR = R / 2;
+            const int ch = sub;
             cx<T> za[NPAIR], zb[NPAIR], tw[NPAIR];
 #pragma unroll
             for (int j2 = 0; j2 < NPAIR; j2++) {
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(256) void k_stft_split(StftParams p) {
                 out[kk] = x1;
             }
         }
-        wave_sync();                                                  // the regions are free again
+        lds_barrier();                                                // the regions are free again
     }
 }
 
@@ -356,9 +385,9 @@ template <int R, int S, typename T> int launch_stft_split(const StftParams& p, i
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
-    int nw = 4;
-    while (nw > 1 && G::total(nw) > 160 * 1024) nw--;
-    const size_t lds = G::total(nw);
+    int teams = G::TEAMS;
+    while (teams > 1 && G::total(teams) > 160 * 1024) teams--;
+    const size_t lds = G::total(teams);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d needs %zu bytes of LDS in the split STFT kernel", G::N, lds); return PVX_ERR_UNSUPPORTED; }
     const void* fn = nullptr;
     switch (x_dtype) {
@@ -370,17 +399,14 @@ template <int R, int S, typename T> int launch_stft_split(const StftParams& p, i
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    if (per_cu * nw > 8) per_cu = 8 / nw > 0 ? 8 / nw : 1;
+    if (per_cu * teams * S > 8) per_cu = 8 / (teams * S) > 0 ? 8 / (teams * S) : 1;
     int64_t nblocks = (int64_t)ncu * per_cu;
-    const int64_t maxb = (p.ws_rows + nw - 1) / nw;
+    const int64_t maxb = (p.ws_rows + teams - 1) / teams;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
-    dim3 grid((unsigned)nblocks), block(64 * nw);
-    switch (x_dtype) {
-        case PVX_F32: hipLaunchKernelGGL((k_stft_split<R, S, T, float>), grid, block, lds, s, p); break;
-        case PVX_F64: hipLaunchKernelGGL((k_stft_split<R, S, T, double>), grid, block, lds, s, p); break;
-        default: hipLaunchKernelGGL((k_stft_split<R, S, T, int16_t>), grid, block, lds, s, p); break;
-    }
-    PVX_HIP_CHECK(hipGetLastError());
+    dim3 grid((unsigned)nblocks), block(64 * teams * S);
+    StftParams arg = p;
+    void* args[] = {&arg};
+    PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     return PVX_OK;
 }
 
