@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=tuple(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f64 / noise / violin lines (N = 1 only anyway)")
-    ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: rocFFT path; 1, 2, 3: fused kernels")
+    ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: general path; 1, 2, 3, 4: fused kernels")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: consecutive steps alternate between two streams (hides the launch gap and the kernel tail; "
                          "per-kernel durations then overlap and no longer compare with rocprofv3's)")
@@ -388,7 +388,7 @@ def main():
         frames_total = FT * world * args.steps
         value = frames_total / elapsed
         # fft mode 0 with a stage-3 span: k_stft_pv.hip (general path, STFT + peaks in one launch, spectrum rows still written)
-        kname = {0: "k_stft_pv", 1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring"}.get(fft_mode, "k_fused_pv")
+        kname = {0: "k_stft_pv", 1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring", 4: "k_fused_rev"}.get(fft_mode, "k_fused_pv")
         # general path: k_stft.hip writes the spectrum rows when it can (no frame buffer, no rocFFT launches)
         names = ["k_stft" if (nl[0] > 0 and nl[1] == 0) else "k_frames", "rocfft_r2c", "k_phase_peaks", kname]
         s_in = 4 if args.precision == 32 else 8
@@ -427,7 +427,7 @@ def main():
                             note="the fused kernels are not HBM-bound: `issue` prices the same launch against vector "
                                  "issue and LDS; throughput_vs_60pct_target = per-GPU frames/s over north_star's "
                                  "1.365e8 frames/s (60 % of 8 TB/s at the 35 168 B/frame of the three-kernel split)")
-            if fft_mode in (1, 2, 3):
+            if fft_mode in (1, 2, 3, 4):
                 roofline["issue"] = issue_bound(dom["kernel"], fpl, dom["ms_per_launch"])
         stage_s = sum(ms[i] for i in range(4)) * 1e-3 / args.steps
         stage = dict(fft_mode=fft_mode, ms_per_step_kernels=round(stage_s * 1e3, 4),

@@ -1,0 +1,523 @@
+// k_fused_rev.hip -- the fused analysis stage (window + FFT + untangle + peaks, one wave64 per frame, the instruction
+// sequence of k_fused.hip / k_fused_ring.hip) with every wave on its own: a wave walks a contiguous range of rows in
+// DESCENDING order over ONE private spectrum buffer.
+//
+//   PV.calc_fft_frame   pypevoc/PVAnalysis.py:150-158
+//   PV.calc_pv_frame    pypevoc/PVAnalysis.py:160-211
+//   PV.run_pv           pypevoc/PVAnalysis.py:213-264
+//
+// A frame's peaks need the PREVIOUS frame's spectrum at the peak bins (PV.py:171, 190).  Walking forwards that means two
+// buffers per wave (k_fused.hip: one wave per SIMD at nfft 2048) or a ring of buffers shared by a workgroup whose waves
+// hand their spectra to each other (k_fused_ring.hip).  Walking backwards it is free: a wave finds the peaks of frame j
+// while X_j is in its buffer and stages bin, X_j[bin] and the 3-bin energy; the transform it runs next leaves X_(j-1) in
+// the same buffer, the staged peaks of frame j pick their previous-spectrum values up there, and every 8 frames all 64
+// lanes do the per-peak arithmetic.  So: one 8.7 KB buffer per wave, two waves per SIMD at nfft 2048, no hand-off
+// between waves, no flags, no waiting for a neighbour that met a dense frame -- and since a wave's next frame now
+// overlaps its current one, its samples are the ones the lane already holds moved up by hop/128 register pairs: 4
+// loads per frame instead of 16 at hop = nfft/4 (H > 0 instantiations; any other hop loads the whole window).
+// Per-frame arithmetic is k_fused.hip's, so results are bit-identical to it and independent of the launch geometry.
+#include <stdlib.h>
+
+#include "pvx_fft.h"
+
+using namespace pvxw;
+using namespace pvxf;
+
+namespace {
+
+constexpr int GFR = 8;              // frames staged before the per-peak pass
+
+typedef unsigned short u16;
+
+template <int R> struct RevGeo {
+    using G = Geo<R>;
+    static constexpr int TW3N = (G::HALF + 8) & ~7;
+    // block-shared tables (bytes)
+    static constexpr size_t OFF_T1 = 0;                              // v2f [R][64]   W_M^(l q)
+    static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 8;    // v2f [R][P]    W_64^(l1 t2)
+    static constexpr size_t OFF_TW3 = OFF_T2 + 64 * 8;               // v2f [TW3N]    W_nfft^k
+    static constexpr size_t OFF_WAVE = OFF_TW3 + (size_t)TW3N * 8;
+    __host__ __device__ static size_t per_wave(int K) {
+        const size_t kpad = (size_t)((K + 3) & ~3);
+        const size_t gs = (size_t)staged_frames(K, GFR);
+        size_t b = (size_t)G::BUFC * 8                               // the wave's spectrum buffer
+                 + GFR * 8 * 2                                       // orow | tot
+                 + (size_t)(G::M + 4 * R) * 4                        // y (padded, ymap<1>)
+                 + gs * kpad * 5 * 4                                 // sval
+                 + kpad * 4 + gs * kpad * 4                          // sel | sbin
+                 + GFR * 4 * 2                                       // cnt | frm
+                 + (size_t)(G::CAP + 64) * 2;                        // ci (u16) + 64 trash slots
+        return (b + 15) & ~(size_t)15;
+    }
+    __host__ __device__ static size_t total(int K, int nw) { return OFF_WAVE + per_wave(K) * nw; }
+};
+
+template <int R, int NW, typename InT, bool AL2, int H>
+__global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
+    using G = Geo<R>;
+    using RG = RevGeo<R>;
+    constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = p.K;
+    const int kpad = (K + 3) & ~3;
+    const int gs = staged_frames(K, GFR);
+
+    v2f* const t1L = (v2f*)(smem + RG::OFF_T1);
+    v2f* const t2L = (v2f*)(smem + RG::OFF_T2);
+    v2f* const tw3 = (v2f*)(smem + RG::OFF_TW3);
+    // per-wave region: everything whose size is known at compile time first, so that those arrays are one base
+    // register plus immediate offsets (each runtime offset costs a scalar register across the whole frame loop)
+    unsigned char* wb = smem + RG::OFF_WAVE + RG::per_wave(K) * wid;
+    float2* const cur = (float2*)wb;                                // X of the row at hand
+    long long* const Lorow = (long long*)(cur + G::BUFC);
+    double* const Ltot = (double*)(Lorow + GFR);
+    float* const Ly = (float*)(Ltot + GFR);
+    int* const Lcnt = (int*)(Ly + M + 4 * R);
+    int* const Lfrm = Lcnt + GFR;
+    u16* const Lci = (u16*)(Lfrm + GFR);
+    int* const Lsel = (int*)(Lci + G::CAP + 64);
+    int* const Lsbin = Lsel + kpad;
+    float* const Lsval = (float*)(Lsbin + gs * kpad);
+
+    // ---- block-shared tables
+    {
+        const v2f* tab = (const v2f*)p.twiddle;                     // W_nfft^j, j < nfft
+        constexpr int NMASK = G::N - 1;
+        for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+            const int q = i >> 6, l = i & 63;
+            t1L[i] = tab[(2 * l * q) & NMASK];                      // W_M^(l q)
+        }
+        for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
+        for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
+    }
+    __syncthreads();
+
+    // ---- lane constants
+    const int Q = lane / P, L1 = lane % P;
+    float csg[G::LOGP > 0 ? G::LOGP : 1];
+    v2f cw[G::LOGP > 0 ? G::LOGP : 1];
+    {
+        const float2* tab = (const float2*)p.twiddle;
+        constexpr int NMASK = G::N - 1;
+#pragma unroll
+        for (int s = 0; s < G::LOGP; s++) {
+            const int h = P >> (s + 1);
+            const bool up = (L1 & h) != 0;
+            csg[s] = up ? -1.f : 1.f;
+            const float2 wvv = tab[((G::N / (2 * h)) * (L1 % h)) & NMASK];
+            cw[s] = up ? pvxc::mk(wvv.x, wvv.y) : pvxc::mk(1.f, 0.f);
+        }
+    }
+    int t1v = 0;                                                    // bitrev(l1)
+#pragma unroll
+    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
+    // the window stays in registers (there is room below 256): read from LDS it costs 16 reads that all
+    // waves of the workgroup issue at the same moment, right after the barrier
+    v2f wv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[lane + 64 * r];
+#pragma unroll
+    for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
+
+    // ---- rows of this wave: [r0, r1), walked downwards, then row r0 - 1 (spectrum only)
+    // row indices fit 32 bits (the launcher checks): 64-bit scalar arithmetic in the frame loop costs SGPR pairs
+    const int W = (int)gridDim.x * NW, w = (int)blockIdx.x * NW + wid;
+    const int r0 = (int)(p.total_rows * (int64_t)w / W), r1 = (int)(p.total_rows * ((int64_t)w + 1) / W);
+    if (r0 >= r1) return;
+    const int Fi = (int)p.F;
+    const int rows1 = Fi + 1;                                       // rows per signal
+
+    // (see k_fused_ring.hip: the flush-only kernel arguments are re-read from the kernel argument segment)
+    const FusedParams* const kargs = (const FusedParams*)__builtin_amdgcn_kernarg_segment_ptr();
+
+    v2f raw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
+    // samples of global row gn = (bn, qn): nullptr when there is nothing to load
+    auto row_src = [&](int gn, int bn, int qn) -> const InT* {
+        if (gn < r0 - 1 || gn < 0 || qn == 0) return nullptr;
+        return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
+    };
+    auto load_pair = [&](const InT* src, int r) {
+        const InT* q = src + 2 * lane + 128 * r;
+        if constexpr (AL2 && sizeof(InT) == 4) raw[r] = *(const v2f*)q;
+        else raw[r] = pvxc::mk(ld1(q), ld1(q + 1));
+    };
+    auto prefetch_part = [&](const InT* src, int part) {
+        if (src == nullptr) return;
+        constexpr int PR = R / 4;
+#pragma unroll
+        for (int r = part * PR; r < (part + 1) * PR; r++) load_pair(src, r);
+    };
+
+    // spectrum of this wave's row into `cur` (zeros for a zero row) + |X|^2 -> Ly, wave-reduced max/min/energy;
+    // fetches the samples of the row below (nsrc) once the raw samples have been consumed
+    auto spectrum = [&](bool zero_row, const InT* nsrc, float& maxe, float& mine, double& tot) {
+        float2* const dst = cur;
+        v2f z[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            z[r] = raw[r] * wv[r];
+            asm volatile("" : "+v"(z[r]));                          // the multiply stays above the loads
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (H > 0) {
+            // The row below is (almost always) the previous frame of the same signal: the lane's samples move up by H
+            // pairs and the hop's new samples come in below them.  Done on EVERY row, without a branch -- with one, the
+            // compiler parks the loaded pairs in temporaries and copies them into place at the end of the branch, i.e.
+            // waits for HBM right there, once per frame.  When the row below is not such a frame (a zero row, the end of
+            // the wave's range) the loads read the start of the signal and nobody uses them: the next real row
+            // reloads its whole window (`full`, below).
+            const InT* ns = (nsrc != nullptr) ? nsrc : (const InT*)p.x;
+#pragma unroll
+            for (int r = R - 1; r >= H; r--) raw[r] = raw[r - H];
+#pragma unroll
+            for (int r = 0; r < H; r++) load_pair(ns, r);
+            nsrc = nullptr;
+        }
+        prefetch_part(nsrc, 0);
+        if (zero_row) {
+            prefetch_part(nsrc, 1); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3);
+#pragma unroll
+            for (int j = 0; j < G::BUFC / 64; j++) dst[lane + 64 * j] = make_float2(0.f, 0.f);
+            wave_sync();
+            return;
+        }
+        dft_regs<R>(z);                                             // stage 1
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 1);
+        v2f* dz = (v2f*)dst;
+#pragma unroll
+        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? pvxc::cmul(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        wave_sync();
+#pragma unroll
+        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
+        prefetch_part(nsrc, 2);
+        wave_sync();
+        dft_regs<R>(z);                                             // stage 2
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_part(nsrc, 3);
+#pragma unroll
+        for (int t0 = 0; t0 < R; t0 += 4) {
+            v2f a[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2L[(t0 + j) * P + L1]) : z[t0 + j];
+            if constexpr (G::LOGP >= 1) {
+                if constexpr (P >= 16) xstep4<8, true>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
+                if constexpr (P >= 8) xstep4<4, true>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
+                if constexpr (P >= 4) xstep4<2, true>(a, csg[G::LOGP - 2], cw[G::LOGP - 2]);
+                xstep4<1, false>(a, csg[G::LOGP - 1], cw[G::LOGP - 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) dz[zpad<R>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
+        }
+        wave_sync();
+        // ---- untangle in place (k_fused.hip): pairs (k, M-k), k = lane + 64 j
+        constexpr int NPAIR = R / 2;
+        float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
+        v2f za[NPAIR], zb[NPAIR], wv8[NPAIR];
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            const int k = lane + 64 * j;
+            const int km = (M - k) & (M - 1);
+            za[j] = dz[zpad<R>(k)];
+            zb[j] = dz[zpad<R>(km)];
+            wv8[j] = tw3[k];
+        }
+        const v2f zc = dz[zpad<R>(G::HALF)];
+        const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f);
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            const int k = lane + 64 * j;
+            const int km = (M - k) & (M - 1);
+            const v2f S = pvxc::add_conj(za[j], zb[j]);
+            const v2f D = pvxc::sub_conj(za[j], zb[j]);
+            const v2f O = pvxc::mul_swap(D, kmih);
+            const v2f Pk = pvxc::cmul(O, wv8[j]);
+            const v2f x0 = __builtin_elementwise_fma(khalf, S, Pk);
+            v2f x1 = pvxc::fms_conj(khalf, S, Pk);
+            int kk = km;
+            if (j == 0) {
+                if (lane == 0) { x1 = pvxc::mk(zc.x, -zc.y); kk = G::HALF; }
+            }
+            const float e0 = __builtin_fmaf(x0.x, x0.x, x0.y * x0.y), e1 = __builtin_fmaf(x1.x, x1.x, x1.y * x1.y);
+            dz[zpad<R>(k)] = x0;
+            dz[zpad<R>(kk)] = x1;
+            Ly[k + 4 * j] = e0; Ly[ymap<1>(kk)] = e1;
+            lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
+        }
+        const double lsum = (double)ls0 + (double)ls1;
+        maxe = wave_max(lmax);
+        mine = wave_min(lmin);
+        tot = wave_sum(lsum);
+        wave_sync();
+    };
+
+    // per-peak pass over this wave's staged frames [0, ng)
+    int LPF = 1;
+    while (LPF < K && LPF < 64) LPF <<= 1;
+    const int gl = lane / LPF, e0 = lane - gl * LPF;
+    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
+    auto flush = [&](int ng) {
+        wave_sync();
+        const FusedParams* q = kargs;
+        asm volatile("" : "+s"(q));                                  // loads through q stay here
+        PeakConst pc;
+        pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
+        const int g = gl;
+        const bool gvalid = g < ng;
+        const int cnt = gvalid ? Lcnt[g] : -1;
+        const int64_t orow = gvalid ? (int64_t)Lorow[g] : 0;
+        double* of = q->f + orow * K;
+        double* om = q->mag + orow * K;
+        double* op = q->ph + orow * K;
+        double* orp = q->realph + orow * K;
+        double* ob = q->binno + orow * K;
+        int nout = 0;
+        for (int eb = 0; eb < K; eb += LPF) {
+            const int e = eb + e0;
+            bool valid = (cnt >= 0) && (e < cnt);
+            int nbin = 0;
+            PeakOut o;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            if (valid) {
+                nbin = Lsbin[g * kpad + e];
+                const float* sv = Lsval + (size_t)(g * kpad + e) * 5;
+                o = peak_math<float>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                valid = o.valid;
+            }
+            const unsigned long long bal = __ballot(valid) & gmask;
+            if (valid) {
+                const int oi = nout + __popcll(bal & ((1ull << lane) - 1ull));
+                ob[oi] = (double)nbin;
+                of[oi] = o.freq;
+                om[oi] = o.mag;
+                op[oi] = o.thisph;
+                orp[oi] = o.thisph + kPi * o.dfb / pc.fstep;          // PV.py:207
+            }
+            nout += __popcll(bal);
+        }
+        if (cnt >= 0) {
+            for (int j = nout + e0; j < K; j += LPF) {                // zero padding, PV.py:226-239
+                ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
+            }
+            if (e0 == 0) {
+                const int64_t fr = Lfrm[g];
+                if (q->totalmag) q->totalmag[orow] = sqrt(Ltot[g]);                                   // PV.py:210
+                if (q->t) q->t[orow] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;         // PV.py:247
+            }
+        }
+        wave_sync();
+    };
+
+    // waves of a CU start their frame loops an eighth of a frame apart (p.stagger x 64 cycles per wave): left alone they
+    // run in lock step -- every wave in the LDS exchange, then every wave in the register stages
+    for (int i = 0; i < wid * p.stagger; i++) __builtin_amdgcn_s_sleep(1);
+    // ---- (signal b, row-in-signal q) of this wave's first row g = r1 - 1; rows go down by one
+    int g = r1 - 1, gb = g / rows1, gq = g - gb * rows1;            // the only division
+    { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
+    int ng = 0;
+    bool pend = false, pend_prev0 = false, pend_own = false;        // the frame staged last still waits for its previous spectrum
+    int pend_nk = 0, own_sl = -1, own_pb = 1;
+    bool prev_zero = false;                                         // (H > 0) the row above was a zero row
+    for (; g >= r0 - 1; --g) {
+        int bn = gb, qn = gq - 1;                                   // (b, q) of row g - 1
+        if (qn < 0) { qn = Fi; bn -= 1; }
+        const bool zero_row = (g < 0) || (gq == 0);
+        if constexpr (H > 0) {
+            // the first frame below a zero row: its window did not slide in
+            if (!zero_row && prev_zero) { const InT* s1 = row_src(g, gb, gq); prefetch_part(s1, 0); prefetch_part(s1, 1); prefetch_part(s1, 2); prefetch_part(s1, 3); }
+            prev_zero = zero_row;
+        }
+        float maxe = 0.f, mine = 0.f;
+        double tot = 0.0;
+        spectrum(zero_row, row_src(g - 1, bn, qn), maxe, mine, tot);
+        if (pend) {
+            // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
+            if (pend_own && !pend_prev0) {
+                // (the usual case: the lane that staged a peak kept its slot and bin -- one LDS round trip)
+                if (own_sl >= 0) {
+                    const float2 pv = cur[zpad<R>(own_pb)];
+                    Lsval[(size_t)own_sl * 5 + 2] = pv.x;
+                    Lsval[(size_t)own_sl * 5 + 3] = pv.y;
+                }
+            } else
+            for (int e = lane; e < pend_nk; e += 64) {
+                const int sl = (ng - 1) * kpad + e;
+                const int nbin = Lsbin[sl];
+                float2 pv;
+                if (pend_prev0) pv = make_float2((float)p.prev0[2 * nbin], (float)p.prev0[2 * nbin + 1]);
+                else pv = cur[zpad<R>(nbin)];
+                Lsval[(size_t)sl * 5 + 2] = pv.x;
+                Lsval[(size_t)sl * 5 + 3] = pv.y;
+            }
+            pend = false;
+            if (ng == gs) { flush(ng); ng = 0; }
+        }
+        if (!zero_row && g >= r0) {
+            bool own = false;                                       // every kept peak is remembered by the lane that staged it
+            own_sl = -1;
+            const int64_t orow = (int64_t)gb * Fi + (gq - 1);
+            // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
+            const float maxy = __builtin_amdgcn_sqrtf(maxe);
+            const double minamp = (double)maxy * p.thr;             // PF.py:60
+            const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
+            int nk = 0;
+            // candidate list (ascending bins) -> Lci
+            const int C = peak_scan_block<R, u16>(Ly, mine, th, Lci, G::CAP, lane);
+            wave_sync();
+            if (C <= 64 && p.rad <= 5 && !(th < 0.0 && C < K)) {
+                // ---- at most one candidate per lane (every frame of music): lane c owns candidate c and fetches
+                // in ONE LDS round trip all that the rest of the frame needs of it -- its score, the 2*rad
+                // neighbours of the salience test (PF.py:126-134; indices clamped into the window like `salient`),
+                // the spectrum around it and the previous spectrum at it -- instead of one round trip each for
+                // ranking, the selected-bin list, the salience test and the staging.  Same selection as
+                // peak_pick_regs: rank by (score desc, bin asc), the npeaks best; then the salience filter.
+                const bool has = lane < C;
+                const int pb = has ? (int)Lci[lane] : 1;
+                const int rad = p.rad;
+                const int lo = pb - rad > 1 ? pb - rad : 1;
+                int hi = pb + rad < M ? pb + rad : M;
+                hi = hi > M - 1 ? M - 1 : hi;
+                const float v = Ly[ymap<1>(pb)];
+                float nb[10];
+#pragma unroll
+                for (int d = 1; d <= 5; d++) {
+                    const int dd = d > rad ? rad : d;
+                    int j0 = pb - dd, j1 = pb + dd;
+                    j0 = j0 < lo ? lo : j0;
+                    j1 = j1 > hi ? hi : j1;
+                    nb[2 * d - 2] = Ly[ymap<1>(j0)];
+                    nb[2 * d - 1] = Ly[ymap<1>(j1)];
+                }
+                const float2 c = cur[zpad<R>(pb)];
+                const float2 vm = cur[zpad<R>(pb - 1)], vp = cur[zpad<R>(pb + 1)];
+                int bad = 0;
+#pragma unroll
+                for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
+                bool take = has;
+                if (C > K) {
+                    const unsigned mykey = has ? __float_as_uint(v - mine) : 0u;     // scores >= 0: bits order like values
+                    int rank = 0;
+                    for (int j = 0; j < C; ++j) {
+                        const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mykey, j);
+                        rank += (kj > mykey || (kj == mykey && j < lane)) ? 1 : 0;
+                    }
+                    take = has && (rank < K);
+                }
+                const bool keep = take && (rad < 0 || bad == 0);
+                const unsigned long long bal = __ballot(keep);
+                if (keep) {
+                    const int sl = ng * kpad + lane_prefix(bal);
+                    // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
+                    const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
+                    const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
+                    Lsbin[sl] = pb;
+                    float* sv = Lsval + (size_t)sl * 5;
+                    sv[0] = c.x; sv[1] = c.y; sv[4] = s3;                  // sv[2], sv[3]: the previous spectrum, one row later
+                    own_sl = sl; own_pb = pb;
+                }
+                own = true;
+                nk = __popcll(bal);
+            } else {
+            // radix select inlined: the call of the out-of-line version saves / restores ~100 scalar registers per frame
+            const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, C, th, mine, lane);
+            for (int eb = 0; eb < nsel; eb += 64) {
+                const int e = eb + lane;
+                int pb = 0;
+                if (e < nsel) pb = Lsel[e];
+                const bool keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, eb, nsel, p.rad, lane)
+                                               : ((e < nsel) && salient<float, 1>(Ly, M, pb, p.rad));
+                const unsigned long long bal = __ballot(keep);
+                if (keep) {
+                    const int sl = ng * kpad + nk + lane_prefix(bal);
+                    const float2 c = cur[zpad<R>(pb)];
+                    // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
+                    const float2 vm = cur[zpad<R>(pb - 1)], vp = cur[zpad<R>(pb + 1)];
+                    const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
+                    const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
+                    Lsbin[sl] = pb;
+                    float* sv = Lsval + (size_t)sl * 5;
+                    sv[0] = c.x; sv[1] = c.y; sv[4] = s3;
+                }
+                nk += __popcll(bal);
+            }
+            }
+            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = orow; Ltot[ng] = tot; }
+            ng++;
+            pend = true; pend_nk = nk; pend_prev0 = (p.prev0 != nullptr) && (orow == 0); pend_own = own;
+        }
+        if (p.spec_out != nullptr && g == p.spec_row) {
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const float2 v = cur[zpad<R>(lane + 64 * j)];
+                p.spec_out[2 * (lane + 64 * j)] = v.x;
+                p.spec_out[2 * (lane + 64 * j) + 1] = v.y;
+            }
+        }
+        wave_sync();                                                // cur / Ly / lists are read: free for the row below
+        gb = bn; gq = qn;
+    }
+    if (ng > 0) flush(ng);
+}
+
+template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipStream_t s) {
+    using RG = RevGeo<R>;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    if (p.total_rows >= 0x7fffff00LL) { pvx_set_error("the fused kernel indexes rows in 32 bits (%lld rows)", (long long)p.total_rows); return PVX_ERR_UNSUPPORTED; }
+    const size_t lds = RG::total(p.K, NW);
+    if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the fused kernel", Geo<R>::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
+    const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
+    const int H = (p.hop == 32 * R) ? R / 4 : (p.hop == 64 * R) ? R / 2 : 0;
+    const void* fn = nullptr;
+#define PVX_REV_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_rev<R, NW, INT, AL, R / 4> : H ? (const void*)k_fused_rev<R, NW, INT, AL, R / 2> : (const void*)k_fused_rev<R, NW, INT, AL, 0>)
+    switch (x_dtype) {
+        case PVX_F32: fn = al2 ? PVX_REV_PICK(float, true) : PVX_REV_PICK(float, false); break;
+        case PVX_F64: fn = PVX_REV_PICK(double, false); break;
+        case PVX_I16: fn = PVX_REV_PICK(int16_t, false); break;
+        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+#undef PVX_REV_PICK
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks_per_cu = (int)((160 * 1024) / lds);
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu * NW > 16) blocks_per_cu = (16 / NW) > 0 ? 16 / NW : 1;
+    int64_t nblocks = (int64_t)ncu * blocks_per_cu;
+    if (p.blocks_override > 0) nblocks = p.blocks_override;
+    const int64_t maxb = (p.total_rows + NW - 1) / NW;              // never more waves than rows
+    if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
+    dim3 grid((unsigned)nblocks), block(64 * NW);
+    FusedParams arg = p;
+    { const char* e = getenv("PVX_REV_STAGGER"); arg.stagger = e ? atoi(e) : 0; }
+    void* args[] = {&arg};
+    PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
+    return PVX_OK;
+}
+
+}  // namespace
+
+int pvx_fused_rev_supported(int nfft, int precision, int K) {
+    if (precision != 32) return 0;
+    switch (nfft) {
+        case 2048: return RevGeo<16>::total(K, 8) <= 160 * 1024;
+        case 1024: return RevGeo<8>::total(K, 12) <= 160 * 1024;
+        case 512: return RevGeo<4>::total(K, 12) <= 160 * 1024;
+        default: return 0;
+    }
+}
+
+int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
+    if (p.total_rows <= 0) return PVX_OK;
+    switch (nfft) {
+        case 2048: return launch_rev<16, 8>(p, x_dtype, s);
+        case 1024: return launch_rev<8, 12>(p, x_dtype, s);
+        case 512: return launch_rev<4, 12>(p, x_dtype, s);
+        default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
+    }
+}

@@ -88,6 +88,7 @@ struct FusedParams {      // k_fused.hip: window + FFT + untangle + peaks in one
     float* spec_out;      // optional: half spectrum (nfft/2 complex) of global row spec_row
     int64_t spec_row;
     int64_t blocks_override;
+    int stagger;          // k_fused_rev.hip: start delay per wave of a workgroup, in units of 64 cycles
 };
 int pvx_fused_supported(int nfft, int precision, int K);
 int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
@@ -95,6 +96,8 @@ int pvx_fused_mw_supported(int nfft, int precision, int K);     // k_fused_mw.hi
 int pvx_launch_fused_mw(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_fused_ring_supported(int nfft, int precision, int K);   // k_fused_ring.hip: workgroup-shared spectrum ring
 int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
+int pvx_fused_rev_supported(int nfft, int precision, int K);    // k_fused_rev.hip: independent waves, rows in descending order
+int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 
 // k_stft.hip: fused float64 STFT into the spectrum workspace
 int pvx_stft_supported(int nfft, int precision);

@@ -378,8 +378,9 @@ def test_streaming_frame_api(amd, oracle):
 
 
 def test_fused_kernel_variants(amd, oracle):
-    """nfft=2048 at precision=32 runs the fused kernels (fft mode 3, the workgroup-ring form, by default;
-    mode 1, one independent wave per frame, on request: same arithmetic, bit-identical results).  Cover the
+    """nfft=2048 at precision=32 runs the fused kernels (fft mode 4 by default: independent waves walking their rows
+    downwards; mode 3, the workgroup-ring form, and mode 1, one independent wave per frame over two buffers, on
+    request: same arithmetic, bit-identical results).  Cover the
     input variants (int16 / float32 aligned / float32 with an odd hop / float64), the streaming entry points
     (previous spectrum handed in, last spectrum handed back) and agreement with the rocFFT path."""
     import ctypes
@@ -389,7 +390,7 @@ def test_fused_kernel_variants(amd, oracle):
     for hop, xin in ((512, x.astype(np.float32)), (333, x.astype(np.float32)), (512, x), (700, x)):
         o = oracle.analyze(x, sr, nfft, hop, K)
         res = {}
-        for mode in (3, 1):
+        for mode in (3, 1, 4):
             os.environ["PVX_FFT_MODE"] = str(mode)
             try:
                 p = run_pv(amd, xin, sr, nfft, hop, K, precision=32)
@@ -403,11 +404,12 @@ def test_fused_kernel_variants(amd, oracle):
             res[mode] = p
         for name in ("f", "mag", "ph", "realph", "binno", "totalmag"):
             assert np.array_equal(np.asarray(getattr(res[3], name)), np.asarray(getattr(res[1], name))), name
-        assert np.array_equal(res[3].oldfft, res[1].oldfft)
+            assert np.array_equal(np.asarray(getattr(res[4], name)), np.asarray(getattr(res[1], name))), name
+        assert np.array_equal(res[3].oldfft, res[1].oldfft) and np.array_equal(res[4].oldfft, res[1].oldfft)
     p = run_pv(amd, x, sr, nfft, 512, K, precision=32)
-    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 3          # the default where it fits
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 4          # the default where it fits
     p = run_pv(amd, x, sr, nfft, 512, 200, precision=32)
-    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 1          # npks too large for the LDS next to the ring
+    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) in (1, 4)     # npks too large for the ring's LDS
     xi = np.round(x * 20000).astype(np.int16)
     o = oracle.analyze(xi.astype(np.float64), sr, nfft, 512, K)
     p = run_pv(amd, xi, sr, nfft, 512, K, precision=32)
@@ -435,7 +437,7 @@ def test_fused_kernel_variants(amd, oracle):
     # independent waves on request)
     for nf, hp in ((512, 128), (512, 77), (1024, 256), (1024, 512)):
         o = oracle.analyze(x, sr, nf, hp, K)
-        for mode in (3, 1):
+        for mode in (3, 1, 4):
             os.environ["PVX_FFT_MODE"] = str(mode)
             try:
                 p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
@@ -444,7 +446,7 @@ def test_fused_kernel_variants(amd, oracle):
             assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == mode
             assert_f32(compare_analysis(pv_result(p), o, nf, hp, sr), absolute=False)
         p = run_pv(amd, x.astype(np.float32), sr, nf, hp, K, precision=32)
-        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 3
+        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 4
     # nfft 4096 / 8192: the multi-wave-per-frame fused kernel (fft mode 2); nfft 2048 can run it too
     xl = _rand_signal(22, 70000)
     for nf, hp, mode in ((4096, 1024, None), (4096, 999, None), (8192, 2048, None), (2048, 512, 2), (2048, 333, 2)):
@@ -473,13 +475,16 @@ def test_fused_kernel_variants(amd, oracle):
         assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
 
 
+@pytest.mark.parametrize("kmode", [3, 4])
 @pytest.mark.parametrize("nfft", [2048, 1024, 512])
-def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft):
+def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmode):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
     of spectra, hand-off through progress counters in LDS) does the arithmetic of mode 1 (k_fused.hip, which the
     other tests pin to the reference and the oracle): every output must be bit-identical, whatever the signal
     (dense candidates -> radix select, exact silence -> zero rows and x/0 frames, threshold 0 -> zero fill),
-    npks, hop, input type, number of signals in the call (zero rows between signals; F = 1) or grid."""
+    npks, hop, input type, number of signals in the call (zero rows between signals; F = 1) or grid.  The same holds
+    for fft mode 4 (k_fused_rev.hip: independent waves walking their rows downwards over one buffer each, the
+    previous spectrum of a frame's peaks picked up one row later; sliding sample window at hop = nfft/4, nfft/2)."""
     from pypevoc_amd import _lib
     rng = np.random.default_rng(77)
     sr = 44100.0
@@ -492,20 +497,20 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft):
 
     def both(make):
         out = {}
-        for mode in (1, 3):
+        for mode in (1, kmode):
             monkeypatch.setenv("PVX_FFT_MODE", str(mode))
             out[mode] = make()
             monkeypatch.delenv("PVX_FFT_MODE")
-        return out[1], out[3]
+        return out[1], out[kmode]
 
     def same(a, b, what):
         for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
 
     for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant)):
-        for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (24, 0.005, nfft // 8)):
+        for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (24, 0.005, nfft // 8), (8, 0.005, nfft // 2)):
             a, b = both(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
-            assert _lib.load().pvx_plan_get_fft_mode(b._plan.handle) == 3
+            assert _lib.load().pvx_plan_get_fft_mode(b._plan.handle) == kmode
             assert _lib.load().pvx_plan_get_fft_mode(a._plan.handle) == 1
             same(a, b, (name, K, thr, hop))
     for xin in (noise.astype(np.float32), np.round(harm * 20000).astype(np.int16)):
@@ -519,7 +524,7 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft):
         for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
     # other grids: one workgroup; more workgroups than fit the rows two iterations each
-    monkeypatch.setenv("PVX_FFT_MODE", "3")
+    monkeypatch.setenv("PVX_FFT_MODE", str(kmode))
     ref = run_pv(amd, harm, sr, nfft, nfft // 4, 8, precision=32)
     for nb in ("1", "3", "1000"):
         monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
