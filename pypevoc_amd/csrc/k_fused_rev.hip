@@ -69,7 +69,13 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     v2f* const tw3 = (v2f*)(smem + RG::OFF_TW3);
     // per-wave region: everything whose size is known at compile time first, so that those arrays are one base
     // register plus immediate offsets (each runtime offset costs a scalar register across the whole frame loop)
-    unsigned char* wb = smem + RG::OFF_WAVE + RG::per_wave(K) * wid;
+    // (the region's offset goes through an opaque scalar move: as a visible constant the compiler folds it into the
+    // immediate offsets of every access -- 16-bit fields -- and then cannot pair the 64-bit accesses of the exchange and
+    // the natural-order pass into ds_write2 / ds_read2, whose two offsets have 8 bits each: 15 more LDS instructions per
+    // frame than k_fused_ring.hip, whose slot address is a run-time value anyway)
+    unsigned wboff = (unsigned)(RG::OFF_WAVE + RG::per_wave(K) * wid);
+    asm volatile("" : "+s"(wboff));
+    unsigned char* wb = smem + wboff;
     float2* const cur = (float2*)wb;                                // X of the row at hand
     long long* const Lorow = (long long*)(cur + G::BUFC);
     double* const Ltot = (double*)(Lorow + GFR);
@@ -189,8 +195,14 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
         v2f* dz = (v2f*)dst;
+        // two rows at a time, twiddles first: adjacent so that the accesses pair into ds_read2st64 / ds_write2
 #pragma unroll
-        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? pvxc::cmul(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        for (int q2 = 0; q2 < R; q2 += 2) {
+            const v2f ta = t1L[q2 * 64 + lane], tb = t1L[(q2 + 1) * 64 + lane];
+            const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], ta) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tb);
+            dz[q2 * PITCH + lane] = pa;
+            dz[(q2 + 1) * PITCH + lane] = pb2;
+        }
         wave_sync();
 #pragma unroll
         for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
