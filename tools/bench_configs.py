@@ -93,10 +93,11 @@ def config4(nsig=128, seconds=30, sr=48000, nfft=2048, hop=512, K=8, reps=10):
     ms_an = e[0].elapsed_time(e[1]) / reps
     ms_pk = e[1].elapsed_time(e[2]) / reps
     valid = int((res[: rows * K] > 0).sum().item())
+    mode = int(lib.pvx_plan_get_fft_mode(plan))
     lib.pvx_plan_destroy(plan)
     return dict(config="4: one GPU's shard of 1024 x 30 s @ 48 kHz: %d signals in one pvx_analyze_dev call, nfft=2048 hop=512 npks=8" % nsig,
                 signals=nsig, frames_per_signal=F, frames=rows, analyze_ms=round(ms_an, 4), frames_per_s=round(rows / ms_an * 1e3, 1),
-                fft_mode=int(lib.pvx_plan_get_fft_mode(plan)) if False else 1,
+                fft_mode=mode,
                 pack_ms=round(ms_pk, 4), wire_MB=round(wire.nbytes / 1e6, 2), result_MB=round(wire.result_numel() * 8 / 1e6, 2),
                 pack_GBps=round((rows * K * 50 + rows * 16) / ms_pk / 1e6, 1), valid_peaks=valid,
                 input_GB=round(nsig * n * 4 / 1e9, 3))
