@@ -84,7 +84,12 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   3  mode 1's arithmetic (bit-identical results) with a workgroup of 8 (nfft 2048) or 12 (nfft 512, 1024)
  *      waves walking as many consecutive frames over a shared ring of spectra in LDS: two / three waves per
  *      SIMD (precision = 32; npks <= 120 at nfft 2048: the staging has to fit the LDS next to the ring)
- * A new plan uses 3 where it is supported, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
+ *   4  mode 1's arithmetic again (bit-identical results) with every wave on its own: a wave walks a contiguous range
+ *      of rows DOWNWARDS over one spectrum buffer, the previous spectrum a frame's peaks need arrives one row later;
+ *      sliding sample window at hop = nfft/4, nfft/2 (precision = 32, nfft in {512, 1024, 2048})
+ * Mode 0 itself runs as one launch (window + FFT + peaks, k_stft_pv) for nfft in {512, 1024, 2048}, as fused STFT +
+ * phase/peak kernel for nfft 4096 / 8192, and through rocFFT otherwise.
+ * A new plan uses 4 where it is supported, else 3, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);
@@ -102,7 +107,7 @@ int pvx_plan_set_progress(pvx_plan* plan, pvx_progress_fn fn, void* user);
  * Stage timing for bench.py's roofline line.  While enabled, hipEvents recorded on the launch
  * stream bracket every stage of every chunk.  pvx_plan_get_timing synchronises with those events
  * and returns, accumulated since the last call: ms[0] framing kernel, ms[1] rocFFT, ms[2]
- * phase/peak kernel, ms[3] fused kernel (fft modes 1-3); launches[i] = stage launches counted.
+ * phase/peak kernel, ms[3] fused kernel (fft modes 1-4, and mode 0's one-launch form); launches[i] = stage launches counted.
  */
 int pvx_plan_set_timing(pvx_plan* plan, int enable);
 int pvx_plan_get_timing(pvx_plan* plan, double* ms /*[4]*/, int64_t* launches /*[4]*/);

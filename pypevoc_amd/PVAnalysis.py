@@ -82,7 +82,8 @@ class _Plan(object):
             while bucket < max_rows and bucket < (1 << 16):
                 bucket <<= 1
         key = (float(sr), int(nfft), int(hop), int(npks), float(pkthresh), int(precision), win.tobytes(), bucket,
-               os.environ.get("PVX_FFT_MODE"), os.environ.get("PVX_MAX_ROWS"), os.environ.get("PVX_FUSED_BLOCKS"), os.environ.get("PVX_FPW"))
+               os.environ.get("PVX_FFT_MODE"), os.environ.get("PVX_MAX_ROWS"), os.environ.get("PVX_FUSED_BLOCKS"), os.environ.get("PVX_FPW"),
+               os.environ.get("PVX_NO_STFT"), os.environ.get("PVX_NO_STFT_PV"))
         plans = cls._pool.setdefault(key, [])
         free = [pl for pl in plans if pl.owner is None or pl.owner() is None]
         if free:
