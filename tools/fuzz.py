@@ -280,7 +280,11 @@ def main():
     t_end = time.time() + budget
     idx = nfail = 0
     tot = dict(runs=0, chk=0, bad=0, f=0.0, ph=0.0, mag=0.0)
+    t_note = time.time() + 60.0
     while time.time() < t_end:
+        if time.time() > t_note:                                    # a line a minute: long runs are not silent
+            print("... %d cases, %d failing so far" % (idx, nfail), flush=True)
+            t_note = time.time() + 60.0
         fails, st = run_case(seed, idx)
         for k in ("runs", "chk", "bad"):
             tot[k] += st[k]
