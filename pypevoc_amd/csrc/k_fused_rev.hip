@@ -324,9 +324,6 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         wave_sync();
     };
 
-    // waves of a CU start their frame loops an eighth of a frame apart (p.stagger x 64 cycles per wave): left alone they
-    // run in lock step -- every wave in the LDS exchange, then every wave in the register stages
-    for (int i = 0; i < wid * p.stagger; i++) __builtin_amdgcn_s_sleep(1);
     // ---- (signal b, row-in-signal q) of this wave's first row g = r1 - 1; rows go down by one
     int g = r1 - 1, gb = g / rows1, gq = g - gb * rows1;            // the only division
     { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
@@ -506,7 +503,6 @@ template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipSt
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * NW);
     FusedParams arg = p;
-    { const char* e = getenv("PVX_REV_STAGGER"); arg.stagger = e ? atoi(e) : 0; }
     void* args[] = {&arg};
     PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     return PVX_OK;

@@ -88,7 +88,6 @@ struct FusedParams {      // k_fused.hip: window + FFT + untangle + peaks in one
     float* spec_out;      // optional: half spectrum (nfft/2 complex) of global row spec_row
     int64_t spec_row;
     int64_t blocks_override;
-    int stagger;          // k_fused_rev.hip: start delay per wave of a workgroup, in units of 64 cycles
 };
 int pvx_fused_supported(int nfft, int precision, int K);
 int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
