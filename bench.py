@@ -337,10 +337,14 @@ def main():
     # steps and the K timed steps of the contract.
     ramp_steps = 0
     if args.clock_warmup_ms > 0:
+        # (the analysis launch alone, into block 0: no pack, no collective -- the ranks of a multi-GPU run loop by wall
+        # time here and must not disagree about how many gathers they have posted)
         t_ramp = time.perf_counter() + args.clock_warmup_ms * 1e-3
+        rp0 = rp2[0]
         while time.perf_counter() < t_ramp:
             for _ in range(64):
-                step()
+                lib.pvx_analyze_dev(plans[0], x.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, rp0[0], rp0[1], rp0[2], rp0[3], rp0[4],
+                                    tp2[0], rp0[5], None, ctypes.c_void_p(cstreams[0].cuda_stream))
             ramp_steps += 64
             torch.cuda.synchronize(dev)
             if ramp_steps >= 1 << 16:
