@@ -8,7 +8,7 @@
 //    is discarded -- PV.py:176 -- so it has no counterpart here)
 //
 // Roofline: HBM.  One wave64 per frame: the half spectrum (nfft/2 complex) is streamed once with
-// 16-byte-per-lane loads and only |X| is kept, in LDS.  Everything else runs out of LDS/registers:
+// 16-byte-per-lane loads and only |X|^2 is kept, in LDS.  Everything else runs out of LDS/registers:
 //   - min / max / energy: DPP row reductions + 4 readlanes (no LDS crossbar traffic);
 //   - candidates = interior local maxima above the threshold, compacted into an LDS list with
 //     ballot + mbcnt (list order = ascending bin, so no sort is ever needed);
