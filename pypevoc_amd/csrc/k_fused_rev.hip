@@ -129,8 +129,13 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
 
     // ---- rows of this wave: [r0, r1), walked downwards, then row r0 - 1 (spectrum only)
     // row indices fit 32 bits (the launcher checks): 64-bit scalar arithmetic in the frame loop costs SGPR pairs
-    const int W = (int)gridDim.x * NW, w = (int)blockIdx.x * NW + wid;
-    const int r0 = (int)(p.total_rows * (int64_t)w / W), r1 = (int)(p.total_rows * ((int64_t)w + 1) / W);
+    // the workgroup's share of the rows, then its waves': the n mod NW waves that take one row more are waves 0, 1, ... --
+    // consecutive waves sit on different SIMDs, so no SIMD carries two long waves while another carries none (a wave has
+    // ~25 rows on BASELINE config 2: one row is 4 % of a SIMD's work; +2 % there over an even split by wave index)
+    const int NB = (int)gridDim.x;
+    const int R0 = (int)(p.total_rows * (int64_t)blockIdx.x / NB), R1 = (int)(p.total_rows * ((int64_t)blockIdx.x + 1) / NB);
+    const int nwg = R1 - R0, base = nwg / NW, extra = nwg - base * NW;
+    const int r0 = R0 + wid * base + (wid < extra ? wid : extra), r1 = r0 + base + (wid < extra ? 1 : 0);
     if (r0 >= r1) return;
     const int Fi = (int)p.F;
     const int rows1 = Fi + 1;                                       // rows per signal
