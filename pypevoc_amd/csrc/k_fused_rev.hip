@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
             int nk = 0;
             // candidate list (ascending bins) -> Lci
-            const int C = peak_scan_block<R, u16>(Ly, mine, th, Lci, G::CAP, lane);
+            const int C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
             wave_sync();
             if (C <= 64 && p.rad <= 5 && !(th < 0.0 && C < K)) {
                 // ---- at most one candidate per lane (every frame of music): lane c owns candidate c and fetches

@@ -432,6 +432,79 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
     return C;
 }
 
+// peak_scan_block for frames with MORE candidates than a wave has lanes (noise, most frames of a recording) when few of
+// them are wanted: before the list is written, candidates that cannot be among the npeaks best are dropped, in registers.
+// The lanes form 64 / GL groups of GL lanes (GL = 8 for npeaks <= 8, 4 for <= 16, 2 for <= 32); every group's best
+// candidate score is a different candidate, so T = the smallest of the group maxima is reached by at least npeaks
+// candidates: a lower bound of the npeaks-th largest score of the row, and everything the selection can take -- ties
+// included, the scores being the very values it ranks (y - miny) -- is >= T.  Cost: a maximum per lane, log2(GL) DPP
+// steps and one wave reduction; on white noise 21 of 280 candidates survive on average, the list fits one lane each and
+// the frame takes the callers' short path.  The exact selection among the survivors is the callers' as before (same list
+// order, same tie rule): the result does not depend on what T drops.
+template <int R, typename CI>
+__device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
+    static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
+    constexpr int n = 64 * R;
+    const float thf = __double2float_rd(th);
+    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
+    const int k0 = R * lane;
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R / 4; j++) {
+        const float4 q = *(const float4*)(y + ymap<1>(k0 + 4 * j));
+        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+    const float left = y[ymap<1>(k0 > 0 ? k0 - 1 : 0)];
+    const float right = y[ymap<1>(k0 + R < n ? k0 + R : n - 1)];
+    int rise[R + 1];                                                 // sign bit set: y[k-1] < y[k]
+    rise[0] = __float_as_int(left) - __float_as_int(v[0]);
+#pragma unroll
+    for (int i = 1; i < R; i++) rise[i] = __float_as_int(v[i - 1]) - __float_as_int(v[i]);
+    rise[R] = __float_as_int(v[R - 1]) - __float_as_int(right);
+    unsigned m = 0;
+    float sc[R];                                                     // scores y - miny (>= 0)
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        sc[i] = v[i] - miny;
+        const int above = thb - __float_as_int(sc[i]);               // sign bit set: score > thf
+        const unsigned t = (unsigned)(rise[i] & ~rise[i + 1] & above);
+        m = (m << 1) | (t >> 31);
+    }
+    if (k0 + R == n) m &= ~(1u << (R - 1));                          // bin n-1 is not interior
+    auto count = [&](unsigned mm, int& pos) -> int {
+        const int cnt = __popc(mm);
+        int C = 0;
+        pos = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long bal = __ballot(((cnt >> b) & 1) != 0);
+            pos += lane_prefix(bal) << b;
+            C += __popcll(bal) << b;
+        }
+        return C;
+    };
+    int pos;
+    int C = count(m, pos);
+    // (th < 0 -- the threshold lies below the row's minimum, as on white noise -- changes nothing here: with more than 64
+    // candidates the selection takes maxima only, and at least npeaks of them survive)
+    if (C > 64 && npeaks <= 32) {                                    // wave-uniform
+        float best = 0.f;                                            // this lane's best candidate score (0: it has none)
+#pragma unroll
+        for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
+        best = fmaxf(best, dpp_f<0xB1>(best));                       // lane pairs
+        if (npeaks <= 16) best = fmaxf(best, dpp_f<0x4E>(best));     // quads
+        if (npeaks <= 8) best = fmaxf(best, dpp_f<0x141>(best));     // groups of 8 lanes
+        const float T = wave_min(best);
+        unsigned keep = 0u;
+#pragma unroll
+        for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
+        m &= keep;
+        C = count(m, pos);
+    }
+    peak_block_write<R, CI>(ci, 0, lane, m, pos, trash + lane);
+    return C;
+}
+
 // The dense-candidate branch of peak_pick_regs, kept out of line: it runs on noise-like frames only, and
 // inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
 // layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).
