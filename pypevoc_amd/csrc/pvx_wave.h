@@ -432,15 +432,16 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
     return C;
 }
 
-// peak_scan_block for frames with MORE candidates than a wave has lanes (noise, most frames of a recording) when few of
-// them are wanted: before the list is written, candidates that cannot be among the npeaks best are dropped, in registers.
-// The lanes form 64 / GL groups of GL lanes (GL = 8 for npeaks <= 8, 4 for <= 16, 2 for <= 32); every group's best
-// candidate score is a different candidate, so T = the smallest of the group maxima is reached by at least npeaks
+// peak_scan_block for frames with MORE candidates than a wave has lanes (noise, most frames of a recording) when npeaks
+// <= 16 of them are wanted: before the list is written, candidates that cannot be among the npeaks best are dropped, in
+// registers.  The 16 quads of lanes each have a best candidate score -- 16 different candidates --, so T = the npeaks-th
+// largest of those (every lane counts the quads that beat its own: 16 broadcasts) is reached by at least npeaks
 // candidates: a lower bound of the npeaks-th largest score of the row, and everything the selection can take -- ties
-// included, the scores being the very values it ranks (y - miny) -- is >= T.  Cost: a maximum per lane, log2(GL) DPP
-// steps and one wave reduction; on white noise 21 of 280 candidates survive on average, the list fits one lane each and
-// the frame takes the callers' short path.  The exact selection among the survivors is the callers' as before (same list
-// order, same tie rule): the result does not depend on what T drops.
+// included, the scores being the very values it ranks (y - miny) -- is >= T.  On white noise 10 of 280 candidates survive
+// on average, on a violin recording 37 of 119 (the smallest of 8 group maxima, cheaper, leaves 98 there: a spectrum that
+// falls off has groups with tiny maxima); the list then fits one lane each and the frame takes the callers' short
+// path.  The exact selection among the survivors is the callers' as before (same list order, same tie rule): the
+// result does not depend on what T drops.
 template <int R, typename CI>
 __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
     static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
@@ -487,14 +488,19 @@ __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, 
     int C = count(m, pos);
     // (th < 0 -- the threshold lies below the row's minimum, as on white noise -- changes nothing here: with more than 64
     // candidates the selection takes maxima only, and at least npeaks of them survive)
-    if (C > 64 && npeaks <= 32) {                                    // wave-uniform
+    // (worth its ~150 instructions from about 200 candidates up: below that the callers' radix select over two or
+    // three keys per lane is cheaper than this plus a ranking pass over the survivors -- a violin recording's frames,
+    // ~120 candidates, ran 8 % slower with it, white noise's, ~280, 16 % faster)
+    if (C > 192 && npeaks <= 16) {                                   // wave-uniform
         float best = 0.f;                                            // this lane's best candidate score (0: it has none)
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
-        best = fmaxf(best, dpp_f<0xB1>(best));                       // lane pairs
-        if (npeaks <= 16) best = fmaxf(best, dpp_f<0x4E>(best));     // quads
-        if (npeaks <= 8) best = fmaxf(best, dpp_f<0x141>(best));     // groups of 8 lanes
-        const float T = wave_min(best);
+        best = fmaxf(best, dpp_f<0xB1>(best));
+        best = fmaxf(best, dpp_f<0x4E>(best));                       // every lane: its quad's best
+        int beaten = 0;                                              // quads whose best beats this one's
+#pragma unroll
+        for (int j = 0; j < 16; j++) beaten += (rl_f(best, 4 * j) > best) ? 1 : 0;
+        const float T = wave_min(beaten < npeaks ? best : INFINITY);
         unsigned keep = 0u;
 #pragma unroll
         for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
