@@ -256,7 +256,12 @@ def run_case(seed, idx, verbose=False):
                 if dph > 1e-8:
                     fails.append("%s: harmonic phase error %g" % (tag, dph))
             tot = (S ** 2).sum(axis=1)
+            # the residual sums the 3-bin energies of ALL harmonics up to Nyquist, re-centred on the measured frequency f1
+            # of the first one (PV.py:466-469): when that first harmonic is at the rounding floor of its frame (a chirp
+            # with nothing at f0), f1 is numerical noise and which bin a harmonic beyond npks lands on is a coin toss
+            # in any arithmetic -- those frames are not compared (case 202:20873: one of 106 harmonics on the next bin)
             fin = np.isfinite(oh["residuals"]) & np.isfinite(ph.residuals) & live & ~flip.any(axis=1)
+            fin &= oh["mag"][:, 0] >= 1e-6 * fmaxh[:, 0]
             if fin.any():
                 e = np.abs(ph.residuals[fin] ** 2 - oh["residuals"][fin] ** 2) / np.maximum(tot[fin], 1e-300)
                 if e.max() > 1e-10:
