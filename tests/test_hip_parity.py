@@ -1089,12 +1089,12 @@ def test_library_first_then_torch_in_a_fresh_process():
         # a second process opening the GPU while this one holds it has been seen to stall once on a pool box (the
         # same command then ran in 13 s): one more try before calling it
         try:
-            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150)
             break
         except subprocess.TimeoutExpired:
             continue
     if r is None:
-        pytest.skip("the child process did not get to the GPU within 2 x 240 s on this box")
+        pytest.skip("the child process did not get to the GPU within 2 x 150 s on this box")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
