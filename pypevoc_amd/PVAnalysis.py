@@ -49,11 +49,27 @@ class _Result(object):
         if v is _MISSING:
             v = obj._fetch_result(self.which)
             obj.__dict__[self.key] = v
+            if isinstance(v, np.ndarray):
+                # the caller gets a plain writable ndarray like the reference's attribute: an in-place edit
+                # (pv.mag[pv.f > 5000] = 0) must take effect in toSinSum / synth / calc_f0, so the fetched
+                # copy is fingerprinted and PV._on_device() compares before it trusts the arrays in HBM
+                obj.__dict__.setdefault("_res_prints", {})[self.key] = _fingerprint(v)
         return v
 
     def __set__(self, obj, v):
         obj.__dict__[self.key] = v
         obj.__dict__["_results_edited"] = True
+
+
+try:
+    from xxhash import xxh3_64_intdigest as _digest
+except ImportError:                                          # pragma: no cover
+    from zlib import crc32 as _digest
+
+
+def _fingerprint(a):
+    """Cheap content hash of a fetched result array (a few GB/s; only arrays the caller has read exist on the host)."""
+    return _digest(memoryview(np.ascontiguousarray(a)).cast("B"))
 
 
 _NP_WINDOWS = (np.hanning, np.hamming, np.blackman, np.bartlett)
@@ -97,6 +113,10 @@ class _Plan(object):
             if prev is not None:
                 prev._release_resident()
                 prev._plan = None
+                # the plan's progress callback is re-installed by its next owner: the old owner's thunk must
+                # neither stay registered (wrong nsamp / hop, freed thunk) nor look "already installed" later
+                prev._progress_cb = None
+                prev._progress_plan = None
         plans.remove(pl) if pl in plans else None
         plans.append(pl)                                     # most recently used last
         pl.owner = weakref.ref(owner)
@@ -234,8 +254,10 @@ class PV(object):
     def _install_progress(self, plan):
         if not self.progress:
             _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, _lib.PROGRESS_FN(), None), "pvx_plan_set_progress")
+            plan.progress_owner = None
             return
-        if self._progress_cb is not None and getattr(self, "_progress_plan", None) is plan:
+        if self._progress_cb is not None and getattr(self, "_progress_plan", None) is plan \
+                and getattr(plan, "progress_owner", None) is self._progress_cb:
             return
         user = self.progress if callable(self.progress) else None
         hop, nsamp = int(self.hop), int(self.nsamp)
@@ -251,6 +273,7 @@ class PV(object):
 
         self._progress_cb = _lib.PROGRESS_FN(report)                           # keep the thunk alive
         self._progress_plan = plan
+        plan.progress_owner = self._progress_cb                                # the thunk lives as long as the plan uses it
         _lib.check(_lib.load().pvx_plan_set_progress(plan.handle, self._progress_cb, None), "pvx_plan_set_progress")
 
     def _signal(self):
@@ -272,8 +295,20 @@ class PV(object):
         return list(a) if which == 6 else a
 
     def _on_device(self):
-        """True while the results of run_pv are in HBM and nobody has replaced them on the host."""
-        return self._resident and not self._results_edited
+        """True while the results of run_pv are in HBM and nobody has replaced or edited them on the host.
+
+        The reference's f / mag / ph / realph are plain ndarrays that toSinSum (PVAnalysis.py:319) and calc_f0
+        (PVAnalysis.py:379) read at call time, so both an assignment (`pv.mag = ...`, _Result.__set__) and an
+        in-place edit of an array the caller has fetched (`pv.mag[pv.f > 5000] = 0`) take the object off the
+        device-resident chain: the host copies then are the results."""
+        if not self._resident or self._results_edited:
+            return False
+        for key, fp in self.__dict__.get("_res_prints", {}).items():
+            v = self.__dict__.get(key, _MISSING)
+            if isinstance(v, np.ndarray) and _fingerprint(v) != fp:
+                self._results_edited = True
+                return False
+        return True
 
     def _release_resident(self):
         """Before the plan's resident block is overwritten: bring what is still only there to the host."""
@@ -417,6 +452,7 @@ class PV(object):
             _lib.check(r, "pvx_analyze_resident")
             for name in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
                 self.__dict__.pop("_res_" + name, None)
+            self.__dict__.pop("_res_prints", None)
             self._resident = True
         self._results_edited = self._xdev is not None
         self.nframes = F
@@ -795,8 +831,14 @@ class SinSum(object):
         i32 = lambda a: a.ctypes.data_as(_lib.c_int32_p)
         _lib.check(_lib.load().pvx_resident_fetch_table(pv._plan.handle, i32(pid), i32(st), i32(ln)), "pvx_resident_fetch_table")
         self._rpv = None
-        self._tab = dict(f=np.ascontiguousarray(pv.f, dtype=np.float64), mag=np.ascontiguousarray(pv.mag, dtype=np.float64),
-                         ph=np.ascontiguousarray(pv.ph, dtype=np.float64), realph=np.ascontiguousarray(pv.realph, dtype=np.float64),
+        # the values this object was built from (toSinSum copies them at call time, PVAnalysis.py:319-321): the PV's
+        # host copies while nobody has touched them, else the untouched arrays that are still in the plan's block
+        stale = pv._resident and not pv._on_device()
+
+        def arr(name, which):
+            return pv._fetch_result(which) if stale else np.ascontiguousarray(getattr(pv, name), dtype=np.float64)
+
+        self._tab = dict(f=arr("f", 0), mag=arr("mag", 1), ph=arr("ph", 2), realph=arr("realph", 3),
                          pid=pid, st=st[:P].copy(), ln=ln[:P].copy())
         self._materialised = False
 
@@ -1031,3 +1073,24 @@ class SinSum(object):
             _, _, _, pid, st, ln = self._pack_partials()
             return pid, st, ln
         return self._tab['pid'], self._tab['st'], self._tab['ln']
+
+
+def _unsupported(name, where):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(
+            "%s (%s) is outside the accelerated PV.run_pv -> toSinSum -> synth path and is not mirrored by "
+            "pypevoc_amd; use the reference class for it (see INTEGRATION.md, 'not mirrored')" % (name, where))
+    method.__name__ = name.split(".")[-1]
+    method.__doc__ = "Not mirrored: %s." % where
+    return method
+
+
+# helpers of the reference classes that the path never calls (plotting, the self-described slow
+# add_point, summaries, and RegPartial methods that are broken on current numpy): a clear error, not an AttributeError
+for _cls, _n, _w in ((SinSum, "add_point", "PVAnalysis.py:832-868"), (SinSum, "get_summary", "PVAnalysis.py:1078-1089"),
+                     (SinSum, "get_part_data_around_freq", "PVAnalysis.py:1091-1111"), (SinSum, "plot_time_freq", "PVAnalysis.py:1002-1031"),
+                     (SinSum, "plot_time_freq_mag", "PVAnalysis.py:1033-1051"), (RegPartial, "prepend_point", "PVAnalysis.py:628-651"),
+                     (RegPartial, "synth_no_phase", "PVAnalysis.py:653-682"), (RegPartial, "get_rel_phase", "PVAnalysis.py:758-794"),
+                     (PV, "plot_time_freq", "PVAnalysis.py:324-346"), (PV, "plot_time_mag", "PVAnalysis.py:348-369")):
+    setattr(_cls, _n, _unsupported(_cls.__name__ + "." + _n, _w))
+

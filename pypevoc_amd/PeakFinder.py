@@ -113,7 +113,15 @@ class PeakFinder(object):
         ''' Filters the peaks by salience (PeakFinder.py:113-136): any peak that is lower than a
             neighbouring point within 'rad' is filtered out.'''
         if sal != 0:
-            raise NotImplementedError("sal != 0 is not used by the phase vocoder path")
+            # Off the phase-vocoder path (PV always passes sal=0, PVAnalysis.py:177): the test `any(w + sal > y[p])`
+            # of PeakFinder.py:129-134 on the <= npeaks selected positions, on the host.  (The window contains the peak
+            # itself, so any sal > 0 drops every peak -- in the reference too.)
+            y = np.asarray(self.y)
+            for i, p in enumerate(self._idx):
+                w = y[max(int(p) - rad, 1):min(int(p) + rad, len(y)) + 1]
+                if np.any(w + sal > self._val[i]):
+                    self._keep[i] = False
+            return
         _, keep = self._run(int(rad))
         self._keep = np.logical_and(self._keep, keep)
 
@@ -145,4 +153,22 @@ class PeakFinder(object):
 
     def get_pos(self):
         return self.pos
+
+
+def _unsupported(name, where):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(
+            "%s (%s) is outside the accelerated PV.run_pv -> toSinSum -> synth path and is not mirrored by "
+            "pypevoc_amd; use the reference class for it (see INTEGRATION.md, 'not mirrored')" % (name, where))
+    method.__name__ = name.split(".")[-1]
+    method.__doc__ = "Not mirrored: %s." % where
+    return method
+
+
+# sub-sample refinement, areas, prominence and export helpers of the reference class: named here so that a caller
+# gets a clear NotImplementedError instead of an AttributeError
+for _n, _w in (("refine", "PeakFinder.py:331-372"), ("refine_opt", "PeakFinder.py:304-329"), ("refine_all", "PeakFinder.py:374-413"),
+               ("get_areas", "PeakFinder.py:415-437"), ("find_prominence", "PeakFinder.py:196-221"),
+               ("filter_by_prominence", "PeakFinder.py:138-153"), ("to_dict", "PeakFinder.py:439-473"), ("plot", "PeakFinder.py:223-267")):
+    setattr(PeakFinder, _n, _unsupported("PeakFinder." + _n, _w))
 

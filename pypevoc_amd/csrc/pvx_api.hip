@@ -231,7 +231,11 @@ extern "C" int64_t pvx_plan_workspace_bytes(const pvx_plan* plan) { return plan 
 
 extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
-    if (mode < 0 || mode > 4) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
+    if (mode < 0 || mode > 5) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
+    if (mode == 5 && !pvx_fused_team_supported(plan->nfft, plan->precision, plan->npks)) {
+        pvx_set_error("the team kernel handles nfft in {4096, 8192} at precision=32 with npks <= 64 (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
+        return PVX_ERR_UNSUPPORTED;
+    }
     if (mode == 4 && !pvx_fused_rev_supported(plan->nfft, plan->precision, plan->npks)) {
         pvx_set_error("the descending-order fused kernel handles nfft in {512, 1024, 2048} at precision=32 while npks leaves it enough LDS (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
         return PVX_ERR_UNSUPPORTED;
@@ -366,18 +370,22 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     // fused kernel tables
     const bool can1 = pvx_fused_supported(nfft, precision, npks) != 0, can2 = pvx_fused_mw_supported(nfft, precision, npks) != 0;
     const bool can3 = pvx_fused_ring_supported(nfft, precision, npks) != 0, can4 = pvx_fused_rev_supported(nfft, precision, npks) != 0;
-    if (can1 || can2 || can3 || can4) {
-        std::vector<float> tw(2 * (size_t)nfft);
+    const bool can5 = pvx_fused_team_supported(nfft, precision, npks) != 0;
+    if (can1 || can2 || can3 || can4 || can5) {
+        const size_t ntt = can5 ? (size_t)pvx_fused_team_table_len(nfft) : 0;       // k_fused_team's lane-ordered twiddles follow the table
+        std::vector<float> tw(2 * ((size_t)nfft + ntt));
         const double pi = 3.141592653589793238462643383279502884;
         for (int j = 0; j < nfft; j++) { tw[2 * j] = (float)cos(2.0 * pi * j / (double)nfft); tw[2 * j + 1] = (float)(-sin(2.0 * pi * j / (double)nfft)); }
+        if (ntt) pvx_fused_team_table(nfft, tw.data(), tw.data() + 2 * (size_t)nfft);
         if (hipMalloc(&p->d_twiddle, tw.size() * 4) != hipSuccess || hipMalloc((void**)&p->d_specrow, (size_t)nfft * 4) != hipSuccess) { pvx_set_error("hipMalloc(fused tables) failed"); plan_free(p); return PVX_ERR_ALLOC; }
         if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         // default: one wave per frame where it exists (nfft <= 2048: independent waves walking their rows downwards
         // over one buffer each, k_fused_rev.hip, while npks leaves them enough LDS), several waves per frame above
-        p->fft_mode = can4 ? 4 : can3 ? 3 : (can1 ? 1 : 2);
+        // (nfft 4096 / 8192: teams of such waves, k_fused_team.hip, while npks <= 64; k_fused_mw.hip beyond)
+        p->fft_mode = can4 ? 4 : can3 ? 3 : can1 ? 1 : can5 ? 5 : 2;
         if (const char* e = getenv("PVX_FFT_MODE")) {
             const int m = atoi(e);
-            if (m == 0 || (m == 1 && can1) || (m == 2 && can2) || (m == 3 && can3) || (m == 4 && can4)) p->fft_mode = m;
+            if (m == 0 || (m == 1 && can1) || (m == 2 && can2) || (m == 3 && can3) || (m == 4 && can4) || (m == 5 && can5)) p->fft_mode = m;
         }
         if (const char* e = getenv("PVX_FUSED_BLOCKS")) { const long long v = atoll(e); if (v > 0) p->fused_blocks = v; }
     }
@@ -520,7 +528,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
                         int64_t spec_row = -1) {
     const int64_t total_rows = nsig * (F + 1);
     int rc;
-    if (p->fft_mode >= 1 && p->fft_mode <= 4) {
+    if (p->fft_mode >= 1 && p->fft_mode <= 5) {
         // one launch: window + FFT + peaks, no intermediate arrays (k_fused.hip / k_fused_mw.hip)
         FusedParams fp;
         fp.x = d_x; fp.sig_stride = sig_stride; fp.F = F; fp.total_rows = total_rows;
@@ -534,7 +542,8 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
         rc = (p->fft_mode == 1) ? pvx_launch_fused(fp, p->nfft, x_dtype, s)
            : (p->fft_mode == 2) ? pvx_launch_fused_mw(fp, p->nfft, x_dtype, s)
-           : (p->fft_mode == 3) ? pvx_launch_fused_ring(fp, p->nfft, x_dtype, s) : pvx_launch_fused_rev(fp, p->nfft, x_dtype, s);
+           : (p->fft_mode == 3) ? pvx_launch_fused_ring(fp, p->nfft, x_dtype, s)
+           : (p->fft_mode == 5) ? pvx_launch_fused_team(fp, p->nfft, x_dtype, s) : pvx_launch_fused_rev(fp, p->nfft, x_dtype, s);
         if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }

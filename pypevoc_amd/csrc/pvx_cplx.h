@@ -69,6 +69,15 @@ __device__ __forceinline__ v2f cmul_k(v2f z, v2f w) {
     return __builtin_elementwise_fma(z.xx, w, t);
 }
 
+// z * conj(w): re = fma(z.x, w.x, z.y w.y), im = fma(z.x, -w.y, z.y w.x)  (k_fused_team.hip: the twiddles of the
+// mirrored half of a split transform are the conjugates of the ones the lane already holds)
+__device__ __forceinline__ v2f cmul_conj(v2f z, v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(z), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(z), "v"(w), "v"(t));
+    return r;
+}
+
 // (c.x * z.y, c.y * z.x): with c = (h, -h) this is -i h z
 __device__ __forceinline__ v2f mul_swap(v2f z, v2f c) {
     v2f r;

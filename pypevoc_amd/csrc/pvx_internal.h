@@ -97,6 +97,10 @@ int pvx_fused_ring_supported(int nfft, int precision, int K);   // k_fused_ring.
 int pvx_launch_fused_ring(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_fused_rev_supported(int nfft, int precision, int K);    // k_fused_rev.hip: independent waves, rows in descending order
 int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
+int pvx_fused_team_supported(int nfft, int precision, int K);   // k_fused_team.hip: nfft 4096 / 8192 as teams of k_fused_rev-shaped waves
+int pvx_launch_fused_team(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
+int pvx_fused_team_table_len(int nfft);                          // complex entries it wants appended to the W_nfft^j table
+void pvx_fused_team_table(int nfft, const float* tw, float* out);
 
 // k_stft.hip: fused float64 STFT into the spectrum workspace
 int pvx_stft_supported(int nfft, int precision);

@@ -511,6 +511,73 @@ __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, 
     return C;
 }
 
+// peak_scan_block_thin for ONE SEGMENT of a row that several waves share (k_fused_team.hip): the wave's lanes own the
+// 64 R consecutive bins from kbase on of the n-bin row y (padded layout); the list holds row bins.  The bound T is
+// taken over the segment's own candidates: at least npeaks candidates of the segment reach it, so it is a lower bound
+// of the npeaks-th largest score of the whole row too, and every wave may thin its segment on its own.
+template <int R, typename CI>
+__device__ __forceinline__ int peak_scan_seg_thin(const float* y, int kbase, int n, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
+    static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
+    const float thf = __double2float_rd(th);
+    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
+    const int k0 = kbase + R * lane;
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R / 4; j++) {
+        const float4 q = *(const float4*)(y + ymap<1>(k0 + 4 * j));
+        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+    const float left = y[ymap<1>(k0 > 0 ? k0 - 1 : 0)];
+    const float right = y[ymap<1>(k0 + R < n ? k0 + R : n - 1)];
+    int rise[R + 1];                                                 // sign bit set: y[k-1] < y[k]
+    rise[0] = __float_as_int(left) - __float_as_int(v[0]);
+#pragma unroll
+    for (int i = 1; i < R; i++) rise[i] = __float_as_int(v[i - 1]) - __float_as_int(v[i]);
+    rise[R] = __float_as_int(v[R - 1]) - __float_as_int(right);
+    unsigned m = 0;
+    float sc[R];                                                     // scores y - miny (>= 0)
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        sc[i] = v[i] - miny;
+        const int above = thb - __float_as_int(sc[i]);               // sign bit set: score > thf
+        const unsigned t = (unsigned)(rise[i] & ~rise[i + 1] & above);
+        m = (m << 1) | (t >> 31);
+    }
+    if (k0 + R == n) m &= ~(1u << (R - 1));                          // bin n-1 is not interior
+    auto count = [&](unsigned mm, int& pos) -> int {
+        const int cnt = __popc(mm);
+        int C = 0;
+        pos = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long bal = __ballot(((cnt >> b) & 1) != 0);
+            pos += lane_prefix(bal) << b;
+            C += __popcll(bal) << b;
+        }
+        return C;
+    };
+    int pos;
+    int C = count(m, pos);
+    if (C > 192 && npeaks <= 16) {                                   // wave-uniform (see peak_scan_block_thin)
+        float best = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
+        best = fmaxf(best, dpp_f<0xB1>(best));
+        best = fmaxf(best, dpp_f<0x4E>(best));
+        int beaten = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) beaten += (rl_f(best, 4 * j) > best) ? 1 : 0;
+        const float T = wave_min(beaten < npeaks ? best : INFINITY);
+        unsigned keep = 0u;
+#pragma unroll
+        for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
+        m &= keep;
+        C = count(m, pos);
+    }
+    peak_block_write<R, CI>(ci, kbase, lane, m, pos, trash + lane);
+    return C;
+}
+
 // The dense-candidate branch of peak_pick_regs, kept out of line: it runs on noise-like frames only, and
 // inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
 // layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).

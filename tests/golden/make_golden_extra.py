@@ -8,6 +8,8 @@
                       distance from the bin centre -- pins which one the reference's float64 arithmetic keeps
   G13_blackman_thr01  a non-default window callable (wind=np.blackman) and pkthresh = 0.1
   G14_npks1           npks = 1 on a two-tone signal whose stronger tone changes half way
+  G15_salience        PeakFinder.filter_by_salience with sal != 0 (PeakFinder.py:113-136; off the PV path, which passes
+                      sal = 0): rows of G8's kind, rad in {1, 5}, sal in {-0.05, -0.5, 0.01}
 """
 import os
 import sys
@@ -56,5 +58,33 @@ def main():
     run("G14_npks1", x14, sr, 1024, 256, 1, synth_hop=256)
 
 
+def salience():
+    from pypevoc.PeakFinder import PeakFinder
+    rng = np.random.default_rng(2025)
+    ys = f32exact(np.abs(rng.standard_normal((8, 512))) * np.exp(-np.arange(512) / 200.0))
+    res = {}
+    for rad in (1, 5):
+        for sal in (-0.05, -0.5, 0.01):
+            k = 12
+            pos = -np.ones((len(ys), k), dtype=np.int32)
+            keep = np.zeros((len(ys), k), dtype=np.int8)
+            for i, y in enumerate(ys):
+                pk = PeakFinder(y, npeaks=k, minrattomax=0.005)
+                pk.filter_by_salience(rad=rad, sal=sal)
+                n = len(pk._idx)
+                pos[i, :n] = pk._idx
+                keep[i, :n] = pk._keep
+            tag = "r%d_s%s" % (rad, ("%g" % sal).replace(".", "p").replace("-", "m"))
+            res["pos_" + tag] = pos
+            res["keep_" + tag] = keep
+    path = os.path.join(HERE, "G15_salience.npz")
+    np.savez_compressed(path, ys=ys.astype(np.float32), **res)
+    print("G15_salience: kept", {k: int(v.sum()) for k, v in res.items() if k.startswith("keep")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "salience":
+        salience()
+    else:
+        main()
+        salience()
