@@ -18,7 +18,7 @@
 // Per-frame arithmetic is k_fused.hip's, so results are bit-identical to it and independent of the launch geometry.
 #include <stdlib.h>
 
-#include "pvx_fft.h"
+#include "pvx_fft4.h"
 
 using namespace pvxw;
 using namespace pvxf;
@@ -31,11 +31,12 @@ typedef unsigned short u16;
 
 template <int R> struct RevGeo {
     using G = Geo<R>;
-    static constexpr int TW3N = (G::HALF + 8) & ~7;
+    static constexpr bool X4 = (R == 16);                            // nfft 2048: four 256-point transforms per wave (pvx_fft4.h)
+    static constexpr int TW3N = X4 ? 512 : ((G::HALF + 8) & ~7);
     // block-shared tables (bytes)
-    static constexpr size_t OFF_T1 = 0;                              // v2f [R][64]   W_M^(l q)
-    static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 8;    // v2f [R][P]    W_64^(l1 t2)
-    static constexpr size_t OFF_TW3 = OFF_T2 + 64 * 8;               // v2f [TW3N]    W_nfft^k
+    static constexpr size_t OFF_T1 = 0;                              // v2f [R][64] W_M^(l q)   | X4: [16][16] W_256^(l q)
+    static constexpr size_t OFF_T2 = OFF_T1 + (X4 ? (size_t)256 * 8 : (size_t)R * 64 * 8);    // v2f [R][P] W_64^(l1 t2) | X4: none
+    static constexpr size_t OFF_TW3 = OFF_T2 + (X4 ? 0 : 64 * 8);    // v2f [TW3N] W_nfft^k     | X4: [2][4][64] join / untangle twiddles of the lane
     static constexpr size_t OFF_WAVE = OFF_TW3 + (size_t)TW3N * 8;
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     using G = Geo<R>;
     using RG = RevGeo<R>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
+    constexpr bool X4 = RG::X4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -91,12 +93,20 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     {
         const v2f* tab = (const v2f*)p.twiddle;                     // W_nfft^j, j < nfft
         constexpr int NMASK = G::N - 1;
-        for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
-            const int q = i >> 6, l = i & 63;
-            t1L[i] = tab[(2 * l * q) & NMASK];                      // W_M^(l q)
+        if constexpr (X4) {
+            for (int i = threadIdx.x; i < 256; i += 64 * NW) t1L[i] = tab[((G::N / 256) * (i & 15) * (i >> 4)) & NMASK];     // [q][l] W_256^(l q)
+            for (int i = threadIdx.x; i < 512; i += 64 * NW) {      // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
+                const int ln = i & 63, u = (i >> 6) & 3, k1 = ln + 64 * (i >> 8);
+                tw3[i] = tab[(u == 0 ? k1 : 2 * u * k1) & NMASK];
+            }
+        } else {
+            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+                const int q = i >> 6, l = i & 63;
+                t1L[i] = tab[(2 * l * q) & NMASK];                  // W_M^(l q)
+            }
+            for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
+            for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
         }
-        for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
-        for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
     }
     __syncthreads();
 
@@ -123,9 +133,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     // waves of the workgroup issue at the same moment, right after the barrier
     v2f wv[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[lane + 64 * r];
+    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[(X4 ? lofs4(lane) / 2 : lane) + 64 * r];
 #pragma unroll
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
+
+    auto XA = [](int k) -> int { if constexpr (X4) return xa4(k); else return zpad<R>(k); };      // slot of bin k in `cur`
 
     // ---- rows of this wave: [r0, r1), walked downwards, then row r0 - 1 (spectrum only)
     // row indices fit 32 bits (the launcher checks): 64-bit scalar arithmetic in the frame loop costs SGPR pairs
@@ -141,7 +153,12 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     const int rows1 = Fi + 1;                                       // rows per signal
 
     // (see k_fused_ring.hip: the flush-only kernel arguments are re-read from the kernel argument segment)
-    const FusedParams* const kargs = (const FusedParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    // (in the CONSTANT address space: scalar loads.  As a generic pointer these were flat loads, and the result stores below
+    // flat stores: with flat operations pending the compiler can only wait with vmcnt(0), and it did so at the start of
+    // every frame's peak search -- a wait for the sample prefetch of the NEXT frame, a quarter of the wave's time)
+    typedef const __attribute__((address_space(4))) FusedParams* kargs_t;
+    typedef __attribute__((address_space(1))) double gdouble;
+    const kargs_t kargs = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
 
     v2f raw[R];
 #pragma unroll
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
     };
     auto load_pair = [&](const InT* src, int r) {
-        const InT* q = src + 2 * lane + 128 * r;
+        const InT* q = src + (X4 ? lofs4(lane) : 2 * lane) + 128 * r;      // X4: pair 4 l + u + 64 r of lane 16 u + l
         if constexpr (AL2 && sizeof(InT) == 4) raw[r] = *(const v2f*)q;
         else raw[r] = pvxc::mk(ld1(q), ld1(q + 1));
     };
@@ -196,10 +213,22 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             wave_sync();
             return;
         }
+        float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
+        v2f* dz = (v2f*)dst;
+        if constexpr (X4) {
+            // four 256-point transforms (one per 16-lane group), then the radix-4 join inside the untangle pass (pvx_fft4.h)
+            fft4_quarters(z, dz, t1L, lane, [&]() { prefetch_part(nsrc, 1); }, [&]() { prefetch_part(nsrc, 2); }, [&]() { prefetch_part(nsrc, 3); });
+            v2f tw[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) tw[j][u] = tw3[(j * 4 + u) * 64 + lane];
+            wave_sync();
+            join4_untangle<256, F4::RP, 64>(dz, Ly, tw, lane, IdentityIA(), lmax, lmin, ls0, ls1);
+        } else {
         dft_regs<R>(z);                                             // stage 1
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
-        v2f* dz = (v2f*)dst;
         // two rows at a time, twiddles first: adjacent so that the accesses pair into ds_read2st64 / ds_write2
 #pragma unroll
         for (int q2 = 0; q2 < R; q2 += 2) {
@@ -233,7 +262,6 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         wave_sync();
         // ---- untangle in place (k_fused.hip): pairs (k, M-k), k = lane + 64 j
         constexpr int NPAIR = R / 2;
-        float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
         v2f za[NPAIR], zb[NPAIR], wv8[NPAIR];
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
@@ -265,6 +293,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             Ly[k + 4 * j] = e0; Ly[ymap<1>(kk)] = e1;
             lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
         }
+        }
         const double lsum = (double)ls0 + (double)ls1;
         maxe = wave_max(lmax);
         mine = wave_min(lmin);
@@ -279,7 +308,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
-        const FusedParams* q = kargs;
+        kargs_t q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
         pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
@@ -287,11 +316,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         const bool gvalid = g < ng;
         const int cnt = gvalid ? Lcnt[g] : -1;
         const int64_t orow = gvalid ? (int64_t)Lorow[g] : 0;
-        double* of = q->f + orow * K;
-        double* om = q->mag + orow * K;
-        double* op = q->ph + orow * K;
-        double* orp = q->realph + orow * K;
-        double* ob = q->binno + orow * K;
+        gdouble* of = (gdouble*)q->f + orow * K;
+        gdouble* om = (gdouble*)q->mag + orow * K;
+        gdouble* op = (gdouble*)q->ph + orow * K;
+        gdouble* orp = (gdouble*)q->realph + orow * K;
+        gdouble* ob = (gdouble*)q->binno + orow * K;
         int nout = 0;
         for (int eb = 0; eb < K; eb += LPF) {
             const int e = eb + e0;
@@ -322,8 +351,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             }
             if (e0 == 0) {
                 const int64_t fr = Lfrm[g];
-                if (q->totalmag) q->totalmag[orow] = sqrt(Ltot[g]);                                   // PV.py:210
-                if (q->t) q->t[orow] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;         // PV.py:247
+                if (q->totalmag) ((gdouble*)q->totalmag)[orow] = sqrt(Ltot[g]);                                   // PV.py:210
+                if (q->t) ((gdouble*)q->t)[orow] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;         // PV.py:247
             }
         }
         wave_sync();
@@ -353,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             if (pend_own && !pend_prev0) {
                 // (the usual case: the lane that staged a peak kept its slot and bin -- one LDS round trip)
                 if (own_sl >= 0) {
-                    const float2 pv = cur[zpad<R>(own_pb)];
+                    const float2 pv = cur[XA(own_pb)];
                     Lsval[(size_t)own_sl * 5 + 2] = pv.x;
                     Lsval[(size_t)own_sl * 5 + 3] = pv.y;
                 }
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 const int nbin = Lsbin[sl];
                 float2 pv;
                 if (pend_prev0) pv = make_float2((float)p.prev0[2 * nbin], (float)p.prev0[2 * nbin + 1]);
-                else pv = cur[zpad<R>(nbin)];
+                else pv = cur[XA(nbin)];
                 Lsval[(size_t)sl * 5 + 2] = pv.x;
                 Lsval[(size_t)sl * 5 + 3] = pv.y;
             }
@@ -406,8 +435,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                     nb[2 * d - 2] = Ly[ymap<1>(j0)];
                     nb[2 * d - 1] = Ly[ymap<1>(j1)];
                 }
-                const float2 c = cur[zpad<R>(pb)];
-                const float2 vm = cur[zpad<R>(pb - 1)], vp = cur[zpad<R>(pb + 1)];
+                const float2 c = cur[XA(pb)];
+                const float2 vm = cur[XA(pb - 1)], vp = cur[XA(pb + 1)];
                 int bad = 0;
 #pragma unroll
                 for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
@@ -447,9 +476,9 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     const int sl = ng * kpad + nk + lane_prefix(bal);
-                    const float2 c = cur[zpad<R>(pb)];
+                    const float2 c = cur[XA(pb)];
                     // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
-                    const float2 vm = cur[zpad<R>(pb - 1)], vp = cur[zpad<R>(pb + 1)];
+                    const float2 vm = cur[XA(pb - 1)], vp = cur[XA(pb + 1)];
                     const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
                     const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
                     Lsbin[sl] = pb;
@@ -466,7 +495,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         if (p.spec_out != nullptr && g == p.spec_row) {
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                const float2 v = cur[zpad<R>(lane + 64 * j)];
+                const float2 v = cur[XA(lane + 64 * j)];
                 p.spec_out[2 * (lane + 64 * j)] = v.x;
                 p.spec_out[2 * (lane + 64 * j) + 1] = v.y;
             }

@@ -63,7 +63,7 @@ template <int S> struct TeamGeo {
     static constexpr size_t OFF_T2 = OFF_T1 + 16 * 64 * 8;               // v2f [16][4]   W_64^(l1 t2)
     static constexpr size_t OFF_X = OFF_T2 + 64 * 8;                     // float2 [S][REG]
     static constexpr size_t OFF_Y = OFF_X + (size_t)S * REG * 8;         // float [YLEN]
-    static constexpr size_t OFF_KEYS = OFF_Y + (size_t)YLEN * 4;         // u32 [S][64]
+    static constexpr size_t OFF_KEYS = OFF_Y + (size_t)YLEN * 4;         // u32 [S][64]; before the keys are written: the scan's trash slots
     static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * 64 * 4;    // double [S]
     static constexpr size_t OFF_MISC = OFF_PSUM + (size_t)S * 8;         // int nw[S] | float pmax[S] | float pmin[S] | int val[S][GFT]
     static constexpr size_t OFF_TW = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
@@ -71,9 +71,8 @@ template <int S> struct TeamGeo {
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFT);
-        size_t b = GFT * 8 * 2                                           // orow | tot
-                 + GFT * 4 * 2                                           // cnt | frm
-                 + (size_t)(CAPW + 64) * 2                               // ci (u16) + 64 trash slots
+        size_t b = GFT * 8 + GFT * 4 * 2                                 // tot | orow | cnt
+                 + (size_t)CAPW * 2                                      // ci (u16)
                  + kpad * 4 + gs * kpad * 4                              // sel | sbin
                  + gs * kpad * 5 * 4;                                    // sval
         return (b + 15) & ~(size_t)15;
@@ -112,14 +111,14 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     unsigned wboff = (unsigned)(TG::off_wave(TWL) + TG::per_wave(K) * wid);
     asm volatile("" : "+s"(wboff));
     unsigned char* wb = smem + wboff;
-    long long* const Lorow = (long long*)wb;
-    double* const Ltot = (double*)(Lorow + GFT);
-    int* const Lcnt = (int*)(Ltot + GFT);
-    int* const Lfrm = Lcnt + GFT;
-    u16* const Lci = (u16*)(Lfrm + GFT);
-    int* const Lsel = (int*)(Lci + TG::CAPW + 64);
+    double* const Ltot = (double*)wb;
+    int* const Lorow = (int*)(Ltot + GFT);                          // output row (the launcher checks that rows fit 32 bits)
+    int* const Lcnt = Lorow + GFT;
+    u16* const Lci = (u16*)(Lcnt + GFT);
+    int* const Lsel = (int*)(Lci + TG::CAPW);
     int* const Lsbin = Lsel + kpad;
     float* const Lsval = (float*)(Lsbin + gs * kpad);
+    const int trash0 = (int)(((const unsigned char*)(Lkeys + wid * 64) - (const unsigned char*)Lci) / 2);    // in u16 slots from Lci
     unsigned xoff = (unsigned)(TG::OFF_X + (size_t)REG * 8 * wid);
     asm volatile("" : "+s"(xoff));
     float2* const cur = (float2*)(smem + xoff);                     // this wave's region: exchange matrix, then E_s
@@ -173,7 +172,12 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     const int Fi = (int)p.F;
     const int rows1 = Fi + 1;                                       // rows per signal
 
-    const FusedParams* const kargs = (const FusedParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    // (in the CONSTANT address space: scalar loads.  As a generic pointer these were flat loads, and the result stores below
+    // flat stores: with flat operations pending the compiler can only wait with vmcnt(0), and it did so at the start of
+    // every frame's peak search -- a wait for the sample prefetch of the NEXT frame, a quarter of the wave's time)
+    typedef const __attribute__((address_space(4))) FusedParams* kargs_t;
+    typedef __attribute__((address_space(1))) double gdouble;
+    const kargs_t kargs = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
 
     v2f raw[R];
 #pragma unroll
@@ -260,6 +264,13 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dz[zpad<R>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
         }
+        // the lane's join / untangle twiddles: fetched before the barrier (from L2 / LDS), their latency under its wait
+        __builtin_amdgcn_sched_barrier(0);                          // (not above the transform's last stage: no registers there)
+        v2f twv[NPS][S];
+#pragma unroll
+        for (int j = 0; j < NPS; j++)
+#pragma unroll
+            for (int s = 0; s < S; s++) twv[j][s] = twg[(j * S + s) * T + lt];
         team_sync();                                                // ---- B1: every E_s is in place
         // ---- join + untangle, in place
         v2f* const xz = (v2f*)X;
@@ -305,10 +316,10 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             v2f a[S], b[S];
 #pragma unroll
             for (int s = 0; s < S; s++) { a[s] = xz[s * REG + sa]; b[s] = xz[s * REG + sb]; }
-            const v2f wu = twg[(j * S + 0) * T + lt];               // W_N^k1
+            const v2f wu = twv[j][0];                               // W_N^k1
 #pragma unroll
             for (int s = 1; s < S; s++) {
-                const v2f wj = twg[(j * S + s) * T + lt];           // W_M^(s k1)
+                const v2f wj = twv[j][s];                           // W_M^(s k1)
                 a[s] = pvxc::cmul(a[s], wj);
                 b[s] = pvxc::cmul_conj(b[s], wj);
             }
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
-        const FusedParams* q = kargs;
+        kargs_t q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
         pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = TG::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
@@ -399,11 +410,11 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
 #pragma unroll
             for (int w = 0; w < S; w++) { const int v = Lval[w * GFT + g]; off += (w < wid) ? v : 0; tot += v; }
         }
-        double* of = q->f + orow * K;
-        double* om = q->mag + orow * K;
-        double* op = q->ph + orow * K;
-        double* orp = q->realph + orow * K;
-        double* ob = q->binno + orow * K;
+        gdouble* of = (gdouble*)q->f + orow * K;
+        gdouble* om = (gdouble*)q->mag + orow * K;
+        gdouble* op = (gdouble*)q->ph + orow * K;
+        gdouble* orp = (gdouble*)q->realph + orow * K;
+        gdouble* ob = (gdouble*)q->binno + orow * K;
         if (valid) {
             const int oi = off + __popcll(bal & ((1ull << lane) - 1ull));
             ob[oi] = (double)nbin;
@@ -419,9 +430,9 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 }
             }
             if (wid == 0 && e0 == 0) {
-                const int64_t fr = Lfrm[g];
-                if (q->totalmag) q->totalmag[orow] = sqrt(Ltot[g]);                                   // PV.py:210
-                if (q->t) q->t[orow] = ((double)(fr * (int64_t)pc.hop) + TG::N / 2.0) / q->sr;        // PV.py:247
+                const int64_t fr = orow % (int64_t)Fi;                                                // frame within its signal
+                if (q->totalmag) ((gdouble*)q->totalmag)[orow] = sqrt(Ltot[g]);                                   // PV.py:210
+                if (q->t) ((gdouble*)q->t)[orow] = ((double)(fr * (int64_t)pc.hop) + TG::N / 2.0) / q->sr;        // PV.py:247
             }
         }
         wave_sync();
@@ -475,7 +486,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             const double minamp = (double)maxy * p.thr;             // PF.py:60
             th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
             // this wave's candidates (ascending bins) -> Lci
-            const int C_w = peak_scan_seg_thin<R, u16>(Ly, L * wid, M, mine, th, Lci, TG::CAPW, lane, K);
+            // (non-candidates go to a trash slot per lane: the wave's key row, which is written after the scan)
+            const int C_w = peak_scan_seg_thin<R, u16>(Ly, L * wid, M, mine, th, Lci, trash0, lane, K);
             wave_sync();
             n_w = C_w;
             if (C_w > 64) {
@@ -522,9 +534,9 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         }
         team_sync();                                                // ---- B3: keys exchanged; X and |X|^2 are free for the row below
         if (real) {
-            int ctot = 0, nlow = 0;
+            int ctot = 0;
 #pragma unroll
-            for (int w = 0; w < S; w++) { const int n = Lnw[w]; ctot += n; nlow += (w < wid) ? n : 0; }
+            for (int w = 0; w < S; w++) ctot += Lnw[w];
             slow = (th < 0.0) && (ctot < K);                        // zeros of pkmskamp qualify too (PF.py:166-187): wave 0, below
             bool take = has;
             if (ctot > K) {
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 }
                 team_sync();
             }
-            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = orow; Ltot[ng] = tot; }
+            if (lane == 0) { Lcnt[ng] = nk; Lorow[ng] = (int)orow; Ltot[ng] = tot; }
             ng++;
             pend = true; pend_nk = nk; pend_prev0 = (p.prev0 != nullptr) && (orow == 0);
         }
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
 
 template <int S> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
     using TG = TeamGeo<S>;
-    constexpr bool TWL = (S == 2);
+    constexpr bool TWL = false;                                     // the twiddles come from L2, prefetched before barrier B1
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -658,7 +670,7 @@ void pvx_fused_team_table(int nfft, const float* tw /* [nfft][2] */, float* out)
 int pvx_fused_team_supported(int nfft, int precision, int K) {
     if (precision != 32 || K > 64) return 0;
     switch (nfft) {
-        case 4096: return TeamGeo<2>::total(K, true) <= 160 * 1024;
+        case 4096: return TeamGeo<2>::total(K, false) <= 160 * 1024;
         case 8192: return TeamGeo<4>::total(K, false) <= 160 * 1024;
         default: return 0;
     }

@@ -1,0 +1,174 @@
+// pvx_fft4.h -- a 1024-point complex transform on ONE wave64 as four 256-point ones, joined inside the untangle pass
+// (k_fused_rev.hip at nfft 2048, k_fused_team.hip at nfft 4096 / 8192).
+//
+//   PV.calc_fft_frame   pypevoc/PVAnalysis.py:150-158   (np.fft.fft of the windowed frame; bins 0 .. nfft/2 - 1 are used)
+//
+// z[j], j < 1024 (z[j] = (x w)[2j] + i (x w)[2j+1]).  Decimation in time by 4: lane = 16 u + l (u < 4, l < 16), register
+// r holds z[4 (l + 16 r) + u] -- the lane's float2 sits at sample offset 8 l + 2 u + 128 r, so one load instruction of the
+// wave still covers 512 contiguous bytes.  A 16-lane group then has a 256-point transform to itself and 256 = 16 x 16
+// fits it exactly: radix-16 over r in registers, twiddle W_256^(l q), transpose through LDS inside the group, radix-16
+// over l in registers -> E_u[q + 16 t] in lane (u, q), register t.  There is NO cross-lane butterfly stage (the 16 x 16
+// x 4 form of k_fused.hip spends 64 DPP moves, 48 packed operations and ~40 hazard no-ops per frame on its 4-lane
+// stage): the last radix-4 -- Z[k1 + 256 t] = sum_u W_4^(u t) W_1024^(u k1) E_u[k1] -- is done by the lane that
+// untangles those bins anyway.  With A = DFT_4(E_u[k1] W_1024^(u k1)) and B = DFT_4(E_u[256 - k1] conj W_1024^(u k1)),
+// (A_t, B_((4 - t) mod 4)) are the untangle pairs (Z[k], Z[M - k]) of k = k1 + 256 t: a lane reads the 8 values of k1
+// and 256 - k1 and writes the 8 bins X[k1 + 256 t], X[(256 - k1) + 256 (3 - t)] back to the same 8 slots.  k1 = 0
+// pairs with itself; the mirrored slots of its lane take the k1 = 128 family (bins 128 + 256 u), which pairs within
+// itself.  Index maps and twiddles: tools/models/fft4_model.py (checked against numpy.fft).
+// The same pass joins the 1024-point sub-transforms of a team of 4 waves (k_fused_team.hip, nfft 8192): quarter =
+// a wave's region, index inside a quarter through `IA`.
+#pragma once
+
+#include "pvx_fft.h"
+
+namespace pvxf {
+
+struct F4 {                                  // LDS layout of a wave's buffer (complex slots)
+    static constexpr int EP = 17;            // exchange matrix: pitch of a q row inside a 16-lane group
+    static constexpr int EU = 272;           // exchange matrix: pitch of a group
+    static constexpr int RP = 272;           // natural order: pitch of a 256-bin quarter (16 slots of padding: the four
+                                             // groups of a store / load instruction fall on different banks)
+    static constexpr int BUF = 1088;         // slots per wave
+};
+// bin k of a buffer in natural order; also valid across the regions of a team (4 RP = BUF)
+__device__ __host__ __forceinline__ int xa4(int k) { return (k >> 8) * F4::RP + (k & 255); }
+// sample offset (floats) of the lane's first pair
+__device__ __forceinline__ int lofs4(int lane) { return 8 * (lane & 15) + 2 * (lane >> 4); }
+
+struct IdentityIA { __device__ __forceinline__ int operator()(int i) const { return i; } };
+struct Xa4IA { __device__ __forceinline__ int operator()(int i) const { return xa4(i); } };
+
+constexpr float kC16 = 0.92387953251128673848f;   // cos(pi/8)
+constexpr float kS16 = 0.38268343236508978178f;   // sin(pi/8)
+constexpr float kH8 = 0.70710678118654752440f;    // sqrt(1/2)
+
+// (S = Za + conj Zb, O = -i/2 (Za - conj Zb) W_pair, twiddle w) -> X[k] = S/2 + O w, X[M-k] = conj(S/2 - O w)
+__device__ __forceinline__ void untangle_so(v2f Sm, v2f O, v2f w, v2f& x0, v2f& x1) {
+    const v2f khalf = pvxc::splat(0.5f);
+    const v2f Pk = pvxc::cmul(O, w);
+    x0 = __builtin_elementwise_fma(khalf, Sm, Pk);
+    x1 = pvxc::fms_conj(khalf, Sm, Pk);
+}
+
+// The four pairs (A_t, B_((4-t) mod 4)), t < 4, with untangle twiddles W_8^t wu -> x0[t] = X[k1 + LQ t], x1[t] = X[(LQ - k1) + LQ (3-t)]
+__device__ __forceinline__ void untangle4(const v2f (&A)[4], const v2f (&B)[4], v2f wu, v2f (&x0)[4], v2f (&x1)[4]) {
+    const v2f kmih = pvxc::mk(0.5f, -0.5f), kmh = pvxc::splat(-0.5f);
+    untangle_so(pvxc::add_conj(A[0], B[0]), pvxc::mul_swap(pvxc::sub_conj(A[0], B[0]), kmih), wu, x0[0], x1[0]);
+    untangle_so(pvxc::add_conj(A[1], B[3]), pvxc::cmul_k(pvxc::mul_swap(pvxc::sub_conj(A[1], B[3]), kmih), pvxc::mk(kH8, -kH8)), wu, x0[1], x1[1]);
+    untangle_so(pvxc::add_conj(A[2], B[2]), pvxc::sub_conj(A[2], B[2]) * kmh, wu, x0[2], x1[2]);
+    untangle_so(pvxc::add_conj(A[3], B[1]), pvxc::cmul_k(pvxc::mul_swap(pvxc::sub_conj(A[3], B[1]), kmih), pvxc::mk(-kH8, -kH8)), wu, x0[3], x1[3]);
+}
+
+__device__ __forceinline__ void dft4(const v2f (&a)[4], v2f (&A)[4]) {
+    const v2f e = a[0] + a[2], f = a[0] - a[2], g = a[1] + a[3], h = a[1] - a[3];
+    A[0] = e + g; A[2] = e - g; A[1] = pvxc::add_mni(f, h); A[3] = pvxc::add_pi(f, h);
+}
+
+// The k1 = LQ/2 family: its four values c_u (already read) pair among themselves -> spv[u] = X[LQ/2 + LQ u]
+__device__ __forceinline__ void special4(const v2f (&c)[4], v2f (&spv)[4]) {
+    const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f);
+    const v2f c1 = pvxc::cmul_k(c[1], pvxc::mk(kH8, -kH8)), c2 = pvxc::mni(c[2]), c3 = pvxc::cmul_k(c[3], pvxc::mk(-kH8, -kH8));
+    const v2f A = c[0] + c2, B = c[0] - c2, C = c1 + c3, D = c1 - c3;
+    const v2f z0 = A + C, z2 = A - C, z1 = pvxc::add_mni(B, D), z3 = pvxc::add_pi(B, D);   // Z[LQ/2 + LQ u]
+    {   // (u = 0, 3): twiddle W_16
+        const v2f Sm = pvxc::add_conj(z0, z3), Dd = pvxc::sub_conj(z0, z3);
+        const v2f Pk = pvxc::cmul_k(pvxc::mul_swap(Dd, kmih), pvxc::mk(kC16, -kS16));
+        spv[0] = __builtin_elementwise_fma(khalf, Sm, Pk);
+        spv[3] = pvxc::fms_conj(khalf, Sm, Pk);
+    }
+    {   // (u = 1, 2): twiddle W_16^3
+        const v2f Sm = pvxc::add_conj(z1, z2), Dd = pvxc::sub_conj(z1, z2);
+        const v2f Pk = pvxc::cmul_k(pvxc::mul_swap(Dd, kmih), pvxc::mk(kS16, -kC16));
+        spv[1] = __builtin_elementwise_fma(khalf, Sm, Pk);
+        spv[2] = pvxc::fms_conj(khalf, Sm, Pk);
+    }
+}
+
+// Radix-4 join fused with the untangle, in place.  xz: the buffer (quarter u at u QP, index i of a quarter at IA(i));
+// LQ: points per quarter; T lanes (lt = this one) share the LQ/2 sets, NPS = LQ / (2 T) per lane; tw[j] = {W_N^k1,
+// W_M^k1, W_M^(2 k1), W_M^(3 k1)} of k1 = lt + T j (M = 4 LQ, N = 2 M).  |X|^2 of every bin -> Ly (padded layout);
+// lmax / lmin / ls0 / ls1 accumulate the lane's max, min and sums of |X|^2.
+template <int LQ, int QP, int T, typename IA>
+__device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&tw)[LQ / (2 * T)][4], int lt, IA ia,
+                                               float& lmax, float& lmin, float& ls0, float& ls1) {
+    constexpr int NPS = LQ / (2 * T);
+    v2f spv[4];
+    {
+        v2f c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = xz[u * QP + ia(LQ / 2)];
+        special4(c, spv);
+    }
+#pragma unroll
+    for (int j = 0; j < NPS; j++) {
+        const int k1 = lt + T * j;
+        const int kb = (LQ - k1) & (LQ - 1);
+        const int sa = ia(k1);
+        int sb = ia(kb);
+        v2f a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = xz[u * QP + sa]; b[u] = xz[u * QP + sb]; }
+#pragma unroll
+        for (int u = 1; u < 4; u++) {
+            a[u] = pvxc::cmul(a[u], tw[j][u]);
+            b[u] = pvxc::cmul_conj(b[u], tw[j][u]);
+        }
+        v2f A[4], B[4], x0[4], x1[4];
+        dft4(a, A);
+        dft4(b, B);
+        untangle4(A, B, tw[j][0], x0, x1);
+        int kbb = kb;                                               // bins of the mirrored slots: kbb + LQ (3 - t)
+        if (j == 0) {
+            if (lt == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) x1[t] = spv[3 - t];
+                kbb = LQ / 2; sb = ia(LQ / 2);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
+            xz[t * QP + sa] = x0[t];                                // X[k1 + LQ t]
+            xz[(3 - t) * QP + sb] = x1[t];                          // X[kbb + LQ (3 - t)]
+            Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
+            Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
+            lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
+        }
+    }
+}
+
+// The four 256-point transforms of a wave, stages 1 and 2 (between them the transpose inside the 16-lane groups), and
+// the natural-order store: quarter u of `dz`, E_u[k'] at u RP + k'.  z: the lane's 16 windowed values.
+// t1: LDS table [16][16] W_256^(l q).  HOOK1 / HOOK2 run after stage 1 / during the transpose (the callers issue
+// their sample prefetches there).
+template <typename H1, typename H2, typename H3>
+__device__ __forceinline__ void fft4_quarters(v2f (&z)[16], v2f* dz, const v2f* t1, int lane, H1 hook1, H2 hook2, H3 hook3) {
+    using pvxw::wave_sync;
+    dft_regs<16>(z);                                                // stage 1: radix-16 over r
+    __builtin_amdgcn_sched_barrier(0);
+    hook1();
+    const int l = lane & 15, u = lane >> 4;
+    v2f* const ew = dz + u * F4::EU + l;
+    // two rows at a time, twiddles first: adjacent so that the accesses pair into ds_read2 / ds_write2
+#pragma unroll
+    for (int q2 = 0; q2 < 16; q2 += 2) {
+        const v2f ta = t1[q2 * 16 + l], tb = t1[(q2 + 1) * 16 + l];
+        const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], ta) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tb);
+        ew[q2 * F4::EP] = pa;
+        ew[(q2 + 1) * F4::EP] = pb2;
+    }
+    wave_sync();
+    const v2f* const er = dz + u * F4::EU + l * F4::EP;
+#pragma unroll
+    for (int l2 = 0; l2 < 16; l2++) z[l2] = er[l2];
+    hook2();
+    wave_sync();
+    dft_regs<16>(z);                                                // stage 2: radix-16 over l
+    __builtin_amdgcn_sched_barrier(0);
+    hook3();
+    v2f* const nw = dz + u * F4::RP + l;
+#pragma unroll
+    for (int t = 0; t < 16; t++) nw[16 * t] = z[t];                 // E_u[l + 16 t]
+}
+
+}  // namespace pvxf

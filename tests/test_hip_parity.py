@@ -414,8 +414,9 @@ def test_fused_kernel_variants(amd, oracle):
             res[mode] = p
         for name in ("f", "mag", "ph", "realph", "binno", "totalmag"):
             assert np.array_equal(np.asarray(getattr(res[3], name)), np.asarray(getattr(res[1], name))), name
-            assert np.array_equal(np.asarray(getattr(res[4], name)), np.asarray(getattr(res[1], name))), name
-        assert np.array_equal(res[3].oldfft, res[1].oldfft) and np.array_equal(res[4].oldfft, res[1].oldfft)
+        assert np.array_equal(res[3].oldfft, res[1].oldfft)
+        # (mode 4 at nfft 2048 is another transform -- pvx_fft4.h -- with its own float32 rounding: same peaks, values to tolerance)
+        assert np.array_equal(res[4].binno, res[1].binno) and np.abs(res[4].f - res[1].f).max() <= 2e-3
     p = run_pv(amd, x, sr, nfft, 512, K, precision=32)
     assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 4          # the default where it fits
     p = run_pv(amd, x, sr, nfft, 512, 200, precision=32)
@@ -487,8 +488,7 @@ def test_fused_kernel_variants(amd, oracle):
         assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
 
 
-@pytest.mark.parametrize("kmode", [3, 4])
-@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+@pytest.mark.parametrize("nfft,kmode", [(2048, 3), (1024, 3), (512, 3), (1024, 4), (512, 4)])
 def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmode):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
     of spectra, hand-off through progress counters in LDS) does the arithmetic of mode 1 (k_fused.hip, which the
@@ -496,7 +496,9 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmo
     (dense candidates -> radix select, exact silence -> zero rows and x/0 frames, threshold 0 -> zero fill),
     npks, hop, input type, number of signals in the call (zero rows between signals; F = 1) or grid.  The same holds
     for fft mode 4 (k_fused_rev.hip: independent waves walking their rows downwards over one buffer each, the
-    previous spectrum of a frame's peaks picked up one row later; sliding sample window at hop = nfft/4, nfft/2)."""
+    previous spectrum of a frame's peaks picked up one row later; sliding sample window at hop = nfft/4, nfft/2) at nfft
+    1024 and 512; at nfft 2048 mode 4 runs another transform (four 256-point ones per wave, pvx_fft4.h: same results to
+    float32 round-off, not bit for bit) and is pinned by test_team_kernel_against_oracle_and_itself."""
     from pypevoc_amd import _lib
     rng = np.random.default_rng(77)
     sr = 44100.0
@@ -553,9 +555,9 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmo
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
 
 
-@pytest.mark.parametrize("nfft", [4096, 8192])
-def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft):
-    """fft mode 5 (k_fused_team.hip: nfft 4096 / 8192 as teams of 2 / 4 waves, each a k_fused_rev-shaped wave over a
+@pytest.mark.parametrize("nfft,kmode", [(2048, 4), (4096, 5), (8192, 5)])
+def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft, kmode):
+    """fft mode 4 at nfft 2048 (k_fused_rev.hip with the four-quarter transform of pvx_fft4.h) and fft mode 5 (k_fused_team.hip: nfft 4096 / 8192 as teams of 2 / 4 waves, each a k_fused_rev-shaped wave over a
     1024-point sub-transform, joined inside the untangle pass; every wave selects, filters and emits its own segment's
     peaks) against the oracle on dense (noise: thinning, per-segment radix select, cross-wave ranking), sparse, silent
     (zero rows, x/0 frames) and quantised (exact ties) input, every npks regime (1, fewer / more than the candidates,
@@ -571,7 +573,7 @@ def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft):
     gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
     quant = np.round(harm * 50) / 50
     high = 0.2 * np.sin(2 * np.pi * 0.23 * sr * t) + 0.1 * np.sin(2 * np.pi * 0.249 * sr * t) + 0.02 * rng.standard_normal(n)   # peaks in every wave's segment
-    monkeypatch.setenv("PVX_FFT_MODE", "5")
+    monkeypatch.setenv("PVX_FFT_MODE", str(kmode))
 
     def same(a, b, what):
         for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
@@ -582,16 +584,16 @@ def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft):
         for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (64, 0.005, nfft // 8),
                             (8, 0.005, nfft // 2), (40, 0.0005, nfft // 4)):
             p = run_pv(amd, x, sr, nfft, hop, K, thr, precision=32)
-            assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 5
+            assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == kmode
             o = oracle.analyze(x, sr, nfft, hop, K, thr)
             c = compare_analysis(pv_result(p), o, nfft, hop, sr)
             if name == "gaps":
                 # frames that hold only a sliver of signal at the edge of the window (|X| ~ 1e-5 of the signal's level,
                 # side lobes within a float32 ulp of each other): which bin tops a lobe is decided by rounding in ANY
                 # float32 transform (fft mode 2 differs from the oracle on the same frames); a few such frames are allowed
-                # to differ and the magnitudes get the headroom of log2(nfft) = 12..13 rounding steps
+                # to differ and the magnitudes / phases of those frames' peaks get twice the usual float32 headroom
                 assert c["bad_peaks"] <= max(2 * K, 0.06 * c["ref_peaks"]), c
-                assert c["ph_norm"] <= 2e-6 and c["realph_norm"] <= 2e-5 and c["f_norm"] <= 2e-5 and c["mag_norm"] <= 2e-6 and c["totalmag_rel"] <= 1e-6, c
+                assert c["ph_norm"] <= 4e-6 and c["realph_norm"] <= 2e-5 and c["f_norm"] <= 2e-5 and c["mag_norm"] <= 2e-6 and c["totalmag_rel"] <= 1e-6, c
             else:
                 assert_f32(c, absolute=False)
     for xin in (noise.astype(np.float32), np.round(harm * 20000).astype(np.int16), harm):
@@ -625,6 +627,8 @@ def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft):
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
     # npks > 64 stays with the multi-wave kernel
     monkeypatch.delenv("PVX_FFT_MODE")
+    if kmode != 5:
+        return
     p = run_pv(amd, harm, sr, nfft, nfft // 4, 65, precision=32)
     assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 2
     p = run_pv(amd, harm, sr, nfft, nfft // 4, 64, precision=32)
@@ -768,6 +772,10 @@ def test_full_size_config2_properties(amd, oracle, monkeypatch):
         monkeypatch.setenv(*env)
         q = run_pv(amd, x, sr, nfft, hop, K)
         monkeypatch.delenv(env[0])
+        if env[0] == "PVX_FFT_MODE":
+            # (another transform since the default's four-quarter form, pvx_fft4.h: same peaks, values to float32 round-off)
+            assert np.array_equal(p.binno, q.binno) and np.abs(p.f - q.f).max() <= 1e-3 and np.abs(p.mag - q.mag).max() <= 1e-6 * p.mag.max()
+            continue
         for k in ("f", "mag", "ph", "realph", "binno", "t"):
             assert np.array_equal(getattr(p, k), getattr(q, k)), (env, k)
         assert p.totalmag == q.totalmag

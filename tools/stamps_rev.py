@@ -1,0 +1,36 @@
+"""Where a wave of k_fused_rev (nfft 2048) spends its cycles: s_memtime stamps of an instrumented build.
+   bash tools/ab/buildstamp_rev.sh && PVX_LIB=tools/ab/libpvx_st.so python tools/stamps_rev.py [noise]"""
+import ctypes, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PVX_STAMPS"] = "1"
+import bench
+from pypevoc_amd import _lib
+lib = _lib.load(); _lib.init(0)
+dev = torch.device("cuda", 0)
+noise = len(sys.argv) > 1 and sys.argv[1] == "noise"
+x = (0.1 * torch.randn(44100 * 600, device=dev)) if noise else torch.from_numpy(bench.c2_signal(600)).to(dev); nsamp = x.numel()
+F = int(lib.pvx_nframes(nsamp, 2048, 512)); K = 8
+packed = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev); base = packed.data_ptr()
+ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
+plan = ctypes.c_void_p(); win = np.hanning(2048)
+_lib.check(lib.pvx_plan_create(ctypes.byref(plan), 44100.0, 2048, 512, K, 0.005, _lib.dptr(win), 32, 0), "plan")
+raw = ctypes.CDLL(_lib.LIB_PATH)
+raw.pvx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+for _ in range(3):
+    lib.pvx_analyze_dev(plan, x.data_ptr(), 0, nsamp, 1, nsamp, *ptrs, None, None)
+torch.cuda.synchronize()
+raw.pvx_debug_stamps(plan, None, 1)
+n = 5
+for _ in range(n):
+    lib.pvx_analyze_dev(plan, x.data_ptr(), 0, nsamp, 1, nsamp, *ptrs, None, None)
+NS = 14
+out = (ctypes.c_uint64 * NS)()
+raw.pvx_debug_stamps(plan, out, 0)
+names = ["0 loop top, row bookkeeping, window multiply", "1 slide + sample loads issued", "2 stage 1 (radix-16)", "3 twiddle + exchange write + reads issued",
+         "4 exchange reads landed + stage 2", "5 natural-order store + twiddle reads, drained", "6 join + untangle + |X|^2 stores", "7 wave reductions (max / min / sum)",
+         "8 previous-spectrum pick-up (+ flush every 8th frame)", "9 candidate scan + list", "10 fetch, rank, salience, staging", "11 loop bottom", "12 (explicit vmcnt(0) after the transform)", "13 (PVX_FUSED_BLOCKS=-5: vmcnt(0) right behind the sample loads = their raw latency)"]
+tot = sum(out)
+frames = n * (F + 2048)          # every wave also transforms the row above its range
+for i in range(NS):
+    print("%-58s %8.1f ticks/frame  %5.1f %%" % (names[i], out[i] / frames, 100.0 * out[i] / max(tot, 1)))
+print("total %.1f s_memtime ticks per frame (100 MHz ticks x clock ratio; two waves share a SIMD)" % (tot / frames))

@@ -36,7 +36,7 @@ def main():
     n = sr * secs
     x = signal(n, sr)
     stream = torch.cuda.current_stream(dev)
-    for nfft in (512, 1024, 2048, 4096, 8192):
+    for nfft in [int(v) for v in os.environ.get("PVX_SWEEP_NFFT", "512,1024,2048,4096,8192").split(",")]:      # PVX_SWEEP_NFFT: a subset
         for hop in (nfft // 4, nfft // 2):
             F = int(lib.pvx_nframes(n, nfft, hop))
             out = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev)
