@@ -97,13 +97,41 @@ def alg_bytes(nfft=NFFT, hop=HOP, npks=NPKS, s=4, c=8):
                 fused=hop * s + out, contract=hop * s + 2 * nfft * s + 2 * (nfft // 2 + 1) * c + out)
 
 
-def f64_traffic():
-    """Measured HBM bytes per launch of k_stft_pv<16, double> on C2 (profiles/r02_traffic_f64.json; tools/prof_traffic.sh)."""
+def csrc_sha16():
+    """Fingerprint of the kernel sources this library was built from (profiles taken with other sources are not quoted)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pypevoc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pypevoc_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel):
+    """HBM bytes per C2 launch of `kernel` from profiles/traffic_latest.json (rocprofv3 PMC, tools/prof_traffic.sh) -- a
+    COMMITTED profile, not a measurement of this run: it is only quoted when it was taken with the kernel sources of
+    this build.  Returns (bytes or None, provenance dict)."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_f64.json")))["kernels"]["k_stft_pv"]
-        return int(d["read_bytes"] + d["write_bytes"])
+        ent = json.load(open(path)).get(kernel)
     except Exception:
-        return None
+        ent = None
+    if not isinstance(ent, dict):
+        return None, dict(source="profiles/traffic_latest.json", note="no entry for %s" % kernel)
+    prov = dict(source="profiles/traffic_latest.json (committed rocprofv3 PMC profile, not measured in this run)",
+                symbol=ent.get("symbol"), profile_csrc_sha16=ent.get("csrc_sha16"), build_csrc_sha16=csrc_sha16(), tag=ent.get("tag"))
+    if ent.get("csrc_sha16") != prov["build_csrc_sha16"]:
+        prov["note"] = "profile predates the kernel sources of this build: not quoted"
+        return None, prov
+    return int(ent["bytes"]), prov
+
+
+def free_port():
+    """A rendezvous port nobody is listening on (bound to port 0 and released)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
 
 def self_launch(args, argv):
@@ -113,29 +141,41 @@ def self_launch(args, argv):
     if have < args.gpus:
         sys.stderr.write("bench.py --gpus %d: this node shows %d GPU(s)\n" % (args.gpus, have))
         return 2
-    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    port = os.environ.get("MASTER_PORT") or str(free_port())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    got_line = False
     for ln in p.stdout.splitlines():            # rank 0 prints the one JSON line; pass anything else to stderr
+        got_line = got_line or ln.startswith("{")
         (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
-    return p.returncode
+    if p.returncode != 0:                       # any rank failing fails the launcher (torch.distributed.run's exit code)
+        sys.stderr.write("bench.py --gpus %d: the %d-rank child run exited with code %d\n" % (args.gpus, args.gpus, p.returncode))
+        return p.returncode
+    if not got_line:
+        sys.stderr.write("bench.py --gpus %d: rank 0 printed no result line\n" % args.gpus)
+        return 4
+    return 0
 
 
 def issue_bound(kernel_name, frames_per_launch, ms_per_launch):
-    """Instruction-issue / LDS view of a fused kernel from the committed SQ counters (profiles/r02_fused_sq.json:
-    rocprofv3 --pmc over tools/run_mode.py, per-launch means) scaled to this run's launch duration."""
-    path = os.path.join(ROOT, "profiles", "r02_fused_sq.json")
+    """Instruction-issue / LDS view of a fused kernel from the COMMITTED SQ counters (profiles/sq_latest.json: rocprofv3
+    --pmc over tools/run_mode.py, per-launch means) scaled to this run's launch duration; only quoted when the profile
+    was taken with the kernel sources of this build."""
+    path = os.path.join(ROOT, "profiles", "sq_latest.json")
     try:
         prof = json.load(open(path))
     except Exception:
         return None
+    if prof.get("_csrc_sha16") != csrc_sha16():
+        return dict(kernel=kernel_name, source="profiles/sq_latest.json", note="profile predates the kernel sources of this build: not quoted",
+                    profile_csrc_sha16=prof.get("_csrc_sha16"), build_csrc_sha16=csrc_sha16())
     ent = None
     for k, v in prof.items():
-        if kernel_name in k:
+        if kernel_name in k and isinstance(v, dict):
             ent = v
     if not ent:
         return None
@@ -147,7 +187,7 @@ def issue_bound(kernel_name, frames_per_launch, ms_per_launch):
     # f64 instructions for ~4.4 (measured, profiles/r02_ubench_valu_issue_cost.txt)
     slow = (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
             + c.get("SQ_INSTS_VALU_ADD_F32", 0) + c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0)) * scale
-    out = dict(kernel=kernel_name, source="profiles/r02_fused_sq.json",
+    out = dict(kernel=kernel_name, source="profiles/sq_latest.json (committed rocprofv3 --pmc profile of this build's sources, scaled to this run's launch duration)",
                valu_insts_per_launch=int(valu),
                valu_issue=dict(bound="valu_issue", unit="wave-instructions/s", achieved=valu / (ms_per_launch * 1e-3),
                                peak=1024 * 2.4e9 / 2.0, frac=round(valu * 2.0 / simd_cycles, 4),
@@ -169,20 +209,23 @@ def cpu_baseline(x_host, sr, o_full, dt_single):
     ncpu = os.cpu_count() or 1
     F = len(o_full["t"])
     nthr = max(1, min(ncpu, F // 64))
-    xs = x_host.astype(np.float64)
+    xs = x_host.astype(np.float64)                                  # outside the clock, like the GPU side's resident input
     bounds = [F * i // nthr for i in range(nthr + 1)]
 
     def work(i):
         f0, f1 = bounds[i], bounds[i + 1]
-        seg = xs[f0 * HOP: (f1 - 1) * HOP + NFFT + 1]
+        seg = xs[f0 * HOP: (f1 - 1) * HOP + NFFT + 1]               # a view: no copy
         return len(pvoracle.analyze(seg, sr, NFFT, HOP, NPKS)["t"])
-    t0 = time.perf_counter()
     with ThreadPoolExecutor(nthr) as ex:
-        done = sum(ex.map(work, range(nthr)))
-    dt_all = time.perf_counter() - t0
+        list(ex.map(lambda i: pvoracle.analyze(xs[: NFFT + HOP + 1], sr, NFFT, HOP, NPKS), range(nthr)))   # threads started, library paged in
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(3):                                          # three passes: ~0.1 s each on a 256-thread host
+            done += sum(ex.map(work, range(nthr)))
+        dt_all = time.perf_counter() - t0
     return dict(value=round(done / dt_all, 1), unit="frames/s", cores=nthr, kind="port",
-                sample="the full N=1 workload once (%d frames): oracle/pvoracle.c, %d threads over contiguous frame "
-                       "ranges, %.2f s wall; host shows %d cores" % (done, nthr, dt_all, ncpu),
+                sample="the full N=1 workload three times (%d frames): oracle/pvoracle.c, a warm pool of %d threads over "
+                       "contiguous frame ranges, float64 input prepared beforehand, %.2f s wall; host shows %d cores" % (done, nthr, dt_all, ncpu),
                 single_thread=dict(value=round(F / dt_single, 1), cores=1, seconds=round(dt_single, 2)),
                 reference_python=dict(value=3518.0, unit="frames/s", cores=1,
                                       host="Intel Xeon @ 2.10 GHz (build container; the Python reference does not "
@@ -200,14 +243,19 @@ def main():
     ap.add_argument("--workload", default="c2", choices=tuple(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f64 / noise / violin lines (N = 1 only anyway)")
-    ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: general path; 1, 2, 3, 4: fused kernels")
+    ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: general path; 1 ... 5: fused kernels")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: consecutive steps alternate between two streams (hides the launch gap and the kernel tail; "
                          "per-kernel durations then overlap and no longer compare with rocprofv3's)")
     ap.add_argument("--seconds", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--shard-signals", type=int, default=0, help=argparse.SUPPRESS)    # tests: fewer signals per GPU than the workload's
+    ap.add_argument("--check-gathered", type=int, default=0,
+                    help="with a gather (N > 1, or PVX_BENCH_FORCE_GATHER=1): compare the gathered + unpacked results of rank 0's first "
+                         "that many signals with the oracle (non-zero exit code on a miss)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # PVX_BENCH_SELF_LAUNCH=1: take the launcher path even for one rank (tests: what `--gpus 8` does on an 8-GPU node)
+    if (args.gpus > 1 or os.environ.get("PVX_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
 
     import torch
@@ -236,6 +284,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.seconds:
         wl["seconds"] = args.seconds
+    if args.shard_signals:
+        wl["nsig"] = args.shard_signals
     sr = wl["sr"]
     x_host = None
     if args.workload == "c2":
@@ -331,10 +381,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- clock ramp: the card idles at a low power state and takes tens of milliseconds of continuous work to reach
-    # its running clocks -- W = 5 steps are 0.8 ms.  Untimed passes of the same step for --clock-warmup-ms (a steady
-    # job's state; measured: 326 M frames/s straight from idle, 358 M over 200 steps, 369 M over 1000), then the W warm-up
-    # steps and the K timed steps of the contract.
+    def timed(nsteps):
+        """Exactly nsteps steps between two fences; returns (wall seconds, HIP-event ms, result block index of the last step)."""
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        e0.record(cstreams[0])
+        if args.streams == 2:
+            cstreams[1].wait_event(e0)
+        last = 0
+        for _ in range(nsteps):
+            last = step()
+        if args.streams == 2:
+            cstreams[0].wait_stream(cstreams[1])
+        e1.record(cstreams[0])
+        fence()
+        return time.perf_counter() - t0, e0.elapsed_time(e1), last
+
+    # ---- from idle first: the W warm-up steps and the K timed steps exactly as the contract says, on a card that has
+    # just been handed the workload (a step is 0.14 ms: W + K steps are 3 ms of work and the card needs tens of
+    # milliseconds of continuous work to leave its idle clocks) -> `value_from_idle`
+    idle = None
+    if args.clock_warmup_ms > 0:
+        for _ in range(args.warmup):
+            step()
+        idle = timed(args.steps)
+    # ---- clock ramp, then the same W + K again -> `value`: untimed passes of the same step for --clock-warmup-ms
+    # (a steady job's state; measured: 326 M frames/s straight from idle, 358 M over 200 steps, 369 M over 1000)
     ramp_steps = 0
     if args.clock_warmup_ms > 0:
         # (the analysis launch alone, into block 0: no pack, no collective -- the ranks of a multi-GPU run loop by wall
@@ -354,22 +428,7 @@ def main():
         step()
     fence()
     # ---- timed region: exactly K steps
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    e0.record(cstreams[0])
-    if args.streams == 2:
-        cstreams[1].wait_event(e0)
-    last = 0
-    for _ in range(args.steps):
-        last = step()
-    if args.streams == 2:
-        cstreams[0].wait_stream(cstreams[1])
-    e1.record(cstreams[0])
-    fence()
-    elapsed_local = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
+    elapsed_local, ev_ms, last = timed(args.steps)
     res = res2[last]
     # ---- the same K steps once more with libpvx_hip's stage events on the launch stream: per-kernel
     # launch durations for the roofline line (kept out of the timed region: the extra event records
@@ -384,15 +443,19 @@ def main():
     _lib.check(lib.pvx_plan_set_timing(plan, 0), "pvx_plan_set_timing")
     fft_mode = int(lib.pvx_plan_get_fft_mode(plan))
     elapsed = elapsed_local
+    elapsed_idle = idle[0] if idle else None
     per_rank_ms = [elapsed_local / args.steps * 1e3]
     if world > 1:
-        tl = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        tl = torch.tensor([elapsed_local, idle[0] if idle else 0.0], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(tl) for _ in range(world)]
         dist.all_gather(allt, tl)
-        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
-        elapsed = max(float(t.item()) for t in allt)
+        per_rank_ms = [float(t[0].item()) / args.steps * 1e3 for t in allt]
+        elapsed = max(float(t[0].item()) for t in allt)
+        if idle:
+            elapsed_idle = max(float(t[1].item()) for t in allt)
 
     gather_info = None
+    gather_check_failed = False
     if gathered and rank == 0:
         # the block rank 0 received from itself must be, bit for bit, what its kernels wrote
         torch.cuda.synchronize(dev)
@@ -402,6 +465,27 @@ def main():
         gather_info = dict(collective="one asynchronous RCCL gather per step to rank 0, double-buffered",
                            rccl_world=int(dist.get_world_size()), wire_bytes_per_rank=int(wire.nbytes),
                            result_bytes_per_rank=int(wire.result_numel() * 8), valid_peaks_gathered=n_ok)
+        if args.check_gathered > 0:
+            # what arrived through pack -> RCCL gather -> unpack, against the oracle on the signals themselves
+            from oracle import pvoracle
+            from tests.parity import compare_analysis
+            pvoracle.build()
+            hfull = full[0].cpu().numpy()
+            nchk = min(args.check_gathered, nsig)
+            bad = []
+            for b in range(nchk):
+                ob = pvoracle.analyze(x[b].cpu().numpy().astype(np.float64), sr, NFFT, HOP, NPKS)
+                got = {k: hfull[i * FT * K:(i + 1) * FT * K].reshape(FT, K)[b * F:(b + 1) * F] for i, k in enumerate(("f", "mag", "ph", "realph", "binno"))}
+                got["totalmag"] = hfull[5 * FT * K: 5 * FT * K + FT][b * F:(b + 1) * F]
+                c = compare_analysis(got, ob, NFFT, HOP, sr)
+                if not (c["bad_peaks"] <= 1e-3 * max(c["ref_peaks"], 1) and c["ph_norm"] <= 2e-6 and c["realph_norm"] <= 2e-5 and c["f_norm"] <= 2e-5
+                        and c["mag_norm"] <= 1e-6 and c["totalmag_rel"] <= 1e-6):
+                    bad.append(b)
+            gather_info["checked_signals"] = nchk
+            gather_info["check_ok"] = not bad
+            if bad:
+                sys.stderr.write("bench.py: gathered results of signals %s differ from the oracle\n" % bad)
+                gather_check_failed = True
 
     rc = 0
     if rank == 0:
@@ -409,7 +493,7 @@ def main():
         frames_total = FT * world * args.steps
         value = frames_total / elapsed
         # fft mode 0 with a stage-3 span: k_stft_pv.hip (general path, STFT + peaks in one launch, spectrum rows still written)
-        kname = {0: "k_stft_pv", 1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring", 4: "k_fused_rev"}.get(fft_mode, "k_fused_pv")
+        kname = {0: "k_stft_pv", 1: "k_fused_pv", 2: "k_fused_mw", 3: "k_fused_ring", 4: "k_fused_rev", 5: "k_fused_team"}.get(fft_mode, "k_fused_pv")
         # general path: k_stft.hip writes the spectrum rows when it can (no frame buffer, no rocFFT launches)
         names = ["k_stft" if (nl[0] > 0 and nl[1] == 0) else "k_frames", "rocfft_r2c", "k_phase_peaks", kname]
         s_in = 4 if args.precision == 32 else 8
@@ -425,21 +509,15 @@ def main():
                 per.append(dict(kernel=names[i], ms_per_launch=dur * 1e3, launches=int(nl[i]),
                                 alg_bytes_per_frame=abk[i], achieved_GBps=ach / 1e9))
         dom = max(per, key=lambda d: d["ms_per_launch"] * d["launches"]) if per else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if dom and os.path.exists(tpath) and args.workload == "c2" and not args.seconds:
-            try:
-                traffic = json.load(open(tpath)).get(dom["kernel"])
-            except Exception:
-                traffic = None
-        if dom and traffic is None and dom["kernel"] == "k_stft_pv" and args.precision == 64 and args.workload == "c2" and not args.seconds:
-            traffic = f64_traffic()
+        traffic, traffic_prov = None, None
+        if dom and args.workload == "c2" and not args.seconds:
+            traffic, traffic_prov = committed_traffic(dom["kernel"] if args.precision == 32 else dom["kernel"] + "_f64")
         roofline = None
         if dom:
             fpl = FT * args.steps / dom["launches"]
             roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["achieved_GBps"], 1),
                             peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(dom["achieved_GBps"] * 1e9 / HBM_PEAK, 4),
-                            traffic=traffic, ms_per_launch=round(dom["ms_per_launch"], 4),
+                            traffic=traffic, traffic_provenance=traffic_prov, ms_per_launch=round(dom["ms_per_launch"], 4),
                             alg_bytes_per_frame=dom["alg_bytes_per_frame"],
                             alg_bytes_per_launch=int(dom["alg_bytes_per_frame"] * fpl),
                             traffic_over_algorithmic=(round(traffic / (dom["alg_bytes_per_frame"] * fpl), 3) if traffic else None),
@@ -448,7 +526,7 @@ def main():
                             note="the fused kernels are not HBM-bound: `issue` prices the same launch against vector "
                                  "issue and LDS; throughput_vs_60pct_target = per-GPU frames/s over north_star's "
                                  "1.365e8 frames/s (60 % of 8 TB/s at the 35 168 B/frame of the three-kernel split)")
-            if fft_mode in (1, 2, 3, 4):
+            if fft_mode in (1, 2, 3, 4, 5):
                 roofline["issue"] = issue_bound(dom["kernel"], fpl, dom["ms_per_launch"])
         stage_s = sum(ms[i] for i in range(4)) * 1e-3 / args.steps
         stage = dict(fft_mode=fft_mode, ms_per_step_kernels=round(stage_s * 1e3, 4),
@@ -457,9 +535,51 @@ def main():
 
         extras_ok = world == 1 and args.workload == "c2" and not args.no_extras
         self_check = cpu = None
+        checks_failed = []
+
+        def check_block(h, o, F_, K_, nfft, hop, precision, what, well_conditioned=True):
+            """A timed result block (host copy, the reference's layout) against the oracle's result on the same signal,
+            every frame; the tolerances of tests/test_hip_parity.py.  `well_conditioned=False` (noise, recordings at float32:
+            thousands of peaks a float32 ulp apart in magnitude): the normalised errors only, and the share of frames whose
+            peak set differs is reported, bounded at 1 %."""
+            from tests.parity import compare_analysis
+            got = {k: h[i * F_ * K_:(i + 1) * F_ * K_].reshape(F_, K_) for i, k in enumerate(("f", "mag", "ph", "realph", "binno"))}
+            got["totalmag"] = h[5 * F_ * K_: 5 * F_ * K_ + F_]
+            c = compare_analysis(got, o, nfft, hop, sr)
+            shares = None
+            if precision == 32:
+                ok = c["ph_norm"] <= 2e-6 and c["mag_norm"] <= 1e-6 and c["totalmag_rel"] <= 1e-6
+                if well_conditioned:
+                    ok = ok and (c["realph_norm"] <= 2e-5 and c["f_norm"] <= 2e-5 and c["bad_peaks"] <= 1e-3 * max(c["ref_peaks"], 1)
+                                 and c["f_abs"] <= 1e-3 and c["mag_rel"] <= 1e-5 and c["ph_abs"] <= 2e-5)
+                else:
+                    # f and realph come from the phase difference to the previous frame's bin: over a weak previous bin they are
+                    # ill-conditioned beyond what the frame-maximum normalisation sees -- 99.9 % of the peaks within the float32
+                    # tolerance, every one within 100 x, at most 1 % of the frames with another peak set
+                    from tests.parity import peak_error_shares
+                    shares = peak_error_shares(got, o, hop, sr)
+                    ok = ok and (shares["f"] >= 0.999 and shares["realph"] >= 0.999 and c["f_norm"] <= 2e-3 and c["realph_norm"] <= 2e-3
+                                 and c["frames_diff"] <= 0.01 * max(c["frames"], 1))
+            else:
+                # (a handful of frames of 51 676 may differ on noise: two candidate magnitudes equal to the last bit, where the
+                # reference's own choice hangs on its libm's rounding of abs(), DESIGN.md section 3.2)
+                ok = (c["bad_peaks"] <= (0 if well_conditioned else 1e-4 * max(c["ref_peaks"], 1)) and c["f_abs"] <= 1e-9 and c["mag_rel"] <= 1e-12
+                      and c["ph_abs"] <= 1e-10 and c["realph_abs"] <= 1e-10 and c["totalmag_rel"] <= 1e-12)
+            ok = ok and bool(np.array_equal(h[5 * F_ * K_ + F_: 5 * F_ * K_ + 2 * F_], o["t"]))
+            d = dict(ok=bool(ok), frames=int(c["frames"]), frames_with_other_peaks=int(c["frames_diff"]), ref_peaks=int(c["ref_peaks"]),
+                     bad_peaks=int(c["bad_peaks"]), f_abs_Hz=float(c["f_abs"]), mag_rel=float(c["mag_rel"]), ph_abs_rad=float(c["ph_abs"]),
+                     realph_abs_rad=float(c["realph_abs"]),
+                     normalised=dict(f=float(c["f_norm"]), ph=float(c["ph_norm"]), realph=float(c["realph_norm"]), mag=float(c["mag_norm"]),
+                                     totalmag_rel=float(c["totalmag_rel"]), share_of_peaks_within_f32_tolerance=shares,
+                                     note="errors in units of a complex-bin perturbation relative to the frame's largest magnitude (tests/parity.py)"),
+                     against="oracle/pvoracle.c on the same signal, all frames of the last timed pass")
+            if not ok:
+                checks_failed.append(what)
+            return d
+
+        o = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             from oracle import pvoracle
-            from tests.parity import compare_analysis
             pvoracle.build()
             xs = x_host.astype(np.float64)
             t1 = time.perf_counter()
@@ -467,28 +587,14 @@ def main():
             dtc = time.perf_counter() - t1
             # ---- what was timed is what is checked: the result block of the last timed step, every frame
             h = res.cpu().numpy()
-            got = {k: h[i * FT * K:(i + 1) * FT * K].reshape(FT, K) for i, k in enumerate(("f", "mag", "ph", "realph", "binno"))}
-            got["totalmag"] = h[5 * FT * K: 5 * FT * K + FT]
-            c = compare_analysis(got, o, NFFT, HOP, sr)
-            if args.precision == 32:
-                ok = (c["bad_peaks"] <= 1e-3 * max(c["ref_peaks"], 1) and c["ph_norm"] <= 2e-6 and c["realph_norm"] <= 2e-5
-                      and c["f_norm"] <= 2e-5 and c["mag_norm"] <= 1e-6 and c["totalmag_rel"] <= 1e-6 and c["f_abs"] <= 1e-3
-                      and c["mag_rel"] <= 1e-5 and c["ph_abs"] <= 2e-5)
-            else:
-                ok = (c["bad_peaks"] == 0 and c["f_abs"] <= 1e-9 and c["mag_rel"] <= 1e-12 and c["ph_abs"] <= 1e-10
-                      and c["realph_abs"] <= 1e-10 and c["totalmag_rel"] <= 1e-12)
-            ok = ok and bool(np.array_equal(h[nres - FT:], o["t"]))
-            self_check = dict(ok=bool(ok), frames=int(c["frames"]), ref_peaks=int(c["ref_peaks"]), bad_peaks=int(c["bad_peaks"]),
-                              f_abs_Hz=float(c["f_abs"]), mag_rel=float(c["mag_rel"]), ph_abs_rad=float(c["ph_abs"]),
-                              realph_abs_rad=float(c["realph_abs"]), against="oracle/pvoracle.c on the same signal, all frames of the last timed step")
-            if not ok:
-                rc = 3
+            self_check = check_block(np.concatenate([h[: 5 * FT * K + FT], h[nres - FT:]]), o, FT, K, NFFT, HOP, args.precision, "headline")
             cpu = cpu_baseline(x_host, sr, o, dtc)
 
-        def quick(pl, xin, steps):
-            """frames/s of `steps` passes over a [1, n] device signal on `pl` (events on the launch stream)."""
+        def quick(pl, xin, steps, nfft=NFFT, hop=HOP, ramp=True):
+            """frames/s of `steps` passes over a [1, n] device signal on `pl` (events on the launch stream); returns the
+            frame count, ms per pass and the result block of the last pass."""
             n = int(xin.numel())
-            Fq = int(lib.pvx_nframes(n, NFFT, HOP))
+            Fq = int(lib.pvx_nframes(n, nfft, hop))
             out = torch.zeros(5 * Fq * K + 2 * Fq, dtype=torch.float64, device=dev)
             b = out.data_ptr()
             ptrs = [b + i * Fq * K * 8 for i in range(5)] + [b + 5 * Fq * K * 8, b + 5 * Fq * K * 8 + Fq * 8]
@@ -496,7 +602,7 @@ def main():
             for _ in range(2):
                 _lib.check(lib.pvx_analyze_dev(pl, xin.data_ptr(), _lib.PVX_F32, n, 1, n, *ptrs, None, sp), "pvx_analyze_dev")
             torch.cuda.synchronize(dev)
-            if args.clock_warmup_ms > 0:                        # the plan / signal set-up above let the card idle
+            if args.clock_warmup_ms > 0 and ramp:               # the plan / signal set-up above let the card idle
                 t_r = time.perf_counter() + min(args.clock_warmup_ms, 100.0) * 1e-3
                 while time.perf_counter() < t_r:
                     for _ in range(16):
@@ -512,16 +618,37 @@ def main():
             msq = a0.elapsed_time(a1) / steps
             return Fq, msq, out
 
-        f64 = workloads = None
+        def host_block(out, Fq):
+            """quick()'s result block on the host in check_block's order: the five arrays, totalmag, t."""
+            h = out.cpu().numpy()
+            return np.concatenate([h[: 5 * Fq * K], h[5 * Fq * K + Fq:], h[5 * Fq * K: 5 * Fq * K + Fq]])
+
+        f64 = workloads = other_nfft = None
         if extras_ok:
+            from oracle import pvoracle
+            pvoracle.build()
+            checks = o is not None                                  # (--no-cpu-baseline also skips the oracle runs)
+            # ---- the other material first (host copies for the oracle): white noise, a tiled violin recording
+            g = torch.Generator(device=dev)
+            g.manual_seed(1)
+            xn = 0.1 * torch.randn(nsamp, device=dev, generator=g)
+            on = pvoracle.analyze(xn.cpu().numpy().astype(np.float64), sr, NFFT, HOP, NPKS) if checks else None
+            xv = ov = None
+            g7 = os.path.join(ROOT, "tests", "golden", "G7_perlman.npz")
+            if os.path.exists(g7):
+                xvh = np.load(g7)["x"].astype(np.float32)
+                xvh = np.tile(xvh, nsamp // len(xvh) + 1)[:nsamp]
+                xv = torch.from_numpy(xvh).to(dev)
+                ov = pvoracle.analyze(xvh.astype(np.float64), sr, NFFT, HOP, NPKS) if checks else None
             # ---- the reference's own precision on the same workload
             p64 = make_plan(64, -1)
-            F64, ms64, _ = quick(p64, x, 5)
+            F64, ms64, out64 = quick(p64, x, args.steps)
             _lib.check(lib.pvx_plan_set_timing(p64, 1), "pvx_plan_set_timing")
-            quick(p64, x, 3)
+            quick(p64, x, 3, ramp=False)                           # exactly 2 + 3 launches of each kernel are recorded
             m64 = (ctypes.c_double * 4)()
             n64 = (ctypes.c_int64 * 4)()
             _lib.check(lib.pvx_plan_get_timing(p64, m64, n64), "pvx_plan_get_timing")
+            _lib.check(lib.pvx_plan_set_timing(p64, 0), "pvx_plan_set_timing")
             ab64 = alg_bytes(s=8, c=16)
             stft = n64[0] > 0 and n64[1] == 0                      # k_stft.hip wrote the spectra: no frame buffer, no rocFFT
             # input samples are float32 in HBM.  k_stft: hop*4 in, (nfft/2)*16 out; framing kernel: hop*4 in, nfft*8 out
@@ -538,40 +665,56 @@ def main():
                                     alg_bytes_per_frame=ab64k[i], achieved_GBps=round(ab64k[i] * fpl / dur / 1e9, 1),
                                     frac=round(ab64k[i] * fpl / dur / HBM_PEAK, 4)))
             stage64 = sum(ab64k[i] for i in range(4) if n64[i])    # what the kernels of this path have to move per frame
-            f64 = dict(value=round(F64 / ms64 * 1e3, 1), unit="frames/s", ms_per_step=round(ms64, 4), dtype="f64",
+            tr64, tr64_prov = committed_traffic("k_stft_pv_f64")
+            f64 = dict(value=round(F64 / ms64 * 1e3, 1), unit="frames/s", ms_per_step=round(ms64, 4), steps=args.steps, dtype="f64",
                        fft_mode=int(lib.pvx_plan_get_fft_mode(p64)),
                        contract_bytes_per_frame=ab64["contract"] - HOP * 4,
-                       roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64, traffic=f64_traffic(),
+                       self_check=(check_block(host_block(out64, F64), o, F64, K, NFFT, HOP, 64, "f64") if checks else None),
+                       roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64, traffic=tr64, traffic_provenance=tr64_prov,
                                      achieved=round(stage64 * F64 / (ms64 * 1e-3) / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                      frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4), kernels=k64))
-            g64 = torch.Generator(device=dev)
-            g64.manual_seed(1)
-            Fn64, msn64, _ = quick(p64, 0.1 * torch.randn(nsamp, device=dev, generator=g64), 5)
-            f64["white_noise"] = dict(value=round(Fn64 / msn64 * 1e3, 1), unit="frames/s", ms_per_step=round(msn64, 4))
+            Fn64, msn64, outn64 = quick(p64, xn, 5)
+            f64["white_noise"] = dict(value=round(Fn64 / msn64 * 1e3, 1), unit="frames/s", ms_per_step=round(msn64, 4),
+                                      self_check=(check_block(host_block(outn64, Fn64), on, Fn64, K, NFFT, HOP, 64, "f64 white noise", well_conditioned=False) if checks else None))
             lib.pvx_plan_destroy(p64)
             # ---- the same geometry on other material (the headline signal has ~10 candidate maxima per frame)
             workloads = {}
-            g = torch.Generator(device=dev)
-            g.manual_seed(1)
-            xn = 0.1 * torch.randn(nsamp, device=dev, generator=g)
             Fn, msn, outn = quick(plan, xn, 10)
             workloads["white_noise"] = dict(value=round(Fn / msn * 1e3, 1), unit="frames/s", ms_per_step=round(msn, 4),
                                             peaks_per_frame=round(int((outn[: Fn * K] > 0).sum().item()) / Fn, 2),
-                                            data="0.1 * N(0,1), 600 s at 44.1 kHz")
-            g7 = os.path.join(ROOT, "tests", "golden", "G7_perlman.npz")
-            if os.path.exists(g7):
-                xv = np.load(g7)["x"].astype(np.float32)
-                xv = np.tile(xv, nsamp // len(xv) + 1)[:nsamp]
-                Fv, msv, outv = quick(plan, torch.from_numpy(xv).to(dev), 10)
+                                            data="0.1 * N(0,1), 600 s at 44.1 kHz",
+                                            self_check=(check_block(host_block(outn, Fn), on, Fn, K, NFFT, HOP, 32, "white noise", well_conditioned=False) if checks else None))
+            if xv is not None:
+                Fv, msv, outv = quick(plan, xv, 10)
                 workloads["violin_g7_tiled"] = dict(value=round(Fv / msv * 1e3, 1), unit="frames/s", ms_per_step=round(msv, 4),
                                                     peaks_per_frame=round(int((outv[: Fv * K] > 0).sum().item()) / Fv, 2),
-                                                    data="tests/golden/G7_perlman.npz (examples/perlmanVn.wav) tiled to 26.46 M samples")
+                                                    data="tests/golden/G7_perlman.npz (examples/perlmanVn.wav) tiled to 26.46 M samples",
+                                                    self_check=(check_block(host_block(outv, Fv), ov, Fv, K, NFFT, HOP, 32, "violin", well_conditioned=False) if checks else None))
+            # ---- the larger transforms of BASELINE config 5 on the same signal (hop = nfft/4): k_fused_team.hip
+            other_nfft = {}
+            for nf in (4096, 8192):
+                hp = nf // 4
+                pl = ctypes.c_void_p()
+                wn = np.hanning(nf)
+                _lib.check(lib.pvx_plan_create(ctypes.byref(pl), float(sr), nf, hp, K, 0.005, _lib.dptr(wn), 32, 0), "pvx_plan_create")
+                Fo, mso, outo = quick(pl, x, 10, nfft=nf, hop=hp)
+                Fon, mson, _ = quick(pl, xn, 10, nfft=nf, hop=hp)
+                oo = pvoracle.analyze(xs, sr, nf, hp, K) if checks else None
+                other_nfft[str(nf)] = dict(value=round(Fo / mso * 1e3, 1), unit="frames/s", ms_per_step=round(mso, 4), hop=hp, frames=Fo,
+                                           fft_mode=int(lib.pvx_plan_get_fft_mode(pl)),
+                                           white_noise=dict(value=round(Fon / mson * 1e3, 1), unit="frames/s", ms_per_step=round(mson, 4)),
+                                           contract_target=round(0.6 * HBM_PEAK / alg_bytes(nfft=nf, hop=hp)["contract"], 1),
+                                           self_check=(check_block(host_block(outo, Fo), oo, Fo, K, nf, hp, 32, "nfft %d" % nf) if checks else None))
+                lib.pvx_plan_destroy(pl)
+        if checks_failed or gather_check_failed:
+            rc = 3
 
         desc = ("BASELINE config 2: one %d-s 44.1 kHz mono signal per GPU" % wl["seconds"]) if args.workload == "c2" else \
                ("BASELINE config 4 shard: %d x %d-s 48 kHz mono signals per GPU in one call" % (nsig, wl["seconds"]))
         line = {
             "metric": "STFT frames/sec (%s kHz, nfft=2048, hop=512)" % ("44.1" if sr == 44100 else "%g" % (sr / 1000.0)),
             "value": round(value, 1), "unit": "frames/s",
+            "value_from_idle": (round(FT * world * args.steps / elapsed_idle, 1) if elapsed_idle else None),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
@@ -583,14 +726,20 @@ def main():
             "roofline": roofline, "stage": stage, "cpu_baseline": cpu, "self_check": self_check,
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "clock_warmup": {"ms": args.clock_warmup_ms, "untimed_steps": ramp_steps,
-                             "note": "untimed passes of the same step before the W warm-up steps: the card needs tens of "
-                                     "milliseconds of continuous work to leave its idle clocks (--clock-warmup-ms 0 times it from idle)"},
+                             "note": "`value_from_idle`: W warm-up + K timed steps right after the workload was made resident; then "
+                                     "untimed passes of the same step for `ms` (the card needs tens of milliseconds of continuous work "
+                                     "to leave its idle clocks), then W + K again: `value`.  --clock-warmup-ms 0: one run, from idle"},
         }
         if f64:
             line["f64"] = f64
         if workloads:
             line["workloads"] = workloads
+        if other_nfft:
+            line["other_nfft"] = other_nfft
         if gather_info:
+            gather_info["ms_per_step_kernels_only"] = stage["step_ms_hip_events"]
+            gather_info["exposed_ms_per_step"] = round(max(0.0, elapsed / args.steps * 1e3 - stage["step_ms_hip_events"]), 4)
+            gather_info["note"] = "exposed = wall time per step minus the analysis kernels' time on the compute stream (launch gaps included)"
             line["gather"] = gather_info
         try:
             ctypes.CDLL(None).fflush(None)        # RCCL's version banner (C stdio) goes out before the JSON line
@@ -599,7 +748,7 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
         if rc:
-            sys.stderr.write("bench.py: the timed output is outside the stated tolerances against the oracle: %s\n" % json.dumps(self_check))
+            sys.stderr.write("bench.py: timed output outside the stated tolerances against the oracle: %s\n" % ", ".join(checks_failed))
     lib.pvx_plan_destroy(plan)
     if plan_b is not None:
         lib.pvx_plan_destroy(plan_b)

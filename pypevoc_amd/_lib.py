@@ -246,23 +246,37 @@ def device_run(nbytes_out, launch):
 # ---- result arrays in page-locked memory ------------------------------------------------------------
 class _HostPool(object):
     """numpy arrays whose memory the DMA engine can write directly (pvx_host_alloc).  A buffer goes back to the
-    pool when the last array / view on it is collected; sizes (64 KB .. 16 MB) are bucketed to powers of two, the pool
-    keeps at most _CAP bytes of idle buffers and hands out at most _LIVE_CAP bytes in all (beyond that: np.empty)."""
+    pool when the last array / view on it is collected; sizes are bucketed to powers of two, the pool keeps at most
+    _CAP (+ _BIG_CAP for the large buckets) bytes of idle buffers and hands out at most _LIVE_CAP bytes in all (beyond
+    that: np.empty).
+    Small results (64 KB .. 16 MB) are always page-locked.  LARGE ones (.. 1 GiB: the waveform of a 10-minute signal is
+    212 MB) only from the second request of their bucket on: page-locking a quarter of a gigabyte costs tens of
+    milliseconds, which a one-off call would never get back (its result arrives through the threaded ring of pvx_api.hip
+    instead: ~30 GB/s, the page faults of the fresh array included), while a process that resynthesises signal after
+    signal gets the link's 55 GB/s and no page faults from then on."""
     _CAP = 64 << 20
-    _LIVE_CAP = 1 << 30
+    _BIG_CAP = 1 << 30
+    _LIVE_CAP = 3 << 30
     _MIN = 64 << 10
-    _MAX = 16 << 20            # beyond this a result pays for its copy anyway and page-locking it costs more than it saves
+    _MAX = 16 << 20
+    _BIG_MAX = 1 << 30
 
     def __init__(self):
         self.free = {}
         self.idle = 0
+        self.idle_big = 0
         self.live = 0
+        self.asked = {}
 
     def _release(self, ptr, size):
         self.live -= size
-        if self.idle + size <= self._CAP:
+        big = size > self._MAX
+        if (self.idle_big + size <= self._BIG_CAP) if big else (self.idle + size <= self._CAP):
             self.free.setdefault(size, []).append(ptr)
-            self.idle += size
+            if big:
+                self.idle_big += size
+            else:
+                self.idle += size
         else:
             try:
                 load().pvx_host_free(ctypes.c_void_p(ptr))
@@ -272,15 +286,23 @@ class _HostPool(object):
     def empty(self, n, dtype=np.float64):
         import weakref
         nbytes = int(n) * np.dtype(dtype).itemsize
-        if nbytes < self._MIN or nbytes > self._MAX:
+        if nbytes < self._MIN or nbytes > self._BIG_MAX:
             return np.empty(n, dtype=dtype)
         size = self._MIN
         while size < nbytes:
             size <<= 1
+        big = size > self._MAX
+        if big:
+            self.asked[size] = self.asked.get(size, 0) + 1
+            if self.asked[size] < 2 and not os.environ.get("PVX_PIN_LARGE_RESULTS"):
+                return np.empty(n, dtype=dtype)
         lst = self.free.get(size)
         if lst:
             ptr = lst.pop()
-            self.idle -= size
+            if big:
+                self.idle_big -= size
+            else:
+                self.idle -= size
         else:
             if self.live + size > self._LIVE_CAP:
                 return np.empty(n, dtype=dtype)

@@ -612,9 +612,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     if (ng > 0) flush(ng);
 }
 
-template <int S> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
+template <int S, bool TWL> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
     using TG = TeamGeo<S>;
-    constexpr bool TWL = false;                                     // the twiddles come from L2, prefetched before barrier B1
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -679,8 +678,8 @@ int pvx_fused_team_supported(int nfft, int precision, int K) {
 int pvx_launch_fused_team(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
-        case 4096: return launch_team<2>(p, x_dtype, s);
-        case 8192: return launch_team<4>(p, x_dtype, s);
+        case 4096: return getenv("PVX_TEAM_TWL") ? launch_team<2, true>(p, x_dtype, s) : launch_team<2, false>(p, x_dtype, s);
+        case 8192: return launch_team<4, false>(p, x_dtype, s);
         default: pvx_set_error("the team kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

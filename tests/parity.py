@@ -43,6 +43,24 @@ def compare_analysis(got, ref, nfft, hop, sr):
     return out
 
 
+def peak_error_shares(got, ref, hop, sr, f_tol=2e-5, realph_tol=2e-5):
+    """Share of the reference's peaks (in frames with the same peak set) whose normalised frequency / unwrapped-phase errors
+    are within the float32 tolerances.  f and realph hang on the phase DIFFERENCE to the previous frame's bin, so a peak
+    over a weak previous bin (noise, recordings) is ill-conditioned in a way the frame-maximum normalisation does not see:
+    on such material the maxima over 400 000 peaks are outliers and the shares are the meaningful figure."""
+    same = peak_rows_equal(got["binno"], got["f"], ref["binno"], ref["f"])
+    v = (ref["f"] > 0) & same[:, None]
+    if not v.any():
+        return dict(f=1.0, realph=1.0, peaks=0)
+    rmag = ref["mag"][v]
+    fmax = np.broadcast_to(ref["mag"].max(axis=1, keepdims=True), ref["mag"].shape)[v]
+    w = np.maximum(fmax, 1e-300) / np.maximum(rmag, 1e-300)
+    dt = hop / float(sr)
+    fn = np.abs(got["f"][v] - ref["f"][v]) * (2 * np.pi * dt) / w
+    rn = np.abs(got["realph"][v] - ref["realph"][v]) / w
+    return dict(f=float((fn <= f_tol).mean()), realph=float((rn <= realph_tol).mean()), peaks=int(v.sum()))
+
+
 def pv_result(p):
     return dict(f=p.f, mag=p.mag, ph=p.ph, realph=p.realph, binno=p.binno, t=p.t,
                 totalmag=np.asarray(p.totalmag))

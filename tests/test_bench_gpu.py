@@ -45,6 +45,28 @@ def test_bench_forced_gather_exercises_rccl():
     assert g["rccl_world"] == 1 and g["valid_peaks_gathered"] > 0 and g["wire_bytes_per_rank"] < g["result_bytes_per_rank"]
 
 
+def test_bench_self_launch_c4_gather_matches_oracle():
+    """The path `bench.py --gpus 8 --workload c4` takes on an 8-GPU node, with the one GPU this box has: bench.py starts
+    its ranks itself (python -m torch.distributed.run as a child process, rendezvous on a port the kernel handed out),
+    every step ends in the RCCL gather of the packed result block (forced at world size 1), and what rank 0 unpacked is
+    checked against the oracle on the signals themselves."""
+    env = {"PVX_BENCH_SELF_LAUNCH": "1", "PVX_BENCH_FORCE_GATHER": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        os.environ.pop(k, None)
+    rc, j, err = _run(["--gpus", "1", "--workload", "c4", "--shard-signals", "3", "--seconds", "5", "--steps", "3", "--warmup", "1",
+                       "--check-gathered", "3"], env=env)
+    assert rc == 0 and j is not None, err[-3000:]
+    g = j["gather"]
+    assert g["rccl_world"] == 1 and g["checked_signals"] == 3 and g["check_ok"] and g["valid_peaks_gathered"] > 0
+    assert j["config"]["signals_per_gpu"] == 3 and j["n_gpus"] == 1 and len(j["per_rank_ms_per_step"]) == 1
+    # a failing rank fails the launcher: an impossible workload argument inside the child
+    rc, j, err = _run(["--gpus", "1", "--workload", "c4", "--shard-signals", "3", "--seconds", "5", "--steps", "1", "--warmup", "0", "--precision", "32",
+                       "--fft-mode", "3"], env=env)       # the ring kernel exists at nfft 2048: fine -> rc 0 (the launcher passes the line through)
+    assert rc == 0 and j is not None, err[-2000:]
+    rc, j, err = _run(["--gpus", "1", "--workload", "c4", "--shard-signals", "3", "--seconds", "5", "--steps", "1", "--warmup", "0", "--fft-mode", "5"], env=env)
+    assert rc != 0 and j is None and "exited with code" in err     # mode 5 does not exist at nfft 2048: the child fails, so does the parent
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count()

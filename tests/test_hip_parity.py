@@ -1294,6 +1294,29 @@ def test_resident_chain_equals_host_chain(amd, oracle):
     assert np.array_equal(p.nharmonics, d["nharmonics"]) and np.allclose(p.hpower, d["hpower"], rtol=1e-9, atol=0)
 
 
+def test_large_host_transfers_through_the_threaded_ring(amd, monkeypatch):
+    """Host arrays of 16 MB and more cross PCIe through a pinned ring fed / drained by four threads (pvx_api.hip,
+    staged_copy): the analysis of a 24 MB pageable signal and the 48 MB waveform that comes back must be bit-identical to
+    the plain hipMemcpy path (PVX_NO_STAGE_THREADS=1) -- including a size that is not a multiple of the 2 MB pieces."""
+    sr = 44100
+    n = 6 * 1024 * 1024 + 12345
+    t = np.arange(n) / float(sr)
+    x = (0.3 * np.sin(2 * np.pi * 440.0 * t * (1 + 0.02 * np.sin(2 * np.pi * 0.5 * t))) + 0.01 * np.random.default_rng(5).standard_normal(n)).astype(np.float32)
+    res = {}
+    for tag in ("threads", "plain"):
+        if tag == "plain":
+            monkeypatch.setenv("PVX_NO_STAGE_THREADS", "1")
+        p = run_pv(amd, x, sr, 2048, 512, 8, precision=32)
+        ss = p.toSinSum()
+        w = np.array(ss.synth(sr, 512))
+        res[tag] = (np.array(p.f), np.array(p.mag), np.array(p.realph), w)
+        monkeypatch.delenv("PVX_NO_STAGE_THREADS", raising=False)
+    assert res["threads"][3].nbytes >= (16 << 20) and x.nbytes >= (16 << 20)
+    for a, b in zip(res["threads"], res["plain"]):
+        assert np.array_equal(a, b)
+    assert np.abs(res["threads"][3]).max() > 0.1
+
+
 def test_in_place_edit_of_a_fetched_result_leaves_the_resident_chain(amd):
     """The reference's f / mag / ph / realph are plain ndarrays that toSinSum (PVAnalysis.py:319) and calc_f0
     (PVAnalysis.py:379) read when they are called, so `pv.mag[pv.f > 2000] = 0` before tracking takes effect there.

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""Copy what tools/gpu_bench_round.sh left under gpurun_out/ into profiles/ (the tracked evidence bench.py and
-DESIGN.md cite):   python tools/collect_profiles.py r02
-  profiles/<tag>_fused_sq.json        SQ counters of the analysis kernel, per-launch means (tools/prof_sq.sh)
-  profiles/traffic_latest.json       HBM bytes per launch of the analysis kernel: FETCH_SIZE x calibration + WRITE_SIZE
-  profiles/<tag>_traffic_pmc.json     the raw FETCH_SIZE / WRITE_SIZE means (run + calibration kernels)
-  profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3`
-  profiles/<tag>_bench*.json          the bench lines of that pass"""
+"""Copy what tools/gpu_bench_round.sh left under gpurun_out/ into profiles/ (the tracked evidence bench.py and DESIGN.md
+cite):   python tools/collect_profiles.py r03
+  profiles/sq_latest.json            SQ counters of every analysis / tracker / resynthesis kernel profiled this round, per-launch
+                                     means (tools/prof_sq.sh), stamped with the fingerprint of the kernel sources (bench.py quotes
+                                     it only when that matches the build it times); the same as profiles/<tag>_sq.json
+  profiles/traffic_latest.json       flat: kernel -> {bytes, read_bytes, write_bytes, bytes_per_frame, symbol, csrc_sha16, tag}:
+                                     HBM bytes per launch on BASELINE config 2 (FETCH_SIZE x calibration + WRITE_SIZE)
+  profiles/<tag>_traffic_pmc.json    the raw FETCH_SIZE / WRITE_SIZE means (run + calibration kernels)
+  profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3`
+  profiles/<tag>_bench*.json, <tag>_configs_3_4.jsonl, <tag>_config5_sweep*.jsonl, <tag>_nfft_harmonic_vs_noise.jsonl"""
+import glob
 import json
 import os
 import re
@@ -13,53 +17,67 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, ROOT)
+from bench import csrc_sha16  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 FRAMES = 51676
+SHA = csrc_sha16()
 
-sq = json.load(open(os.path.join(G, "sq_%s" % tag, "summary.json")))
-keep = {k: v for k, v in sq.items() if "k_fused" in k or "k_phase" in k or "k_frames" in k}
-keep["_frames_per_launch"] = FRAMES
-keep["_method"] = ("rocprofv3 --pmc <8 SQ counters per pass> -- python3 tools/run_mode.py -1 harmonic 8 4 (tools/prof_sq.sh): "
-                   "BASELINE config 2 signal, plan default fft mode; values are means over the kernel's launches; "
-                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, "
-                   "SQ_BUSY_CU_CYCLES and SQ_LDS_IDX_ACTIVE cycles summed over CUs")
-json.dump(keep, open(os.path.join(P, "%s_fused_sq.json" % tag), "w"), indent=1)
 
-run = json.load(open(os.path.join(G, "traffic_%s" % tag, "run.json")))
-cal = json.load(open(os.path.join(G, "traffic_%s" % tag, "cal.json")))
-json.dump(dict(run={k: v for k, v in run.items() if "k_" in k}, calibration=cal), open(os.path.join(P, "%s_traffic_pmc.json" % tag), "w"), indent=1)
-calk = [v for k, v in cal.items() if "k_read<HIP_vector_type<float, 2u>" in k][0]
-factor = (1 << 30) / (calk["FETCH_SIZE"]["mean"] * 1024.0)              # 8-byte-per-lane reads of 1 GiB
-wcal = [v for k, v in cal.items() if "k_write<double>" in k][0]
-wfactor = (1 << 30) / (wcal["WRITE_SIZE"]["mean"] * 1024.0)
-out = {}
-detail = {}
-for k, v in run.items():
-    if "k_fused" not in k or "FETCH_SIZE" not in v:
+def short_name(k):
+    m = re.search(r"(k_[a-z_0-9]+)", k)
+    return m.group(1) if m else k
+
+
+# ---- SQ counters: every summary.json under gpurun_out/sq_<tag>*/
+sq = {"_csrc_sha16": SHA, "_tag": tag, "_frames_per_launch": FRAMES,
+      "_method": ("rocprofv3 --pmc <8 SQ counters per pass> -- python3 tools/run_mode.py -1 harmonic 8 4 [precision] | tools/run_chain.py "
+                  "(tools/prof_sq.sh): BASELINE config 2 signal, plan default fft mode; values are means over the kernel's launches; "
+                  "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_BUSY_CU_CYCLES and "
+                  "SQ_LDS_IDX_ACTIVE cycles summed over CUs")}
+for d in sorted(glob.glob(os.path.join(G, "sq_%s*" % tag))):
+    f = os.path.join(d, "summary.json")
+    if not os.path.exists(f):
         continue
-    short = re.search(r"(k_[a-z_0-9]+)", k).group(1)
-    rd = v["FETCH_SIZE"]["mean"] * 1024.0 * factor
-    wr = v["WRITE_SIZE"]["mean"] * 1024.0 * wfactor
-    out[short] = int(rd + wr)
-    detail[short] = dict(kernel=k, frames_per_launch=FRAMES, FETCH_SIZE_KB_mean=v["FETCH_SIZE"]["mean"], fetch_calibration_factor=factor,
-                         WRITE_SIZE_KB_mean=v["WRITE_SIZE"]["mean"], write_calibration_factor=wfactor, read_bytes=int(rd), write_bytes=int(wr),
-                         bytes_per_frame=round((rd + wr) / FRAMES, 1))
-old = {}
-try:
-    old = json.load(open(os.path.join(P, "traffic_latest.json")))
-except Exception:
-    pass
-for k, v in old.items():
-    if not k.startswith("_") and k not in out:
-        out[k] = v
-out["_detail"] = dict(kernels=detail, previous_round=old.get("_detail"),
-                      method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `tools/run_mode.py -1 harmonic 8 10` "
-                             "(tools/prof_traffic.sh); FETCH_SIZE calibrated on tools/fetch_calib (1 GiB streamed with 8-byte-per-lane loads "
-                             "reports 1/2 of the bytes on gfx950), WRITE_SIZE reads exact",
-                      source=["profiles/%s_traffic_pmc.json" % tag])
+    what = os.path.basename(d)[len("sq_%s" % tag):].strip("_") or "f32"
+    for k, v in json.load(open(f)).items():
+        if "k_" in k and "SQ_WAVES" in v:
+            sq["%s | %s" % (what, k)] = v
+json.dump(sq, open(os.path.join(P, "sq_latest.json"), "w"), indent=1)
+shutil.copy(os.path.join(P, "sq_latest.json"), os.path.join(P, "%s_sq.json" % tag))
+
+# ---- HBM traffic
+out = {}
+raw = {}
+for d in sorted(glob.glob(os.path.join(G, "traffic_%s*" % tag))):
+    rf, cf = os.path.join(d, "run.json"), os.path.join(d, "cal.json")
+    if not (os.path.exists(rf) and os.path.exists(cf)):
+        continue
+    what = os.path.basename(d)[len("traffic_%s" % tag):].strip("_")
+    run, cal = json.load(open(rf)), json.load(open(cf))
+    raw[what or "f32"] = dict(run={k: v for k, v in run.items() if "k_" in k}, calibration=cal)
+    calk = [v for k, v in cal.items() if "k_read<HIP_vector_type<float, 2u>" in k][0]
+    factor = (1 << 30) / (calk["FETCH_SIZE"]["mean"] * 1024.0)              # 8-byte-per-lane reads of 1 GiB
+    wcal = [v for k, v in cal.items() if "k_write<double>" in k][0]
+    wfactor = (1 << 30) / (wcal["WRITE_SIZE"]["mean"] * 1024.0)
+    for k, v in run.items():
+        if "k_" not in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        rd = v["FETCH_SIZE"]["mean"] * 1024.0 * factor
+        wr = v["WRITE_SIZE"]["mean"] * 1024.0 * wfactor
+        name = short_name(k) + ("_" + what if what else "")
+        out[name] = dict(bytes=int(rd + wr), read_bytes=int(rd), write_bytes=int(wr), bytes_per_frame=round((rd + wr) / FRAMES, 1),
+                         frames_per_launch=FRAMES, symbol=k, csrc_sha16=SHA, tag=tag, fetch_calibration_factor=round(factor, 4),
+                         write_calibration_factor=round(wfactor, 4), launches=int(v["FETCH_SIZE"]["n"]))
+out["_method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_traffic.sh) over tools/run_mode.py / "
+                  "tools/run_chain.py on BASELINE config 2; FETCH_SIZE calibrated on tools/fetch_calib (1 GiB streamed with 8-byte-per-lane "
+                  "loads reports half of the bytes on gfx950), WRITE_SIZE reads exact; earlier rounds: git log -- profiles/traffic_latest.json")
 json.dump(out, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
+json.dump(raw, open(os.path.join(P, "%s_traffic_pmc.json" % tag), "w"), indent=1)
+
 st = os.path.join(G, "stats_%s" % tag, "r_kernel_stats.csv")
 if os.path.exists(st):
     shutil.copy(st, os.path.join(P, "%s_kernel_stats.csv" % tag))
@@ -74,18 +92,4 @@ for src, dst in (("configs_%s.jsonl" % tag, "%s_configs_3_4.jsonl" % tag), ("swe
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s):
         shutil.copy(s, os.path.join(P, dst))
-t64 = os.path.join(G, "traffic_%s_f64" % tag, "run.json")
-if os.path.exists(t64):
-    r64 = json.load(open(t64))
-    o64 = {}
-    for k, v in r64.items():
-        if ("k_stft" in k or "k_phase_peaks" in k) and "FETCH_SIZE" in v:
-            short = re.search(r"(k_[a-z_0-9]+)", k).group(1)
-            rd = v["FETCH_SIZE"]["mean"] * 1024.0 * factor
-            wr = v["WRITE_SIZE"]["mean"] * 1024.0 * wfactor
-            o64[short] = dict(kernel=k, read_bytes=int(rd), write_bytes=int(wr), bytes_per_frame=round((rd + wr) / FRAMES, 1),
-                              FETCH_SIZE_KB_mean=v["FETCH_SIZE"]["mean"], WRITE_SIZE_KB_mean=v["WRITE_SIZE"]["mean"])
-    json.dump(dict(kernels=o64, frames_per_launch=FRAMES, method="tools/prof_traffic.sh OUT -1 harmonic 8 64 (float64 plan), same calibration as traffic_latest.json"),
-              open(os.path.join(P, "%s_traffic_f64.json" % tag), "w"), indent=1)
-    print(json.dumps({k: v["bytes_per_frame"] for k, v in o64.items()}))
-print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))
+print(json.dumps({k: v["bytes_per_frame"] for k, v in out.items() if isinstance(v, dict)}))

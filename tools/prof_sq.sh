@@ -1,8 +1,10 @@
 #!/bin/bash
 # SQ counter passes (rocprofv3 --pmc, <= 8 SQ counters per pass) over tools/run_mode.py.
-#   bash tools/prof_sq.sh OUTDIR MODE [harmonic|noise] [K]      (run on the GPU box, from the repo root)
+#   bash tools/prof_sq.sh OUTDIR MODE [harmonic|noise] [K] [PRECISION]      (run on the GPU box, from the repo root)
+#   PVX_PROF_PROG="tools/run_chain.py 2": profile that program instead of tools/run_mode.py (its arguments replace MODE ...)
 set -u
-OUT=$1; MODE=$2; KIND=${3:-harmonic}; K=${4:-8}
+OUT=$1; MODE=$2; KIND=${3:-harmonic}; K=${4:-8}; PREC=${5:-32}
+PROG=${PVX_PROF_PROG:-tools/run_mode.py $MODE $KIND $K 4 $PREC}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 G_A="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
@@ -13,6 +15,6 @@ G_E="SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_LEVEL_WAVES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_
 i=0
 for G in "$G_A" "$G_B" "$G_C" "$G_D" "$G_E"; do
   i=$((i+1))
-  rocprofv3 --pmc $G GRBM_GUI_ACTIVE -d "$OUT/g$i" -o r --output-format csv -- python3 tools/run_mode.py "$MODE" "$KIND" "$K" 4 > "$OUT/g$i.log" 2>&1
+  rocprofv3 --pmc $G GRBM_GUI_ACTIVE -d "$OUT/g$i" -o r --output-format csv -- python3 $PROG > "$OUT/g$i.log" 2>&1
 done
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.json"
