@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
     constexpr int G = NT / TS;       // groups: group g adds contributions g, g + G, ... to its own accumulators
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
     const int NB = p.nbatch;
-    const int64_t seg = blockIdx.x;                    // output samples [seg*h, seg*h + h)
+    const int64_t seg = (int64_t)blockIdx.x + p.seg0;  // output samples [seg*h, seg*h + h)
     const double dh = (double)h;
     const double overlap = p.hop_a / (double)p.nfft;   // PVAnalysis.py:824
     const double fstep = p.sr / (double)p.nfft;        // PVAnalysis.py:825
@@ -454,13 +454,18 @@ int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
     while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
     if (nb < 1) nb = 1;
     p.nbatch = nb;
+    // a slice of the segments (p.seg_count > 0: pvx_synth_resident launches the waveform in slices whose DMA to the host
+    // runs under the next slice's kernel); the geometry above is that of the whole waveform either way
+    if (p.seg0 < 0 || p.seg0 > nseg) { pvx_set_error("bad segment slice"); return PVX_ERR_INVALID; }
+    const int64_t nlaunch = (p.seg_count > 0 && p.seg0 + p.seg_count < nseg) ? p.seg_count : nseg - p.seg0;
+    if (nlaunch <= 0) return PVX_OK;
     const size_t lds = synth_lds_bytes(h, nb, WL, groups);
     if (lds > 158 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
 #define PVX_SYNTH(NT_)                                                                                                      \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
             PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_synth_ola<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_synth_ola<NT_>, dim3((unsigned)nseg), dim3(NT_), lds, s, p);                                   \
+        hipLaunchKernelGGL(k_synth_ola<NT_>, dim3((unsigned)nlaunch), dim3(NT_), lds, s, p);                                \
     } while (0)
     if (nt == 512) PVX_SYNTH(512);
     else PVX_SYNTH(256);

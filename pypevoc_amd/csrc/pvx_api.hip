@@ -156,6 +156,7 @@ struct pvx_plan {
     int frames_per_wave = 2;     // k_phase_peaks: frames a wave handles one after the other (latency floor of a chunked launch; PVX_FPW)
     // ---- host entry points: plan-owned, grow-only buffers (no hipMalloc / hipFree per call)
     hipStream_t s_host = nullptr;          // non-blocking stream of the host entry points
+    hipStream_t s_copy = nullptr;          // second stream: DMA of finished waveform slices under the next slice's kernel
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     void* d_in[2] = {nullptr, nullptr};    // input chunks (double-buffered: H2D of chunk i+1 under the kernels of chunk i)
     size_t in_cap[2] = {0, 0};
@@ -224,6 +225,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_w) (void)hipFree(p->d_w);
     if (p->d_desc) (void)hipFree(p->d_desc);
     if (p->s_host) (void)hipStreamDestroy(p->s_host);
+    if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
     delete p;
 }
 
@@ -1182,6 +1184,9 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
                              double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,
                              double* d_w, int64_t wlen, void* stream, int flags);
 extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge);
+static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
+                       const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count);
 
 // ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
 extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
@@ -1253,6 +1258,31 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         return PVX_OK;
     }
     if ((rc = grow_dev(&p->d_w, &p->w_cap, (size_t)wlen * 8)) != PVX_OK) return rc;
+    if (pinned && bytes >= kStageMin && getenv("PVX_NO_SYNTH_SLICES") == nullptr) {
+        // a large waveform into page-locked memory: the segments are computed in slices and the DMA of a finished slice
+        // (second stream) runs under the next slice's kernel -- the link, not kernel + link, is what the call costs
+        if ((rc = stage_ring(p)) != PVX_OK) return rc;                   // (its events)
+        if (!p->s_copy) PVX_HIP_CHECK(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+        const int NS = 2 * kStageThreads;
+        const int64_t nseg = (wlen + hop_synth - 1) / hop_synth, per = (nseg + NS - 1) / NS;
+        for (int i = 0; i < NS; i++) {
+            const int64_t s0 = (int64_t)i * per;
+            if (s0 >= nseg) break;
+            const int64_t cnt = nseg - s0 < per ? nseg - s0 : per;
+            rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft, p->hop, hop_synth,
+                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt);
+            if (rc != PVX_OK) return rc;
+            PVX_HIP_CHECK(hipEventRecord(p->ev_ring[i], p->s_host));
+            PVX_HIP_CHECK(hipStreamWaitEvent(p->s_copy, p->ev_ring[i], 0));
+            const int64_t o = s0 * hop_synth, c = (wlen - o < cnt * hop_synth) ? wlen - o : cnt * hop_synth;
+            PVX_HIP_CHECK(hipMemcpyAsync(w + o, p->d_w + o, (size_t)c * 8, hipMemcpyDeviceToHost, p->s_copy));
+        }
+        tr.mark("slices + copies issued");
+        PVX_HIP_CHECK(hipStreamSynchronize(p->s_copy));
+        PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
+        tr.mark("here");
+        return PVX_OK;
+    }
     rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
                              p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0);
     if (rc != PVX_OK) return rc;
@@ -1669,6 +1699,18 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
     sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr; sp.no_phcor = (flags & PVX_SYNTH_NO_PHCOR) ? 1 : 0;
     return pvx_launch_synth(sp, (hipStream_t)stream);
+}
+
+// one slice of the waveform's segments (internal: pvx_synth_resident overlaps the slices' kernels with their copies)
+static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
+                       const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count) {
+    SynthParams sp;
+    sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
+    sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
+    sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
+    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr; sp.no_phcor = 0; sp.seg0 = seg0; sp.seg_count = seg_count;
+    return pvx_launch_synth(sp, stream);
 }
 
 extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,

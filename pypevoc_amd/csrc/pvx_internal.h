@@ -157,6 +157,8 @@ struct SynthParams {
     int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
     int no_phcor;         // PVX_SYNTH_NO_PHCOR: fstep=None partials (PV.py:710-713)
     int nbatch;           // contributions gathered per round (set by pvx_launch_synth from the LDS budget)
+    int64_t seg0 = 0;     // first output segment (hop) of this launch ...
+    int64_t seg_count = 0;   // ... and how many (0: all from seg0 on)
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
 

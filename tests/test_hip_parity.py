@@ -1315,6 +1315,13 @@ def test_large_host_transfers_through_the_threaded_ring(amd, monkeypatch):
     for a, b in zip(res["threads"], res["plain"]):
         assert np.array_equal(a, b)
     assert np.abs(res["threads"][3]).max() > 0.1
+    # from the second request of its size on a large result is page-locked (pypevoc_amd/_lib.py, _HostPool) and the waveform
+    # is computed in slices whose DMA runs under the next slice's kernel: the same samples, with and without the slices
+    w2 = np.array(ss.synth(sr, 512))
+    monkeypatch.setenv("PVX_NO_SYNTH_SLICES", "1")
+    w3 = np.array(ss.synth(sr, 512))
+    monkeypatch.delenv("PVX_NO_SYNTH_SLICES")
+    assert np.array_equal(w2, res["threads"][3]) and np.array_equal(w3, res["threads"][3])
 
 
 def test_in_place_edit_of_a_fetched_result_leaves_the_resident_chain(amd):
