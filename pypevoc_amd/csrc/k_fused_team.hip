@@ -8,13 +8,14 @@
 //   PV.run_pv           pypevoc/PVAnalysis.py:213-264
 //
 // The transform.  z[j] = (x w)[2j] + i (x w)[2j+1], j < M = nfft/2 = S L, L = 1024.  Wave s takes the sub-sequence
-// z[S i + s] (decimation in time), transforms it with k_fused_rev's stages (radix-16 registers, LDS exchange, radix-16
-// registers, 4-lane DPP stage) and leaves E_s[k1], k1 < L, in natural order in region s of the team's spectrum buffer.
-// After barrier B1 the join and the real-FFT untangle run as ONE pass, in place: with A = DFT_S(E_s[k1] W_M^(s k1)) and
-// B = DFT_S(E_s[L-k1] conj(W_M^(s k1))) the pairs (A_t, B_((S-t) mod S)) are exactly the untangle pairs
-// (Z[k], conj Z[M-k]) of k = k1 + L t, so a lane that reads the 2 S values of k1 and L - k1 writes the 2 S bins
-// X[k1 + L t], X[(L - k1) + L (S-1-t)] back to the same 2 S slots: the same LDS traffic per lane as k_fused_rev's
-// untangle, no extra pass for the join.  (k1 = 0 pairs with itself: its lane's mirrored slots take the k1 = L/2 family.)
+// z[S i + s] (decimation in time) and transforms it as k_fused_rev<16> does (pvx_fft4.h): four 256-point transforms, one
+// per 16-lane group, radix-16 registers -> LDS transpose inside the group -> radix-16 registers, no cross-lane stage.
+// After barrier B1 the join and the real-FFT untangle run as ONE pass, in place, the pairs of the radix-J join being
+// exactly the untangle pairs (Z[k], conj Z[M-k]) (pvx_fft4.h):
+//   S = 2: the 8 quarters of the two waves are joined by a radix-8 pass (join8_untangle): a lane reads the 16 values of
+//          k1 and 256 - k1 and writes 16 bins back to the same slots -- the LDS traffic of k_fused_rev's untangle;
+//   S = 4: every wave first joins its own four quarters (join4_plain, in place), the team's radix-4 join then runs inside
+//          the untangle (join4_untangle over the waves' regions).
 // The peaks.  After B2 (row complete, waves' max / min / energy exchanged) every wave scans ITS 1024 bins, owns its
 // candidates (one per lane; dense segments are first thinned / reduced to their npks best, k_fused_rev's code) and
 // fetches in one LDS round trip all it needs of them; the waves exchange their candidates' keys (B3) and every wave
@@ -29,7 +30,7 @@
 // npks <= 64 (one staged peak per lane); larger npks stay with k_fused_mw.hip.
 #include <stdlib.h>
 
-#include "pvx_fft.h"
+#include "pvx_fft4.h"
 
 using namespace pvxw;
 using namespace pvxf;
@@ -48,26 +49,24 @@ __device__ __forceinline__ void team_sync() {
 }
 
 template <int S> struct TeamGeo {
-    using G = Geo<16>;
-    static constexpr int L = G::M;                       // 1024 complex points per wave
+    static constexpr int L = 1024;                       // complex points per wave
     static constexpr int M = L * S;                      // bins 0..M-1
     static constexpr int N = 2 * M;                      // nfft
     static constexpr int T = 64 * S;                     // lanes per team
-    static constexpr int NPS = 512 / T;                  // (k1, L-k1) sets per lane in the join
-    static constexpr int REG = G::BUFC;                  // complex slots per wave region
+    static constexpr int REG = F4::BUF;                  // complex slots per wave region (4 quarters of 272)
     static constexpr int YLEN = M + (M >> 6) * 4;        // |X|^2 row, padded layout (ymap<1>)
     static constexpr int CAPW = L / 2 + 4;               // candidate list capacity per wave
-    static constexpr int TWN = NPS * S * T;              // join / untangle twiddles, lane-ordered
+    static constexpr int TWN = 512 * S;                  // join / untangle twiddles of the team, lane-ordered (global table)
+    static constexpr int J4N = (S == 4) ? 4 * 3 * 64 : 0;   // S = 4: twiddles of the in-wave radix-4 join
     // block-shared (bytes)
-    static constexpr size_t OFF_T1 = 0;                                  // v2f [16][64]  W_L^(l q)
-    static constexpr size_t OFF_T2 = OFF_T1 + 16 * 64 * 8;               // v2f [16][4]   W_64^(l1 t2)
-    static constexpr size_t OFF_X = OFF_T2 + 64 * 8;                     // float2 [S][REG]
+    static constexpr size_t OFF_T1 = 0;                                  // v2f [16][16]  W_256^(l q)
+    static constexpr size_t OFF_J4 = OFF_T1 + 256 * 8;                   // v2f [4][3][64] W_1024^(u k1) (S = 4)
+    static constexpr size_t OFF_X = OFF_J4 + (size_t)J4N * 8;            // float2 [S][REG]
     static constexpr size_t OFF_Y = OFF_X + (size_t)S * REG * 8;         // float [YLEN]
     static constexpr size_t OFF_KEYS = OFF_Y + (size_t)YLEN * 4;         // u32 [S][64]; before the keys are written: the scan's trash slots
     static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * 64 * 4;    // double [S]
     static constexpr size_t OFF_MISC = OFF_PSUM + (size_t)S * 8;         // int nw[S] | float pmax[S] | float pmin[S] | int val[S][GFT]
-    static constexpr size_t OFF_TW = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
-    __host__ __device__ static size_t off_wave(bool twl) { return OFF_TW + (twl ? (size_t)TWN * 8 : 0); }
+    static constexpr size_t OFF_WAVE = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFT);
@@ -77,17 +76,13 @@ template <int S> struct TeamGeo {
                  + gs * kpad * 5 * 4;                                    // sval
         return (b + 15) & ~(size_t)15;
     }
-    __host__ __device__ static size_t total(int K, bool twl) { return off_wave(twl) + per_wave(K) * S; }
+    __host__ __device__ static size_t total(int K) { return OFF_WAVE + per_wave(K) * S; }
 };
 
-// bin k of the team's spectrum buffer: region k / L, k_fused_rev's padded natural order inside it
-template <int S> __device__ __forceinline__ int xa(int k) { return (k >> 10) * TeamGeo<S>::REG + zpad<16>(k & 1023); }
-
-template <int S, typename InT, bool AL2, int H, bool TWL>
+template <int S, typename InT, bool AL2, int H>
 __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
-    using G = Geo<16>;
     using TG = TeamGeo<S>;
-    constexpr int R = 16, P = G::P, PITCH = G::PITCH, L = TG::L, M = TG::M, T = TG::T, NPS = TG::NPS, REG = TG::REG;
+    constexpr int R = 16, L = TG::L, M = TG::M, T = TG::T, REG = TG::REG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -97,7 +92,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     const int gs = staged_frames(K, GFT);
 
     v2f* const t1L = (v2f*)(smem + TG::OFF_T1);
-    v2f* const t2L = (v2f*)(smem + TG::OFF_T2);
+    v2f* const j4L = (v2f*)(smem + TG::OFF_J4);
     float2* const X = (float2*)(smem + TG::OFF_X);
     float* const Ly = (float*)(smem + TG::OFF_Y);
     unsigned* const Lkeys = (unsigned*)(smem + TG::OFF_KEYS);
@@ -106,9 +101,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     float* const Lpmax = (float*)(Lnw + S);
     float* const Lpmin = Lpmax + S;
     int* const Lval = (int*)(Lpmin + S);
-    const v2f* const twL = (const v2f*)(smem + TG::OFF_TW);
     // per-wave region (see k_fused_rev.hip for the opaque offset)
-    unsigned wboff = (unsigned)(TG::off_wave(TWL) + TG::per_wave(K) * wid);
+    unsigned wboff = (unsigned)(TG::OFF_WAVE + TG::per_wave(K) * wid);
     asm volatile("" : "+s"(wboff));
     unsigned char* wb = smem + wboff;
     double* const Ltot = (double*)wb;
@@ -127,41 +121,21 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     // ---- block-shared tables
     {
         const v2f* tab = (const v2f*)p.twiddle;                     // W_nfft^j, j < nfft; then the team table
-        for (int i = lt; i < R * 64; i += T) {
-            const int q = i >> 6, l = i & 63;
-            t1L[i] = tab[(2 * S * l * q) & NMASK];                  // W_L^(l q)
-        }
-        for (int i = lt; i < 64; i += T) t2L[i] = tab[((TG::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
-        if constexpr (TWL) {
-            v2f* tw = (v2f*)(smem + TG::OFF_TW);
-            for (int i = lt; i < TG::TWN; i += T) tw[i] = tab[TG::N + i];
+        for (int i = lt; i < 256; i += T) t1L[i] = tab[((TG::N / 256) * (i & 15) * (i >> 4)) & NMASK];          // [q][l] W_256^(l q)
+        if constexpr (S == 4) {
+            for (int i = lt; i < TG::J4N; i += T) {                 // [j][u-1][lane]: W_1024^(u k1), k1 = lane + 64 j
+                const int ln = i & 63, u = (i >> 6) % 3 + 1, k1 = ln + 64 * (i / 192);
+                j4L[i] = tab[((TG::N / 1024) * u * k1) & NMASK];
+            }
         }
     }
     __syncthreads();
-    const v2f* const twg = TWL ? twL : (const v2f*)p.twiddle + TG::N;      // [NPS][S][T]: W_N^k1, W_M^(s k1)
+    const v2f* const twg = (const v2f*)p.twiddle + TG::N;           // the team's join / untangle twiddles, lane-ordered
 
-    // ---- lane constants of the 1024-point transform (k_fused_rev.hip)
-    const int Q = lane / P, L1 = lane % P;
-    float csg[G::LOGP];
-    v2f cw[G::LOGP];
-    {
-        const float2* tab = (const float2*)p.twiddle;
-#pragma unroll
-        for (int s = 0; s < G::LOGP; s++) {
-            const int h = P >> (s + 1);
-            const bool up = (L1 & h) != 0;
-            csg[s] = up ? -1.f : 1.f;
-            const float2 wvv = tab[((TG::N / (2 * h)) * (L1 % h)) & NMASK];
-            cw[s] = up ? pvxc::mk(wvv.x, wvv.y) : pvxc::mk(1.f, 0.f);
-        }
-    }
-    int t1v = 0;                                                    // bitrev(l1)
-#pragma unroll
-    for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
-    // the wave's share of the window: pairs j = S (lane + 64 r) + wid
+    // the wave's share of the window: pairs j = S (4 l + u + 64 r) + wid of lane 16 u + l (pvx_fft4.h)
     v2f wv[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[S * (lane + 64 * r) + wid];
+    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[S * (lofs4(lane) / 2 + 64 * r) + wid];
 #pragma unroll
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
 
@@ -187,7 +161,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
     };
     auto load_pair = [&](const InT* src, int r) {
-        const InT* q = src + 2 * S * lane + 2 * wid + 128 * S * r;
+        const InT* q = src + S * lofs4(lane) + 2 * wid + 128 * S * r;
         if constexpr (AL2 && sizeof(InT) == 4) raw[r] = *(const v2f*)q;
         else raw[r] = pvxc::mk(ld1(q), ld1(q + 1));
     };
@@ -196,15 +170,6 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         constexpr int PR = R / 4;
 #pragma unroll
         for (int r = part * PR; r < (part + 1) * PR; r++) load_pair(src, r);
-    };
-
-    const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f), kmh = pvxc::splat(-0.5f);
-    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, HQ = 0.70710678118654752440f;
-    // (Za, conj-partner Zb, twiddle W_N^k) -> X[k], X[M-k]   (k_fused.hip's untangle)
-    auto untangle_o = [&](v2f Sm, v2f O, v2f w, v2f& x0, v2f& x1) {
-        const v2f Pk = pvxc::cmul(O, w);
-        x0 = __builtin_elementwise_fma(khalf, Sm, Pk);
-        x1 = pvxc::fms_conj(khalf, Sm, Pk);
     };
 
     // spectrum of the team's row into X (zeros for a zero row) + |X|^2 -> Ly, team-reduced max / min / energy.
@@ -235,134 +200,30 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             team_sync();
             return;
         }
-        dft_regs<R>(z);                                             // stage 1
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch_part(nsrc, 1);
         v2f* dz = (v2f*)cur;
-#pragma unroll
-        for (int q2 = 0; q2 < R; q2 += 2) {
-            const v2f ta = t1L[q2 * 64 + lane], tb = t1L[(q2 + 1) * 64 + lane];
-            const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], ta) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tb);
-            dz[q2 * PITCH + lane] = pa;
-            dz[(q2 + 1) * PITCH + lane] = pb2;
-        }
-        wave_sync();
-#pragma unroll
-        for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
-        prefetch_part(nsrc, 2);
-        wave_sync();
-        dft_regs<R>(z);                                             // stage 2
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch_part(nsrc, 3);
-#pragma unroll
-        for (int t0 = 0; t0 < R; t0 += 4) {
-            v2f a[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2L[(t0 + j) * P + L1]) : z[t0 + j];
-            xstep4<2, true>(a, csg[G::LOGP - 2], cw[G::LOGP - 2]);
-            xstep4<1, false>(a, csg[G::LOGP - 1], cw[G::LOGP - 1]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) dz[zpad<R>(Q + R * (t0 + j) + G::R2 * t1v)] = a[j];
-        }
-        // the lane's join / untangle twiddles: fetched before the barrier (from L2 / LDS), their latency under its wait
-        __builtin_amdgcn_sched_barrier(0);                          // (not above the transform's last stage: no registers there)
-        v2f twv[NPS][S];
-#pragma unroll
-        for (int j = 0; j < NPS; j++)
-#pragma unroll
-            for (int s = 0; s < S; s++) twv[j][s] = twg[(j * S + s) * T + lt];
-        team_sync();                                                // ---- B1: every E_s is in place
-        // ---- join + untangle, in place
+        // the wave's four 256-point transforms -> quarter u of its region, natural order (pvx_fft4.h)
+        fft4_quarters(z, dz, t1L, lane, [&]() { prefetch_part(nsrc, 1); }, [&]() { prefetch_part(nsrc, 2); }, [&]() { prefetch_part(nsrc, 3); });
         v2f* const xz = (v2f*)X;
         float lmax = -INFINITY, lmin = INFINITY, ls0 = 0.f, ls1 = 0.f;
-        // the k1 = L/2 family (bins L/2 + L u): its S values pair among themselves; every lane computes it (a few
-        // instructions on wave-uniform constants), lane 0 of the team stores it in the slots its k1 = 0 set leaves free
-        v2f spv[S];
-        {
-            v2f c[S];
+        if constexpr (S == 2) {
+            // the lane's join / untangle twiddles: fetched before the barrier (from L2), their latency under its wait
+            __builtin_amdgcn_sched_barrier(0);
+            v2f twv[8];
 #pragma unroll
-            for (int s = 0; s < S; s++) c[s] = xz[s * REG + zpad<R>(L / 2)];
-            if constexpr (S == 2) {
-                const v2f z0 = pvxc::add_mni(c[0], c[1]), z1 = pvxc::add_pi(c[0], c[1]);      // Z[L/2], Z[3L/2]
-                const v2f Sm = pvxc::add_conj(z0, z1), D = pvxc::sub_conj(z0, z1);
-                const v2f O = pvxc::mul_swap(D, kmih);
-                const v2f Pk = pvxc::cmul_k(O, pvxc::mk(HQ, -HQ));                            // W_N^(L/2) = W_8
-                spv[0] = __builtin_elementwise_fma(khalf, Sm, Pk);
-                spv[1] = pvxc::fms_conj(khalf, Sm, Pk);
-            } else {
-                const v2f c1 = pvxc::cmul_k(c[1], pvxc::mk(HQ, -HQ)), c2 = pvxc::mni(c[2]), c3 = pvxc::cmul_k(c[3], pvxc::mk(-HQ, -HQ));
-                const v2f A = c[0] + c2, B = c[0] - c2, C = c1 + c3, D = c1 - c3;
-                const v2f z0 = A + C, z2 = A - C, z1 = pvxc::add_mni(B, D), z3 = pvxc::add_pi(B, D);   // Z[L/2 + L u]
-                {   // (u = 0, 3): W_N^(L/2) = W_16
-                    const v2f Sm = pvxc::add_conj(z0, z3), Dd = pvxc::sub_conj(z0, z3);
-                    const v2f Pk = pvxc::cmul_k(pvxc::mul_swap(Dd, kmih), pvxc::mk(C1, -S1));
-                    spv[0] = __builtin_elementwise_fma(khalf, Sm, Pk);
-                    spv[3] = pvxc::fms_conj(khalf, Sm, Pk);
-                }
-                {   // (u = 1, 2): W_N^(L/2 + L) = W_16^3
-                    const v2f Sm = pvxc::add_conj(z1, z2), Dd = pvxc::sub_conj(z1, z2);
-                    const v2f Pk = pvxc::cmul_k(pvxc::mul_swap(Dd, kmih), pvxc::mk(S1, -C1));
-                    spv[1] = __builtin_elementwise_fma(khalf, Sm, Pk);
-                    spv[2] = pvxc::fms_conj(khalf, Sm, Pk);
-                }
-            }
-        }
+            for (int c = 0; c < 8; c++) twv[c] = twg[c * T + lt];
+            team_sync();                                            // ---- B1: all eight quarters are in place
+            join8_untangle(xz, Ly, twv, lt, wid == 0, lmax, lmin, ls0, ls1);
+        } else {
+            wave_sync();
+            join4_plain(dz, j4L, lane);                             // the wave's 1024-point result, in place
+            __builtin_amdgcn_sched_barrier(0);
+            v2f twv[2][4];
 #pragma unroll
-        for (int j = 0; j < NPS; j++) {
-            const int k1 = lt + T * j;
-            const int kb = (L - k1) & (L - 1);
-            const int sa = zpad<R>(k1);
-            int sb = zpad<R>(kb);
-            v2f a[S], b[S];
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int s = 0; s < S; s++) { a[s] = xz[s * REG + sa]; b[s] = xz[s * REG + sb]; }
-            const v2f wu = twv[j][0];                               // W_N^k1
-#pragma unroll
-            for (int s = 1; s < S; s++) {
-                const v2f wj = twv[j][s];                           // W_M^(s k1)
-                a[s] = pvxc::cmul(a[s], wj);
-                b[s] = pvxc::cmul_conj(b[s], wj);
-            }
-            v2f x0[S], x1[S];
-            if constexpr (S == 2) {
-                const v2f A0 = a[0] + a[1], A1 = a[0] - a[1], B0 = b[0] + b[1], B1 = b[0] - b[1];
-                // t = 0: (A0, B0), W_N^k1;   t = 1: (A1, B1), W_N^(k1 + L) = -i W_N^k1
-                untangle_o(pvxc::add_conj(A0, B0), pvxc::mul_swap(pvxc::sub_conj(A0, B0), kmih), wu, x0[0], x1[0]);
-                untangle_o(pvxc::add_conj(A1, B1), pvxc::sub_conj(A1, B1) * kmh, wu, x0[1], x1[1]);
-            } else {
-                v2f A[4], B[4];
-                {
-                    const v2f e = a[0] + a[2], f = a[0] - a[2], g = a[1] + a[3], h = a[1] - a[3];
-                    A[0] = e + g; A[2] = e - g; A[1] = pvxc::add_mni(f, h); A[3] = pvxc::add_pi(f, h);
-                }
-                {
-                    const v2f e = b[0] + b[2], f = b[0] - b[2], g = b[1] + b[3], h = b[1] - b[3];
-                    B[0] = e + g; B[2] = e - g; B[1] = pvxc::add_mni(f, h); B[3] = pvxc::add_pi(f, h);
-                }
-                // t: (A_t, B_((4 - t) mod 4)), W_N^(k1 + L t) = W_8^t W_N^k1
-                untangle_o(pvxc::add_conj(A[0], B[0]), pvxc::mul_swap(pvxc::sub_conj(A[0], B[0]), kmih), wu, x0[0], x1[0]);
-                untangle_o(pvxc::add_conj(A[1], B[3]), pvxc::cmul_k(pvxc::mul_swap(pvxc::sub_conj(A[1], B[3]), kmih), pvxc::mk(HQ, -HQ)), wu, x0[1], x1[1]);
-                untangle_o(pvxc::add_conj(A[2], B[2]), pvxc::sub_conj(A[2], B[2]) * kmh, wu, x0[2], x1[2]);
-                untangle_o(pvxc::add_conj(A[3], B[1]), pvxc::cmul_k(pvxc::mul_swap(pvxc::sub_conj(A[3], B[1]), kmih), pvxc::mk(-HQ, -HQ)), wu, x0[3], x1[3]);
-            }
-            int kbb = kb;                                           // bins of the mirrored slots: kbb + L (S-1-t)
-            if (j == 0) {
-                if (lt == 0) {
-                    // k1 = 0: x1[t] would be X[M - L t] (bin M, or a duplicate of x0[S-t]); the slots take bins L/2 + L u
-#pragma unroll
-                    for (int t = 0; t < S; t++) x1[t] = spv[S - 1 - t];
-                    kbb = L / 2; sb = zpad<R>(L / 2);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < S; t++) {
-                const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
-                xz[t * REG + sa] = x0[t];                           // X[k1 + L t]
-                xz[(S - 1 - t) * REG + sb] = x1[t];                 // X[kbb + L (S-1-t)]
-                Ly[ymap<1>(k1 + L * t)] = e0;
-                Ly[ymap<1>(kbb + L * (S - 1 - t))] = e1;
-                lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
-            }
+                for (int u = 0; u < 4; u++) twv[j][u] = twg[(j * 4 + u) * T + lt];
+            team_sync();                                            // ---- B1: every E_s is in place
+            join4_untangle<1024, F4::BUF, 256>(xz, Ly, twv, lt, Xa4IA(), lmax, lmin, ls0, ls1);
         }
         {
             const float wm = wave_max(lmax), wn = wave_min(lmin);
@@ -460,12 +321,12 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
             if (!pend_prev0) {
                 if (own_sl >= 0) {
-                    const float2 pv = X[xa<S>(own_pb)];
+                    const float2 pv = X[xa4(own_pb)];
                     Lsval[(size_t)own_sl * 5 + 2] = pv.x;
                     Lsval[(size_t)own_sl * 5 + 3] = pv.y;
                 }
             } else
-            for (int e = lane; e < pend_nk; e += 64) {
+            for (int e = fresh_lane(); e < pend_nk; e += 64) {      // (rare: the first frame of a streamed call)
                 const int sl = (ng - 1) * kpad + e;
                 const int nbin = Lsbin[sl];
                 Lsval[(size_t)sl * 5 + 2] = (float)p.prev0[2 * nbin];
@@ -516,8 +377,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 nb[2 * d - 2] = Ly[ymap<1>(j0)];
                 nb[2 * d - 1] = Ly[ymap<1>(j1)];
             }
-            c = X[xa<S>(pb)];
-            vm = X[xa<S>(pb - 1)]; vp = X[xa<S>(pb + 1)];
+            c = X[xa4(pb)];
+            vm = X[xa4(pb - 1)]; vp = X[xa4(pb + 1)];
 #pragma unroll
             for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
             mykey = has ? __float_as_uint(v - mine) : 0u;           // scores >= 0: bits order like values
@@ -527,7 +388,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         if (p.spec_out != nullptr && g == p.spec_row) {
 #pragma unroll
             for (int j = 0; j < M / T; j++) {
-                const float2 v = X[xa<S>(lt + T * j)];
+                const float2 v = X[xa4(lt + T * j)];
                 p.spec_out[2 * (lt + T * j)] = v.x;
                 p.spec_out[2 * (lt + T * j) + 1] = v.y;
             }
@@ -581,17 +442,18 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 // fewer maxima than npks under a negative threshold: all maxima, then the first non-maximum interior
                 // bins (peak_pick_regs' first branch, on the whole row) -- wave 0 alone, then one more barrier
                 if (wid == 0) {
-                    const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, ctot, th, mine, lane);
-                    const int e = lane;
+                    const int ln = fresh_lane();
+                    const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, ctot, th, mine, ln);
+                    const int e = ln;
                     int sb2 = 1;
                     if (e < nsel) sb2 = Lsel[e];
-                    const bool keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, 0, nsel, p.rad, lane)
+                    const bool keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, 0, nsel, p.rad, ln)
                                                    : ((e < nsel) && salient<float, 1>(Ly, M, sb2, p.rad));
                     const unsigned long long bal = __ballot(keep);
                     if (keep) {
                         const int sl = ng * kpad + lane_prefix(bal);
-                        const float2 cc = X[xa<S>(sb2)];
-                        const float2 cm = X[xa<S>(sb2 - 1)], cp = X[xa<S>(sb2 + 1)];
+                        const float2 cc = X[xa4(sb2)];
+                        const float2 cm = X[xa4(sb2 - 1)], cp = X[xa4(sb2 + 1)];
                         const float em = (sb2 > 1) ? __builtin_fmaf(cm.x, cm.x, cm.y * cm.y) : 0.f;
                         const float s3 = (em + __builtin_fmaf(cc.x, cc.x, cc.y * cc.y)) + __builtin_fmaf(cp.x, cp.x, cp.y * cp.y);
                         Lsbin[sl] = sb2;
@@ -612,7 +474,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     if (ng > 0) flush(ng);
 }
 
-template <int S, bool TWL> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
+template <int S> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
     using TG = TeamGeo<S>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -621,13 +483,13 @@ template <int S, bool TWL> int launch_team(const FusedParams& p, int x_dtype, hi
     }
     if (p.total_rows >= 0x7fffff00LL) { pvx_set_error("the fused kernel indexes rows in 32 bits (%lld rows)", (long long)p.total_rows); return PVX_ERR_UNSUPPORTED; }
     if (p.K > 64 || p.rad > 5) { pvx_set_error("the team kernel takes npks <= 64 and rad <= 5 (npks=%d rad=%d)", p.K, p.rad); return PVX_ERR_UNSUPPORTED; }
-    const size_t lds = TG::total(p.K, TWL);
+    const size_t lds = TG::total(p.K);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the team kernel", TG::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
     constexpr int R = 16;
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     const int H = (p.hop == 32 * R * S) ? R / 4 : (p.hop == 64 * R * S) ? R / 2 : 0;
     const void* fn = nullptr;
-#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4, TWL> : H ? (const void*)k_fused_team<S, INT, AL, R / 2, TWL> : (const void*)k_fused_team<S, INT, AL, 0, TWL>)
+#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4> : H ? (const void*)k_fused_team<S, INT, AL, R / 2> : (const void*)k_fused_team<S, INT, AL, 0>)
     switch (x_dtype) {
         case PVX_F32: fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); break;
         case PVX_F64: fn = PVX_TEAM_PICK(double, false); break;
@@ -651,26 +513,28 @@ template <int S, bool TWL> int launch_team(const FusedParams& p, int x_dtype, hi
 
 }  // namespace
 
-// lane-ordered twiddles of the join / untangle pass, appended to the plan's W_nfft^j table: entry (j S + s) T + lt is
-// W_N^k1 (s = 0) or W_M^(s k1) = W_N^(2 s k1), k1 = lt + T j
-int pvx_fused_team_table_len(int nfft) { return (nfft == 4096 || nfft == 8192) ? 512 * (nfft / 4096) * 2 : 0; }
+// lane-ordered twiddles of the team's join / untangle pass, appended to the plan's W_nfft^j table (N = nfft, M = N/2):
+//   nfft 4096 (S = 2, 128 lanes, k1 = lt):            entry c * 128 + lt = W_N^k1 (c = 0), W_M^(c k1) (c = 1..7)
+//   nfft 8192 (S = 4, 256 lanes, k1 = lt + 256 j):    entry (j * 4 + u) * 256 + lt = W_N^k1 (u = 0), W_M^(u k1) (u = 1..3)
+int pvx_fused_team_table_len(int nfft) { return (nfft == 4096 || nfft == 8192) ? 512 * (nfft / 2048) : 0; }
 void pvx_fused_team_table(int nfft, const float* tw /* [nfft][2] */, float* out) {
-    const int S = nfft / 2048, T = 64 * S, NPS = 512 / T;
-    for (int j = 0; j < NPS; j++)
-        for (int s = 0; s < S; s++)
+    const int S = nfft / 2048, T = 64 * S;
+    const int nj = (S == 2) ? 1 : 2, nc = (S == 2) ? 8 : 4;
+    for (int j = 0; j < nj; j++)
+        for (int c = 0; c < nc; c++)
             for (int lt = 0; lt < T; lt++) {
                 const int k1 = lt + T * j;
-                const int idx = (s == 0 ? k1 : 2 * s * k1) & (nfft - 1);
-                out[2 * ((j * S + s) * T + lt)] = tw[2 * idx];
-                out[2 * ((j * S + s) * T + lt) + 1] = tw[2 * idx + 1];
+                const int idx = (c == 0 ? k1 : 2 * c * k1) & (nfft - 1);
+                out[2 * ((j * nc + c) * T + lt)] = tw[2 * idx];
+                out[2 * ((j * nc + c) * T + lt) + 1] = tw[2 * idx + 1];
             }
 }
 
 int pvx_fused_team_supported(int nfft, int precision, int K) {
     if (precision != 32 || K > 64) return 0;
     switch (nfft) {
-        case 4096: return TeamGeo<2>::total(K, false) <= 160 * 1024;
-        case 8192: return TeamGeo<4>::total(K, false) <= 160 * 1024;
+        case 4096: return TeamGeo<2>::total(K) <= 160 * 1024;
+        case 8192: return TeamGeo<4>::total(K) <= 160 * 1024;
         default: return 0;
     }
 }
@@ -678,8 +542,8 @@ int pvx_fused_team_supported(int nfft, int precision, int K) {
 int pvx_launch_fused_team(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
-        case 4096: return getenv("PVX_TEAM_TWL") ? launch_team<2, true>(p, x_dtype, s) : launch_team<2, false>(p, x_dtype, s);
-        case 8192: return launch_team<4, false>(p, x_dtype, s);
+        case 4096: return launch_team<2>(p, x_dtype, s);
+        case 8192: return launch_team<4>(p, x_dtype, s);
         default: pvx_set_error("the team kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

@@ -137,6 +137,99 @@ __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&t
     }
 }
 
+// The plain radix-4 join of a wave's four quarters, in place (a team of 4 waves joins the waves' 1024-point results in a
+// second pass, join4_untangle over the regions): E[k1 + 256 t] = sum_u W_4^(u t) W_1024^(u k1) E_u[k1], k1 = lane + 64 j.
+// tw: LDS table [4][3][64] of W_1024^(u k1), u = 1..3.
+__device__ __forceinline__ void join4_plain(v2f* dz, const v2f* tw, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k1 = lane + 64 * j;
+        v2f a[4], A[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = dz[u * F4::RP + k1];
+#pragma unroll
+        for (int u = 1; u < 4; u++) a[u] = pvxc::cmul(a[u], tw[(j * 3 + (u - 1)) * 64 + lane]);
+        dft4(a, A);
+#pragma unroll
+        for (int t = 0; t < 4; t++) dz[t * F4::RP + k1] = A[t];
+    }
+}
+
+// Radix-8 join fused with the untangle for a team of TWO waves (nfft 4096): the eight 256-point quarters E_c, c = 2 u + s
+// (wave s, quarter u), sit at slot (c & 1) BUF + (c >> 1) RP + k1; lane lt < 128 takes k1 = lt: the 16 values of k1 and
+// 256 - k1 in, the 16 bins X[k1 + 256 t], X[(256 - k1) + 256 (7 - t)] out (slot t RP + k1: natural order across both
+// regions), in place.  tw = {W_N^k1, W_M^k1, ..., W_M^(7 k1)} (M = 2048, N = 4096).  The k1 = 128 family (bins 128 + 256 u)
+// goes to the mirrored slots of lane 0, which only wave 0 computes (`special`).
+__device__ __forceinline__ void join8_untangle(v2f* xz, float* Ly, const v2f (&tw)[8], int lt, bool special,
+                                               float& lmax, float& lmin, float& ls0, float& ls1) {
+    const v2f khalf = pvxc::splat(0.5f), kmih = pvxc::mk(0.5f, -0.5f), kmh = pvxc::splat(-0.5f);
+    constexpr float C32[4] = {0.98078528040323044913f, 0.83146961230254523708f, 0.55557023301960222474f, 0.19509032201612826785f};   // cos((1 + 2t) pi / 16)
+    constexpr float S32[4] = {0.19509032201612826785f, 0.55557023301960222474f, 0.83146961230254523708f, 0.98078528040323044913f};   // sin((1 + 2t) pi / 16)
+    // W_16^t, t < 8
+    constexpr float W16r[8] = {1.f, kC16, kH8, kS16, 0.f, -kS16, -kH8, -kC16};
+    constexpr float W16i[8] = {0.f, -kS16, -kH8, -kC16, -1.f, -kC16, -kH8, -kS16};
+    auto slot = [](int c, int k) -> int { return (c & 1) * F4::BUF + (c >> 1) * F4::RP + k; };
+    v2f spv[8];
+    if (special) {                                                  // wave-uniform
+        v2f c[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) {
+            const v2f v = xz[slot(cc, 128)];
+            c[cc] = (cc == 0) ? v : (cc == 4) ? pvxc::mni(v) : pvxc::cmul_k(v, pvxc::mk(W16r[cc], W16i[cc]));     // W_M^(128 c) = W_16^c
+        }
+        dft_regs<8>(c);                                             // Z[128 + 256 u]
+#pragma unroll
+        for (int t = 0; t < 4; t++) {                               // pairs (t, 7 - t), twiddle W_N^(128 + 256 t) = W_32^(1 + 2 t)
+            const v2f Sm = pvxc::add_conj(c[t], c[7 - t]), Dd = pvxc::sub_conj(c[t], c[7 - t]);
+            const v2f Pk = pvxc::cmul_k(pvxc::mul_swap(Dd, kmih), pvxc::mk(C32[t], -S32[t]));
+            spv[t] = __builtin_elementwise_fma(khalf, Sm, Pk);
+            spv[7 - t] = pvxc::fms_conj(khalf, Sm, Pk);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++) spv[t] = pvxc::splat(0.f);
+    }
+    const int k1 = lt;
+    const int kb = (256 - k1) & 255;
+    v2f a[8], b[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) { a[c] = xz[slot(c, k1)]; b[c] = xz[slot(c, kb)]; }
+#pragma unroll
+    for (int c = 1; c < 8; c++) {
+        a[c] = pvxc::cmul(a[c], tw[c]);
+        b[c] = pvxc::cmul_conj(b[c], tw[c]);
+    }
+    dft_regs<8>(a);
+    dft_regs<8>(b);
+    v2f x0[8], x1[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        // (A_t, B_((8 - t) mod 8)), twiddle W_16^t W_N^k1
+        const v2f zb = b[(8 - t) & 7];
+        const v2f Sm = pvxc::add_conj(a[t], zb), D = pvxc::sub_conj(a[t], zb);
+        v2f O;
+        if (t == 0) O = pvxc::mul_swap(D, kmih);
+        else if (t == 4) O = D * kmh;
+        else O = pvxc::cmul_k(pvxc::mul_swap(D, kmih), pvxc::mk(W16r[t], W16i[t]));
+        untangle_so(Sm, O, tw[0], x0[t], x1[t]);
+    }
+    int kbb = kb, sbk = kb;
+    if (lt == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) x1[t] = spv[7 - t];
+        kbb = 128; sbk = 128;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
+        xz[t * F4::RP + k1] = x0[t];                                // X[k1 + 256 t]
+        xz[(7 - t) * F4::RP + sbk] = x1[t];                         // X[kbb + 256 (7 - t)]
+        Ly[pvxw::ymap<1>(k1 + 256 * t)] = e0;
+        Ly[pvxw::ymap<1>(kbb + 256 * (7 - t))] = e1;
+        lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
+    }
+}
+
 // The four 256-point transforms of a wave, stages 1 and 2 (between them the transpose inside the 16-lane groups), and
 // the natural-order store: quarter u of `dz`, E_u[k'] at u RP + k'.  z: the lane's 16 windowed values.
 // t1: LDS table [16][16] W_256^(l q).  HOOK1 / HOOK2 run after stage 1 / during the transpose (the callers issue

@@ -23,6 +23,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// the lane index, computed on the spot (v_mbcnt): in rarely executed branches of a long frame loop, using the kernel's
+// `lane` variable keeps it (and what the compiler derives from it) alive across the whole loop -- as spilled registers
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ int lane_prefix(unsigned long long bal) {   // set bits of bal below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
