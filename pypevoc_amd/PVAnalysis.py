@@ -149,6 +149,17 @@ class _Plan(object):
 
 
 class PV(object):
+    """Phase vocoder (pypevoc.PVAnalysis.PV, PVAnalysis.py:71-417) on an MI355X.
+
+    NOTE -- one behavioural difference from the reference if you only switch the import: the default `precision=32`
+    runs the transform in float32 on the device (results are float64 arrays of float32-FFT accuracy: same peak bins,
+    |df| <= 1e-3 Hz, |dmag|/mag <= 1e-5, |dph| <= 2e-5 rad, waveform <= 1e-4 max|w|).  Pass
+    `precision=64` for the reference's own float64 arithmetic end to end (|df| <= 1e-9 Hz, identical partial tables).
+
+    Everything else follows the reference: constructor arguments, attributes (`f, mag, ph, realph, binno, t, totalmag,
+    nframes, win, wfact, fstep, dt, fbin, wfbin, oldfft, ...`), array layouts, `run_pv() / toSinSum() / calc_f0() /
+    calc_harmonic_power() / calc_fft_frame() / calc_pv_frame()`.  The result arrays live in GPU memory until they are read;
+    assigning or editing one takes effect in the later steps exactly as with the reference's ndarrays."""
     f = _Result("f", 0)
     mag = _Result("mag", 1)
     ph = _Result("ph", 2)

@@ -15,7 +15,7 @@ precision=32 (float32 frames + spectra, float64 per-peak arithmetic): a float32 
         |dmag|/mag <= 1e-5, |dph| <= 2e-5 rad;
     peak bins identical on >= 99.9 % of the reference's peaks (100 % on every fixture today);
     waveform |dw| <= 1e-4 * max|w|.
-Measured values (tools/gpu_diag.py on MI355X) are 5-100x inside these bounds; see DESIGN.md.
+Measured values on MI355X (bench.py self_check) are 5-100x inside these bounds.
 """
 import os
 

@@ -1,3 +1,5 @@
+"""Wall time of BASELINE config 2 through the whole path (host signal in, host waveform out), the previous round's
+objects released outside the clock.   python tools/time_c2_chain.py"""
 import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pypevoc_amd, bench
