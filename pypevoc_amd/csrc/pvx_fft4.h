@@ -132,7 +132,7 @@ __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&t
             xz[(3 - t) * QP + sb] = x1[t];                          // X[kbb + LQ (3 - t)]
             Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
             Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
-            lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
+            lmax = pvxw::max3f(lmax, e0, e1); lmin = pvxw::min3f(lmin, e0, e1); ls0 += e0; ls1 += e1;
         }
     }
 }
@@ -226,7 +226,7 @@ __device__ __forceinline__ void join8_untangle(v2f* xz, float* Ly, const v2f (&t
         xz[(7 - t) * F4::RP + sbk] = x1[t];                         // X[kbb + 256 (7 - t)]
         Ly[pvxw::ymap<1>(k1 + 256 * t)] = e0;
         Ly[pvxw::ymap<1>(kbb + 256 * (7 - t))] = e1;
-        lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
+        lmax = pvxw::max3f(lmax, e0, e1); lmin = pvxw::min3f(lmin, e0, e1); ls0 += e0; ls1 += e1;
     }
 }
 

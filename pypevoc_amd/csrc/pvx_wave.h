@@ -53,6 +53,10 @@ __device__ __forceinline__ double rl_d(double v, int l) {
     int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// three-operand maximum / minimum (one instruction; the compiler only forms them now and then)
+__device__ __forceinline__ float max3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 #define PVX_ROW_REDUCE(v, OP, DPP)            \
     v = OP(v, DPP<0xB1>(v));                  \
     v = OP(v, DPP<0x4E>(v));                  \
