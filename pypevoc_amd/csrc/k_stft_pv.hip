@@ -25,7 +25,7 @@
 
 #include <type_traits>
 
-#include "pvx_stft.h"
+#include "pvx_stft4.h"
 
 using namespace pvxw;
 using namespace pvxf;
@@ -56,9 +56,15 @@ template <int R, typename T> __host__ __device__ inline size_t pv_search_bytes(i
 // the untangle's twiddles W_nfft^k, k < nfft/4, from the first octant of the table (k <= nfft/8) and its symmetry
 // W^(nfft/4 - k) = (-Im, -Re) W^k (exact in the host's table, pvx_plan_create): 4 KB of LDS instead of 8 at nfft 2048,
 // which is what lets a seventh wave's buffer in
+// R = 16 (nfft 2048): the four-quarter transform of pvx_stft4.h -- t1 is [16][16] W_256^(l q), there is no t2, and the
+// untangle's table becomes the lane-ordered join / untangle twiddles [2][4][64]: 28 KB of tables instead of 37 at float64
 template <int R, typename T> struct PvGeo : StftGeo<R, T> {
-    static constexpr int TW8N = (StftGeo<R, T>::HALF / 2 + 1 + 7) & ~7;
-    static constexpr size_t OFF_BUF = StftGeo<R, T>::OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);          // cx [NW][BUFC]
+    static constexpr bool X4 = (R == 16);
+    static constexpr int TW8N = X4 ? 512 : ((StftGeo<R, T>::HALF / 2 + 1 + 7) & ~7);
+    static constexpr size_t OFF_T1 = StftGeo<R, T>::OFF_T1;
+    static constexpr size_t OFF_T2 = X4 ? OFF_T1 + (size_t)256 * 2 * sizeof(T) : StftGeo<R, T>::OFF_T2;
+    static constexpr size_t OFF_TW3 = X4 ? OFF_T2 : StftGeo<R, T>::OFF_TW3;
+    static constexpr size_t OFF_BUF = OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);                          // cx [NW][BUFC]
 };
 template <int R, typename T> __host__ __device__ inline size_t pv_total_lds(int nw, int K) {
     return PvGeo<R, T>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
@@ -77,6 +83,7 @@ template <int R, typename T, typename InT, int H>
 __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
     using G = PvGeo<R, T>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
+    constexpr bool X4 = G::X4;
     const StftParams& p = a.s;
     const PeaksParams& pk = a.p;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,9 +112,17 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         const cx<T>* tab = (const cx<T>*)p.twiddle;
         constexpr int NMASK = G::N - 1;
         for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = ((const T*)p.win)[i];
+        if constexpr (X4) {
+            for (int i = threadIdx.x; i < 256; i += blockDim.x) t1L[i] = tab[((G::N / 256) * (i & 15) * (i >> 4)) & NMASK];    // [q][l] W_256^(l q)
+            for (int i = threadIdx.x; i < 512; i += blockDim.x) {   // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
+                const int ln = i & 63, u = (i >> 6) & 3, k1 = ln + 64 * (i >> 8);
+                tw3[i] = tab[(u == 0 ? k1 : 2 * u * k1) & NMASK];
+            }
+        } else {
         for (int i = threadIdx.x; i < R * 64; i += blockDim.x) t1L[i] = tab[(2 * (i & 63) * (i >> 6)) & NMASK];
         for (int i = threadIdx.x; i < 64; i += blockDim.x) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
         for (int i = threadIdx.x; i <= G::HALF / 2; i += blockDim.x) tw3[i] = tab[i];
+        }
     }
     __syncthreads();
     const int Q = lane / P, L1 = lane % P;
@@ -149,12 +164,13 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
     // the arithmetic are float64 (int16 and float32 samples are exact in float32: half the registers across the frame)
     using RawT = typename std::conditional<(sizeof(T) == 8 && sizeof(InT) == 8), double, float>::type;
     RawT raw[2 * R];
+    const int lofs = X4 ? lofs4(lane) : 2 * lane;                     // sample offset of the lane's first pair (X4: pair 4 l + u of lane 16 u + l)
     auto prefetch_part = [&](const InT* src, int part) {
         if (src == nullptr) return;
         constexpr int PR = R / 4;
 #pragma unroll
         for (int r = part * PR; r < (part + 1) * PR; r++) {
-            const InT* q = src + 2 * lane + 128 * r;
+            const InT* q = src + lofs + 128 * r;
             raw[2 * r] = (RawT)q[0]; raw[2 * r + 1] = (RawT)q[1];
         }
     };
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         cx<T> z[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            z[r] = mkc<T>((T)raw[2 * r] * winL[2 * lane + 128 * r], (T)raw[2 * r + 1] * winL[2 * lane + 128 * r + 1]);
+            z[r] = mkc<T>((T)raw[2 * r] * winL[lofs + 128 * r], (T)raw[2 * r + 1] * winL[lofs + 128 * r + 1]);
             asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
                 for (int r = 0; r < R - H; r++) { raw[2 * r] = raw[2 * (r + H)]; raw[2 * r + 1] = raw[2 * (r + H) + 1]; }
 #pragma unroll
                 for (int r = R - H; r < R; r++) {
-                    const InT* q = nsrc + 2 * lane + 128 * r;
+                    const InT* q = nsrc + lofs + 128 * r;
                     raw[2 * r] = (RawT)q[0]; raw[2 * r + 1] = (RawT)q[1];
                 }
                 nsrc = nullptr;                                       // nothing else to fetch for row j + 1
@@ -277,6 +293,24 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
             for (int k = lane; k < M; k += 64) out[k] = mkc<T>((T)0, (T)0);
             continue;
         }
+        constexpr bool LATE = sizeof(RawT) == 8 && R == 16;
+        if constexpr (X4) {
+            // ---- four 256-point transforms, then the radix-4 join inside the untangle (pvx_stft4.h): bins straight to the
+            // workspace row, |X|^2 of every bin to LDS where the transform buffer was
+            fft4_quartersT<T>(z, dz, t1L, lane, [&]() { prefetch_part(nsrc, 1); }, [&]() { if constexpr (!LATE) prefetch_part(nsrc, 2); },
+                              [&]() { if constexpr (!LATE) prefetch_part(nsrc, 3); });
+            int lu = lane;
+            asm volatile("" : "+v"(lu));                             // (see flush: addresses derived here, not hoisted)
+            wave_sync();
+            Join4In<T> in;
+            join4_read<T>(dz, lu, in);
+            wave_sync();                                              // dz is free: the magnitude row goes there
+            if constexpr (LATE) { __builtin_amdgcn_sched_barrier(0); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3); __builtin_amdgcn_sched_barrier(0); }
+            join4_emit<T>(in, tw3, lu, [&](int k, cx<T> x) {
+                out[k] = x;
+                if (with_peaks) y[k] = x.x * x.x + x.y * x.y;
+            });
+        } else {
         dftT<R, T>(z);                                                // stage 1
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
@@ -287,7 +321,6 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
         // float64 samples: the second half of the next row is fetched after the transform (with all of it in flight
         // through stages 2 and 3 the kernel needs more than 256 registers)
-        constexpr bool LATE = sizeof(RawT) == 8 && R == 16;
         if constexpr (!LATE) prefetch_part(nsrc, 2);
         wave_sync();
         dftT<R, T>(z);                                                // stage 2
@@ -344,6 +377,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
                 y[k] = x0.x * x0.x + x0.y * x0.y;
                 y[kk] = x1.x * x1.x + x1.y * x1.y;
             }
+        }
         }
         wave_sync();
         if (!with_peaks) continue;
