@@ -442,11 +442,17 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
                 bool take = has;
                 if (C > K) {
-                    const unsigned mykey = has ? __float_as_uint(v - mine) : 0u;     // scores >= 0: bits order like values
+                    // keys (score, 63 - lane): unique, ties go to the lower bin; scores >= 0: bits order like values
+                    const unsigned mykey = has ? __float_as_uint(v - mine) : 0u;
+                    const unsigned long long my64 = ((unsigned long long)mykey << 32) | (unsigned)(63 - lane);
                     int rank = 0;
-                    for (int j = 0; j < C; ++j) {
-                        const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mykey, j);
-                        rank += (kj > mykey || (kj == mykey && j < lane)) ? 1 : 0;
+                    for (int j = 0; j < C; j += 4) {                   // (lanes from C on hold key 0: below every candidate's)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mykey, j + u);
+                            const unsigned long long k64 = ((unsigned long long)kj << 32) | (unsigned)(63 - j - u);
+                            rank += (k64 > my64) ? 1 : 0;
+                        }
                     }
                     take = has && (rank < K);
                 }

@@ -401,21 +401,21 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             slow = (th < 0.0) && (ctot < K);                        // zeros of pkmskamp qualify too (PF.py:166-187): wave 0, below
             bool take = has;
             if (ctot > K) {
-                // rank of this lane's candidate among all the team's: larger score, or equal score and lower bin
+                // rank of this lane's candidate among all the team's: larger score, or equal score and lower bin -- one
+                // compare of (score, 64 (S - 1 - wave) + 63 - lane): unique keys, four list entries per trip (the lanes
+                // behind a wave's list hold score 0: below every candidate's)
+                const unsigned long long my64 = ((unsigned long long)mykey << 32) | (unsigned)(64 * (S - 1 - wid) + 63 - lane);
                 int rank = 0;
 #pragma unroll
                 for (int w = 0; w < S; w++) {
                     const int n = Lnw[w];
-                    if (w == wid) {
-                        for (int j = 0; j < n; ++j) {
-                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mykey, j);
-                            rank += (kj > mykey || (kj == mykey && j < lane)) ? 1 : 0;
-                        }
-                    } else {
-                        const unsigned ko = Lkeys[w * 64 + lane];
-                        for (int j = 0; j < n; ++j) {
-                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)ko, j);
-                            rank += (kj > mykey || (kj == mykey && w < wid)) ? 1 : 0;
+                    const unsigned ko = (w == wid) ? mykey : Lkeys[w * 64 + lane];
+                    for (int j = 0; j < n; j += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)ko, j + u);
+                            const unsigned long long k64 = ((unsigned long long)kj << 32) | (unsigned)(64 * (S - 1 - w) + 63 - j - u);
+                            rank += (k64 > my64) ? 1 : 0;
                         }
                     }
                 }

@@ -454,6 +454,19 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
 // falls off has groups with tiny maxima); the list then fits one lane each and the frame takes the callers' short
 // path.  The exact selection among the survivors is the callers' as before (same list order, same tie rule): the
 // result does not depend on what T drops.
+// The bound T of peak_scan_block_thin from the lanes' best candidate scores (0: no candidate).
+// (Tried: the exact npeaks-th largest of the 64 lane bests -- one more broadcast per lane at or above T -- and thinning
+// from 64 candidates on: both slower on a violin recording and on noise; a broadcast costs what ten candidates cost the
+// radix select.)
+__device__ __forceinline__ float thin_bound(float best, int npeaks) {
+    float qb = fmaxf(best, dpp_f<0xB1>(best));
+    qb = fmaxf(qb, dpp_f<0x4E>(qb));                                 // every lane: its quad's best
+    int beaten = 0;                                                  // quads whose best beats this one's
+#pragma unroll
+    for (int j = 0; j < 16; j++) beaten += (rl_f(qb, 4 * j) > qb) ? 1 : 0;
+    return wave_min(beaten < npeaks ? qb : INFINITY);
+}
+
 template <int R, typename CI>
 __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
     static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
@@ -507,12 +520,7 @@ __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, 
         float best = 0.f;                                            // this lane's best candidate score (0: it has none)
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
-        best = fmaxf(best, dpp_f<0xB1>(best));
-        best = fmaxf(best, dpp_f<0x4E>(best));                       // every lane: its quad's best
-        int beaten = 0;                                              // quads whose best beats this one's
-#pragma unroll
-        for (int j = 0; j < 16; j++) beaten += (rl_f(best, 4 * j) > best) ? 1 : 0;
-        const float T = wave_min(beaten < npeaks ? best : INFINITY);
+        const float T = thin_bound(best, npeaks);
         unsigned keep = 0u;
 #pragma unroll
         for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
@@ -574,12 +582,7 @@ __device__ __forceinline__ int peak_scan_seg_thin(const float* y, int kbase, int
         float best = 0.f;
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
-        best = fmaxf(best, dpp_f<0xB1>(best));
-        best = fmaxf(best, dpp_f<0x4E>(best));
-        int beaten = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) beaten += (rl_f(best, 4 * j) > best) ? 1 : 0;
-        const float T = wave_min(beaten < npeaks ? best : INFINITY);
+        const float T = thin_bound(best, npeaks);
         unsigned keep = 0u;
 #pragma unroll
         for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
@@ -728,10 +731,16 @@ __device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int*
         // a few more candidates than wanted (the usual case): every lane owns one and counts the
         // candidates that beat it, broadcast one by one with readlane.  "beats" = larger score, or equal
         // score and lower bin (np.argmax takes the first maximum).
+        // (one compare of the unique keys (score, 63 - lane), four list entries per trip: the lanes from C on hold score 0)
+        const unsigned long long my64 = ((unsigned long long)mine << 32) | (unsigned)(63 - lane);
         int rank = 0;
-        for (int j = 0; j < C; ++j) {
-            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mine, j);
-            rank += (kj > mine || (kj == mine && j < lane)) ? 1 : 0;
+        for (int j = 0; j < C; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mine, j + u);
+                const unsigned long long k64 = ((unsigned long long)kj << 32) | (unsigned)(63 - j - u);
+                rank += (k64 > my64) ? 1 : 0;
+            }
         }
         const bool take = (lane < C) && (rank < npeaks);
         const unsigned long long bk = __ballot(take);

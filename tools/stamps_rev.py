@@ -1,5 +1,5 @@
 """Where a wave of k_fused_rev (nfft 2048) spends its cycles: s_memtime stamps of an instrumented build.
-   bash tools/ab/buildstamp_rev.sh && PVX_LIB=tools/ab/libpvx_st.so python tools/stamps_rev.py [noise]"""
+   bash tools/ab/buildstamp_rev.sh && PVX_LIB=tools/ab/libpvx_st.so python tools/stamps_rev.py [noise|violin]"""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PVX_STAMPS"] = "1"
@@ -7,8 +7,13 @@ import bench
 from pypevoc_amd import _lib
 lib = _lib.load(); _lib.init(0)
 dev = torch.device("cuda", 0)
-noise = len(sys.argv) > 1 and sys.argv[1] == "noise"
-x = (0.1 * torch.randn(44100 * 600, device=dev)) if noise else torch.from_numpy(bench.c2_signal(600)).to(dev); nsamp = x.numel()
+what = sys.argv[1] if len(sys.argv) > 1 else "harmonic"
+if what == "noise": x = 0.1 * torch.randn(44100 * 600, device=dev)
+elif what == "violin":
+    xv = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "G7_perlman.npz"))["x"].astype(np.float32)
+    x = torch.from_numpy(np.tile(xv, 44100 * 600 // len(xv) + 1)[: 44100 * 600]).to(dev)
+else: x = torch.from_numpy(bench.c2_signal(600)).to(dev)
+nsamp = x.numel()
 F = int(lib.pvx_nframes(nsamp, 2048, 512)); K = 8
 packed = torch.empty(5 * F * K + 2 * F, dtype=torch.float64, device=dev); base = packed.data_ptr()
 ptrs = [base + i * F * K * 8 for i in range(5)] + [base + 5 * F * K * 8, base + 5 * F * K * 8 + F * 8]
