@@ -146,27 +146,31 @@ __host__ __device__ inline size_t synth_lds_bytes(int h, int nb, int wl, int gro
     return (size_t)h * 8 * groups + (size_t)nb * wl * 8 * 3 + (size_t)nb * sizeof(CParam) + (size_t)nb * wl * 4 + (size_t)nb * 4 * 7 + (size_t)HT * 8;
 }
 
+#ifndef PVX_SYNTH_WAVES
+#define PVX_SYNTH_WAVES 4
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES, PVX_SYNTH_WAVES))) void k_synth_ola(SynthParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wcnt[NT / 64];
     __shared__ int qnext;
 
-    constexpr int SP = 4;            // samples per thread held in registers while a batch is added
+#ifndef PVX_SYNTH_SP
+#define PVX_SYNTH_SP 1
+#endif
+    constexpr int SP = PVX_SYNTH_SP; // samples per thread held in registers while a batch is added
     constexpr int G = NT / TS;       // groups: group g adds contributions g, g + G, ... to its own accumulators
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
     const int NB = p.nbatch;
     const int64_t seg = (int64_t)blockIdx.x + p.seg0;  // output samples [seg*h, seg*h + h)
-    const double dh = (double)h;
-    const double overlap = p.hop_a / (double)p.nfft;   // PVAnalysis.py:824
-    const double fstep = p.sr / (double)p.nfft;        // PVAnalysis.py:825
-    const double dfr = 1. / overlap / 2.;              // PVAnalysis.py:687
-    const int edgsam = (int)(dfr * h * p.edge);        // PVAnalysis.py:740
-    const double dfr_s = (double)p.nfft / (double)p.hop_a / 2.;      // PVAnalysis.py:1055
-    const int64_t edgsamp = (int64_t)(p.edge * h * dfr_s);           // PVAnalysis.py:1056 (integer, Python 2)
-    const int EF = edgsam > 0 ? (edgsam + h - 1) / h : 0;            // frames an edge can reach
-    const int WB = (int)ceil(dfr + 0.5) + 2;                         // points needed behind the node
-    const int WL = WB + 4;                                           // window length (<= WMAX, host-checked)
+    const double dh = p.c_dh;                          // (double)h
+    const double fstep = p.c_fstep;                    // sr / nfft, PVAnalysis.py:825
+    const double dfr = p.c_dfr;                        // 1 / (hop_a / nfft) / 2, PVAnalysis.py:687, 824
+    const int edgsam = p.c_edgsam;                     // (int)(dfr * h * edge), PVAnalysis.py:740
+    const int64_t edgsamp = p.c_edgsamp;               // (int)(edge * h * (nfft / hop_a / 2.)), PVAnalysis.py:1055-1056 (integer, Python 2)
+    const int EF = p.c_EF;                             // frames an edge can reach
+    const int WB = p.c_WB;                             // ceil(dfr + .5) + 2: points needed behind the node
+    const int WL = p.c_WL;                             // window length WB + 4 (<= WMAX, host-checked)
 
     double* acc = (double*)smem;                       // [G][h] accumulators; row 0 is the output
     double* wf = acc + (size_t)G * h;                  // windows of partial points, j in [j0, j0 + wn)
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
             const double* pf = wf + (size_t)bb * WL;
             const double* pm = wm + (size_t)bb * WL;
             const double* pr = wr + (size_t)bb * WL;
-            const double offf = dfr + .5, offm = dfr;                     // PVAnalysis.py:701-702
+            const double offf = p.c_offf, offm = dfr;                     // dfr + .5, dfr: PVAnalysis.py:701-702
             CParam c;
             c.kind = kind;
             if (kind == 1) {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(NT) void k_synth_ola(SynthParams p) {
             if (kind == 0) {
                 // the per-sample form: 2 pi / sr folded into the two-piece phase polynomial (the sample loop is this
                 // kernel's bound; the folding moves the phase by a few ulp of ~1e4 rad, 1e-12 of the waveform)
-                const double sc = kPi2 / p.sr;
+                const double sc = p.c_sc;                                 // 2 pi / sr
                 c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
             }
             prm[bb] = c;
@@ -454,6 +458,20 @@ int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
     while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
     if (nb < 1) nb = 1;
     p.nbatch = nb;
+    {
+        const double overlap = p.hop_a / (double)p.nfft;              // PVAnalysis.py:824
+        p.c_dh = (double)h;
+        p.c_fstep = p.sr / (double)p.nfft;                            // PVAnalysis.py:825
+        p.c_dfr = 1. / overlap / 2.;                                  // PVAnalysis.py:687
+        p.c_offf = p.c_dfr + .5;
+        p.c_sc = kPi2 / p.sr;
+        p.c_edgsam = (int)(p.c_dfr * h * p.edge);                     // PVAnalysis.py:740
+        const double dfr_s = (double)p.nfft / (double)p.hop_a / 2.;   // PVAnalysis.py:1055
+        p.c_edgsamp = (int64_t)(p.edge * h * dfr_s);                  // PVAnalysis.py:1056
+        p.c_EF = p.c_edgsam > 0 ? (p.c_edgsam + h - 1) / h : 0;
+        p.c_WB = (int)ceil(p.c_dfr + 0.5) + 2;
+        p.c_WL = p.c_WB + 4;
+    }
     // a slice of the segments (p.seg_count > 0: pvx_synth_resident launches the waveform in slices whose DMA to the host
     // runs under the next slice's kernel); the geometry above is that of the whole waveform either way
     if (p.seg0 < 0 || p.seg0 > nseg) { pvx_set_error("bad segment slice"); return PVX_ERR_INVALID; }

@@ -159,6 +159,12 @@ struct SynthParams {
     int nbatch;           // contributions gathered per round (set by pvx_launch_synth from the LDS budget)
     int64_t seg0 = 0;     // first output segment (hop) of this launch ...
     int64_t seg_count = 0;   // ... and how many (0: all from seg0 on)
+    // launch-wide constants, derived once by pvx_launch_synth with the reference's own expressions (as kernel arguments
+    // they live in scalar registers; derived in the kernel they were float64 vector arithmetic, i.e. a register pair each
+    // across the whole kernel)
+    double c_dh, c_fstep, c_dfr, c_offf, c_sc;
+    int c_edgsam, c_EF, c_WB, c_WL;
+    int64_t c_edgsamp;
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
 
