@@ -138,11 +138,17 @@ __device__ inline double prefix_sum(const CParam& c, int m) {
 #define PVX_STAMP(slot) do { } while (0)
 #endif
 
-constexpr int HT = 512;    // pid -> contribution hash table of a batch (>= 4 * NBMAX: short probe chains)
-constexpr int TS = 256;    // threads across the samples of a segment; NT / TS groups share the contributions
+constexpr int HTMAX = 512; // pid -> contribution hash table of a batch: the power of two >= 4 * batch (short probe chains), 2^c_htbits entries
+constexpr int TSMAX = 256; // threads across the samples of a segment (fewer in a smaller workgroup); NT / TS groups share the contributions
 
-// LDS (dynamic): acc [G][h] | wf wm wr [NB][WL] doubles | prm [NB] | wslots [NB][WL] | cb_* 7 x [NB] | hkey hval [HT] ints
+// LDS (dynamic): acc [G][h] | wf wm wr [NB][WL] doubles | prm [NB] | wslots [NB][WL] | cb_* 7 x [NB] | hkey hval [2^htbits] ints
+__host__ __device__ inline int synth_htbits(int nb) {
+    int b = 4;
+    while ((1 << b) < 4 * nb && (1 << b) < HTMAX) b++;
+    return b;
+}
 __host__ __device__ inline size_t synth_lds_bytes(int h, int nb, int wl, int groups) {
+    const int HT = 1 << synth_htbits(nb);
     return (size_t)h * 8 * groups + (size_t)nb * wl * 8 * 3 + (size_t)nb * sizeof(CParam) + (size_t)nb * wl * 4 + (size_t)nb * 4 * 7 + (size_t)HT * 8;
 }
 
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
 #define PVX_SYNTH_SP 1
 #endif
     constexpr int SP = PVX_SYNTH_SP; // samples per thread held in registers while a batch is added
+    constexpr int TS = NT < TSMAX ? NT : TSMAX;
     constexpr int G = NT / TS;       // groups: group g adds contributions g, g + G, ... to its own accumulators
     const int h = p.hop_s, K = p.K, tid = threadIdx.x;
     const int NB = p.nbatch;
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
     int* cb_j0 = cb_kind + NB;
     int* cb_wn = cb_j0 + NB;
     int* hkey = cb_wn + NB;
+    const int htbits = p.c_htbits, HT = 1 << htbits;
     int* hval = hkey + HT;
 
     PVX_STAMP(0);
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
         __syncthreads();
         for (int bb = tid; bb < nb; bb += NT) {
             const int pid = cb_pid[bb];                               // unique within a segment's candidates
-            unsigned hh = ((unsigned)pid * 2654435761u) >> 23;        // 9 bits
+            unsigned hh = ((unsigned)pid * 2654435761u) >> (32 - htbits);
             while (atomicCAS(&hkey[hh], -1, pid) != -1) hh = (hh + 1) & (HT - 1);
             hval[hh] = bb;
         }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
                 if (f2 < 0 || f2 >= p.F) continue;
                 const int pid = p.partial_id[f2 * K + s2];
                 if (pid < 0) continue;
-                unsigned hh = ((unsigned)pid * 2654435761u) >> 23;
+                unsigned hh = ((unsigned)pid * 2654435761u) >> (32 - htbits);
                 int k;
                 while ((k = hkey[hh]) != -1 && k != pid) hh = (hh + 1) & (HT - 1);
                 if (k == pid) {
@@ -451,13 +459,18 @@ int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
     // (512 = two groups: f64 issue is already saturated by two waves per SIMD, and 1024 threads would cap the kernel
     // at 128 registers, which the four-sample loop body does not fit)
     if (nseg < 1024 && NC >= 16) nt = 512;
-    if (const char* e = getenv("PVX_SYNTH_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) nt = v; }
-    while (nt > 256 && synth_lds_bytes(h, 4, WL, nt / TS) > 150 * 1024) nt >>= 1;
-    const int groups = nt / TS;
+    // a long waveform: workgroups of two waves -- a segment's set-up (candidates, windows, parameters: dependent loads and
+    // serial float64 on a handful of lanes, three quarters of a workgroup's time) keeps ONE wave busy, so smaller
+    // workgroups mean more set-ups in flight per CU (7 x 2 waves at config 2's shape: 0.82 -> 0.69 ms)
+    else if (nseg >= 2048) nt = 128;
+    if (const char* e = getenv("PVX_SYNTH_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) nt = v; }
+    while (nt > 256 && synth_lds_bytes(h, 4, WL, nt / TSMAX) > 150 * 1024) nt >>= 1;
+    const int groups = nt > TSMAX ? nt / TSMAX : 1;
     const size_t budget = (nseg > 512 ? 72 : 150) * 1024;
     while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
     if (nb < 1) nb = 1;
     p.nbatch = nb;
+    p.c_htbits = synth_htbits(nb);
     {
         const double overlap = p.hop_a / (double)p.nfft;              // PVAnalysis.py:824
         p.c_dh = (double)h;
@@ -486,6 +499,8 @@ int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
         hipLaunchKernelGGL(k_synth_ola<NT_>, dim3((unsigned)nlaunch), dim3(NT_), lds, s, p);                                \
     } while (0)
     if (nt == 512) PVX_SYNTH(512);
+    else if (nt == 128) PVX_SYNTH(128);
+    else if (nt == 64) PVX_SYNTH(64);
     else PVX_SYNTH(256);
 #undef PVX_SYNTH
     PVX_HIP_CHECK(hipGetLastError());

@@ -163,7 +163,7 @@ struct SynthParams {
     // they live in scalar registers; derived in the kernel they were float64 vector arithmetic, i.e. a register pair each
     // across the whole kernel)
     double c_dh, c_fstep, c_dfr, c_offf, c_sc;
-    int c_edgsam, c_EF, c_WB, c_WL;
+    int c_edgsam, c_EF, c_WB, c_WL, c_htbits;
     int64_t c_edgsamp;
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);

@@ -1,7 +1,7 @@
 // Where the resynthesis kernel's time goes on a short signal (F = 239 frames, K = 100 partials alive throughout,
 // nfft 4096, hop 1024: config 3's shape): s_memtime stamps of the middle workgroup at its step boundaries.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DPVX_SYNTH_STAMPS -Iinclude -Ipypevoc_amd/csrc \
-//         tools/ubench/synth_phases.hip -o tools/ubench/synth_phases && tools/ubench/synth_phases [threads]
+//         tools/ubench/synth_phases.hip -o tools/ubench/synth_phases && tools/ubench/synth_phases [threads [F K nfft hop]]
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -13,8 +13,9 @@ void pvx_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprin
 
 int main(int argc, char** argv) {
     if (argc > 1) setenv("PVX_SYNTH_THREADS", argv[1], 1);
-    const int64_t F = 239;
-    const int K = 100, nfft = 4096, hop = 1024;
+    // [threads] [F K nfft hop]: e.g. `synth_phases 256 51676 8 2048 512` = BASELINE config 2's shape
+    const int64_t F = argc > 2 ? atoll(argv[2]) : 239;
+    const int K = argc > 3 ? atoi(argv[3]) : 100, nfft = argc > 4 ? atoi(argv[4]) : 4096, hop = argc > 5 ? atoi(argv[5]) : 1024;
     const size_t n = (size_t)F * K;
     std::vector<double> f(n), m(n), r(n);
     std::vector<int32_t> pid(n), st(K, 0), ln(K, (int32_t)F);
