@@ -297,41 +297,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
         __syncthreads();
         PVX_STAMP(3);
         const int qn = qnext;
-        // ---- step 5: thread b derives the closed-form parameters of contribution b.  fsig and msig
-        // are piecewise linear (two pieces per hop), so the phase prefix sum of PVAnalysis.py:705-708 is
-        // a quadratic in the sample index: no scan, no barrier, every sample independent.
+        // ---- step 5: the closed-form parameters of the contributions.  fsig and msig are piecewise linear (two pieces per
+        // hop), so the phase prefix sum of PVAnalysis.py:705-708 is a quadratic in the sample index: no scan, no barrier,
+        // every sample independent.  5a: the interpolations a contribution needs (np.interp at three or four positions,
+        // the two pieces of fsig and of msig) are independent of each other -- eight lanes per contribution take one
+        // each (same function, different arguments) and leave their results in the contribution's record; 5b: thread b
+        // combines them.  (One thread per contribution doing all of it in turn was 30 % of a workgroup's time.)
+        for (int t = tid; t < nb * 8; t += NT) {
+            const int bb = t >> 3, k = t & 7;
+            const int nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
+            const double* pf = wf + (size_t)bb * WL;
+            const double* pm = wm + (size_t)bb * WL;
+            const double offf = p.c_offf, offm = dfr;                     // dfr + .5, dfr: PVAnalysis.py:701-702
+            const double nbase = dh * (double)ii;
+            CParam* c = prm + bb;
+            if (k < 4) {
+                // k = 0, 1, 2: fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729) -> smb, tmb, step for now;
+                // k = 3: the edge's amplitude msig[0] (attack) / msig[hop * nfr] (release) -> amp
+                const bool need = (k == 3) ? (kind != 0) : ((kind != 1) && (k < 2 || (kind == 0 && ii < nfr - 1)));
+                if (need) {
+                    const double x = (k == 3) ? ((kind == 1) ? 0.0 : dh * (double)nfr) : nbase + (double)k * dh;
+                    const double v = interp_w(x, dh, k == 3 ? offm : offf, nfr, k == 3 ? pm : pf, j0);
+                    if (k == 0) c->smb = v; else if (k == 1) c->tmb = v; else if (k == 2) c->step = v; else c->amp = v;
+                }
+            } else if (k < 6 && kind != 1) {
+                // fsig(nbase + q) = fa0 + fsa q for q < fmb, fb0 + fsb q beyond; msig likewise
+                const bool isf = (k == 4);
+                const Piece2 q = make_piece2(nbase, dh, isf ? offf : offm, nfr, isf ? pf : pm, j0);
+                const double a0 = q.sa * (nbase - q.xa) + q.fa, b0 = q.sb * (nbase - q.xb) + q.fb;
+                const double d = ceil(q.b1 - nbase);
+                const int mb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+                if (isf) { c->fa0 = a0; c->fsa = q.sa; c->fb0 = b0; c->fsb = q.sb; c->fmb = mb; }
+                else { c->ma0 = a0; c->msa = q.sa; c->mb0 = b0; c->msb = q.sb; c->mmb = mb; }
+            }
+        }
+        __syncthreads();
         for (int bb = tid; bb < nb; bb += NT) {
             const int st = cb_st[bb], nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
             const double* pf = wf + (size_t)bb * WL;
-            const double* pm = wm + (size_t)bb * WL;
             const double* pr = wr + (size_t)bb * WL;
-            const double offf = p.c_offf, offm = dfr;                     // dfr + .5, dfr: PVAnalysis.py:701-702
-            CParam c;
+            CParam c = prm[bb];
             c.kind = kind;
             if (kind == 1) {
-                // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam
+                // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amp = msig[0] (5a)
                 c.o0 = (long long)st * h - edgsam;
-                c.amp = interp_w(0.0, dh, offm, nfr, pm, j0);             // msig[0]
                 c.cfr = pf[0 - j0] * 1.0 / p.sr;
                 c.ph0 = pr[0 - j0];
             } else {
-                const double nbase = dh * (double)ii;
+                const double fs0 = c.smb, fs1 = c.tmb, fs2 = c.step;      // (5a)
                 // phase corrections, PVAnalysis.py:711-718
-                const double fs0 = interp_w(nbase, dh, offf, nfr, pf, j0);
-                const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf, j0);
                 const double phcor = p.no_phcor ? 0.0 : kPi * (fs1 - fs0) / fstep / 2.;          // PVAnalysis.py:710-715
                 c.ph0 = pr[ii - j0] + phcor;                              // PVAnalysis.py:721
-                // fsig(nbase + q) = fa0 + fsa q for q < fmb, fb0 + fsb q beyond; msig likewise
-                const Piece2 qf = make_piece2(nbase, dh, offf, nfr, pf, j0);
-                const Piece2 qm = make_piece2(nbase, dh, offm, nfr, pm, j0);
-                c.fa0 = qf.sa * (nbase - qf.xa) + qf.fa; c.fsa = qf.sa;
-                c.fb0 = qf.sb * (nbase - qf.xb) + qf.fb; c.fsb = qf.sb;
-                c.ma0 = qm.sa * (nbase - qm.xa) + qm.fa; c.msa = qm.sa;
-                c.mb0 = qm.sb * (nbase - qm.xb) + qm.fb; c.msb = qm.sb;
-                double d = ceil(qf.b1 - nbase);
-                c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
-                d = ceil(qm.b1 - nbase);
-                c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
                 const double tm = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
                 c.smb = c.fa0 * (double)c.fmb + c.fsa * tm;               // sum of the first fmb terms
                 c.tmb = tm;
@@ -339,14 +355,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WA
                 const double lastph = kPi2 * (prefix_sum(c, h - 1) / p.sr) + c.ph0;
                 c.step = 0.0;
                 if (kind == 2) {
-                    // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam
+                    // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amp = msig[hop*(ii+1)] (5a)
                     c.o0 = ((long long)st + nfr) * h;
-                    c.amp = interp_w(dh * (double)nfr, dh, offm, nfr, pm, j0);        // msig[hop*(ii+1)]
                     c.cfr = pf[nfr - 1 - j0] * 1.0 / p.sr;
                     c.ph0 = lastph;
                 } else if (ii < nfr - 1) {
                     // discontinuity ramp towards the next point, PVAnalysis.py:724-729
-                    const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf, j0);
                     const double phcornext = p.no_phcor ? 0.0 : kPi * (fs2 - fs1) / fstep / 2.;
                     const double phend = lastph + kPi2 * fs1 / p.sr;
                     const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
