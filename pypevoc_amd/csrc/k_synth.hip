@@ -152,11 +152,15 @@ __host__ __device__ inline size_t synth_lds_bytes(int h, int nb, int wl, int gro
     return (size_t)h * 8 * groups + (size_t)nb * wl * 8 * 3 + (size_t)nb * sizeof(CParam) + (size_t)nb * wl * 4 + (size_t)nb * 4 * 7 + (size_t)HT * 8;
 }
 
+// Waves per SIMD the register allocation aims at: the kernel waits on its set-up loads (one wave of a workgroup busy
+// for most of its time), so occupancy is worth more than registers -- five waves (96 registers) in the two-wave
+// workgroups of a long waveform, four in the larger ones (measured on config 2: 2 waves 1.35 ms, 4: 0.82, 5 with
+// two-wave workgroups and batches of 16: 0.54, 6: 0.55, 8: 0.60 -- spilling by then).
 #ifndef PVX_SYNTH_WAVES
-#define PVX_SYNTH_WAVES 4
+#define PVX_SYNTH_WAVES(NT) ((NT) <= 128 ? 5 : 4)
 #endif
 template <int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES, PVX_SYNTH_WAVES))) void k_synth_ola(SynthParams p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(NT), PVX_SYNTH_WAVES(NT)))) void k_synth_ola(SynthParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wcnt[NT / 64];
     __shared__ int qnext;
@@ -482,6 +486,11 @@ int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
     const int groups = nt > TSMAX ? nt / TSMAX : 1;
     const size_t budget = (nseg > 512 ? 72 : 150) * 1024;
     while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
+    // two-wave workgroups: batches of max(16, 2 npks) -- a segment's live contributions (<= npks bodies and the odd edge; a
+    // fuller segment takes another round) instead of all (2 EF + 1) npks candidates: 11 KB of LDS per workgroup instead of
+    // 23, ten workgroups per CU
+    if (nt == 128) { const int cap = p.K * 2 > 16 ? p.K * 2 : 16; if (nb > cap) nb = cap; }
+    if (const char* e = getenv("PVX_SYNTH_NB")) { const int v = atoi(e); if (v >= 4 && v <= NBMAX && v < nb) nb = v; }     // tests: more rounds
     if (nb < 1) nb = 1;
     p.nbatch = nb;
     p.c_htbits = synth_htbits(nb);

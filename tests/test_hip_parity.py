@@ -207,8 +207,8 @@ def test_synth_matches_reference(amd, name):
 
 
 def test_synth_workgroup_shapes_and_result_arrays(amd, monkeypatch):
-    """k_synth_ola with one and two groups of contributions per segment (256 / 512 threads; the sums associate
-    differently, float64 round-off apart) and the page-locked result arrays of the resident chain: writable,
+    """k_synth_ola with one and two groups of contributions per segment (64 .. 256 / 512 threads; the sums of two
+    groups associate differently, float64 round-off apart), batches smaller than a segment's contributions, and the page-locked result arrays of the resident chain: writable,
     and a later result does not touch an earlier one that is still alive."""
     g = load_golden("G7_perlman")
     h = int(g["hop"])
@@ -216,10 +216,17 @@ def test_synth_workgroup_shapes_and_result_arrays(amd, monkeypatch):
     p = run_golden(amd, g, 32)
     ss = p.toSinSum()
     ws = {}
-    for nt in ("256", "512"):
+    for nt in ("64", "128", "256", "512"):
         monkeypatch.setenv("PVX_SYNTH_THREADS", nt)
         ws[nt] = ss.synth(g["sr"], h)
         assert np.abs(ws[nt] - ref).max() <= 1e-4 * np.abs(ref).max()
+    # one group of contributions per segment (<= 256 threads): the same additions in the same order, whatever the
+    # workgroup -- also when a segment's contributions take several rounds of a small batch
+    assert np.array_equal(ws["64"], ws["256"]) and np.array_equal(ws["128"], ws["256"])
+    monkeypatch.setenv("PVX_SYNTH_THREADS", "128")
+    monkeypatch.setenv("PVX_SYNTH_NB", "8")
+    assert np.array_equal(ss.synth(g["sr"], h), ws["256"])
+    monkeypatch.delenv("PVX_SYNTH_NB")
     monkeypatch.delenv("PVX_SYNTH_THREADS")
     assert np.abs(ws["256"] - ws["512"]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     keep = ws["512"].copy()
