@@ -122,8 +122,9 @@ try:
         per = F if ("fused" in name or "stft" in name or "phase" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
         if per is None:
             continue
-        if "k_synth_ola" in name:                # launched in slices as well as whole: per output segment = per 4 waves (256 threads)
-            per = g("SQ_WAVES") / 4.0
+        ms = re.search(r"k_synth_ola<(\d+)>", name)
+        if ms:                                    # launched in slices as well as whole: per output segment = per workgroup
+            per = g("SQ_WAVES") / (int(ms.group(1)) / 64.0)
         rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.3f | %.2f |" % (
             what, short.group(1)[:44] if short else name[:44], g("SQ_INSTS_VALU") / per, g("SQ_INSTS_SALU") / per, g("SQ_INSTS_LDS") / per,
             g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
