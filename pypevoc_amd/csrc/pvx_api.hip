@@ -668,20 +668,21 @@ static int host_stream(pvx_plan* p) {
 }
 
 // Large host <-> device transfers of PAGEABLE caller memory.  A plain hipMemcpy stages through the runtime's own pinned
-// buffers on one thread (~20 GB/s host-side; measured on BASELINE config 2's 106 MB signal: 4.9 ms -> 2.7 ms; eight threads on 1 MB pieces: 3.4 ms); here kStageThreads threads copy 2 MB pieces between the caller's array and a
+// buffers on one thread (~20 GB/s host-side; measured on BASELINE config 2's 106 MB signal: 4.9 ms -> 2.7 ms with four threads on 2 MB pieces, 2.3 ms on 4 MB pieces; eight threads on 1 MB pieces: 3.4 ms; `tools/ab/stage_ab.sh`); here kStageThreads threads copy 4 MB pieces between the caller's array and a
 // pinned ring (two slots per thread) while the DMA engine moves the other slots: the host copies run in parallel with each
 // other and with the DMA, the link (PCIe Gen5 x16, ~55 GB/s) becomes the limit.  The DMAs are queued on `s`: work issued on
 // `s` afterwards is ordered behind them; the calls return when every host-side copy is done (H2D) / every byte has
 // arrived in the caller's array (D2H).
-static const int kStageThreads = 4;
-static const size_t kStagePiece = (size_t)2 << 20;
+static const int kStageMaxThreads = 8;
+static const int kStageThreads = [] { const char* e = getenv("PVX_STAGE_THREADS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= kStageMaxThreads) ? v : 4; }();
+static const size_t kStagePiece = [] { const char* e = getenv("PVX_STAGE_PIECE_MB"); const int v = e ? atoi(e) : 0; return (size_t)((v >= 1 && v <= 16) ? v : 4) << 20; }();
 static const size_t kStageMin = (size_t)16 << 20;           // below this a plain copy is as good
 
 static int stage_ring(pvx_plan* p) {
     if (!p->h_ring && hipHostMalloc(&p->h_ring, kStagePiece * 2 * kStageThreads, hipHostMallocDefault) != hipSuccess) {
         p->h_ring = nullptr; pvx_set_error("hipHostMalloc(staging ring) failed"); return PVX_ERR_ALLOC;
     }
-    for (int i = 0; i < 2 * kStageThreads; i++)
+    for (int i = 0; i < 16; i++)
         if (!p->ev_ring[i]) PVX_HIP_CHECK(hipEventCreateWithFlags(&p->ev_ring[i], hipEventDisableTiming));
     return PVX_OK;
 }
@@ -692,7 +693,7 @@ static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to
     int devid = 0;
     (void)hipGetDevice(&devid);
     const size_t npieces = (bytes + kStagePiece - 1) / kStagePiece;
-    int err[kStageThreads] = {0};
+    int err[kStageMaxThreads] = {0};
     auto worker = [&](int t) {
         if (hipSetDevice(devid) != hipSuccess) { err[t] = 1; return; }
         size_t k = 0;
@@ -721,7 +722,7 @@ static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to
             }
         }
     };
-    std::thread th[kStageThreads];
+    std::thread th[kStageMaxThreads];
     for (int t = 1; t < kStageThreads; t++) th[t] = std::thread(worker, t);
     worker(0);
     for (int t = 1; t < kStageThreads; t++) th[t].join();
@@ -1263,7 +1264,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         // (second stream) runs under the next slice's kernel -- the link, not kernel + link, is what the call costs
         if ((rc = stage_ring(p)) != PVX_OK) return rc;                   // (its events)
         if (!p->s_copy) PVX_HIP_CHECK(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
-        const int NS = 2 * kStageThreads;
+        const int NS = 8;                                                // slices (ev_ring holds 16 events)
         const int64_t nseg = (wlen + hop_synth - 1) / hop_synth, per = (nseg + NS - 1) / NS;
         for (int i = 0; i < NS; i++) {
             const int64_t s0 = (int64_t)i * per;
