@@ -108,9 +108,10 @@ class PVBatch(object):
         t = np.zeros((B, F))
         tm = np.zeros((B, F))
         if F > 0 and B > 0:
-            if self._plan is None:
-                self._plan = _Plan(self.sr, self.nfft, self.hop, K, self.peakthresh, self.win, self.precision,
-                                   max_rows=B * (F + 1))
+            # a pooled plan (PVAnalysis._Plan.acquire: creating one, with its tables and buffers, costs more than a
+            # batch of short signals); the results leave for the host inside the call, so the plan is handed back at once
+            self._plan = _Plan.acquire(self, self.sr, self.nfft, self.hop, K, self.peakthresh, self.win, self.precision,
+                                       max_rows=B * (F + 1))
             if self._xdev is not None:
                 n = B * F * K
 
@@ -131,11 +132,21 @@ class PVBatch(object):
                                     self.nsamp, B, self.nsamp, *[_lib.dptr(out[k]) for k in FIELDS],
                                     _lib.dptr(t), _lib.dptr(tm), None, None)
                 _lib.check(r, "pvx_analyze")
+        if self._plan is not None:
+            self._plan.owner = None
+            self._plan = None
         for k in FIELDS:
             setattr(self, k, out[k])
         self.t = t[0] if B > 0 else np.zeros(F)
         self.totalmag = tm
         return self
+
+    # (what _Plan.acquire asks of an owner whose plan it takes away: nothing is resident here)
+    _progress_cb = None
+    _progress_plan = None
+
+    def _release_resident(self):
+        pass
 
 
 def gather_results(local, nitems, group=None, dst=0):

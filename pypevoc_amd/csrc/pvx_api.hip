@@ -145,6 +145,8 @@ struct pvx_plan {
     float* spec_host = nullptr;  // when set: the fused kernels write that row straight into this page-locked host block
     // PVHarmonic: per-frame f0 / previous-row tables and the carried spectrum of the last valid frame
     double* d_hf0 = nullptr;
+    unsigned char* d_hx = nullptr;         // pvx_harmonic_analyze: the host signal's device copy (kept: allocating and freeing
+    size_t hx_cap = 0;                     // hundreds of MB per call cost more than the analysis)
     int32_t* d_hprev = nullptr;
     void* d_carry = nullptr;
     int64_t harm_cap = 0;
@@ -206,6 +208,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_specrow) (void)hipFree(p->d_specrow);
     if (p->d_hf0) (void)hipFree(p->d_hf0);
+    if (p->d_hx) (void)hipFree(p->d_hx);
     if (p->d_hprev) (void)hipFree(p->d_hprev);
     if (p->d_carry) (void)hipFree(p->d_carry);
     for (int i = 0; i < 2; i++) {
@@ -678,18 +681,21 @@ static const int kStageThreads = [] { const char* e = getenv("PVX_STAGE_THREADS"
 static const size_t kStagePiece = [] { const char* e = getenv("PVX_STAGE_PIECE_MB"); const int v = e ? atoi(e) : 0; return (size_t)((v >= 1 && v <= 16) ? v : 4) << 20; }();
 static const size_t kStageMin = (size_t)16 << 20;           // below this a plain copy is as good
 
-static int stage_ring(pvx_plan* p) {
-    if (!p->h_ring && hipHostMalloc(&p->h_ring, kStagePiece * 2 * kStageThreads, hipHostMallocDefault) != hipSuccess) {
-        p->h_ring = nullptr; pvx_set_error("hipHostMalloc(staging ring) failed"); return PVX_ERR_ALLOC;
+struct StageRing { void** h_ring; hipEvent_t* ev_ring; };     // a plan's ring, or the process-wide one of the plan-less entry points
+static int stage_ring(StageRing r) {
+    if (!*r.h_ring && hipHostMalloc(r.h_ring, kStagePiece * 2 * kStageThreads, hipHostMallocDefault) != hipSuccess) {
+        *r.h_ring = nullptr; pvx_set_error("hipHostMalloc(staging ring) failed"); return PVX_ERR_ALLOC;
     }
     for (int i = 0; i < 16; i++)
-        if (!p->ev_ring[i]) PVX_HIP_CHECK(hipEventCreateWithFlags(&p->ev_ring[i], hipEventDisableTiming));
+        if (!r.ev_ring[i]) PVX_HIP_CHECK(hipEventCreateWithFlags(&r.ev_ring[i], hipEventDisableTiming));
     return PVX_OK;
 }
+static int stage_ring(pvx_plan* p) { return stage_ring(StageRing{&p->h_ring, p->ev_ring}); }
 
-static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s) {
-    int rc = stage_ring(p);
+static int staged_copy(StageRing p_, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s) {
+    int rc = stage_ring(p_);
     if (rc != PVX_OK) return rc;
+    struct { void* h_ring; hipEvent_t* ev_ring; } pp = {*p_.h_ring, p_.ev_ring}, *p = &pp;
     int devid = 0;
     (void)hipGetDevice(&devid);
     const size_t npieces = (bytes + kStagePiece - 1) / kStagePiece;
@@ -730,6 +736,56 @@ static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to
         if (err[t]) { pvx_set_error("staged host transfer failed (%s)", hipGetErrorString(hipGetLastError())); return PVX_ERR_HIP; }
     return PVX_OK;
 }
+
+static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s) {
+    return staged_copy(StageRing{&p->h_ring, p->ev_ring}, dev, host, bytes, to_device, s);
+}
+// Transfers between the CALLER's arrays and device memory.  A hipMemcpy of a pageable array of 1 MB or more makes the
+// runtime register (pin in place) that memory; when the caller frees the array -- result arrays: every call -- the next
+// transfer of the process waits tens of milliseconds for the unmapping (measured: PVHarmonic.run_pv 8 -> 32 ms per
+// call).  So nothing of the caller's above kDirectMax is ever handed to hipMemcpy: page-locked arrays go straight, large
+// pageable ones through the threaded ring, the ones in between bounce through the process-wide ring's memory.
+static const size_t kDirectMax = (size_t)512 << 10;
+static void* g_ring = nullptr;
+static hipEvent_t g_ring_ev[16] = {};
+static std::mutex g_ring_mu;
+static bool host_is_pinned(const void* host) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+static int user_copy(void* dev, void* host, size_t bytes, bool to_device) {
+    if (bytes == 0) return PVX_OK;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    if (bytes <= kDirectMax || host_is_pinned(host)) {
+        PVX_HIP_CHECK(to_device ? hipMemcpy(dev, host, bytes, kind) : hipMemcpy(host, dev, bytes, kind));
+        return PVX_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    const StageRing ring{&g_ring, g_ring_ev};
+    if (bytes >= kStageMin && getenv("PVX_NO_STAGE_THREADS") == nullptr) {
+        const int rc = staged_copy(ring, dev, host, bytes, to_device, nullptr);
+        if (rc != PVX_OK) return rc;
+        PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
+        return PVX_OK;
+    }
+    int rc = stage_ring(ring);
+    if (rc != PVX_OK) return rc;
+    const size_t cap = kStagePiece * 2 * kStageThreads;
+    for (size_t o = 0; o < bytes; o += cap) {
+        const size_t c = bytes - o < cap ? bytes - o : cap;
+        if (to_device) {
+            memcpy(g_ring, (const char*)host + o, c);
+            PVX_HIP_CHECK(hipMemcpy((char*)dev + o, g_ring, c, kind));
+        } else {
+            PVX_HIP_CHECK(hipMemcpy(g_ring, (const char*)dev + o, c, kind));
+            memcpy((char*)host + o, g_ring, c);
+        }
+    }
+    return PVX_OK;
+}
+static int host_to_device(void* dev, const void* host, size_t bytes) { return user_copy(dev, (void*)host, bytes, true); }
+static int device_to_host(void* host, const void* dev, size_t bytes) { return user_copy((void*)dev, host, bytes, false); }
 
 struct HostOut { double *f, *mag, *ph, *realph, *binno, *t, *totalmag; };
 
@@ -851,12 +907,11 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
         const HostOut d = block_ptrs(p->d_out[c & 1], c_frames, K);
         const size_t r0 = by_frames ? (size_t)u0 : (size_t)u0 * F;
         const size_t nk = (size_t)c_frames * K * sizeof(double), n1 = (size_t)c_frames * sizeof(double);
-        PVX_HIP_CHECK(hipMemcpy(ho->f + r0 * K, d.f, nk, hipMemcpyDeviceToHost));
-        PVX_HIP_CHECK(hipMemcpy(ho->mag + r0 * K, d.mag, nk, hipMemcpyDeviceToHost));
-        PVX_HIP_CHECK(hipMemcpy(ho->ph + r0 * K, d.ph, nk, hipMemcpyDeviceToHost));
-        PVX_HIP_CHECK(hipMemcpy(ho->realph + r0 * K, d.realph, nk, hipMemcpyDeviceToHost));
-        PVX_HIP_CHECK(hipMemcpy(ho->binno + r0 * K, d.binno, nk, hipMemcpyDeviceToHost));
-        if (ho->totalmag) PVX_HIP_CHECK(hipMemcpy(ho->totalmag + r0, d.totalmag, n1, hipMemcpyDeviceToHost));
+        int rcc;
+        if ((rcc = device_to_host(ho->f + r0 * K, d.f, nk)) != PVX_OK || (rcc = device_to_host(ho->mag + r0 * K, d.mag, nk)) != PVX_OK ||
+            (rcc = device_to_host(ho->ph + r0 * K, d.ph, nk)) != PVX_OK || (rcc = device_to_host(ho->realph + r0 * K, d.realph, nk)) != PVX_OK ||
+            (rcc = device_to_host(ho->binno + r0 * K, d.binno, nk)) != PVX_OK) return rcc;
+        if (ho->totalmag && (rcc = device_to_host(ho->totalmag + r0, d.totalmag, n1)) != PVX_OK) return rcc;
         return PVX_OK;
     };
 
@@ -897,7 +952,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
             if (threaded && in_bytes >= kStageMin) {
                 if ((rc = staged_copy(p, p->d_in[b], (void*)((const char*)x + in_off), in_bytes, true, s)) != PVX_OK) { p->progress_live = false; return rc; }
             } else {
-                PVX_HIP_CHECK(hipMemcpy(p->d_in[b], (const char*)x + in_off, in_bytes, hipMemcpyHostToDevice));
+                if ((rc = host_to_device(p->d_in[b], (const char*)x + in_off, in_bytes)) != PVX_OK) { p->progress_live = false; return rc; }
             }
         }
         tr.mark("staged + H2D issued");
@@ -1038,8 +1093,7 @@ extern "C" int pvx_resident_fetch(pvx_plan* p, int which, double* host) {
     const double* src[7] = {all.f, all.mag, all.ph, all.realph, all.binno, all.t, all.totalmag};
     const size_t bytes = (size_t)rows * (which < 5 ? p->npks : 1) * sizeof(double);
     PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-    PVX_HIP_CHECK(hipMemcpy(host, src[which], bytes, hipMemcpyDeviceToHost));
-    return PVX_OK;
+    return device_to_host(host, src[which], bytes);
 }
 
 extern "C" const double* pvx_resident_ptr(pvx_plan* p, int which) {
@@ -1105,7 +1159,7 @@ extern "C" int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks,
     if ((rc = dy.alloc(yb)) != PVX_OK || (rc = dpos.alloc((size_t)nrows * cap * 4)) != PVX_OK ||
         (rc = dkeep.alloc((size_t)nrows * cap)) != PVX_OK || (rc = dcount.alloc((size_t)nrows * 4)) != PVX_OK)
         return rc;
-    PVX_HIP_CHECK(hipMemcpy(dy.p, y, yb, hipMemcpyHostToDevice));
+    if ((rc = host_to_device(dy.p, y, yb)) != PVX_OK) return rc;
     PVX_HIP_CHECK(hipMemset(dpos.p, 0xff, (size_t)nrows * cap * 4));
     PVX_HIP_CHECK(hipMemset(dkeep.p, 0, (size_t)nrows * cap));
     PeakRowsParams pp;
@@ -1115,9 +1169,8 @@ extern "C" int pvx_peakfinder(const double* y, int64_t nrows, int n, int npeaks,
     rc = pvx_launch_peak_rows(pp, nullptr);
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
-    PVX_HIP_CHECK(hipMemcpy(pos, dpos.p, (size_t)nrows * cap * 4, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(keep, dkeep.p, (size_t)nrows * cap, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(count, dcount.p, (size_t)nrows * 4, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(pos, dpos.p, (size_t)nrows * cap * 4)) != PVX_OK || (rc = device_to_host(keep, dkeep.p, (size_t)nrows * cap)) != PVX_OK ||
+        (rc = device_to_host(count, dcount.p, (size_t)nrows * 4)) != PVX_OK) return rc;
     return PVX_OK;
 }
 
@@ -1225,9 +1278,9 @@ extern "C" int pvx_resident_fetch_table(pvx_plan* p, int32_t* partial_id, int32_
     if (rc != PVX_OK) return rc;
     if (p->res_P < 0) { pvx_set_error("no resident partial table (pvx_track_resident first)"); return PVX_ERR_INVALID; }
     PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-    if (partial_id) PVX_HIP_CHECK(hipMemcpy(partial_id, p->d_pid, (size_t)p->res_F * p->npks * 4, hipMemcpyDeviceToHost));
-    if (part_start && p->res_P) PVX_HIP_CHECK(hipMemcpy(part_start, p->d_pst, (size_t)p->res_P * 4, hipMemcpyDeviceToHost));
-    if (part_len && p->res_P) PVX_HIP_CHECK(hipMemcpy(part_len, p->d_pln, (size_t)p->res_P * 4, hipMemcpyDeviceToHost));
+    if (partial_id && (rc = device_to_host(partial_id, p->d_pid, (size_t)p->res_F * p->npks * 4)) != PVX_OK) return rc;
+    if (part_start && p->res_P && (rc = device_to_host(part_start, p->d_pst, (size_t)p->res_P * 4)) != PVX_OK) return rc;
+    if (part_len && p->res_P && (rc = device_to_host(part_len, p->d_pln, (size_t)p->res_P * 4)) != PVX_OK) return rc;
     return PVX_OK;
 }
 
@@ -1324,7 +1377,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
             tr.mark("copied out (threaded ring)");
         } else {
             PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-            PVX_HIP_CHECK(hipMemcpy(w, p->d_w, bytes, hipMemcpyDeviceToHost));
+            if ((rc = device_to_host(w, p->d_w, bytes)) != PVX_OK) return rc;
         }
     }
     return PVX_OK;
@@ -1342,8 +1395,7 @@ extern "C" int pvx_f0_resident(pvx_plan* p, double fmin, double fmax, double thr
     int32_t* d_im = (int32_t*)(d_fm + rows);
     if ((rc = pvx_launch_f0(all.f, all.mag, rows, p->npks, fmin, fmax, thr, d_fm, d_im, p->s_host)) != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-    PVX_HIP_CHECK(hipMemcpy(fm, d_fm, (size_t)rows * 8, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(idx, d_im, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(fm, d_fm, (size_t)rows * 8)) != PVX_OK || (rc = device_to_host(idx, d_im, (size_t)rows * 4)) != PVX_OK) return rc;
     return PVX_OK;
 }
 
@@ -1370,8 +1422,7 @@ extern "C" int pvx_harmonic_power_resident(pvx_plan* p, double f_threshold, doub
     if (top >= F) { pvx_set_error("index %d is out of bounds for axis 0 with size %lld", (int)top, (long long)F); return PVX_ERR_SIZE; }
     if ((rc = pvx_launch_hpower(all.f, F, K, f_threshold, d_rp, d_hp, d_nh, p->s_host)) != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
-    PVX_HIP_CHECK(hipMemcpy(hpower, d_hp, n * 8, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(nharm, d_nh, n * 8, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(hpower, d_hp, n * 8)) != PVX_OK || (rc = device_to_host(nharm, d_nh, n * 8)) != PVX_OK) return rc;
     return PVX_OK;
 }
 
@@ -1388,15 +1439,13 @@ extern "C" int64_t pvx_track(const double* f, const double* mag, int64_t F, int 
     if ((rc = df.alloc(n * 8)) != PVX_OK || (rc = dm.alloc(n * 8)) != PVX_OK || (rc = dpid.alloc(n * 4)) != PVX_OK ||
         (rc = dst.alloc(n * 4)) != PVX_OK || (rc = dln.alloc(n * 4)) != PVX_OK)
         return rc;
-    PVX_HIP_CHECK(hipMemcpy(df.p, f, n * 8, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dm.p, mag, n * 8, hipMemcpyHostToDevice));
+    if ((rc = host_to_device(df.p, f, n * 8)) != PVX_OK || (rc = host_to_device(dm.p, mag, n * 8)) != PVX_OK) return rc;
     const int64_t P = pvx_track_dev((const double*)df.p, (const double*)dm.p, F, K, maxpitchjmp, (int32_t*)dpid.p,
                                     (int32_t*)dst.p, (int32_t*)dln.p, dcap, nullptr);
     if (P < 0) return P;
     if (P > cap) { pvx_set_error("%lld partials exceed the caller's capacity %lld", (long long)P, (long long)cap); return PVX_ERR_SIZE; }
-    PVX_HIP_CHECK(hipMemcpy(partial_id, dpid.p, n * 4, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(part_start, dst.p, (size_t)P * 4, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(part_len, dln.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(partial_id, dpid.p, n * 4)) != PVX_OK || (rc = device_to_host(part_start, dst.p, (size_t)P * 4)) != PVX_OK ||
+        (rc = device_to_host(part_len, dln.p, (size_t)P * 4)) != PVX_OK) return rc;
     return P;
 }
 
@@ -1516,10 +1565,14 @@ extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype,
     if (!f || !mag || !ph || !residual) { pvx_set_error("null output array"); return PVX_ERR_INVALID; }
     const size_t xbytes = (size_t)nsamp * dtype_size(x_dtype);
     const size_t fk = (size_t)F * p->npks * sizeof(double), f1 = (size_t)F * sizeof(double);
-    DevBuf dx, dout, dprev;
-    if ((rc = dx.alloc(xbytes)) != PVX_OK) return rc;
+    HostTrace tr("harmonic");
+    DevBuf dout, dprev;
+    if ((rc = grow_dev(&p->d_hx, &p->hx_cap, xbytes)) != PVX_OK) return rc;
+    struct { void* p; } dx = {p->d_hx};
     if ((rc = dout.alloc(3 * fk + 2 * f1)) != PVX_OK) return rc;
-    PVX_HIP_CHECK(hipMemcpy(dx.p, x, xbytes, hipMemcpyHostToDevice));
+    tr.mark("device buffers");
+    if ((rc = host_to_device(dx.p, x, xbytes)) != PVX_OK) return rc;
+    tr.mark("signal on the device");
     if (prev0) {
         if ((rc = dprev.alloc(sizeof(double) * 2 * p->N2)) != PVX_OK) return rc;
         PVX_HIP_CHECK(hipMemcpy(dprev.p, prev0, sizeof(double) * 2 * p->N2, hipMemcpyHostToDevice));
@@ -1533,11 +1586,11 @@ extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype,
     p->progress_live = false;
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
-    PVX_HIP_CHECK(hipMemcpy(f, d_f, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(mag, d_mag, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(ph, d_ph, fk, hipMemcpyDeviceToHost));
-    PVX_HIP_CHECK(hipMemcpy(residual, d_res, f1, hipMemcpyDeviceToHost));
-    if (t) PVX_HIP_CHECK(hipMemcpy(t, d_t, f1, hipMemcpyDeviceToHost));
+    tr.mark("kernels");
+    if ((rc = device_to_host(f, d_f, fk)) != PVX_OK || (rc = device_to_host(mag, d_mag, fk)) != PVX_OK || (rc = device_to_host(ph, d_ph, fk)) != PVX_OK ||
+        (rc = device_to_host(residual, d_res, f1)) != PVX_OK) return rc;
+    if (t && (rc = device_to_host(t, d_t, f1)) != PVX_OK) return rc;
+    tr.mark("results on the host");
     if (last_spec) {
         // oldfft after the loop = spectrum of the last analysed frame (PV.py:491), else unchanged
         if (any) {
@@ -1595,13 +1648,12 @@ extern "C" int64_t pvx_heterodyne(const double* x, const double* hetsig, int64_t
     DevBuf dx, dh, dout, dic;
     if ((rc = dx.alloc((size_t)n * 8)) != PVX_OK || (rc = dh.alloc((size_t)n * 16)) != PVX_OK ||
         (rc = dout.alloc((size_t)nfr * 16)) != PVX_OK || (rc = dic.alloc((size_t)nfr * 8)) != PVX_OK) return rc;
-    PVX_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dh.p, hetsig, (size_t)n * 16, hipMemcpyHostToDevice));
+    if ((rc = host_to_device(dx.p, x, (size_t)n * 8)) != PVX_OK || (rc = host_to_device(dh.p, hetsig, (size_t)n * 16)) != PVX_OK) return rc;
     const int64_t r = pvx_heterodyne_dev((const double*)dx.p, (const double*)dh.p, n, wind, wlen, hop, (double*)dout.p,
                                          (int64_t*)dic.p, nullptr);
     if (r < 0) return r;
-    PVX_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)nfr * 16, hipMemcpyDeviceToHost));
-    if (icent) PVX_HIP_CHECK(hipMemcpy(icent, dic.p, (size_t)nfr * 8, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(out, dout.p, (size_t)nfr * 16)) != PVX_OK) return rc;
+    if (icent && (rc = device_to_host(icent, dic.p, (size_t)nfr * 8)) != PVX_OK) return rc;
     return nfr;
 }
 
@@ -1634,10 +1686,10 @@ extern "C" int64_t pvx_rms_frames(const double* x, int64_t n, const double* wind
     if (!x || !out) { pvx_set_error("null rms array"); return PVX_ERR_INVALID; }
     DevBuf dx, dout;
     if ((rc = dx.alloc((size_t)n * 8)) != PVX_OK || (rc = dout.alloc((size_t)nfr * 8)) != PVX_OK) return rc;
-    PVX_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    if ((rc = host_to_device(dx.p, x, (size_t)n * 8)) != PVX_OK) return rc;
     const int64_t r = pvx_rms_frames_dev((const double*)dx.p, n, wind, wlen, hop, (double*)dout.p, nullptr);
     if (r < 0) return r;
-    PVX_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)nfr * 8, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(out, dout.p, (size_t)nfr * 8)) != PVX_OK) return rc;
     return nfr;
 }
 
@@ -1741,18 +1793,15 @@ extern "C" int pvx_synth_flags(const double* f, const double* mag, const double*
         (rc = dpid.alloc(n * 4)) != PVX_OK || (rc = dst.alloc((size_t)P * 4)) != PVX_OK ||
         (rc = dln.alloc((size_t)P * 4)) != PVX_OK || (rc = dw.alloc((size_t)wlen * 8)) != PVX_OK)
         return rc;
-    PVX_HIP_CHECK(hipMemcpy(df.p, f, n * 8, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dm.p, mag, n * 8, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dr.p, realph, n * 8, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dpid.p, partial_id, n * 4, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dst.p, part_start, (size_t)P * 4, hipMemcpyHostToDevice));
-    PVX_HIP_CHECK(hipMemcpy(dln.p, part_len, (size_t)P * 4, hipMemcpyHostToDevice));
+    if ((rc = host_to_device(df.p, f, n * 8)) != PVX_OK || (rc = host_to_device(dm.p, mag, n * 8)) != PVX_OK || (rc = host_to_device(dr.p, realph, n * 8)) != PVX_OK ||
+        (rc = host_to_device(dpid.p, partial_id, n * 4)) != PVX_OK || (rc = host_to_device(dst.p, part_start, (size_t)P * 4)) != PVX_OK ||
+        (rc = host_to_device(dln.p, part_len, (size_t)P * 4)) != PVX_OK) return rc;
     rc = pvx_synth_dev_flags((const double*)df.p, (const double*)dm.p, (const double*)dr.p, (const int32_t*)dpid.p, F, K,
                              (const int32_t*)dst.p, (const int32_t*)dln.p, P, sr, nfft, hop_analysis, hop_synth, edge, minframes,
                              (double*)dw.p, wlen, nullptr, flags);
     if (rc != PVX_OK) return rc;
     PVX_HIP_CHECK(hipStreamSynchronize(nullptr));
-    PVX_HIP_CHECK(hipMemcpy(w, dw.p, (size_t)wlen * 8, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(w, dw.p, (size_t)wlen * 8)) != PVX_OK) return rc;
     return PVX_OK;
 }
 

@@ -18,3 +18,4 @@ python tools/bench_configs.py > gpurun_out/configs_${T}.jsonl 2> gpurun_out/conf
 python tools/sweep_config5.py > gpurun_out/sweep5_${T}.jsonl 2> gpurun_out/sweep5_${T}.err
 python tools/sweep_config5.py 3600 64 > gpurun_out/sweep5_${T}_f64.jsonl 2>> gpurun_out/sweep5_${T}.err
 python tools/ab_nfft.py 512,1024,2048,4096,8192 > gpurun_out/ab_nfft_${T}.jsonl 2>/dev/null
+cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/next_rows_${T} -o r --output-format csv -- python3 /root/repo/tools/bench_next_rows.py > /root/repo/gpurun_out/next_rows_${T}.jsonl 2> /root/repo/gpurun_out/next_rows_${T}.err; cd /root/repo
