@@ -1205,6 +1205,31 @@ def test_device_resident_signal_is_analysed_in_place(amd):
         assert np.array_equal(getattr(hb, k), getattr(db, k)), k
 
 
+def test_caller_arrays_of_every_size_class_cross_the_link_unchanged(amd):
+    """Nothing of the caller's above 512 KB is handed to hipMemcpy (the runtime would pin it in place): small arrays go
+    direct, arrays up to 16 MB bounce through the ring's page-locked memory, larger pageable ones take the threaded ring,
+    page-locked ones go straight.  Host-in / host-out entry points over the three classes against the device-resident
+    batch of the same signals (which never stages anything)."""
+    import torch
+    rng = np.random.default_rng(5)
+    for nsig, nsamp, K in ((2, 30000, 8), (6, 400000, 20), (24, 400000, 20)):        # inputs 0.24 / 9.6 / 38 MB, result arrays 7 KB / 0.7 / 3 MB
+        t = np.arange(nsamp) / 44100.0
+        xb = np.stack([0.3 * np.sin(2 * np.pi * (200.0 + 37.0 * i) * t) + 0.01 * rng.standard_normal(nsamp) for i in range(nsig)]).astype(np.float32)
+        hb = amd.PVBatch(xb, 44100, nfft=2048, hop=512, npks=K).run_pv()
+        db = amd.PVBatch(torch.from_numpy(xb).cuda(), 44100, nfft=2048, hop=512, npks=K).run_pv()
+        for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            assert np.array_equal(getattr(hb, k), getattr(db, k)), (nsig, k)
+    # the plan-less reductions: 2.4 MB (bounce) and 24 MB (ring) of float64 signal
+    from pypevoc_amd import SoundUtils
+    for n in (300000, 3000000):
+        x = rng.standard_normal(n)
+        r, tt = SoundUtils.RMSWind(x, 44100, 1024, 512)
+        w = np.blackman(1024)
+        for i in (0, len(r) // 2, len(r) - 1):
+            seg = x[i * 512:i * 512 + 1024]
+            assert abs(r[i] - np.sqrt(np.sum((seg * w) ** 2) / np.sum(w ** 2))) <= 1e-12
+
+
 def test_library_first_then_torch_in_a_fresh_process():
     """`import pypevoc_amd` + an analysis BEFORE `import torch` must leave torch usable: both have to end
     up on the same HIP runtime (pypevoc_amd/_lib.py::_share_hip_runtime_with_torch)."""

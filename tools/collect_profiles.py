@@ -92,4 +92,16 @@ for src, dst in (("configs_%s.jsonl" % tag, "%s_configs_3_4.jsonl" % tag), ("swe
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s):
         shutil.copy(s, os.path.join(P, dst))
+# the "next" rows (tools/bench_next_rows.py under rocprofv3 --kernel-trace --stats): its lines + the durations of its kernels
+s = os.path.join(G, "next_rows_%s.jsonl" % tag)
+if os.path.exists(s) and os.path.getsize(s):
+    lines = [ln for ln in open(s).read().splitlines() if ln.startswith("{")]
+    ks = os.path.join(G, "next_rows_%s" % tag, "r_kernel_stats.csv")
+    if os.path.exists(ks):
+        import csv
+        for r in csv.DictReader(open(ks)):
+            if any(k in r["Name"] for k in ("k_harmonic_rows", "k_stft<", "k_heterodyne", "k_rms_frames", "k_hpower", "k_f0")):
+                lines.append(json.dumps({"kernel": r["Name"].replace("(anonymous namespace)::", "").split("(")[0].strip(), "calls": int(r["Calls"]),
+                                         "avg_us": round(float(r["AverageNs"]) / 1e3, 1)}))
+    open(os.path.join(P, "%s_next_rows.jsonl" % tag), "w").write("\n".join(lines) + "\n")
 print(json.dumps({k: v["bytes_per_frame"] for k, v in out.items() if isinstance(v, dict)}))

@@ -108,6 +108,20 @@ for d in cf:
                  (M(d["frames_per_s"]), d["pack_ms"], d["wire_MB"], d["result_MB"]))
 if cf:
     L.append("")
+nr = jl("%s_next_rows.jsonl" % tag)
+if nr:
+    L.append("**The rows SURVEY 8(f) marks next (N1-N4), on config 2's signal through the Python mirrors (`tools/bench_next_rows.py` -> `profiles/%s_next_rows.jsonl`; host arrays in and out unless the line says resident; best of 5).**" % tag)
+    L.append("")
+    L.append("| row | call | frames/s | what crosses the link / note |")
+    L.append("|---|---|---|---|")
+    for d in nr:
+        if "row" in d:
+            L.append("| %s | %.3f ms | %s | %s |" % (d["row"], d["ms"], M(d["frames_per_s"]), d["shape"]))
+    kk = ["`%s` %.0f us" % (d["kernel"][:40], d["avg_us"]) for d in nr if "kernel" in d]
+    if kk:
+        L.append("")
+        L.append("Their kernels (rocprofv3 kernel trace of the same run, average per launch): " + "; ".join(kk) + ".")
+    L.append("")
 try:
     sq = json.load(open(os.path.join(P, "sq_latest.json")))
     rows = []
