@@ -41,10 +41,17 @@ template <> struct Vec16<double> { using type = double2; static constexpr int CP
 constexpr int GMAX = 8;               // frames a wave batches before the per-peak pass
 
 // LDS per wave (bytes), shared with the host-side sizing below
-__host__ __device__ __forceinline__ size_t peaks_lds_per_wave(int N2, int K, size_t ts) {
+__host__ __device__ __forceinline__ size_t peaks_lds_per_wave(int N2, int K, size_t ts, bool cand = false) {
     const size_t n2pad = (size_t)((N2 + 3) & ~3);
     const size_t cap = (n2pad / 2 + 4 + 1) & ~(size_t)1;
     const size_t kpad = (size_t)((K + 3) & ~3);
+    if (cand) {
+        // candidate variant (the split transform left the row's candidates): cs[cap] T | ci[cap] u16 | sel | lst | cnt | tot
+        size_t b = cap * ts + cap * 2 + kpad * 4 + (size_t)GMAX * kpad * 4 + GMAX * 4;
+        b = (b + 7) & ~(size_t)7;
+        b += GMAX * 8;
+        return (b + 15) & ~(size_t)15;
+    }
     // y[n2pad] T | ci[cap] u16 | sel[kpad] int | lst[GMAX][kpad] int | cnt[GMAX] int | tot[GMAX] double
     // (no score list and 16-bit bins: 10 bytes of LDS per bin at float64 instead of 14, i.e. 8 waves per CU instead of
     // 4 at nfft 4096 -- what this latency-bound kernel's speed hangs on there)
@@ -54,7 +61,17 @@ __host__ __device__ __forceinline__ size_t peaks_lds_per_wave(int N2, int K, siz
     return (b + 15) & ~(size_t)15;
 }
 
-template <typename T>
+// |X|^2 of a spectrum row in global memory, indexed like the LDS row (the candidate variant's salience test and its
+// rare "fewer maxima than npks under a negative threshold" search read the few bins they need from the row itself)
+template <typename T> struct RowMag {
+    const T* cur;
+    __device__ __forceinline__ T operator[](int k) const { const T re = cur[2 * k], im = cur[2 * k + 1]; return re * re + im * im; }
+};
+
+// CAND: the transform kernel (k_stft_split) left every row's candidates -- bins and |X|^2 of the interior local maxima
+// above the threshold, max / min / sum of |X|^2 -- so phase A loads a few hundred bytes per row instead of streaming
+// nfft/2 complex bins: same candidates, same selection (the energy is summed in another order: totalmag to round-off).
+template <typename T, bool CAND>
 __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -64,9 +81,9 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     const int n2pad = (N2 + 3) & ~3;
     const int cap = (n2pad / 2 + 4 + 1) & ~1;
     const int kpad = (K + 3) & ~3;
-    unsigned char* base = smem + peaks_lds_per_wave(N2, K, sizeof(T)) * wid;
-    T* y = (T*)base;
-    unsigned short* ci = (unsigned short*)(y + n2pad);
+    unsigned char* base = smem + peaks_lds_per_wave(N2, K, sizeof(T), CAND) * wid;
+    T* y = (T*)base;                                                   // CAND: the candidates' scores (cs)
+    unsigned short* ci = (unsigned short*)(y + (CAND ? cap : n2pad));
     int* sel = (int*)(ci + cap);
     int* lst = sel + kpad;                       // [GMAX][kpad]
     int* cntv = lst + GMAX * kpad;               // [GMAX]
@@ -88,6 +105,37 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
         }
         const T* cur = (const T*)p.spec + (size_t)(rel + 1) * p.ldo * 2;
         wave_sync();                                                 // y / cs / ci / sel free again
+        if constexpr (CAND) {
+            const double* st = p.cand_stats + (size_t)(rel + 1) * 4;
+            const T maxv = (T)st[0], minv = (T)st[1];
+            const double tot = st[2];
+            const int C = (int)st[3];
+            double minamp;
+            if constexpr (sizeof(T) == 4) minamp = (double)sqrtf(maxv) * p.thr;          // PF.py:60
+            else minamp = sqrt((double)maxv) * p.thr;
+            const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
+            const size_t rb = (size_t)(rel + 1) * p.cand_cap;
+            const T* gy = (const T*)p.cand_y + rb;
+            const unsigned short* gb = p.cand_bin + rb;
+            T* cs = y;
+            for (int c = lane; c < C; c += 64) { ci[c] = gb[c]; cs[c] = (T)(gy[c] - minv); }
+            wave_sync();
+            const RowMag<T> ym{cur};
+            int nsel = 0;
+            if (N2 >= 3) nsel = peak_pick<T, 0, true, true>(ym, cs, ci, sel, N2, K, C, th, lane, minv);
+            int nk = 0;
+            for (int e0 = 0; e0 < nsel; e0 += 64) {
+                const int e = e0 + lane;
+                int pb = 0;
+                bool keep = false;
+                if (e < nsel) { pb = sel[e]; keep = salient<T>(ym, N2, pb, p.rad); }
+                const unsigned long long bal = __ballot(keep);
+                if (keep) lst[g * kpad + nk + lane_prefix(bal)] = pb;
+                nk += __popcll(bal);
+            }
+            if (lane == 0) { cntv[g] = nk; totv[g] = tot; }
+            continue;
+        }
         // ---- stream the row: |X| -> LDS, extremes and energy (PV.py:173, 210; PF.py:60, 164)
         T lmax = (T)-INFINITY, lmin = (T)INFINITY;
         double lsum = 0.0;
@@ -280,6 +328,9 @@ __global__ __launch_bounds__(256) void k_peak_rows(PeakRowsParams p) {
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves) {
     return peaks_lds_per_wave(N2, K, precision == 32 ? 4 : 8) * (size_t)waves;
 }
+static size_t peaks_lds_bytes_cand(int N2, int K, int precision, int waves) {
+    return peaks_lds_per_wave(N2, K, precision == 32 ? 4 : 8, true) * (size_t)waves;
+}
 
 static constexpr size_t kMaxLds = 160 * 1024;
 
@@ -288,9 +339,11 @@ int pvx_launch_phase_peaks(const PeaksParams& pin, int precision, hipStream_t s)
     PeaksParams p = pin;
     if (p.frames_per_wave < 1) p.frames_per_wave = 1;
     if (p.frames_per_wave > GMAX) p.frames_per_wave = GMAX;
+    const bool cand = p.cand_bin != nullptr && p.cand_y != nullptr && p.cand_stats != nullptr;
     int waves = 4;
-    while (waves > 1 && pvx_phase_peaks_lds_bytes(p.N2, p.K, precision, waves) > kMaxLds / 2) waves >>= 1;
-    const size_t lds = pvx_phase_peaks_lds_bytes(p.N2, p.K, precision, waves);
+    auto ldsb = [&](int w) { return cand ? peaks_lds_bytes_cand(p.N2, p.K, precision, w) : pvx_phase_peaks_lds_bytes(p.N2, p.K, precision, w); };
+    while (waves > 1 && ldsb(waves) > kMaxLds / 2) waves >>= 1;
+    const size_t lds = ldsb(waves);
     if (lds > kMaxLds) {
         pvx_set_error("nfft=%d with npks=%d needs %zu bytes of LDS per wave (limit %zu)", p.nfft, p.K, lds, kMaxLds);
         return PVX_ERR_UNSUPPORTED;
@@ -299,16 +352,11 @@ int pvx_launch_phase_peaks(const PeaksParams& pin, int precision, hipStream_t s)
     const int64_t nblocks = (p.nrows + per_block - 1) / per_block;
     if (nblocks > 0x7fffffffLL) { pvx_set_error("too many rows in one launch"); return PVX_ERR_INVALID; }
     dim3 grid((unsigned)nblocks), block(64 * waves);
-    if (precision == 32) {
-        if (lds > 64 * 1024)
-            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_phase_peaks<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_phase_peaks<float>, grid, block, lds, s, p);
-    } else {
-        if (lds > 64 * 1024)
-            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_phase_peaks<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_phase_peaks<double>, grid, block, lds, s, p);
-    }
-    PVX_HIP_CHECK(hipGetLastError());
+    const void* fn = precision == 32 ? (cand ? (const void*)k_phase_peaks<float, true> : (const void*)k_phase_peaks<float, false>)
+                                     : (cand ? (const void*)k_phase_peaks<double, true> : (const void*)k_phase_peaks<double, false>);
+    if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {&p};
+    PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     return PVX_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "pvx_stft.h"
+#include "pvx_wave.h"
 
 using namespace pvxw;
 using namespace pvxf;
@@ -195,7 +196,7 @@ template <int R, int S, typename T> struct SplitGeo {
 // wait for the prefetched samples of the next row
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int R, int S, typename T, typename InT>
+template <int R, int S, typename T, typename InT, bool CAND>
 __global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p) {
     using G = SplitGeo<R, S, T>;
     using G1 = StftGeo<R, T>;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p)
             }
         }
         lds_barrier();                                                // Z is complete
+        T ey[CAND ? R : 1];                                           // (CAND) |X|^2 of this wave's bins
         if (have && !real) {
             // the zero frame in front of every signal (PV.py:121): this wave's share of a row of zeros
             for (int k = lane + 64 * sub; k < M; k += 64 * S) out[k] = mkc<T>((T)0, (T)0);
@@ -350,28 +352,107 @@ __global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p)
             const cx<T> zc = zat(M / 2);
             constexpr int NPAIR = R / 2;
             const int ch = sub;
-            cx<T> za[NPAIR], zb[NPAIR], tw[NPAIR];
+            // (with the candidates: in two batches of pairs -- the |X|^2 values stay in registers until every wave has
+            // read its pairs, and with all of a wave's pairs in flight at once beside them the float64-input kernels spill)
+            constexpr int NBATCH = CAND ? 2 : 1, PB = NPAIR / NBATCH;
 #pragma unroll
-            for (int j2 = 0; j2 < NPAIR; j2++) {
+            for (int bt = 0; bt < NBATCH; bt++) {
+            cx<T> za[PB], zb[PB], tw[PB];
+#pragma unroll
+            for (int j3 = 0; j3 < PB; j3++) {
+                const int j2 = bt * PB + j3;
                 const int k = lane + 64 * (ch * NPAIR + j2);
-                za[j2] = zat(k);
-                zb[j2] = zat((M - k) & (M - 1));
-                tw[j2] = tab[k];                                      // W_N^k, k < M/2
+                za[j3] = zat(k);
+                zb[j3] = zat((M - k) & (M - 1));
+                tw[j3] = tab[k];                                      // W_N^k, k < M/2
             }
 #pragma unroll
-            for (int j2 = 0; j2 < NPAIR; j2++) {
+            for (int j3 = 0; j3 < PB; j3++) {
+                const int j2 = bt * PB + j3;
                 const int k = lane + 64 * (ch * NPAIR + j2);
                 const int km = (M - k) & (M - 1);
-                const cx<T> Sm = mkc<T>(za[j2].x + zb[j2].x, za[j2].y - zb[j2].y);
-                const cx<T> D = mkc<T>(za[j2].x - zb[j2].x, za[j2].y + zb[j2].y);
+                const cx<T> Sm = mkc<T>(za[j3].x + zb[j3].x, za[j3].y - zb[j3].y);
+                const cx<T> D = mkc<T>(za[j3].x - zb[j3].x, za[j3].y + zb[j3].y);
                 const cx<T> O = mkc<T>((T)0.5 * D.y, (T)-0.5 * D.x);
-                const cx<T> Pk = cmulT(O, tw[j2]);
+                const cx<T> Pk = cmulT(O, tw[j3]);
                 const cx<T> x0 = mkc<T>(fmaT((T)0.5, Sm.x, Pk.x), fmaT((T)0.5, Sm.y, Pk.y));
                 cx<T> x1 = mkc<T>(fmaT((T)0.5, Sm.x, -Pk.x), -fmaT((T)0.5, Sm.y, -Pk.y));
                 int kk = km;
                 if (ch == 0 && j2 == 0 && lane == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = M / 2; }      // bin 0 pairs with itself; its slot takes bin M/2
                 out[k] = x0;
                 out[kk] = x1;
+                if constexpr (CAND) {
+                    // |X|^2 of both bins, k_phase_peaks' formula (k_peaks.hip): plain products and one sum
+                    ey[2 * j2] = x0.x * x0.x + x0.y * x0.y;
+                    ey[2 * j2 + 1] = x1.x * x1.x + x1.y * x1.y;
+                }
+            }
+            }
+        }
+        if constexpr (CAND) {
+            // ---- the row's candidate peaks, while its magnitudes are on chip (the peak kernel then reads a few hundred
+            // bytes of this row instead of streaming its nfft/2 complex bins back from HBM): |X|^2 -> LDS where Z was,
+            // extremes and energy over the team, every wave scans its M/S bins (PF.py:166-174 with the threshold of
+            // PF.py:60, 69-70 exactly as k_phase_peaks forms it), the lists go out in ascending bin order
+            constexpr int SEG = M / S, CAPW = SEG / 2 + 4, NPAIR = R / 2;
+            lds_barrier();                                            // every wave has read its pairs: the regions are free
+            T* const yL = (T*)buf;
+            unsigned short* const ciL = (unsigned short*)(yL + M) + (size_t)sub * CAPW;
+            double* const partL = (double*)(((uintptr_t)((unsigned short*)(yL + M) + (size_t)S * CAPW) + 15) & ~(uintptr_t)15);    // [S][4]
+            if (real) {
+                T lmax = (T)-INFINITY, lmin = (T)INFINITY;
+                double lsum = 0.0;
+#pragma unroll
+                for (int j2 = 0; j2 < NPAIR; j2++) {
+                    const int k = lane + 64 * (sub * NPAIR + j2);
+                    int kk = (M - k) & (M - 1);
+                    if (sub == 0 && j2 == 0 && lane == 0) kk = M / 2;
+                    const T e0 = ey[2 * j2], e1 = ey[2 * j2 + 1];
+                    yL[k] = e0;
+                    yL[kk] = e1;
+                    lmax = e0 > lmax ? e0 : lmax; lmax = e1 > lmax ? e1 : lmax;
+                    lmin = e0 < lmin ? e0 : lmin; lmin = e1 < lmin ? e1 : lmin;
+                    lsum += (double)e0 + (double)e1;
+                }
+                const double wmx = (double)wave_max(lmax), wmn = (double)wave_min(lmin), wsm = wave_sum(lsum);
+                if (lane == 0) { partL[sub * 4] = wmx; partL[sub * 4 + 1] = wmn; partL[sub * 4 + 2] = wsm; }
+            }
+            lds_barrier();                                            // the row of |X|^2 and the waves' partial extremes
+            int C_w = 0;
+            double mx = 0.0, mn = 0.0, sm = 0.0;
+            if (real) {
+                mx = partL[0]; mn = partL[1]; sm = partL[2];
+#pragma unroll
+                for (int w2 = 1; w2 < S; w2++) {
+                    mx = partL[w2 * 4] > mx ? partL[w2 * 4] : mx;
+                    mn = partL[w2 * 4 + 1] < mn ? partL[w2 * 4 + 1] : mn;
+                    sm += partL[w2 * 4 + 2];
+                }
+                double minamp;
+                if constexpr (sizeof(T) == 4) minamp = (double)sqrtf((float)mx) * p.cand_thr;       // PF.py:60 (k_phase_peaks)
+                else minamp = sqrt(mx) * p.cand_thr;
+                const double th = (minamp != 0.0) ? minamp * minamp - mn : 0.0;
+                // (S = 4: up to 512 registers per wave, all of the scan's LDS reads in flight at once; S = 2 has 256: the loop form)
+                C_w = pvxw::peak_scan<T, (S == 4 ? SEG / 64 : 0), false>((const T*)yL, sub * SEG, SEG, M, (T)mn, th, (T*)nullptr, ciL, lane);
+                if (lane == 0) partL[sub * 4 + 3] = (double)C_w;
+            }
+            lds_barrier();                                            // the waves' candidate counts (and this wave's list)
+            if (real) {
+                int off = 0, total = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < S; w2++) { const int c = (int)partL[w2 * 4 + 3]; off += (w2 < sub) ? c : 0; total += c; }
+                const size_t rb = (size_t)j * p.cand_cap;
+                T* const gy = (T*)p.cand_y + rb;
+                unsigned short* const gb = p.cand_bin + rb;
+                for (int i = lane; i < C_w; i += 64) {
+                    const int b = (int)ciL[i];
+                    gb[off + i] = (unsigned short)b;
+                    gy[off + i] = yL[b];
+                }
+                if (sub == 0 && lane == 0) {
+                    double* st = p.cand_stats + (size_t)j * 4;
+                    st[0] = mx; st[1] = mn; st[2] = sm; st[3] = (double)total;
+                }
             }
         }
         lds_barrier();                                                // the regions are free again
@@ -390,10 +471,11 @@ template <int R, int S, typename T> int launch_stft_split(const StftParams& p, i
     const size_t lds = G::total(teams);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d needs %zu bytes of LDS in the split STFT kernel", G::N, lds); return PVX_ERR_UNSUPPORTED; }
     const void* fn = nullptr;
+    const bool cand = p.cand_bin != nullptr && p.cand_y != nullptr && p.cand_stats != nullptr && p.cand_cap >= G::M / 2 + 4;
     switch (x_dtype) {
-        case PVX_F32: fn = (const void*)k_stft_split<R, S, T, float>; break;
-        case PVX_F64: fn = (const void*)k_stft_split<R, S, T, double>; break;
-        case PVX_I16: fn = (const void*)k_stft_split<R, S, T, int16_t>; break;
+        case PVX_F32: fn = cand ? (const void*)k_stft_split<R, S, T, float, true> : (const void*)k_stft_split<R, S, T, float, false>; break;
+        case PVX_F64: fn = cand ? (const void*)k_stft_split<R, S, T, double, true> : (const void*)k_stft_split<R, S, T, double, false>; break;
+        case PVX_I16: fn = cand ? (const void*)k_stft_split<R, S, T, int16_t, true> : (const void*)k_stft_split<R, S, T, int16_t, false>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -457,6 +539,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
     StftParams p;
     p.x = fp.x; p.nsamp = fp.nsamp; p.sig_stride = fp.sig_stride; p.F = fp.F; p.R0 = fp.R0; p.ws_rows = fp.ws_rows;
     p.total_rows = fp.total_rows; p.hop = fp.hop; p.win = fp.win; p.twiddle = twiddle; p.spec = spec; p.ldo = ldo;
+    p.cand_y = fp.cand_y; p.cand_bin = fp.cand_bin; p.cand_stats = fp.cand_stats; p.cand_cap = fp.cand_cap; p.cand_thr = fp.cand_thr;
     if (precision == 64) {
         switch (fp.nfft) {
             case 512: return launch_stft_r<4, double>(p, x_dtype, s);

@@ -128,6 +128,10 @@ struct pvx_plan {
     double* d_wfbin = nullptr;
     void* d_frames = nullptr; // [max_rows+1][ldi]
     void* d_spec = nullptr;   // [max_rows+1][ldo] complex
+    void* d_cand_y = nullptr;              // the split transform's candidate peaks per workspace row (pvx_stft.h): |X|^2 [max_rows+1][cand_cap],
+    unsigned short* d_cand_bin = nullptr;  // bins, and [max_rows+1][4] max / min / sum / count
+    double* d_cand_stats = nullptr;
+    int cand_cap = 0;
     void* d_work = nullptr;
     size_t work_bytes = 0;
     int64_t ws_bytes = 0;
@@ -202,6 +206,9 @@ static void plan_free(pvx_plan* p) {
     if (p->d_wfbin) (void)hipFree(p->d_wfbin);
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_spec) (void)hipFree(p->d_spec);
+    if (p->d_cand_y) (void)hipFree(p->d_cand_y);
+    if (p->d_cand_bin) (void)hipFree(p->d_cand_bin);
+    if (p->d_cand_stats) (void)hipFree(p->d_cand_stats);
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->d_rspec) (void)hipFree(p->d_rspec);
     if (p->d_twiddle64) (void)hipFree(p->d_twiddle64);
@@ -412,6 +419,31 @@ static int ensure_spec_ws(pvx_plan* p) {
     p->ws_bytes += (int64_t)sbytes;
     return PVX_OK;
 }
+// nfft 8192 on the general path (k_stft_split -> k_phase_peaks): the transform leaves every row's candidate peaks, the peak
+// kernel does not stream the 64 KB rows again (float64, config 2's signal: 0.79 -> 0.63 ms; PVX_NO_CAND=1: the two kernels
+// as before).  At nfft 4096 (teams of two waves at 256 registers: the scan's reads cannot all be in flight) the scan costs
+// the transform kernel what it saves the peak kernel: off unless PVX_CAND_4096=1.
+static bool plan_wants_cand(const pvx_plan* p) {
+    if (!p->use_stft || p->use_stft_pv || getenv("PVX_NO_CAND") != nullptr) return false;
+    return p->nfft == 8192 || (p->nfft == 4096 && getenv("PVX_CAND_4096") != nullptr);
+}
+static int ensure_cand_ws(pvx_plan* p) {
+    if (p->d_cand_bin) return PVX_OK;
+    const int cap = p->N2 / 2 + 8;
+    const size_t rows = (size_t)p->max_rows + 1, rs = real_size(p->precision);
+    if (hipMalloc(&p->d_cand_y, rows * cap * rs) != hipSuccess || hipMalloc((void**)&p->d_cand_bin, rows * cap * 2) != hipSuccess ||
+        hipMalloc((void**)&p->d_cand_stats, rows * 4 * sizeof(double)) != hipSuccess) {
+        pvx_set_error("hipMalloc of the candidate workspace failed");
+        if (p->d_cand_y) (void)hipFree(p->d_cand_y);
+        if (p->d_cand_bin) (void)hipFree(p->d_cand_bin);
+        if (p->d_cand_stats) (void)hipFree(p->d_cand_stats);
+        p->d_cand_y = nullptr; p->d_cand_bin = nullptr; p->d_cand_stats = nullptr;
+        return PVX_ERR_ALLOC;
+    }
+    p->cand_cap = cap;
+    p->ws_bytes += (int64_t)(rows * cap * (rs + 2) + rows * 32);
+    return PVX_OK;
+}
 
 // frames + spectrum workspace and the rocFFT plan (fft mode 0, calc_fft_frame): created on first use.
 // With k_stft in charge of the analysis the rocFFT side only serves pvx_stft_frames: two rows, its own output.
@@ -562,6 +594,8 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         if ((rc = ensure_rocfft(p, true)) != PVX_OK) return rc;
         PVX_FFT_CHECK(rocfft_execution_info_set_stream(p->info, s));
     }
+    const bool cand = plan_wants_cand(p);
+    if (cand && (rc = ensure_cand_ws(p)) != PVX_OK) return rc;
     for (int64_t R0 = 0; R0 < total_rows; R0 += p->max_rows) {
         const int64_t nrows = (total_rows - R0 < p->max_rows) ? (total_rows - R0) : p->max_rows;
         FrameParams fp;
@@ -575,6 +609,10 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         pp.wfbin = p->d_wfbin; pp.prev0 = d_prev0;
         pp.f = d_f; pp.mag = d_mag; pp.ph = d_ph; pp.realph = d_realph; pp.binno = d_binno;
         pp.t = d_t; pp.totalmag = d_totalmag; pp.frames_per_wave = p->frames_per_wave;
+        if (cand) {
+            fp.cand_y = p->d_cand_y; fp.cand_bin = p->d_cand_bin; fp.cand_stats = p->d_cand_stats; fp.cand_cap = p->cand_cap; fp.cand_thr = p->pkthresh;
+            pp.cand_y = p->d_cand_y; pp.cand_bin = p->d_cand_bin; pp.cand_stats = p->d_cand_stats; pp.cand_cap = p->cand_cap;
+        }
         if (p->use_stft && p->use_stft_pv) {
             // window + FFT + untangle + peaks of every row in one kernel (k_stft_pv.hip); the spectrum rows still land in
             // the workspace

@@ -50,6 +50,12 @@ struct FrameParams {
     const void* win;      // window * (1/wfact), T[nfft]
     void* frames;         // T [ws_rows][ldi]
     int64_t ldi;          // elements per workspace row
+    // optional candidate output of the split transform (pvx_stft.h: StftParams)
+    void* cand_y = nullptr;
+    unsigned short* cand_bin = nullptr;
+    double* cand_stats = nullptr;
+    int cand_cap = 0;
+    double cand_thr = 0.0;
 };
 
 struct PeaksParams {
@@ -63,6 +69,11 @@ struct PeaksParams {
     const double* prev0;  // optional [N2][2] spectrum preceding frame 0 of signal 0
     double *f, *mag, *ph, *realph, *binno, *t, *totalmag;
     int frames_per_wave;
+    // optional: the rows' candidate peaks left by the split transform (row rel + 1 of the workspace = this launch's row rel)
+    const void* cand_y = nullptr;
+    const unsigned short* cand_bin = nullptr;
+    const double* cand_stats = nullptr;
+    int cand_cap = 0;
 };
 
 struct PeakRowsParams {   // standalone PeakFinder

@@ -122,6 +122,14 @@ struct StftParams {
     const void* twiddle;      // cx<T> [nfft]  W_nfft^j
     void* spec;               // cx<T> [ws_rows][ldo]
     int64_t ldo;
+    // optional (k_stft_split): the row's candidate peaks for k_phase_peaks, which then does not stream the row again --
+    // cand_bin / cand_y [ws_rows][cand_cap]: bins (ascending) and |X|^2 of the interior local maxima above the threshold
+    // (PF.py:60, 69-70, 166-174 with pkthresh = cand_thr); cand_stats [ws_rows][4]: max |X|^2, min |X|^2, sum |X|^2, count
+    void* cand_y = nullptr;
+    unsigned short* cand_bin = nullptr;
+    double* cand_stats = nullptr;
+    int cand_cap = 0;
+    double cand_thr = 0.0;
 };
 
 }  // namespace pvxs

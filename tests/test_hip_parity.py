@@ -562,6 +562,38 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmo
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
 
 
+@pytest.mark.parametrize("nfft", [4096, 8192])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_candidates_from_the_split_transform_select_the_same_peaks(amd, monkeypatch, nfft, precision):
+    """General path at nfft 4096 / 8192: k_stft_split leaves every row's candidate peaks (bins, |X|^2, extremes) and
+    k_phase_peaks<CAND> works from those lists instead of streaming the row again (default at nfft 8192) -- the same
+    values as the row-streaming form in every array; the energy is summed in another order (totalmag to round-off)."""
+    from pypevoc_amd import _lib
+    rng = np.random.default_rng(81)
+    sr = 44100.0
+    n = 30000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    flat = np.zeros(n); flat[::nfft // 2 + 7] = 1.0                                # impulses: flat spectra, thresholds below the row minimum
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+    monkeypatch.setenv("PVX_CAND_4096", "1")
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("flat", flat)):
+        for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (100, 0.0, nfft // 2), (600, 1e-9, nfft // 4)):
+            monkeypatch.delenv("PVX_NO_CAND", raising=False)
+            a = run_pv(amd, x, sr, nfft, hop, K, thr, precision=precision)
+            assert _lib.load().pvx_plan_get_fft_mode(a._plan.handle) == 0
+            ra = pv_result(a)
+            monkeypatch.setenv("PVX_NO_CAND", "1")
+            b = run_pv(amd, x, sr, nfft, hop, K, thr, precision=precision)
+            rb = pv_result(b)
+            for k in ("f", "mag", "ph", "realph", "binno", "t"):
+                assert np.array_equal(ra[k], rb[k]), (name, K, thr, hop, k)
+            tm_a, tm_b = np.asarray(ra["totalmag"]), np.asarray(rb["totalmag"])
+            assert np.abs(tm_a - tm_b).max() <= (1e-13 if precision == 64 else 1e-6) * max(1e-30, np.abs(tm_b).max()), (name, K)
+
+
 @pytest.mark.parametrize("nfft,kmode", [(2048, 4), (4096, 5), (8192, 5)])
 def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft, kmode):
     """fft mode 4 at nfft 2048 (k_fused_rev.hip with the four-quarter transform of pvx_fft4.h) and fft mode 5 (k_fused_team.hip: nfft 4096 / 8192 as teams of 2 / 4 waves, each a k_fused_rev-shaped wave over a
