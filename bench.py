@@ -259,6 +259,8 @@ def main():
     if (args.gpus > 1 or os.environ.get("PVX_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    # (the pool's driver only supports dmabuf IPC: RCCL and cross-process tensor sharing need this before the runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
