@@ -32,6 +32,8 @@ Also on the same JSON line (rank 0):
   f64          -- the same workload at the reference's own precision (float64 end to end, PVAnalysis.py:155-157).
   workloads    -- the same geometry on 10 min of white noise and on a tiled violin recording (fixture G7):
                   the headline signal is the best case for the peak search.
+  chain        -- the rest of the path on the headline step's results, device to device: tracker (pvx_track_dev) and
+                  resynthesis (pvx_synth_dev) as frames/s, both checked against the oracle on the same arrays.
   cpu_baseline -- the oracle (C port of the reference algorithm) timed on this host: all cores (threads over
                   frame ranges) and one thread; the Python reference's own figure from BASELINE.md beside it.
 """
@@ -634,7 +636,7 @@ def main():
             h = out.cpu().numpy()
             return np.concatenate([h[: 5 * Fq * K], h[5 * Fq * K + Fq:], h[5 * Fq * K: 5 * Fq * K + Fq]])
 
-        f64 = workloads = other_nfft = None
+        f64 = workloads = other_nfft = chain = None
         if extras_ok:
             from oracle import pvoracle
             pvoracle.build()
@@ -717,6 +719,76 @@ def main():
                                            contract_target=round(0.6 * HBM_PEAK / alg_bytes(nfft=nf, hop=hp)["contract"], 1),
                                            self_check=(check_block(host_block(outo, Fo), oo, Fo, K, nf, hp, 32, "nfft %d" % nf) if checks else None))
                 lib.pvx_plan_destroy(pl)
+            # ---- the rest of the path on the headline step's results, device to device (tracker and
+            # resynthesis as frames/s): PV.toSinSum (pvx_track_dev) and SinSum.synth (pvx_synth_dev) on the (F, K) arrays
+            # the timed step left in HBM; the partial table against the oracle's tracker on the same arrays, the first
+            # frames' waveform against the oracle's resynthesis of them
+            if nsig == 1:
+                nK = F * K
+                rb = res.data_ptr()
+                d_f, d_mag, d_rp = rb, rb + nK * 8, rb + 3 * nK * 8
+                pid_d = torch.empty(nK, dtype=torch.int32, device=dev)
+                pst_d = torch.empty(nK, dtype=torch.int32, device=dev)
+                pln_d = torch.empty(nK, dtype=torch.int32, device=dev)
+                sp = ctypes.c_void_p(stream.cuda_stream)
+
+                def track_once():
+                    P_ = lib.pvx_track_dev(d_f, d_mag, F, K, 0.5, pid_d.data_ptr(), pst_d.data_ptr(), pln_d.data_ptr(), nK, sp)
+                    _lib.check(P_, "pvx_track_dev")
+                    return int(P_)
+
+                P = track_once()
+                tt = []
+                for _ in range(5):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    track_once()                                     # (returns the number of partials: synchronous)
+                    tt.append(time.perf_counter() - t0)
+                ms_trk = min(tt) * 1e3
+                chain = dict(tracker=dict(value=round(F / ms_trk * 1e3, 1), unit="frames/s", ms=round(ms_trk, 4), partials=P,
+                                          what="pvx_track_dev on the resident (F, K) arrays, table left in HBM; wall time of the call (it returns the partial count)"))
+                if P > 0:
+                    maxend = int((pst_d[:P].to(torch.int64) + pln_d[:P].to(torch.int64) - 1).max().item())
+                    wlen = int(lib.pvx_synth_len(maxend, NFFT, HOP, HOP, 1.0))
+                    w_d = torch.empty(wlen, dtype=torch.float64, device=dev)
+
+                    def synth_once():
+                        _lib.check(lib.pvx_synth_dev(d_f, d_mag, d_rp, pid_d.data_ptr(), F, K, pst_d.data_ptr(), pln_d.data_ptr(), P, float(sr), NFFT, HOP, HOP,
+                                                     1.0, 3, w_d.data_ptr(), wlen, sp), "pvx_synth_dev")
+
+                    synth_once()
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    for _ in range(5):
+                        synth_once()
+                    e1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    ms_syn = e0.elapsed_time(e1) / 5
+                    chain["resynthesis"] = dict(value=round(F / ms_syn * 1e3, 1), unit="frames/s", ms=round(ms_syn, 4), samples_out=wlen,
+                                                samples_per_s=round(wlen / ms_syn * 1e3, 1), output_GBps=round(wlen * 8 / ms_syn / 1e6, 1),
+                                                what="pvx_synth_dev, waveform left in HBM; HIP events over 5 launches")
+                    if checks:
+                        hres = res.cpu().numpy()
+                        hf, hm, hr = (hres[i * nK:(i + 1) * nK].reshape(F, K) for i in (0, 1, 3))
+                        opid, ost, oln = pvoracle.track(hf, hm)
+                        same_tab = (P == len(ost) and np.array_equal(pid_d.cpu().numpy().reshape(F, K), opid) and
+                                    np.array_equal(pst_d[:P].cpu().numpy(), ost) and np.array_equal(pln_d[:P].cpu().numpy(), oln))
+                        chain["tracker"]["check"] = dict(ok=bool(same_tab), against="oracle/pvoracle.c tracker on the same (F, K) arrays: partial ids, starts and lengths identical")
+                        # the oracle's resynthesis of the first frames (its own table of them: partials still alive at the
+                        # cut end there, so the last frames' releases differ and are left out)
+                        FC = min(F, 3000)
+                        cpid, cst, cln = pvoracle.track(hf[:FC], hm[:FC])
+                        ow = pvoracle.synth(hf[:FC], hm[:FC], hr[:FC], cpid, cst, cln, sr, NFFT, HOP, HOP)
+                        ncmp = (FC - 8) * HOP
+                        hw = w_d[:ncmp].cpu().numpy()
+                        err = float(np.abs(hw - ow[:ncmp]).max())
+                        okw = err <= 1e-9 * max(1.0, float(np.abs(ow[:ncmp]).max()))
+                        chain["resynthesis"]["check"] = dict(ok=bool(okw), max_abs_err=err, samples_compared=int(ncmp),
+                                                             against="oracle/pvoracle.c resynthesis of the first %d frames of the same arrays" % FC)
+                        if not (same_tab and okw):
+                            sys.stderr.write("bench.py: the tracker / resynthesis of the headline results differ from the oracle: %s\n" % json.dumps(chain))
+                            checks_failed.append("chain")
         if checks_failed or gather_check_failed:
             rc = 3
 
@@ -747,6 +819,8 @@ def main():
             line["workloads"] = workloads
         if other_nfft:
             line["other_nfft"] = other_nfft
+        if chain:
+            line["chain"] = chain
         if gather_info:
             gather_info["ms_per_step_kernels_only"] = stage["step_ms_hip_events"]
             gather_info["exposed_ms_per_step"] = round(max(0.0, elapsed / args.steps * 1e3 - stage["step_ms_hip_events"]), 4)

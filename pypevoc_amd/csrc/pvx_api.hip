@@ -1266,9 +1266,14 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     if (F < 0 || K <= 0 || cap < 0) { pvx_set_error("bad tracker argument"); return PVX_ERR_INVALID; }
     if (F == 0) return 0;
     if (!d_f || !d_mag || !d_partial_id || !d_part_start || !d_part_len) { pvx_set_error("null tracker array"); return PVX_ERR_INVALID; }
-    DevBuf ws;
-    if ((rc = ws.alloc(track_ws_bytes(F, K))) != PVX_OK) return rc;
-    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, (char*)ws.p, (hipStream_t)stream, nullptr);
+    // the workspace of the plan-less tracker is kept (allocating and freeing it cost as much as the kernels); the call is
+    // synchronous, one at a time through it
+    static std::mutex mu;
+    static char* ws = nullptr;
+    static size_t ws_cap = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((rc = grow_dev(&ws, &ws_cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
+    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, ws, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,

@@ -37,6 +37,19 @@ def test_bench_line_and_self_check():
         assert 0.0 < r["issue"]["valu_issue"]["frac"] <= 1.0
 
 
+def test_bench_extras_are_all_checked_against_the_oracle():
+    """The default line's extra objects on a short signal: float64, the other material, nfft 4096 / 8192, and the rest of
+    the path (tracker + resynthesis on the headline results) -- every one of them carries an oracle check that passed."""
+    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "30"])
+    assert rc == 0 and j is not None, err[-2000:]
+    assert j["f64"]["self_check"]["ok"] and j["f64"]["white_noise"]["self_check"]["ok"]
+    assert all(w["self_check"]["ok"] for w in j["workloads"].values())
+    assert all(w["self_check"]["ok"] for w in j["other_nfft"].values())
+    c = j["chain"]
+    assert c["tracker"]["check"]["ok"] and c["tracker"]["partials"] > 0 and c["tracker"]["value"] > 0
+    assert c["resynthesis"]["check"]["ok"] and c["resynthesis"]["check"]["max_abs_err"] <= 1e-9 and c["resynthesis"]["value"] > 0
+
+
 def test_bench_forced_gather_exercises_rccl():
     rc, j, err = _run(["--steps", "4", "--warmup", "1", "--seconds", "20", "--no-extras", "--no-cpu-baseline"],
                       env={"PVX_BENCH_FORCE_GATHER": "1", "MASTER_PORT": "29641"})

@@ -68,6 +68,14 @@ if b:
         s = w.get("self_check") or {}
         L.append("| `other_nfft.%s` (fft mode %d) | %s | white noise %s; contract-priced target %s; self-check ok = %s (%d peaks, %d missed) |" %
                  (nf, w["fft_mode"], M(w["value"]), M(w["white_noise"]["value"]), M(w["contract_target"]), s.get("ok"), s.get("ref_peaks", 0), s.get("bad_peaks", 0)))
+    ch = b.get("chain") or {}
+    if ch.get("tracker"):
+        t_, r_ = ch["tracker"], ch.get("resynthesis") or {}
+        L.append("| `chain.tracker` (`k_track.hip`) | %s | %.3f ms (wall time of `pvx_track_dev`), %d partials; table identical to the oracle's: %s |" %
+                 (M(t_["value"]), t_["ms"], t_["partials"], (t_.get("check") or {}).get("ok")))
+        if r_:
+            L.append("| `chain.resynthesis` (`k_synth_ola`) | %s | %.3f ms per launch, %.1f M samples out (%.0f GB/s written); first 3000 frames against the oracle: ok = %s, \\|Δw\\| ≤ %.1e |" %
+                     (M(r_["value"]), r_["ms"], r_["samples_out"] / 1e6, r_["output_GBps"], (r_.get("check") or {}).get("ok"), (r_.get("check") or {}).get("max_abs_err", 0)))
     c = b.get("cpu_baseline")
     if c:
         L.append("| `cpu_baseline` | %s on %d threads | one thread %s; the Python reference %s (BASELINE.md) |" %
