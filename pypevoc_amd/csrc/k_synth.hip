@@ -4,25 +4,38 @@
 // The reference synthesises partial after partial and adds each one into the output
 // (PVAnalysis.py:1060-1069).  Every hop-long body segment of a partial depends only on a few
 // neighbouring points of that partial, and partial body segment ii lands exactly on output samples
-// [(start+ii)*h, (start+ii+1)*h).  So the sum is restated as a GATHER: one workgroup owns one output
-// segment of h samples and adds up
+// [(start+ii)*h, (start+ii+1)*h).  So the sum is restated as a GATHER over output segments of h samples:
+// segment `seg` is the sum of
 //   - the body segments of the (<= K) peaks of analysis frame `seg`,
 //   - the raised-cosine attacks of partials that start within the next ceil(E/h) frames,
-//   - the releases of partials that ended within the previous ceil(E/h) frames,
-// in LDS accumulators, then stores the segment once (coalesced).  No atomics; the order of the
-// additions is fixed (frame, then slot), so the output is reproducible run to run.
+//   - the releases of partials that ended within the previous ceil(E/h) frames.
+// No atomics; the order of the additions is fixed (kind, then node index), so the output is reproducible.
 //
-// fsig and msig (np.interp of the partial's f / mag, PVAnalysis.py:701-702) are piecewise linear with
-// breakpoints one hop apart, so inside a segment each is two linear pieces and the cumulative phase
-// (PVAnalysis.py:705-708) is a quadratic in the sample index: every sample is evaluated independently
-// (no scan, no barrier), the per-contribution constants are derived once by one thread each.
-// Bound: f64 VALU (one cos per partial sample); HBM traffic is 8*h bytes written per segment plus
-// a few hundred bytes of table reads.
+// Four kernels:
+//   k_synth_alloc    one thread per partial: where the points of a partial that will sound live in the
+//                    partial-major copy of the analysis arrays (wave prefix sum + one atomic per wave)
+//   k_synth_scatter  one thread per (frame, slot) node: f / mag / realph of every partial, contiguous
+//   k_synth_params   one thread per node: the closed form of that node's contribution(s) -- fsig and msig
+//                    (np.interp of the partial's f / mag, PVAnalysis.py:701-702) are piecewise linear with
+//                    breakpoints one hop apart, so inside a segment each is two linear pieces and the cumulative
+//                    phase (PVAnalysis.py:705-708) is a quadratic in the sample index; attack / release are pure
+//                    sinusoids under a raised cosine.  One 160-byte record per body, 64 bytes per edge, and one bit
+//                    per node and kind (the wave's ballot) saying which records exist.
+//   k_synth_samples  one thread per RUN of R consecutive output samples: walks the set bits of its segment,
+//                    and for each contribution seeds exp(i phase) and exp(i phase increment) exactly (two sincos)
+//                    at the run's first sample, then advances both by complex rotations -- the phase is
+//                    quadratic, so its increment is linear and ITS increment constant: z *= w, w *= r, ten
+//                    float64 instructions per sample instead of a forty-instruction cosine.  The recurrence is
+//                    re-seeded every run, so its error stays below R^2 * 1e-16.  R sums live in registers across
+//                    all contributions and are stored once.
+// Bound: float64 VALU issue (sample loop).  HBM: 8*h bytes written per segment, 160 B per body record
+// written and read once (cache-resident between the two launches).
 // All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
 #include <math.h>
 #include <stdlib.h>
 
-#include <type_traits>
+#include <map>
+#include <mutex>
 
 #include "pvx_internal.h"
 
@@ -30,57 +43,62 @@ namespace {
 
 constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kPi2 = 2.0 * kPi;
-constexpr int WMAX = 40;   // longest window of partial points (needs ceil(dfr + .5) + 6 <= WMAX)
-constexpr int NBMAX = 128; // contributions whose windows are gathered together (fewer if LDS is short)
 
-// cos for the phase arguments of this kernel (1e3 .. 1e5 rad, sometimes far more): x = n pi + r by a two-term
-// Cody-Waite reduction with fused multiply-adds (n * pi is exact inside the fma, so r carries < 1 ulp of error for
-// |n| < 2^30), then cos r = 1 - 2 sin^2(r/2) with the fdlibm sine polynomial on |r/2| <= pi/4.  Absolute error
-// < 4e-16 in a fifth of the instructions of the library routine, which stays for arguments beyond the reduction's
-// range (kept out of line: its Payne-Hanek tables would otherwise set the kernel's register count).
-__device__ __attribute__((noinline)) double cos_far(double x) { return cos(x); }
-constexpr double kNear = 5.0e8;       // |x| below this: the two-term reduction holds (n < 2^28)
 __device__ __forceinline__ double fma3(double a, double b, double c) {
     // a*b + c with c left in place: the compiler's two-address v_fmac form copies every polynomial constant first
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-template <bool FAR> __device__ __forceinline__ double fcos(double x) {
-    if constexpr (FAR) return cos_far(x);
-    const double n = rint(x * 3.18309886183790691216e-01);                 // 1/pi
-    double r = __builtin_fma(-n, 3.14159265358979311600e+00, x);
-    r = __builtin_fma(-n, 1.22464679914735320717e-16, r);
-    const double hr = 0.5 * r, z = hr * hr;
+// sin and cos of one argument: x = n pi/2 + r by a two-term Cody-Waite reduction with fused multiply-adds -- n * pio2_hi is
+// exact inside the fma and x - n pio2_hi = r + n pio2_lo is of order one, so r carries < 1 ulp of error as long as n itself
+// is exact (|x| < 2^50: phase arguments of this kernel reach 1e4, with time stretching 1e6) --, the fdlibm kernel
+// polynomials on |r| <= pi/4, then the quadrant (n mod 4 taken in float64: n may exceed an int).  Absolute error < 3e-16.
+// Beyond 2^50 rad an argument's own ulp exceeds 0.1 rad: its cosine says nothing about the signal; the reduction's
+// remainder is then forced into range so that the result stays a bounded number (no library call in these kernels: a call
+// makes every live sum of a thread a callee-saved register).
+__device__ __forceinline__ void fsincos(double x, double& s, double& c) {
+    const double n = rint(x * 6.36619772367581382433e-01);                 // 2/pi
+    double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+    r = fabs(r) <= 1.0 ? r : 0.0;
+    const double z = r * r;
     double ps = fma3(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     ps = fma3(z, ps, 2.75573137070700676789e-06);
     ps = fma3(z, ps, -1.98412698298579493134e-04);
     ps = fma3(z, ps, 8.33333333332248946124e-03);
     ps = fma3(z, ps, -1.66666666666666324348e-01);
-    const double sn = __builtin_fma(hr * z, ps, hr);                       // sin(r/2)
-    const double v = __builtin_fma(-2.0 * sn, sn, 1.0);
-    return ((int)n & 1) ? -v : v;
+    const double sn = __builtin_fma(r * z, ps, r);
+    double pc = fma3(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma3(z, pc, -2.75573143513906633035e-07);
+    pc = fma3(z, pc, 2.48015872894767294178e-05);
+    pc = fma3(z, pc, -1.38888888888741095749e-03);
+    pc = fma3(z, pc, 4.16666666666666019037e-02);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)__builtin_fma(-4.0, rint(n * 0.25), n);              // n mod 4 in {-2 .. 2}
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
 }
-
-// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); fp through the window
-__device__ inline double interp_w(double x, double h, double off, int nfr, const double* fp, int j0) {
-    if (nfr == 1) return fp[0 - j0];
+// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702)
+__device__ inline double interp_w(double x, double h, double off, int nfr, const double* fp) {
+    if (nfr == 1) return fp[0];
     const double xlast = h * (off + (double)(nfr - 1));
     const double xfirst = h * (off + 0.0);
-    if (x > xlast) return fp[nfr - 1 - j0];
-    if (x < xfirst) return fp[0 - j0];
+    if (x > xlast) return fp[nfr - 1];
+    if (x < xfirst) return fp[0];
     int j = (int)floor(x / h - off);
     if (j < 0) j = 0;
     if (j > nfr - 1) j = nfr - 1;
     // settle on xp[j] <= x < xp[j+1] with the same xp values numpy compares against
     while (j > 0 && x < h * (off + (double)j)) j--;
     while (j < nfr - 1 && x >= h * (off + (double)(j + 1))) j++;
-    if (j == nfr - 1) return fp[j - j0];
+    if (j == nfr - 1) return fp[j];
     const double xj = h * (off + (double)j);
-    if (xj == x) return fp[j - j0];
+    if (xj == x) return fp[j];
     const double xj1 = h * (off + (double)(j + 1));
-    const double slope = (fp[j + 1 - j0] - fp[j - j0]) / (xj1 - xj);
-    return slope * (x - xj) + fp[j - j0];
+    const double slope = (fp[j + 1] - fp[j]) / (xj1 - xj);
+    return slope * (x - xj) + fp[j];
 }
 
 // np.interp restricted to a run of fewer than h consecutive sample positions x0, x0+1, ...: the
@@ -89,16 +107,16 @@ __device__ inline double interp_w(double x, double h, double off, int nfr, const
 // evaluation formula as interp_w / numpy, hence the same values.
 struct Piece2 { double b1, xa, fa, sa, xb, fb, sb; };
 
-__device__ inline void piece_of(int j, double h, double off, int nfr, const double* fp, int j0, double& xj, double& fj, double& sj) {
-    if (j < 0) { xj = 0.0; fj = fp[0 - j0]; sj = 0.0; return; }                     // left of xp[0]: fp[0]
-    if (j >= nfr - 1) { xj = 0.0; fj = fp[nfr - 1 - j0]; sj = 0.0; return; }        // at / right of xp[last]
+__device__ inline void piece_of(int j, double h, double off, int nfr, const double* fp, double& xj, double& fj, double& sj) {
+    if (j < 0) { xj = 0.0; fj = fp[0]; sj = 0.0; return; }                          // left of xp[0]: fp[0]
+    if (j >= nfr - 1) { xj = 0.0; fj = fp[nfr - 1]; sj = 0.0; return; }             // at / right of xp[last]
     xj = h * (off + (double)j);
     const double xj1 = h * (off + (double)(j + 1));
-    fj = fp[j - j0];
-    sj = (fp[j + 1 - j0] - fp[j - j0]) / (xj1 - xj);
+    fj = fp[j];
+    sj = (fp[j + 1] - fp[j]) / (xj1 - xj);
 }
 
-__device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, const double* fp, int j0) {
+__device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, const double* fp) {
     Piece2 q;
     int j;
     if (nfr == 1 || x0 < h * (off + 0.0)) j = -1;
@@ -110,422 +128,585 @@ __device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, c
         while (j < nfr - 1 && x0 >= h * (off + (double)(j + 1))) j++;
     }
     if (nfr == 1) j = nfr;                                       // constant everywhere
-    piece_of(j, h, off, nfr, fp, j0, q.xa, q.fa, q.sa);
-    piece_of(j + 1, h, off, nfr, fp, j0, q.xb, q.fb, q.sb);
+    piece_of(j, h, off, nfr, fp, q.xa, q.fa, q.sa);
+    piece_of(j + 1, h, off, nfr, fp, q.xb, q.fb, q.sb);
     q.b1 = (j + 1 <= nfr - 1 && nfr > 1) ? h * (off + (double)(j + 1)) : INFINITY;
     return q;
 }
 
-// closed-form parameters of one contribution (see step 5 of the kernel)
-struct CParam {
-    int kind, fmb, mmb, far;                 // far: some phase argument may leave the fast cosine's range
+// ---- records ---------------------------------------------------------------------------------------------------------
+// body of node (frame, slot), sample m of its segment (0 <= m < h):
+//   phase(m) = ph0 + step m + [m <= fmb: fa0 m + fsa T(m) | smb + fb0 (m - fmb) + fsb (T(m) - tmb)],  T(m) = m (m - 1) / 2
+//   (coefficients pre-scaled by 2 pi / sr), amplitude(m) = m < mmb ? ma0 + msa m : mb0 + msb m       (PVAnalysis.py:734-736)
+// so phase(m+1) - phase(m) = step + (m < fmb ? fa0 + fsa m : fb0 + fsb m), and its own increment is fsa, then fsb.
+// da / db = exp(i fsa) - 1, exp(i fsb) - 1; wb = exp(i (step + fb0 + fsb fmb)): the increment's rotation at the break.
+struct __attribute__((aligned(32))) BodyRec {
+    double ph0, step, fa0, fsa, fb0, fsb, smb, tmb;
+    double ma0, msa, mb0, msb;
+    double dar, dai, dbr, dbi, wbr, wbi;
+    int fmb, mmb, pad0, pad1;
+};
+static_assert(sizeof(BodyRec) == 160, "BodyRec layout");
+// attack: sample j of [0, edgsam) at output index o0 + j is ah (1 - cos(pi j / edgsam)) cos(ph0 - 2 pi (edgsam - j) cfr);
+// release: ah (1 + cos(pi j / edgsam)) cos(ph0 + 2 pi (j + 1) cfr)                                  (PVAnalysis.py:740-751)
+struct __attribute__((aligned(32))) EdgeRec {
+    double ph0, cfr, ah, wr, wi;     // (wr, wi) = exp(i 2 pi cfr)
     long long o0;
-    double ph0, step, amp, cfr;
-    double fa0, fsa, fb0, fsb, smb, tmb;     // fsig pieces and the sum / triangular number at the break
-    double ma0, msa, mb0, msb;               // msig pieces
+    int pad0, pad1;
+};
+static_assert(sizeof(EdgeRec) == 64, "EdgeRec layout");
+
+struct SynthK {
+    const double *f, *mag, *realph;
+    const int32_t *pid, *pst, *pln;
+    int64_t F, P, N;
+    int K, h, minframes, no_phcor, edgsam, EF, rps;
+    int64_t edgsamp;
+    double sr, dh, fstep, dfr, offf, sc, vr, vi;     // (vr, vi) = exp(i pi / edgsam)
+    // workspace
+    unsigned long long* cursor;
+    long long* off;                  // [P]  first point of the partial in the partial-major arrays; -1: it does not sound
+    double *cf, *cm, *cr;            // [N]  partial-major f / mag / realph
+    BodyRec* body;                   // [(fb1 - fb0) K]
+    EdgeRec *att, *rel;              // [(fx1 - fx0) K]
+    unsigned long long *bbits, *xbits, *abits, *rbits;   // bodies for k_synth_bodies | for k_synth_extras | attacks | releases
+    int c1, c2, R;                   // the cuts of k_synth_bodies' runs and their length (RunCuts)
+    int64_t fx0, fx1, fb0, fb1;      // frames whose edges / bodies this slice holds
+    int64_t seg0, nseg;              // output segments of the sample launch
+    double* w;
+    int64_t wlen;
 };
 
-// sum_{q=0}^{m-1} fsig(nbase + q) for the two-piece linear fsig of a contribution
-__device__ inline double prefix_sum(const CParam& c, int m) {
-    const double tm = 0.5 * (double)m * (double)(m - 1);
-    if (m <= c.fmb) return c.fa0 * (double)m + c.fsa * tm;
-    return c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
-}
-// tools/ubench/synth_phases.hip builds this file with PVX_SYNTH_STAMPS: s_memtime stamps of one workgroup in slot_of[]
-#ifdef PVX_SYNTH_STAMPS
-#define PVX_STAMP(slot) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ((long long*)p.slot_of)[slot] = (long long)clock64(); } while (0)
-#else
-#define PVX_STAMP(slot) do { } while (0)
-#endif
-
-constexpr int HTMAX = 512; // pid -> contribution hash table of a batch: the power of two >= 4 * batch (short probe chains), 2^c_htbits entries
-constexpr int TSMAX = 256; // threads across the samples of a segment (fewer in a smaller workgroup); NT / TS groups share the contributions
-
-// LDS (dynamic): acc [G][h] | wf wm wr [NB][WL] doubles | prm [NB] | wslots [NB][WL] | cb_* 7 x [NB] | hkey hval [2^htbits] ints
-__host__ __device__ inline int synth_htbits(int nb) {
-    int b = 4;
-    while ((1 << b) < 4 * nb && (1 << b) < HTMAX) b++;
-    return b;
-}
-__host__ __device__ inline size_t synth_lds_bytes(int h, int nb, int wl, int groups) {
-    const int HT = 1 << synth_htbits(nb);
-    return (size_t)h * 8 * groups + (size_t)nb * wl * 8 * 3 + (size_t)nb * sizeof(CParam) + (size_t)nb * wl * 4 + (size_t)nb * 4 * 7 + (size_t)HT * 8;
+// PVAnalysis.py:1061, 1067: partials that sound
+__device__ __forceinline__ bool sounds(const SynthK& q, int st, int nfr) {
+    return !(nfr < q.minframes || nfr < 1) && !((int64_t)st * q.h - q.edgsam + q.edgsamp < 0);
 }
 
-// Waves per SIMD the register allocation aims at: the kernel waits on its set-up loads (one wave of a workgroup busy
-// for most of its time), so occupancy is worth more than registers -- five waves (96 registers) in the two-wave
-// workgroups of a long waveform, four in the larger ones (measured on config 2: 2 waves 1.35 ms, 4: 0.82, 5 with
-// two-wave workgroups and batches of 16: 0.54, 6: 0.55, 8: 0.60 -- spilling by then).
-#ifndef PVX_SYNTH_WAVES
-#define PVX_SYNTH_WAVES(NT) ((NT) <= 128 ? 5 : 4)
-#endif
-template <int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(NT), PVX_SYNTH_WAVES(NT)))) void k_synth_ola(SynthParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int wcnt[NT / 64];
-    __shared__ int qnext;
-
-#ifndef PVX_SYNTH_SP
-#define PVX_SYNTH_SP 1
-#endif
-    constexpr int SP = PVX_SYNTH_SP; // samples per thread held in registers while a batch is added
-    constexpr int TS = NT < TSMAX ? NT : TSMAX;
-    constexpr int G = NT / TS;       // groups: group g adds contributions g, g + G, ... to its own accumulators
-    const int h = p.hop_s, K = p.K, tid = threadIdx.x;
-    const int NB = p.nbatch;
-    const int64_t seg = (int64_t)blockIdx.x + p.seg0;  // output samples [seg*h, seg*h + h)
-    const double dh = p.c_dh;                          // (double)h
-    const double fstep = p.c_fstep;                    // sr / nfft, PVAnalysis.py:825
-    const double dfr = p.c_dfr;                        // 1 / (hop_a / nfft) / 2, PVAnalysis.py:687, 824
-    const int edgsam = p.c_edgsam;                     // (int)(dfr * h * edge), PVAnalysis.py:740
-    const int64_t edgsamp = p.c_edgsamp;               // (int)(edge * h * (nfft / hop_a / 2.)), PVAnalysis.py:1055-1056 (integer, Python 2)
-    const int EF = p.c_EF;                             // frames an edge can reach
-    const int WB = p.c_WB;                             // ceil(dfr + .5) + 2: points needed behind the node
-    const int WL = p.c_WL;                             // window length WB + 4 (<= WMAX, host-checked)
-
-    double* acc = (double*)smem;                       // [G][h] accumulators; row 0 is the output
-    double* wf = acc + (size_t)G * h;                  // windows of partial points, j in [j0, j0 + wn)
-    double* wm = wf + (size_t)NB * WL;
-    double* wr = wm + (size_t)NB * WL;
-    CParam* prm = (CParam*)(wr + (size_t)NB * WL);
-    int* wslots = (int*)(prm + NB);
-    int* cb_pid = wslots + (size_t)NB * WL;
-    int* cb_st = cb_pid + NB;
-    int* cb_nfr = cb_st + NB;
-    int* cb_ii = cb_nfr + NB;
-    int* cb_kind = cb_ii + NB;
-    int* cb_j0 = cb_kind + NB;
-    int* cb_wn = cb_j0 + NB;
-    int* hkey = cb_wn + NB;
-    const int htbits = p.c_htbits, HT = 1 << htbits;
-    int* hval = hkey + HT;
-
-    PVX_STAMP(0);
-    for (int m = tid; m < G * h; m += NT) acc[m] = 0.0;
-
-    // contributions: kind 0 = body of a peak of frame seg; 1 = attack of a partial starting at
-    // frame seg+1 .. seg+EF; 2 = release of a partial whose last frame is seg-EF .. seg-1.
-    // Candidates q = (frame - fr_lo) * K + slot are examined NT at a time; the valid ones are taken
-    // in order, NB per round, and the windows of partial points of a whole batch are gathered
-    // together: four global round trips per batch instead of four per contribution (on a short signal
-    // this kernel is bound by those dependent loads, so a batch is as large as LDS allows).
-    const int64_t fr_lo = seg - EF;
-    const int NC = (2 * EF + 1) * K;
-    for (int qbase = 0; qbase < NC;) {
-        // ---- round step 1: examine candidates qbase + [0, NT)
-        __syncthreads();
-        bool valid = false;
-        int c_pid_ = 0, c_st_ = 0, c_nfr_ = 0, c_ii_ = 0, c_kind_ = 0;
-        const int q = qbase + tid;
-        if (q < NC) {
-            const int64_t fr = fr_lo + q / K;
-            const int sl = q % K;
-            if (fr >= 0 && fr < p.F) {
-                const int pid = p.partial_id[fr * K + sl];
-                if (pid >= 0) {
-                    const int st = p.part_start[pid], nfr = p.part_len[pid];
-                    const int kind = (fr == seg) ? 0 : (fr > seg ? 1 : 2);
-                    const int ii = (int)(fr - st);                    // index of this point in its partial
-                    valid = !(nfr < p.minframes || nfr < 1)           // PVAnalysis.py:1061
-                            && !((int64_t)st * h - edgsam + edgsamp < 0)   // PVAnalysis.py:1067
-                            && !(kind == 1 && ii != 0) && !(kind == 2 && ii != nfr - 1);
-                    c_pid_ = pid; c_st_ = st; c_nfr_ = nfr; c_ii_ = ii; c_kind_ = kind;
-                }
-            }
-        }
-        // ---- step 2: ordered compaction of the valid candidates
-        const unsigned long long bal = __ballot(valid);
-        const int lane_ = tid & 63, wid_ = tid >> 6;
-        if (lane_ == 0) wcnt[wid_] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, total = 0;
+__global__ __launch_bounds__(256) void k_synth_alloc(SynthK q) {
+    const int64_t pid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    long long len = 0;
+    if (pid < q.P) {
+        const int st = q.pst[pid], nfr = q.pln[pid];
+        if (sounds(q, st, nfr)) len = nfr;
+    }
+    long long incl = len;
 #pragma unroll
-        for (int w = 0; w < NT / 64; w++) { if (w < wid_) woff += wcnt[w]; total += wcnt[w]; }
-        const int pos = woff + __popcll(bal & ((1ull << lane_) - 1ull));
-        if (tid == 0) qnext = qbase + NT;
-        __syncthreads();
-        if (valid && pos < NB) {
-            cb_pid[pos] = c_pid_; cb_st[pos] = c_st_; cb_nfr[pos] = c_nfr_; cb_ii[pos] = c_ii_; cb_kind[pos] = c_kind_;
-            const int j0 = (c_ii_ - WB > 0) ? c_ii_ - WB : 0;
-            int j1 = c_ii_ + 3;
-            if (j1 > c_nfr_ - 1) j1 = c_nfr_ - 1;
-            cb_j0[pos] = j0; cb_wn[pos] = j1 - j0 + 1;                // <= WB + 4 = WL
-            if (pos == NB - 1) qnext = q + 1;                         // the rest is re-examined next round
-        }
-        __syncthreads();
-        const int nb = total < NB ? total : NB;
-        PVX_STAMP(1);
-        // ---- step 3: slots of the window points of the whole batch.  A partial sits in one slot per frame, somewhere
-        // among K: instead of searching K slots per window point, the rows of partial_id the windows can reach
-        // (frames seg-EF-WB .. seg+EF+3) are read once and every entry looks its partial up in a hash table of the batch
-        for (int i = tid; i < HT; i += NT) hkey[i] = -1;
-        __syncthreads();
-        for (int bb = tid; bb < nb; bb += NT) {
-            const int pid = cb_pid[bb];                               // unique within a segment's candidates
-            unsigned hh = ((unsigned)pid * 2654435761u) >> (32 - htbits);
-            while (atomicCAS(&hkey[hh], -1, pid) != -1) hh = (hh + 1) & (HT - 1);
-            hval[hh] = bb;
-        }
-        __syncthreads();
-        {
-            const int64_t fr_min = seg - EF - WB;
-            const int nrows = 2 * EF + WB + 4;
-            for (int idx = tid; idx < nrows * K; idx += NT) {
-                const int row = idx / K, s2 = idx - row * K;
-                const int64_t f2 = fr_min + row;
-                if (f2 < 0 || f2 >= p.F) continue;
-                const int pid = p.partial_id[f2 * K + s2];
-                if (pid < 0) continue;
-                unsigned hh = ((unsigned)pid * 2654435761u) >> (32 - htbits);
-                int k;
-                while ((k = hkey[hh]) != -1 && k != pid) hh = (hh + 1) & (HT - 1);
-                if (k == pid) {
-                    const int bb = hval[hh];
-                    const int64_t d = f2 - ((int64_t)cb_st[bb] + cb_j0[bb]);
-                    if (d >= 0 && d < cb_wn[bb]) wslots[bb * WL + (int)d] = s2;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const long long total = __shfl(incl, 63);
+    long long base = 0;
+    if (lane == 63 && total > 0) base = (long long)atomicAdd(q.cursor, (unsigned long long)total);
+    base = __shfl(base, 63);
+    if (pid < q.P) q.off[pid] = (len > 0 && base + incl <= q.N) ? base + incl - len : -1;   // (a table that claims more points than there are nodes is not followed)
+}
+
+__global__ __launch_bounds__(256) void k_synth_scatter(SynthK q) {
+    const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (node >= q.N) return;
+    const int pid = q.pid[node];
+    if (pid < 0 || pid >= q.P) return;
+    const long long off = q.off[pid];
+    if (off < 0) return;
+    const int64_t fr = node / q.K;
+    const int64_t ii = fr - q.pst[pid];
+    if (ii < 0 || ii >= q.pln[pid]) return;
+    q.cf[off + ii] = q.f[node];
+    q.cm[off + ii] = q.mag[node];
+    q.cr[off + ii] = q.realph[node];
+}
+
+__global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
+    const int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nloc = (q.fx1 - q.fx0) * q.K;
+    bool isb = false, isx = false, isa = false, isr = false;
+    if (li < nloc) {
+        const int64_t node = q.fx0 * q.K + li;
+        const int64_t fr = node / q.K;
+        const int pid = q.pid[node];
+        if (pid >= 0 && pid < q.P) {
+            const long long off = q.off[pid];
+            const int st = q.pst[pid], nfr = q.pln[pid];
+            const int64_t ii64 = fr - st;
+            if (off >= 0 && ii64 >= 0 && ii64 < nfr) {
+                const int ii = (int)ii64, h = q.h;
+                const double dh = q.dh;
+                const double* pf = q.cf + off;
+                const double* pm = q.cm + off;
+                const double* pr = q.cr + off;
+                const double offf = q.offf, offm = q.dfr;                       // dfr + .5, dfr: PVAnalysis.py:701-702
+                if (ii == 0) {
+                    // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amplitude msig[0]
+                    EdgeRec e;
+                    e.o0 = (long long)st * h - q.edgsam;
+                    e.cfr = pf[0] * 1.0 / q.sr;
+                    e.ph0 = pr[0];
+                    e.ah = interp_w(0.0, dh, offm, nfr, pm) / 2.;
+                    fsincos(kPi2 * e.cfr, e.wi, e.wr);
+                    e.pad0 = e.pad1 = 0;
+                    q.att[li] = e;
+                    isa = true;
                 }
-            }
-        }
-        __syncthreads();
-        PVX_STAMP(2);
-        // ---- step 4: their values
-        for (int idx = tid; idx < nb * WL; idx += NT) {
-            const int bb = idx / WL, d = idx - bb * WL;
-            if (d < cb_wn[bb]) {
-                const int64_t node = ((int64_t)cb_st[bb] + cb_j0[bb] + d) * K + wslots[idx];
-                wf[idx] = p.f[node];
-                wm[idx] = p.mag[node];
-                wr[idx] = p.realph[node];
-            }
-        }
-        __syncthreads();
-        PVX_STAMP(3);
-        const int qn = qnext;
-        // ---- step 5: the closed-form parameters of the contributions.  fsig and msig are piecewise linear (two pieces per
-        // hop), so the phase prefix sum of PVAnalysis.py:705-708 is a quadratic in the sample index: no scan, no barrier,
-        // every sample independent.  5a: the interpolations a contribution needs (np.interp at three or four positions,
-        // the two pieces of fsig and of msig) are independent of each other -- eight lanes per contribution take one
-        // each (same function, different arguments) and leave their results in the contribution's record; 5b: thread b
-        // combines them.  (One thread per contribution doing all of it in turn was 30 % of a workgroup's time.)
-        for (int t = tid; t < nb * 8; t += NT) {
-            const int bb = t >> 3, k = t & 7;
-            const int nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
-            const double* pf = wf + (size_t)bb * WL;
-            const double* pm = wm + (size_t)bb * WL;
-            const double offf = p.c_offf, offm = dfr;                     // dfr + .5, dfr: PVAnalysis.py:701-702
-            const double nbase = dh * (double)ii;
-            CParam* c = prm + bb;
-            if (k < 4) {
-                // k = 0, 1, 2: fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729) -> smb, tmb, step for now;
-                // k = 3: the edge's amplitude msig[0] (attack) / msig[hop * nfr] (release) -> amp
-                const bool need = (k == 3) ? (kind != 0) : ((kind != 1) && (k < 2 || (kind == 0 && ii < nfr - 1)));
-                if (need) {
-                    const double x = (k == 3) ? ((kind == 1) ? 0.0 : dh * (double)nfr) : nbase + (double)k * dh;
-                    const double v = interp_w(x, dh, k == 3 ? offm : offf, nfr, k == 3 ? pm : pf, j0);
-                    if (k == 0) c->smb = v; else if (k == 1) c->tmb = v; else if (k == 2) c->step = v; else c->amp = v;
-                }
-            } else if (k < 6 && kind != 1) {
-                // fsig(nbase + q) = fa0 + fsa q for q < fmb, fb0 + fsb q beyond; msig likewise
-                const bool isf = (k == 4);
-                const Piece2 q = make_piece2(nbase, dh, isf ? offf : offm, nfr, isf ? pf : pm, j0);
-                const double a0 = q.sa * (nbase - q.xa) + q.fa, b0 = q.sb * (nbase - q.xb) + q.fb;
-                const double d = ceil(q.b1 - nbase);
-                const int mb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
-                if (isf) { c->fa0 = a0; c->fsa = q.sa; c->fb0 = b0; c->fsb = q.sb; c->fmb = mb; }
-                else { c->ma0 = a0; c->msa = q.sa; c->mb0 = b0; c->msb = q.sb; c->mmb = mb; }
-            }
-        }
-        __syncthreads();
-        for (int bb = tid; bb < nb; bb += NT) {
-            const int st = cb_st[bb], nfr = cb_nfr[bb], ii = cb_ii[bb], kind = cb_kind[bb], j0 = cb_j0[bb];
-            const double* pf = wf + (size_t)bb * WL;
-            const double* pr = wr + (size_t)bb * WL;
-            CParam c = prm[bb];
-            c.kind = kind;
-            if (kind == 1) {
-                // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amp = msig[0] (5a)
-                c.o0 = (long long)st * h - edgsam;
-                c.cfr = pf[0 - j0] * 1.0 / p.sr;
-                c.ph0 = pr[0 - j0];
-            } else {
-                const double fs0 = c.smb, fs1 = c.tmb, fs2 = c.step;      // (5a)
-                // phase corrections, PVAnalysis.py:711-718
-                const double phcor = p.no_phcor ? 0.0 : kPi * (fs1 - fs0) / fstep / 2.;          // PVAnalysis.py:710-715
-                c.ph0 = pr[ii - j0] + phcor;                              // PVAnalysis.py:721
-                const double tm = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
-                c.smb = c.fa0 * (double)c.fmb + c.fsa * tm;               // sum of the first fmb terms
-                c.tmb = tm;
-                // ph[h-1] + ph0 (before the discontinuity ramp): prefix over q = 0 .. h-2
-                const double lastph = kPi2 * (prefix_sum(c, h - 1) / p.sr) + c.ph0;
-                c.step = 0.0;
-                if (kind == 2) {
-                    // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amp = msig[hop*(ii+1)] (5a)
-                    c.o0 = ((long long)st + nfr) * h;
-                    c.cfr = pf[nfr - 1 - j0] * 1.0 / p.sr;
-                    c.ph0 = lastph;
-                } else if (ii < nfr - 1) {
-                    // discontinuity ramp towards the next point, PVAnalysis.py:724-729
-                    const double phcornext = p.no_phcor ? 0.0 : kPi * (fs2 - fs1) / fstep / 2.;
-                    const double phend = lastph + kPi2 * fs1 / p.sr;
-                    const double arg = pr[ii + 1 - j0] + phcornext - phend + kPi;
-                    double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
-                    if (md != 0.0 && md < 0.0) md += kPi2;
-                    c.step = (md - kPi) / dh;                             // np.linspace(0, dph, h+1)[:-1]
-                }
-            }
-            // can a phase argument of this contribution leave the fast cosine's range?  (a bound, not the maximum)
-            double bound;
-            if (kind == 1 || kind == 2) bound = fabs(c.ph0) + kPi2 * ((double)edgsam + 1.0) * fabs(c.cfr);
-            else bound = fabs(c.ph0) + dh * fabs(c.step)
-                         + (kPi2 / p.sr) * (fabs(c.smb) + dh * (fabs(c.fa0) + fabs(c.fb0) + dh * (fabs(c.fsa) + fabs(c.fsb))));
-            c.far = !(bound < kNear);
-            if (kind == 0) {
-                // the per-sample form: 2 pi / sr folded into the two-piece phase polynomial (the sample loop is this
-                // kernel's bound; the folding moves the phase by a few ulp of ~1e4 rad, 1e-12 of the waveform)
-                const double sc = p.c_sc;                                 // 2 pi / sr
-                c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
-            }
-            prm[bb] = c;
-        }
-        __syncthreads();
-        PVX_STAMP(4);
-        // ---- step 6: the samples.  Thread (g, tl) adds contributions g, g + G, ... (in candidate order) to samples
-        // tl, tl + TS, ... held in registers: the parameters of a contribution are read once for SP samples
-        {
-            const int g = tid / TS, tl = tid - g * TS;
-            double* accg = acc + (size_t)g * h;
-            for (int m0 = tl; m0 < h; m0 += TS * SP) {
-                double a_[SP];
-#pragma unroll
-                for (int u = 0; u < SP; u++) a_[u] = (m0 + u * TS < h) ? accg[m0 + u * TS] : 0.0;
-                auto add = [&](const CParam& c, auto far_tag) {
-                    constexpr bool FAR = decltype(far_tag)::value;
-#pragma unroll
-                    for (int u = 0; u < SP; u++) {
-                        const int m = m0 + u * TS;
-                        if (m >= h) continue;
-                        const double dm = (double)m;
-                        if (c.kind == 0) {
-                            // phase = ph0 + step m + [m <= fmb: fa0 m + fsa T(m) | smb + fb0 (m - fmb) + fsb (T(m) - T(fmb))],
-                            // T(m) = m (m - 1) / 2, coefficients pre-scaled by 2 pi / sr; both pieces, then one select
-                            const double tm = 0.5 * dm * (double)(m - 1);
-                            const double pa = __builtin_fma(c.fsa, tm, c.fa0 * dm);
-                            const double pb = __builtin_fma(c.fsb, tm - c.tmb, __builtin_fma(c.fb0, (double)(m - c.fmb), c.smb));
-                            const double ph_m = (m <= c.fmb ? pa : pb) + __builtin_fma(c.step, dm, c.ph0);
-                            const bool ma = m < c.mmb;
-                            const double ms = __builtin_fma(ma ? c.msa : c.msb, dm, ma ? c.ma0 : c.mb0);
-                            a_[u] = __builtin_fma(ms, fcos<FAR>(ph_m), a_[u]);    // PVAnalysis.py:734-736
-                        } else {
-                            const long long j = seg * (long long)h + m - c.o0;
-                            if (j >= 0 && j < edgsam) {
-                                const double cw = fcos<false>(kPi * (double)j / (double)edgsam);
-                                if (c.kind == 1) {
-                                    // flipud(realph[0] - 2 pi cumsum(f0/sr)): element j uses the (edgsam-j)-term sum
-                                    a_[u] += (c.amp * (1 - cw) / 2.) * fcos<FAR>(c.ph0 - kPi2 * ((double)(edgsam - j) * c.cfr));
-                                } else {
-                                    a_[u] += (c.amp * (1 + cw) / 2.) * fcos<FAR>(c.ph0 + kPi2 * ((double)(j + 1) * c.cfr));
-                                }
-                            }
-                        }
+                const bool wantb = fr >= q.fb0 && fr < q.fb1;
+                isr = (ii == nfr - 1);
+                if (wantb || isr) {
+                    BodyRec c;
+                    const double nbase = dh * (double)ii;
+                    // fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729)
+                    const double fs0 = interp_w(nbase, dh, offf, nfr, pf);
+                    const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf);
+                    // fsig(nbase + m) = fa0 + fsa m for m < fmb, fb0 + fsb m beyond; msig likewise
+                    {
+                        const Piece2 p2 = make_piece2(nbase, dh, offf, nfr, pf);
+                        c.fa0 = p2.sa * (nbase - p2.xa) + p2.fa; c.fsa = p2.sa;
+                        c.fb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.fsb = p2.sb;
+                        const double d = ceil(p2.b1 - nbase);
+                        c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
                     }
-                };
-                for (int bb = g; bb < nb; bb += G) {
-                    const CParam c = prm[bb];
-                    if (c.far) add(c, std::true_type{});
-                    else add(c, std::false_type{});
+                    {
+                        const Piece2 p2 = make_piece2(nbase, dh, offm, nfr, pm);
+                        c.ma0 = p2.sa * (nbase - p2.xa) + p2.fa; c.msa = p2.sa;
+                        c.mb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.msb = p2.sb;
+                        const double d = ceil(p2.b1 - nbase);
+                        c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+                    }
+                    // phase corrections, PVAnalysis.py:710-715
+                    const double phcor = q.no_phcor ? 0.0 : kPi * (fs1 - fs0) / q.fstep / 2.;
+                    c.ph0 = pr[ii] + phcor;                                   // PVAnalysis.py:721
+                    const double tmb = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
+                    c.smb = c.fa0 * (double)c.fmb + c.fsa * tmb;              // sum of the first fmb terms
+                    c.tmb = tmb;
+                    // ph[h-1] + ph0 (before the discontinuity ramp): prefix over the h - 1 terms fsig(nbase + 0 .. h-2)
+                    double lastsum;
+                    {
+                        const int m = h - 1;
+                        const double tm = 0.5 * (double)m * (double)(m - 1);
+                        lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
+                    }
+                    const double lastph = kPi2 * (lastsum / q.sr) + c.ph0;
+                    c.step = 0.0;
+                    if (ii < nfr - 1) {
+                        // discontinuity ramp towards the next point, PVAnalysis.py:724-729
+                        const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf);
+                        const double phcornext = q.no_phcor ? 0.0 : kPi * (fs2 - fs1) / q.fstep / 2.;
+                        const double phend = lastph + kPi2 * fs1 / q.sr;
+                        const double arg = pr[ii + 1] + phcornext - phend + kPi;
+                        double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
+                        if (md != 0.0 && md < 0.0) md += kPi2;
+                        c.step = (md - kPi) / dh;                             // np.linspace(0, dph, h+1)[:-1]
+                    }
+                    if (isr) {
+                        // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amplitude msig[hop*nfr]
+                        EdgeRec e;
+                        e.o0 = ((long long)st + nfr) * h;
+                        e.cfr = pf[nfr - 1] * 1.0 / q.sr;
+                        e.ph0 = lastph;
+                        e.ah = interp_w(dh * (double)nfr, dh, offm, nfr, pm) / 2.;
+                        fsincos(kPi2 * e.cfr, e.wi, e.wr);
+                        e.pad0 = e.pad1 = 0;
+                        q.rel[li] = e;
+                    }
+                    if (wantb) {
+                        // 2 pi / sr folded into the two-piece phase polynomial
+                        const double sc = q.sc;
+                        c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
+                        // rotations of the increment: exp(i x) - 1 = (-2 sin^2(x/2), 2 sin(x/2) cos(x/2)) -- x is tiny
+                        double s2, c2;
+                        fsincos(0.5 * c.fsa, s2, c2); c.dar = -2.0 * s2 * s2; c.dai = 2.0 * s2 * c2;
+                        fsincos(0.5 * c.fsb, s2, c2); c.dbr = -2.0 * s2 * s2; c.dbi = 2.0 * s2 * c2;
+                        const double xb = c.step + __builtin_fma(c.fsb, (double)c.fmb, c.fb0);
+                        fsincos(xb, c.wbi, c.wbr);
+                        c.pad0 = c.pad1 = 0;
+                        q.body[(fr - q.fb0) * q.K + (node - fr * q.K)] = c;
+                        // does every run of k_synth_bodies lie on one piece of fsig and one of msig?  (a change at position x
+                        // is harmless at 0, h, a cut, or a multiple of R past the cut before it)
+                        auto on_edge = [&](int x) {
+                            if (x <= 0 || x >= h || x == q.c1 || x == q.c2) return true;
+                            const int base = x > q.c2 ? q.c2 : (x > q.c1 ? q.c1 : 0);
+                            return (x - base) % q.R == 0;
+                        };
+                        isb = on_edge(c.fmb) && on_edge(c.mmb);
+                        isx = !isb;
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < SP; u++) if (m0 + u * TS < h) accg[m0 + u * TS] = a_[u];
             }
         }
-        qbase = qn;
-        PVX_STAMP(5);
     }
-    __syncthreads();
-    for (int m = tid; m < h; m += NT) {
-        const int64_t o = seg * (int64_t)h + m;
-        double v = acc[m];
-#pragma unroll
-        for (int g = 1; g < G; g++) v += acc[(size_t)g * h + m];          // fixed order: reproducible run to run
-        if (o < p.wlen) p.w[o] = v;
+    const unsigned long long bb = __ballot(isb), bx = __ballot(isx), ba = __ballot(isa), br = __ballot(isr);
+    if ((threadIdx.x & 63) == 0) {
+        const int64_t w = li >> 6;
+        q.bbits[w] = bb; q.xbits[w] = bx; q.abits[w] = ba; q.rbits[w] = br;
     }
-    PVX_STAMP(6);
 }
+
+// z *= w (complex)
+#define PVX_CMUL(zr, zi, wr, wi)                                        \
+    do {                                                                \
+        const double t_ = __builtin_fma(zr, wr, -(zi * wi));            \
+        zi = __builtin_fma(zr, wi, zi * wr);                            \
+        zr = t_;                                                        \
+    } while (0)
+// w += w * d (d = exp(i x) - 1, |d| << 1: the rounding errors scale with |d|, not with |w|)
+#define PVX_CROT(wr, wi, dr, di)                                        \
+    do {                                                                \
+        const double t_ = __builtin_fma(wr, dr, __builtin_fma(-wi, di, wr)); \
+        wi = __builtin_fma(wr, di, __builtin_fma(wi, dr, wi));          \
+        wr = t_;                                                        \
+    } while (0)
+
+// What the sample kernels need of a slice (kept apart from SynthK: every field is a scalar register pair for the whole kernel)
+struct SampK {
+    const BodyRec* body;                 // [(fb1 - fb0) K]
+    const EdgeRec *att, *rel;            // [(fx1 - fx0) K]
+    const unsigned long long *bbits, *xbits, *abits, *rbits;
+    double* w;
+    int64_t wlen, seg0, nthreads;
+    int fx0, fx1, fb0, fb1;              // frames whose edges / bodies the slice holds
+    int K, h, EF, edgsam, rps;
+    int c1, c2, n0, n1;                  // k_synth_bodies: the cuts of a segment's runs (RunCuts)
+    double vr, vi;                       // k_synth_extras: exp(i pi / edgsam)
+};
+
+// Waves per SIMD the register allocation aims at (R sums = 2 R registers + the recurrences' state; the compiler fills
+// whatever it is given with samples in flight)
+#ifndef PVX_SYNTH_WAVES
+#define PVX_SYNTH_WAVES(R) ((R) <= 16 ? 4 : 3)
+#endif
+
+// the set bits [n0, n1) of a bit array, in ascending order
+template <class Fn> __device__ __forceinline__ void for_bits(const unsigned long long* bits, int n0, int n1, Fn&& fn) {
+    for (int wd = n0 >> 6; wd <= ((n1 - 1) >> 6); wd++) {
+        unsigned long long mb = bits[wd];
+        if (wd == (n0 >> 6)) mb &= ~0ull << (n0 & 63);
+        if (wd == ((n1 - 1) >> 6) && (n1 & 63)) mb &= (1ull << (n1 & 63)) - 1ull;
+        while (mb) {
+            const int li = (wd << 6) + __builtin_ctzll(mb);
+            mb &= mb - 1ull;
+            fn(li);
+        }
+    }
+}
+
+// seeds of a body at sample s on the pieces (fa, ma): z = exp(i phase(s)), w = exp(i (phase(s+1) - phase(s))), amplitude
+#define PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)                                                                        \
+    double ph_, dl_;                                                                                                \
+    if (fa) {                                                                                                       \
+        const double fa0_ = (c)->fa0, fsa_ = (c)->fsa;                                                              \
+        ph_ = __builtin_fma(fsa_, ts, fa0_ * ds);                                                                   \
+        dl_ = __builtin_fma(fsa_, ds, fa0_);                                                                        \
+    } else {                                                                                                        \
+        const double fb0_ = (c)->fb0, fsb_ = (c)->fsb;                                                              \
+        ph_ = __builtin_fma(fsb_, ts - (c)->tmb, __builtin_fma(fb0_, (double)((s) - (c)->fmb), (c)->smb));          \
+        dl_ = __builtin_fma(fsb_, ds, fb0_);                                                                        \
+    }                                                                                                               \
+    {                                                                                                               \
+        const double step_ = (c)->step;                                                                             \
+        ph_ += __builtin_fma(step_, ds, (c)->ph0);                                                                  \
+        dl_ += step_;                                                                                               \
+    }                                                                                                               \
+    double zr, zi, wr, wi;                                                                                          \
+    fsincos(ph_, zi, zr);                                                                                           \
+    fsincos(dl_, wi, wr);                                                                                           \
+    const double dr = (fa) ? (c)->dar : (c)->dbr, di = (fa) ? (c)->dai : (c)->dbi;                                  \
+    const double dms = (ma) ? (c)->msa : (c)->msb;                                                                  \
+    double ms = __builtin_fma(dms, ds, (ma) ? (c)->ma0 : (c)->mb0);
+
+// ---- the bodies whose pieces change at the launch-wide cuts (all of them, but for float rounding of an odd dfr): one thread
+// per run of R samples, R sums in registers over all bodies of the segment, ONE unrolled loop
+template <int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= q.nthreads) return;
+    const int64_t segl = gid / q.rps;
+    const int run = (int)(gid - segl * q.rps);
+    const int seg = (int)(q.seg0 + segl);
+    const int h = q.h, K = q.K;
+    // the run's samples [s, s + len)
+    int s, len;
+    if (run < q.n0) { s = run * R; len = q.c1 - s; }
+    else if (run < q.n0 + q.n1) { s = q.c1 + (run - q.n0) * R; len = q.c2 - s; }
+    else { s = q.c2 + (run - q.n0 - q.n1) * R; len = h - s; }
+    if (len > R) len = R;
+    const double ds = (double)s, ts = 0.5 * ds * (double)(s - 1);
+    double a[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) a[k] = 0.0;
+    if (seg >= q.fb0 && seg < q.fb1) {
+        const int n0 = (seg - q.fx0) * K, n1 = n0 + K;                  // (a slice holds at most 2^20 + 2 EF K nodes)
+        const BodyRec* rec = q.body - (q.fb0 - q.fx0) * K;
+        for_bits(q.bbits, n0, n1, [&](const int li) {
+            const BodyRec* c = rec + li;
+            // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
+            const bool fa = s < c->fmb, ma = s < c->mmb;
+            PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                a[k] = __builtin_fma(ms, zr, a[k]);                      // PVAnalysis.py:734-736
+                PVX_CMUL(zr, zi, wr, wi);
+                PVX_CROT(wr, wi, dr, di);
+                ms += dms;
+            }
+        });
+    }
+    const int64_t o = (int64_t)seg * h + s;
+    double* dst = q.w + o;
+    if (len == R && o + R <= q.wlen && (o & 1) == 0) {
+#pragma unroll
+        for (int k = 0; k < R; k += 2) *(double2*)(dst + k) = make_double2(a[k], a[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+            if (k < len && o + k < q.wlen) dst[k] = a[k];
+    }
+}
+
+// ---- everything else, added to what k_synth_bodies stored: attacks, releases, and the bodies whose pieces change inside a
+// run.  One thread per run of R samples [s, s + R) of a segment; a thread without work returns at once.
+template <int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_synth_extras(SampK q) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= q.nthreads) return;
+    const int64_t segl = gid / q.rps;
+    const int run = (int)(gid - segl * q.rps);
+    const int seg = (int)(q.seg0 + segl);
+    const int h = q.h, K = q.K;
+    const int s = run * R;
+    const int len = h - s < R ? h - s : R;
+    const double ds = (double)s, ts = 0.5 * ds * (double)(s - 1);
+    const int64_t o = (int64_t)seg * h + s;
+    double* dst = q.w + o;
+    double a[R];
+    bool loaded = false;
+    auto load = [&]() {
+        if (loaded) return;
+        loaded = true;
+#pragma unroll
+        for (int k = 0; k < R; k++) a[k] = (k < len && o + k < q.wlen) ? dst[k] : 0.0;
+    };
+#pragma unroll
+    for (int k = 0; k < R; k++) a[k] = 0.0;
+#pragma unroll 1
+    for (int kind = 0; kind < 3; kind++) {
+        // kind 0: bodies of frame seg; 1: attacks of partials starting at frames seg+1 .. seg+EF; 2: releases of partials
+        // whose last frame is seg-EF .. seg-1
+        int f0 = kind == 0 ? seg : (kind == 1 ? seg + 1 : seg - q.EF);
+        int f1 = kind == 0 ? seg + 1 : (kind == 1 ? seg + q.EF + 1 : seg);
+        const int lo = kind == 0 ? q.fb0 : q.fx0, hi = kind == 0 ? q.fb1 : q.fx1;
+        if (f0 < lo) f0 = lo;
+        if (f1 > hi) f1 = hi;
+        if (f1 <= f0) continue;
+        const unsigned long long* bits = kind == 0 ? q.xbits : (kind == 1 ? q.abits : q.rbits);
+        const int n0 = (f0 - q.fx0) * K, n1 = (f1 - q.fx0) * K;
+        for_bits(bits, n0, n1, [&](const int li) {
+            if (kind == 0) {
+                const BodyRec* c = q.body + (li - (q.fb0 - q.fx0) * K);
+                // leading samples of the run on the first piece of fsig (samples m < fmb; m = fmb sits on both) / of msig
+                int nfa = c->fmb - s, nma = c->mmb - s;
+                nfa = nfa < 0 ? 0 : (nfa > len ? len : nfa);
+                nma = nma < 0 ? 0 : (nma > len ? len : nma);
+                const int k1 = nfa < nma ? nfa : nma, k2 = nfa < nma ? nma : nfa;
+                load();
+#pragma unroll 1
+                for (int part = 0; part < 3; part++) {
+                    // each pair of pieces is a quadratic of its own: it is followed from s and added where it holds
+                    const int klo = part == 0 ? 0 : (part == 1 ? k1 : k2);
+                    const int khi = part == 0 ? k1 : (part == 1 ? k2 : len);
+                    if (klo >= khi) continue;
+                    const bool fa = klo < nfa, ma = klo < nma;
+                    PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        const double v = __builtin_fma(ms, zr, a[k]);
+                        a[k] = (k >= klo && k < khi) ? v : a[k];
+                        PVX_CMUL(zr, zi, wr, wi);
+                        PVX_CROT(wr, wi, dr, di);
+                        ms += dms;
+                    }
+                }
+            } else {
+                const EdgeRec* e = (kind == 1 ? q.att : q.rel) + li;
+                const long long j0l = (long long)seg * h + s - e->o0;
+                if (j0l + R <= 0 || j0l >= q.edgsam) return;
+                load();
+                const int j0 = (int)j0l;
+                const double cfr = e->cfr;
+                const double x = (kind == 1) ? e->ph0 - kPi2 * ((double)(q.edgsam - j0) * cfr)
+                                             : e->ph0 + kPi2 * ((double)(j0 + 1) * cfr);
+                double zr, zi, ur, ui;
+                fsincos(x, zi, zr);
+                fsincos(kPi * (double)j0 / (double)q.edgsam, ui, ur);
+                const double ah = e->ah, ahs = (kind == 1) ? -ah : ah;
+                const double ewr = e->wr, ewi = e->wi;
+                const unsigned ulo = (unsigned)(-j0), un = (unsigned)q.edgsam;       // sample k sounds when 0 <= j0 + k < edgsam
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const double v = __builtin_fma(__builtin_fma(ahs, ur, ah), zr, a[k]);
+                    a[k] = ((unsigned)k - ulo < un) ? v : a[k];
+                    PVX_CMUL(zr, zi, ewr, ewi);
+                    PVX_CMUL(ur, ui, q.vr, q.vi);
+                }
+            }
+        });
+    }
+    if (!loaded) return;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+        if (k < len && o + k < q.wlen) dst[k] = a[k];
+}
+
+// ---- workspace ---------------------------------------------------------------------------------------------------------
+constexpr int64_t kSliceNodes = (int64_t)1 << 20;   // nodes of one params / samples launch pair: bounds the records' memory
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct WsLayout { size_t cursor, off, cf, cm, cr, body, att, rel, bb, xb, ab, rb, total; int64_t slice_segs; };
+WsLayout ws_layout(int64_t F, int K, int64_t P, int EF) {
+    WsLayout L;
+    const int64_t N = F * K;
+    int64_t slice = kSliceNodes / K - 2 * EF;
+    if (slice < 64) slice = 64;
+    const int64_t fb = slice < F ? slice : F;                                   // body frames of a slice
+    const int64_t fx = (slice + 2 * EF) < F ? (slice + 2 * EF) : F;             // with the edges' reach
+    size_t o = 0;
+    L.cursor = o; o += 256;
+    L.off = o; o += up256((size_t)P * 8);
+    L.cf = o; o += up256((size_t)N * 8);
+    L.cm = o; o += up256((size_t)N * 8);
+    L.cr = o; o += up256((size_t)N * 8);
+    L.body = o; o += up256((size_t)fb * K * sizeof(BodyRec));
+    L.att = o; o += up256((size_t)fx * K * sizeof(EdgeRec));
+    L.rel = o; o += up256((size_t)fx * K * sizeof(EdgeRec));
+    const size_t words = (size_t)(fx * K) / 64 + 8;
+    L.bb = o; o += up256(words * 8);
+    L.xb = o; o += up256(words * 8);
+    L.ab = o; o += up256(words * 8);
+    L.rb = o; o += up256(words * 8);
+    L.total = o;
+    L.slice_segs = slice;
+    return L;
+}
+
+// calls without a caller-owned workspace (pvx_synth_dev / pvx_synth): one grow-only buffer per stream -- calls on one
+// stream are ordered by the stream, calls on different streams must not share
+struct StreamWs { void* p = nullptr; size_t cap = 0; };
+std::mutex g_ws_mu;
+std::map<hipStream_t, StreamWs> g_ws;
 
 }  // namespace
 
-int pvx_launch_synth(const SynthParams& p_in, hipStream_t s) {
-    SynthParams p = p_in;
+size_t pvx_synth_ws_bytes(int64_t F, int K, int64_t P, int nfft, int hop_a, int hop_s, double edge) {
+    const double dfr = 1. / (hop_a / (double)nfft) / 2.;
+    const int edgsam = (int)(dfr * hop_s * edge);
+    const int EF = edgsam > 0 ? (edgsam + hop_s - 1) / hop_s : 0;
+    return ws_layout(F, K, P, EF).total;
+}
+
+int pvx_launch_synth_v1(const SynthParams& p_in, hipStream_t s);
+
+int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     if (p.wlen <= 0) return PVX_OK;
+    static const bool v1 = getenv("PVX_SYNTH_V1") != nullptr;
+    if (v1) return pvx_launch_synth_v1(p, s);
     const int h = p.hop_s;
-    const double dfr = 1. / (p.hop_a / (double)p.nfft) / 2.;
-    if ((int)ceil(dfr + 0.5) + 6 > WMAX) {
-        pvx_set_error("nfft/hop = %g is too large for the resynthesis window (dfr=%g)", (double)p.nfft / p.hop_a, dfr);
-        return PVX_ERR_UNSUPPORTED;
-    }
-    if ((size_t)h * sizeof(double) > 120 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
-    const int64_t nseg = (p.wlen + h - 1) / h;
-    if (nseg > 0x7fffffffLL) { pvx_set_error("too many output segments"); return PVX_ERR_INVALID; }
-    // batch: every candidate of a segment in one round if LDS allows (two workgroups per CU when the grid is long)
-    const int WL = (int)ceil(dfr + 0.5) + 6;
-    const int edgsam = (int)(dfr * h * p.edge);
-    const int EF = edgsam > 0 ? (edgsam + h - 1) / h : 0;
-    const int64_t NC = (int64_t)(2 * EF + 1) * p.K;
-    int nb = NC < NBMAX ? (int)NC : NBMAX;
-    // a short signal leaves most of the chip idle at 256 threads per segment: more waves share a segment's contributions
-    int nt = 256;
-    // (512 = two groups: f64 issue is already saturated by two waves per SIMD, and 1024 threads would cap the kernel
-    // at 128 registers, which the four-sample loop body does not fit)
-    if (nseg < 1024 && NC >= 16) nt = 512;
-    // a long waveform: workgroups of two waves -- a segment's set-up (candidates, windows, parameters: dependent loads and
-    // serial float64 on a handful of lanes, three quarters of a workgroup's time) keeps ONE wave busy, so smaller
-    // workgroups mean more set-ups in flight per CU (7 x 2 waves at config 2's shape: 0.82 -> 0.69 ms)
-    else if (nseg >= 2048) nt = 128;
-    if (const char* e = getenv("PVX_SYNTH_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) nt = v; }
-    while (nt > 256 && synth_lds_bytes(h, 4, WL, nt / TSMAX) > 150 * 1024) nt >>= 1;
-    const int groups = nt > TSMAX ? nt / TSMAX : 1;
-    const size_t budget = (nseg > 512 ? 72 : 150) * 1024;
-    while (nb > 4 && synth_lds_bytes(h, nb, WL, groups) > budget) nb >>= 1;
-    // two-wave workgroups: batches of max(16, 2 npks) -- a segment's live contributions (<= npks bodies and the odd edge; a
-    // fuller segment takes another round) instead of all (2 EF + 1) npks candidates: 11 KB of LDS per workgroup instead of
-    // 23, ten workgroups per CU
-    if (nt == 128) { const int cap = p.K * 2 > 16 ? p.K * 2 : 16; if (nb > cap) nb = cap; }
-    if (const char* e = getenv("PVX_SYNTH_NB")) { const int v = atoi(e); if (v >= 4 && v <= NBMAX && v < nb) nb = v; }     // tests: more rounds
-    if (nb < 1) nb = 1;
-    p.nbatch = nb;
-    p.c_htbits = synth_htbits(nb);
+    const int64_t nseg_all = (p.wlen + h - 1) / h;
+    if (nseg_all > 0x7fffffffLL) { pvx_set_error("too many output segments"); return PVX_ERR_INVALID; }
+    if ((int64_t)p.F * p.K > ((int64_t)1 << 40)) { pvx_set_error("too many analysis points"); return PVX_ERR_INVALID; }
+    SynthK q;
+    q.f = p.f; q.mag = p.mag; q.realph = p.realph; q.pid = p.partial_id; q.pst = p.part_start; q.pln = p.part_len;
+    q.F = p.F; q.P = p.P; q.N = p.F * p.K; q.K = p.K; q.h = h; q.minframes = p.minframes; q.no_phcor = p.no_phcor;
     {
         const double overlap = p.hop_a / (double)p.nfft;              // PVAnalysis.py:824
-        p.c_dh = (double)h;
-        p.c_fstep = p.sr / (double)p.nfft;                            // PVAnalysis.py:825
-        p.c_dfr = 1. / overlap / 2.;                                  // PVAnalysis.py:687
-        p.c_offf = p.c_dfr + .5;
-        p.c_sc = kPi2 / p.sr;
-        p.c_edgsam = (int)(p.c_dfr * h * p.edge);                     // PVAnalysis.py:740
+        q.sr = p.sr;
+        q.dh = (double)h;
+        q.fstep = p.sr / (double)p.nfft;                              // PVAnalysis.py:825
+        q.dfr = 1. / overlap / 2.;                                    // PVAnalysis.py:687
+        q.offf = q.dfr + .5;
+        q.sc = kPi2 / p.sr;
+        q.edgsam = (int)(q.dfr * h * p.edge);                         // PVAnalysis.py:740
         const double dfr_s = (double)p.nfft / (double)p.hop_a / 2.;   // PVAnalysis.py:1055
-        p.c_edgsamp = (int64_t)(p.edge * h * dfr_s);                  // PVAnalysis.py:1056
-        p.c_EF = p.c_edgsam > 0 ? (p.c_edgsam + h - 1) / h : 0;
-        p.c_WB = (int)ceil(p.c_dfr + 0.5) + 2;
-        p.c_WL = p.c_WB + 4;
+        q.edgsamp = (int64_t)(p.edge * h * dfr_s);                    // PVAnalysis.py:1056
+        q.EF = q.edgsam > 0 ? (q.edgsam + h - 1) / h : 0;
+        q.vr = q.edgsam > 0 ? cos(kPi / (double)q.edgsam) : 1.0;
+        q.vi = q.edgsam > 0 ? sin(kPi / (double)q.edgsam) : 0.0;
+    }
+    static const int run_env = [] { const char* e = getenv("PVX_SYNTH_RUN"); return e ? atoi(e) : 0; }();
+    // samples per thread: 32 (two sincos per 32 samples); a short waveform takes runs of 16 so that more of the chip works
+    int R = (nseg_all * ((h + 31) / 32) < 256 * 64) ? 16 : 32;
+    if (run_env == 16 || run_env == 32) R = run_env;
+    SampK k;
+    {
+        // where the pieces of fsig / msig change inside a segment: np.interp's breakpoints are h (dfr + .5 + j) and h (dfr + j)
+        // (PVAnalysis.py:701-702), i.e. at ceil(h frac(dfr + .5)) and ceil(h frac(dfr)) for every contribution that has a
+        // break at all -- launch-wide positions (0 or h: none).  Runs never straddle them, so a run follows ONE quadratic.
+        // (A contribution whose own break differs -- float rounding of a non-dyadic dfr -- is handled in the kernel, slower.)
+        auto brk = [&](double off) { const double fr = off - floor(off); return fr == 0.0 ? h : (int)ceil((double)h * fr); };
+        int b1 = brk(q.offf), b2 = brk(q.dfr);
+        if (b1 > b2) { const int t = b1; b1 = b2; b2 = t; }
+        if (getenv("PVX_SYNTH_NO_CUTS")) { b1 = b2 = h; }                   // tests: the pieces change inside runs -> k_synth_extras
+        k.c1 = b1; k.c2 = b2;
+        k.n0 = (b1 + R - 1) / R; k.n1 = (b2 - b1 + R - 1) / R;
+        k.rps = k.n0 + k.n1 + (h - b2 + R - 1) / R;
+        q.c1 = b1; q.c2 = b2; q.R = R;
+    }
+    q.rps = k.rps;
+    constexpr int RX = 16;                                                   // k_synth_extras' runs
+
+    const WsLayout L = ws_layout(p.F, p.K, p.P, q.EF);
+    char* base = (char*)p.ws;
+    if (!base) {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        StreamWs& w = g_ws[s];
+        if (w.cap < L.total) {
+            if (w.p) (void)hipFree(w.p);                              // (synchronises with the device: no kernel still uses it)
+            w.p = nullptr; w.cap = 0;
+            if (hipMalloc(&w.p, L.total) != hipSuccess) { pvx_set_error("hipMalloc(%zu) of the resynthesis workspace failed", L.total); w.p = nullptr; return PVX_ERR_ALLOC; }
+            w.cap = L.total;
+        }
+        base = (char*)w.p;
+    } else if (p.ws_bytes < L.total) {
+        pvx_set_error("resynthesis workspace of %zu bytes, %zu needed", p.ws_bytes, L.total);
+        return PVX_ERR_SIZE;
+    }
+    q.cursor = (unsigned long long*)(base + L.cursor);
+    q.off = (long long*)(base + L.off);
+    q.cf = (double*)(base + L.cf); q.cm = (double*)(base + L.cm); q.cr = (double*)(base + L.cr);
+    q.body = (BodyRec*)(base + L.body); q.att = (EdgeRec*)(base + L.att); q.rel = (EdgeRec*)(base + L.rel);
+    q.bbits = (unsigned long long*)(base + L.bb); q.xbits = (unsigned long long*)(base + L.xb); q.abits = (unsigned long long*)(base + L.ab); q.rbits = (unsigned long long*)(base + L.rb);
+    q.w = p.w; q.wlen = p.wlen;
+    q.fx0 = q.fx1 = q.fb0 = q.fb1 = 0; q.seg0 = 0; q.nseg = 0;
+
+    if (!p.skip_prepare) {
+        PVX_HIP_CHECK(hipMemsetAsync(q.cursor, 0, 8, s));
+        hipLaunchKernelGGL(k_synth_alloc, dim3((unsigned)((p.P + 255) / 256)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(k_synth_scatter, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, s, q);
     }
     // a slice of the segments (p.seg_count > 0: pvx_synth_resident launches the waveform in slices whose DMA to the host
-    // runs under the next slice's kernel); the geometry above is that of the whole waveform either way
-    if (p.seg0 < 0 || p.seg0 > nseg) { pvx_set_error("bad segment slice"); return PVX_ERR_INVALID; }
-    const int64_t nlaunch = (p.seg_count > 0 && p.seg0 + p.seg_count < nseg) ? p.seg_count : nseg - p.seg0;
-    if (nlaunch <= 0) return PVX_OK;
-    const size_t lds = synth_lds_bytes(h, nb, WL, groups);
-    if (lds > 158 * 1024) { pvx_set_error("synthesis hop %d too large (LDS)", h); return PVX_ERR_UNSUPPORTED; }
-#define PVX_SYNTH(NT_)                                                                                                      \
-    do {                                                                                                                    \
-        if (lds > 48 * 1024)                                                                                                \
-            PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_synth_ola<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_synth_ola<NT_>, dim3((unsigned)nlaunch), dim3(NT_), lds, s, p);                                \
-    } while (0)
-    if (nt == 512) PVX_SYNTH(512);
-    else if (nt == 128) PVX_SYNTH(128);
-    else if (nt == 64) PVX_SYNTH(64);
-    else PVX_SYNTH(256);
-#undef PVX_SYNTH
+    // runs under the next slice's kernel)
+    if (p.seg0 < 0 || p.seg0 > nseg_all) { pvx_set_error("bad segment slice"); return PVX_ERR_INVALID; }
+    const int64_t seg_end = (p.seg_count > 0 && p.seg0 + p.seg_count < nseg_all) ? p.seg0 + p.seg_count : nseg_all;
+    static const int64_t slice_env = [] { const char* e = getenv("PVX_SYNTH_SLICE"); return e ? atoll(e) : 0LL; }();   // tests: more slices
+    const int64_t slice = (slice_env >= 1 && slice_env < L.slice_segs) ? slice_env : L.slice_segs;
+    for (int64_t s0 = p.seg0; s0 < seg_end; s0 += slice) {
+        const int64_t s1 = s0 + slice < seg_end ? s0 + slice : seg_end;
+        q.seg0 = s0; q.nseg = s1 - s0;
+        q.fb0 = s0 < p.F ? s0 : p.F; q.fb1 = s1 < p.F ? s1 : p.F;
+        q.fx0 = s0 - q.EF > 0 ? s0 - q.EF : 0; if (q.fx0 > p.F) q.fx0 = p.F;
+        q.fx1 = s1 + q.EF < p.F ? s1 + q.EF : p.F;
+        const int64_t nloc = (q.fx1 - q.fx0) * p.K;
+        if (nloc > 0) hipLaunchKernelGGL(k_synth_params, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, s, q);
+        k.body = q.body; k.att = q.att; k.rel = q.rel; k.bbits = q.bbits; k.xbits = q.xbits; k.abits = q.abits; k.rbits = q.rbits;
+        k.w = q.w; k.wlen = q.wlen; k.seg0 = s0; k.nthreads = q.nseg * k.rps;
+        k.fx0 = (int)q.fx0; k.fx1 = (int)q.fx1; k.fb0 = (int)q.fb0; k.fb1 = (int)q.fb1;
+        k.K = p.K; k.h = h; k.EF = q.EF; k.edgsam = q.edgsam; k.vr = q.vr; k.vi = q.vi;
+        const dim3 grid((unsigned)((k.nthreads + 255) / 256));
+        if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(256), 0, s, k);
+        SampK kx = k;
+        kx.rps = (h + RX - 1) / RX;
+        kx.nthreads = q.nseg * kx.rps;
+        hipLaunchKernelGGL(k_synth_extras<RX>, dim3((unsigned)((kx.nthreads + 255) / 256)), dim3(256), 0, s, kx);
+    }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
 }

@@ -1283,7 +1283,7 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge);
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
-                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count);
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first);
 
 // ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
 extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
@@ -1367,7 +1367,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
             if (s0 >= nseg) break;
             const int64_t cnt = nseg - s0 < per ? nseg - s0 : per;
             rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft, p->hop, hop_synth,
-                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt);
+                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0);
             if (rc != PVX_OK) return rc;
             PVX_HIP_CHECK(hipEventRecord(p->ev_ring[i], p->s_host));
             PVX_HIP_CHECK(hipStreamWaitEvent(p->s_copy, p->ev_ring[i], 0));
@@ -1800,8 +1800,9 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 // one slice of the waveform's segments (internal: pvx_synth_resident overlaps the slices' kernels with their copies)
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
-                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count) {
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first) {
     SynthParams sp;
+    sp.skip_prepare = first ? 0 : 1;          // the partial-major copy of the analysis arrays is made with the first slice
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;

@@ -176,8 +176,14 @@ struct SynthParams {
     double c_dh, c_fstep, c_dfr, c_offf, c_sc;
     int c_edgsam, c_EF, c_WB, c_WL, c_htbits;
     int64_t c_edgsamp;
+    // device workspace of pvx_synth_ws_bytes() bytes (nullptr: a grow-only buffer per stream, owned by the library);
+    // skip_prepare: the partial-major copy of the analysis arrays is already in `ws` (a later slice of the same waveform)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    int skip_prepare = 0;
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);
+size_t pvx_synth_ws_bytes(int64_t F, int K, int64_t P, int nfft, int hop_a, int hop_s, double edge);
 
 // PVHarmonic.run_pv (k_harmonic.hip): f0-guided bin sampling on the spectra of the general path
 struct HarmParams {
