@@ -165,6 +165,8 @@ struct SynthK {
     double sr, dh, fstep, dfr, offf, sc, vr, vi;     // (vr, vi) = exp(i pi / edgsam)
     // workspace
     unsigned long long* cursor;
+    int* segflag;                    // [output segments]: 1 where k_synth_extras has something to add (k_synth_scatter zeroes, k_synth_params sets)
+    int64_t nseg_all;
     long long* off;                  // [P]  first point of the partial in the partial-major arrays; -1: it does not sound
     double *cf, *cm, *cr;            // [N]  partial-major f / mag / realph
     BodyRec* body;                   // [(fb1 - fb0) K]
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void k_synth_alloc(SynthK q) {
 
 __global__ __launch_bounds__(256) void k_synth_scatter(SynthK q) {
     const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (node < q.nseg_all) q.segflag[node] = 0;
     if (node >= q.N) return;
     const int pid = q.pid[node];
     if (pid < 0 || pid >= q.P) return;
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                     e.pad0 = e.pad1 = 0;
                     q.att[li] = e;
                     isa = true;
+                    for (int64_t sg = fr - q.EF; sg < fr; sg++) if (sg >= 0 && sg < q.nseg_all) q.segflag[sg] = 1;
                 }
                 const bool wantb = fr >= q.fb0 && fr < q.fb1;
                 isr = (ii == nfr - 1);
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                         fsincos(kPi2 * e.cfr, e.wi, e.wr);
                         e.pad0 = e.pad1 = 0;
                         q.rel[li] = e;
+                        for (int64_t sg = fr + 1; sg <= fr + q.EF; sg++) if (sg < q.nseg_all) q.segflag[sg] = 1;
                     }
                     if (wantb) {
                         // 2 pi / sr folded into the two-piece phase polynomial
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                         };
                         isb = on_edge(c.fmb) && on_edge(c.mmb);
                         isx = !isb;
+                        if (isx && fr < q.nseg_all) q.segflag[fr] = 1;
                     }
                 }
             }
@@ -361,8 +367,9 @@ struct SampK {
     const BodyRec* body;                 // [(fb1 - fb0) K]
     const EdgeRec *att, *rel;            // [(fx1 - fx0) K]
     const unsigned long long *bbits, *xbits, *abits, *rbits;
+    const int* segflag;                  // per output segment: k_synth_extras has something to add (set by k_synth_params)
     double* w;
-    int64_t wlen, seg0, nthreads;
+    int64_t wlen, seg0, nseg, nthreads;
     int fx0, fx1, fb0, fb1;              // frames whose edges / bodies the slice holds
     int K, h, EF, edgsam, rps;
     int c1, c2, n0, n1;                  // k_synth_bodies: the cuts of a segment's runs (RunCuts)
@@ -414,13 +421,26 @@ template <class Fn> __device__ __forceinline__ void for_bits(const unsigned long
     double ms = __builtin_fma(dms, ds, (ma) ? (c)->ma0 : (c)->mb0);
 
 // ---- the bodies whose pieces change at the launch-wide cuts (all of them, but for float rounding of an odd dfr): one thread
-// per run of R samples, R sums in registers over all bodies of the segment, ONE unrolled loop
+// per run of R samples, R sums in registers over all bodies of the segment, ONE unrolled loop.  A workgroup's 256 runs are
+// consecutive, so the records of its segments are consecutive too: they are staged through LDS a tile at a time (one
+// coalesced round of loads per tile instead of a dependent round trip per contribution and thread), and the finished sums
+// leave through LDS as well, so that a store instruction writes 64-byte pieces instead of 16 bytes per 256.
+constexpr int kTile = 32;                        // records per wave and LDS tile (32 x 160 B = 5 KB = the wave's store staging)
+constexpr int kLaneB = 80;                       // bytes per lane in the store staging: 64 + 16 (conflict-free 16-byte rows)
 template <int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= q.nthreads) return;
-    const int64_t segl = gid / q.rps;
-    const int run = (int)(gid - segl * q.rps);
+    // everything is per wave (a wave's 64 runs are consecutive, so are the records of their segments): no workgroup barrier
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][kTile * sizeof(BodyRec)];
+    __shared__ long long s_o[256];
+    __shared__ int s_len[256];
+    static_assert(kTile * sizeof(BodyRec) == 64 * kLaneB, "store staging = record tile");
+    const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    unsigned char* lds = lds_all[tid >> 6];
+    const int64_t gid0 = (int64_t)blockIdx.x * 256, gid = gid0 + tid;
+    const bool live = gid < q.nthreads;
+    const int64_t g = live ? gid : q.nthreads - 1;
+    const int64_t segl = g / q.rps;
+    const int run = (int)(g - segl * q.rps);
     const int seg = (int)(q.seg0 + segl);
     const int h = q.h, K = q.K;
     // the run's samples [s, s + len)
@@ -431,46 +451,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
     if (len > R) len = R;
     const double ds = (double)s, ts = 0.5 * ds * (double)(s - 1);
     double a[R];
+    // where this thread's run goes, for the lanes that move it between memory and the wave's staging rows (four lanes per
+    // run, 8 doubles at a time: an instruction then touches the 64 contiguous bytes of 16 runs)
+    const bool flagged = live && q.segflag[seg] != 0;      // k_synth_extras has left this segment's attacks / releases in w
+    s_o[tid] = (int64_t)seg * h + s;
+    s_len[tid] = live ? (flagged ? -len : len) : 0;
+    __builtin_amdgcn_wave_barrier();
+    long long oo[4];
+    int ll[4];
 #pragma unroll
-    for (int k = 0; k < R; k++) a[k] = 0.0;
-    if (seg >= q.fb0 && seg < q.fb1) {
-        const int n0 = (seg - q.fx0) * K, n1 = n0 + K;                  // (a slice holds at most 2^20 + 2 EF K nodes)
-        const BodyRec* rec = q.body - (q.fb0 - q.fx0) * K;
-        for_bits(q.bbits, n0, n1, [&](const int li) {
-            const BodyRec* c = rec + li;
-            // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
-            const bool fa = s < c->fmb, ma = s < c->mmb;
-            PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
+    for (int i = 0; i < 4; i++) { oo[i] = s_o[wbase + 16 * i + (lane >> 2)]; ll[i] = s_len[wbase + 16 * i + (lane >> 2)]; }
+    if (__ballot(flagged) != 0ull) {
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                a[k] = __builtin_fma(ms, zr, a[k]);                      // PVAnalysis.py:734-736
-                PVX_CMUL(zr, zi, wr, wi);
-                PVX_CROT(wr, wi, dr, di);
-                ms += dms;
+        for (int c8 = 0; c8 < R / 8; c8++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = 8 * c8 + 2 * (lane & 3);
+                const long long o = oo[i] + k;
+                double2 v = make_double2(0.0, 0.0);
+                if (ll[i] < 0) {
+                    const bool v0 = k < -ll[i] && o < q.wlen, v1 = k + 1 < -ll[i] && o + 1 < q.wlen;
+                    if (v0 && v1 && (o & 1) == 0) v = *(const double2*)(q.w + o);
+                    else {
+                        if (v0) v.x = q.w[o];
+                        if (v1) v.y = q.w[o + 1];
+                    }
+                }
+                *(double2*)(lds + (16 * i + (lane >> 2)) * kLaneB + 16 * (lane & 3)) = v;
             }
-        });
-    }
-    const int64_t o = (int64_t)seg * h + s;
-    double* dst = q.w + o;
-    if (len == R && o + R <= q.wlen && (o & 1) == 0) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < R; k += 2) *(double2*)(dst + k) = make_double2(a[k], a[k + 1]);
+            for (int j = 0; j < 4; j++) {
+                const double2 v = *(const double2*)(lds + lane * kLaneB + 16 * j);
+                a[8 * c8 + 2 * j] = v.x; a[8 * c8 + 2 * j + 1] = v.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < R; k++)
-            if (k < len && o + k < q.wlen) dst[k] = a[k];
+        for (int k = 0; k < R; k++) a[k] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) ll[i] = ll[i] < 0 ? -ll[i] : ll[i];
+    const bool mine = live && seg >= q.fb0 && seg < q.fb1;
+    const int m0 = (seg - q.fx0) * K, m1 = m0 + K;                          // (a slice holds at most 2^20 + 2 EF K nodes)
+    // the wave's segments and their body nodes (slice-local indices; wave-uniform)
+    {
+        const int64_t gfirst = gid0 + wbase, glast = gfirst + 63 < q.nthreads - 1 ? gfirst + 63 : q.nthreads - 1;
+        int seg_lo = (int)(q.seg0 + gfirst / q.rps), seg_hi = (int)(q.seg0 + glast / q.rps) + 1;
+        if (gfirst >= q.nthreads) seg_hi = seg_lo;
+        if (seg_lo < q.fb0) seg_lo = q.fb0;
+        if (seg_hi > q.fb1) seg_hi = q.fb1;
+        const int nlo = __builtin_amdgcn_readfirstlane((seg_lo - q.fx0) * K), nhi = __builtin_amdgcn_readfirstlane((seg_hi - q.fx0) * K);
+        const BodyRec* rec = q.body - (q.fb0 - q.fx0) * K;
+        for (int tile = nlo; tile < nhi; tile += kTile) {
+            const int cnt = nhi - tile < kTile ? nhi - tile : kTile;
+            // (LDS operations of one wave execute in order: the copy below is behind the previous tile's reads, the
+            // reads behind the copy)
+            {
+                const int4* src = (const int4*)(rec + tile);
+                int4* dst = (int4*)lds;
+                for (int i = lane; i < cnt * (int)(sizeof(BodyRec) / 16); i += 64) dst[i] = src[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int a0 = m0 > tile ? m0 : tile, a1 = m1 < tile + cnt ? m1 : tile + cnt;
+            if (mine && a1 > a0) {
+                for_bits(q.bbits, a0, a1, [&](const int li) {
+                    const BodyRec* c = (const BodyRec*)lds + (li - tile);
+                    // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
+                    const bool fa = s < c->fmb, ma = s < c->mmb;
+#ifdef PVX_AB_REP
+#pragma unroll 1
+                    for (int rep_ = 0; rep_ < PVX_AB_REP; rep_++) {
+#endif
+                    PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        a[k] = __builtin_fma(ms, zr, a[k]);                      // PVAnalysis.py:734-736
+                        PVX_CMUL(zr, zi, wr, wi);
+                        PVX_CROT(wr, wi, dr, di);
+                        ms += dms;
+                    }
+#ifdef PVX_AB_REP
+                    }
+#endif
+                });
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- the sums leave the same way
+#ifdef PVX_AB_NOSTORE
+#pragma unroll
+    for (int k = 0; k < R; k++) asm volatile("" :: "v"(a[k]));
+    if (q.wlen < 0)
+#endif
+#pragma unroll
+    for (int c8 = 0; c8 < R / 8; c8++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) *(double2*)(lds + lane * kLaneB + 16 * j) = make_double2(a[8 * c8 + 2 * j], a[8 * c8 + 2 * j + 1]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double2 v = *(const double2*)(lds + (16 * i + (lane >> 2)) * kLaneB + 16 * (lane & 3));
+            const int k = 8 * c8 + 2 * (lane & 3);
+            const long long o = oo[i] + k;
+            const bool v0 = k < ll[i] && o < q.wlen, v1 = k + 1 < ll[i] && o + 1 < q.wlen;
+#ifdef PVX_AB_SC1
+            if (v0 && v1 && (o & 1) == 0) { typedef double d2_ __attribute__((ext_vector_type(2))); const d2_ vv = {v.x, v.y}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q.w + o), "v"(vv) : "memory"); }
+#elif defined(PVX_AB_NT)
+            if (v0 && v1 && (o & 1) == 0) { typedef double d2_ __attribute__((ext_vector_type(2))); const d2_ vv = {v.x, v.y}; __builtin_nontemporal_store(vv, (d2_*)(q.w + o)); }
+#else
+            if (v0 && v1 && (o & 1) == 0) *(double2*)(q.w + o) = v;
+#endif
+            else {
+                if (v0) q.w[o] = v.x;
+                if (v1) q.w[o + 1] = v.y;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---- everything else, added to what k_synth_bodies stored: attacks, releases, and the bodies whose pieces change inside a
 // run.  One thread per run of R samples [s, s + R) of a segment; a thread without work returns at once.
-template <int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_synth_extras(SampK q) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= q.nthreads) return;
-    const int64_t segl = gid / q.rps;
-    const int run = (int)(gid - segl * q.rps);
-    const int seg = (int)(q.seg0 + segl);
+#ifndef PVX_EXTRAS_WAVES
+#define PVX_EXTRAS_WAVES 3
+#endif
+// XB = false: attacks and releases; XB = true: the irregular bodies (launched only where a contribution's own break can
+// differ from the launch-wide one: pvx_launch_synth)
+template <int R, bool XB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_WAVES, PVX_EXTRAS_WAVES))) void k_synth_extras(SampK q) {
+    // The slice's segments in chunks of 16; workgroup b takes chunks b, b + gridDim.x, ...  The flags of 16 chunks are
+    // fetched in one go (k_synth_params wrote them long ago: a launch without work costs one load), the flagged segments
+    // of a chunk are listed in LDS and their runs dealt to the threads.
+    __shared__ int s_list[16][16];
+    __shared__ int s_n[16];
+    const int tid_ = threadIdx.x;
+    const int64_t nchunks = (q.nseg + 15) >> 4;
+#pragma unroll 1
+    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += (int64_t)gridDim.x * 16) {
+    __syncthreads();
+    {
+        // thread (i, j): segment j of chunk c0 + i gridDim.x
+        const int i = tid_ >> 4, j = tid_ & 15;
+        const int64_t ch = c0 + (int64_t)i * gridDim.x, sl_ = ch * 16 + j;
+        const bool f = ch < nchunks && sl_ < q.nseg && q.segflag[q.seg0 + sl_] != 0;
+        // (lanes 16 i' .. 16 i' + 15 of a wave are one chunk: its flagged segments in ascending order)
+        const unsigned long long bal = __ballot(f);
+        const unsigned m16 = (unsigned)(bal >> ((tid_ & 63) & ~15)) & 0xffffu;
+        if (f) s_list[i][__popc(m16 & ((1u << j) - 1u))] = (int)(q.seg0 + sl_);
+        if (j == 0) s_n[i] = __popc(m16);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ic = 0; ic < 16; ic++) {
+    const int total = s_n[ic] * q.rps;
+#pragma unroll 1
+    for (int t = tid_; t < total; t += 256) {
+    const int segl = t / q.rps;
+    const int run = t - segl * q.rps;
+    const int seg = s_list[ic][segl];
     const int h = q.h, K = q.K;
     const int s = run * R;
     const int len = h - s < R ? h - s : R;
@@ -478,17 +619,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int64_t o = (int64_t)seg * h + s;
     double* dst = q.w + o;
     double a[R];
-    bool loaded = false;
-    auto load = [&]() {
-        if (loaded) return;
-        loaded = true;
+    // (the attack / release launch leaves EVERY run of a flagged segment, zeros included: k_synth_bodies starts from them)
 #pragma unroll
-        for (int k = 0; k < R; k++) a[k] = (k < len && o + k < q.wlen) ? dst[k] : 0.0;
-    };
-#pragma unroll
-    for (int k = 0; k < R; k++) a[k] = 0.0;
+    for (int k = 0; k < R; k++) a[k] = (XB && k < len && o + k < q.wlen) ? dst[k] : 0.0;
 #pragma unroll 1
-    for (int kind = 0; kind < 3; kind++) {
+    for (int kind = XB ? 0 : 1; kind < (XB ? 1 : 3); kind++) {
         // kind 0: bodies of frame seg; 1: attacks of partials starting at frames seg+1 .. seg+EF; 2: releases of partials
         // whose last frame is seg-EF .. seg-1
         int f0 = kind == 0 ? seg : (kind == 1 ? seg + 1 : seg - q.EF);
@@ -500,14 +635,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const unsigned long long* bits = kind == 0 ? q.xbits : (kind == 1 ? q.abits : q.rbits);
         const int n0 = (f0 - q.fx0) * K, n1 = (f1 - q.fx0) * K;
         for_bits(bits, n0, n1, [&](const int li) {
-            if (kind == 0) {
+            if constexpr (XB) {
                 const BodyRec* c = q.body + (li - (q.fb0 - q.fx0) * K);
                 // leading samples of the run on the first piece of fsig (samples m < fmb; m = fmb sits on both) / of msig
                 int nfa = c->fmb - s, nma = c->mmb - s;
                 nfa = nfa < 0 ? 0 : (nfa > len ? len : nfa);
                 nma = nma < 0 ? 0 : (nma > len ? len : nma);
                 const int k1 = nfa < nma ? nfa : nma, k2 = nfa < nma ? nma : nfa;
-                load();
 #pragma unroll 1
                 for (int part = 0; part < 3; part++) {
                     // each pair of pieces is a quadratic of its own: it is followed from s and added where it holds
@@ -529,7 +663,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const EdgeRec* e = (kind == 1 ? q.att : q.rel) + li;
                 const long long j0l = (long long)seg * h + s - e->o0;
                 if (j0l + R <= 0 || j0l >= q.edgsam) return;
-                load();
                 const int j0 = (int)j0l;
                 const double cfr = e->cfr;
                 const double x = (kind == 1) ? e->ph0 - kPi2 * ((double)(q.edgsam - j0) * cfr)
@@ -550,18 +683,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         });
     }
-    if (!loaded) return;
 #pragma unroll
     for (int k = 0; k < R; k++)
         if (k < len && o + k < q.wlen) dst[k] = a[k];
+    }
+    }
+    }
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------
 constexpr int64_t kSliceNodes = (int64_t)1 << 20;   // nodes of one params / samples launch pair: bounds the records' memory
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
-struct WsLayout { size_t cursor, off, cf, cm, cr, body, att, rel, bb, xb, ab, rb, total; int64_t slice_segs; };
-WsLayout ws_layout(int64_t F, int K, int64_t P, int EF) {
+struct WsLayout { size_t segflag, cursor, off, cf, cm, cr, body, att, rel, bb, xb, ab, rb, total; int64_t slice_segs; };
+WsLayout ws_layout(int64_t F, int K, int64_t P, int EF, int64_t nseg_all) {
     WsLayout L;
     const int64_t N = F * K;
     int64_t slice = kSliceNodes / K - 2 * EF;
@@ -582,6 +717,7 @@ WsLayout ws_layout(int64_t F, int K, int64_t P, int EF) {
     L.xb = o; o += up256(words * 8);
     L.ab = o; o += up256(words * 8);
     L.rb = o; o += up256(words * 8);
+    L.segflag = o; o += up256((size_t)(nseg_all + 16) * 4);
     L.total = o;
     L.slice_segs = slice;
     return L;
@@ -599,7 +735,7 @@ size_t pvx_synth_ws_bytes(int64_t F, int K, int64_t P, int nfft, int hop_a, int 
     const double dfr = 1. / (hop_a / (double)nfft) / 2.;
     const int edgsam = (int)(dfr * hop_s * edge);
     const int EF = edgsam > 0 ? (edgsam + hop_s - 1) / hop_s : 0;
-    return ws_layout(F, K, P, EF).total;
+    return ws_layout(F, K, P, EF, F + 2 + EF + 2).total;     // (segments of the longest waveform these frames can give)
 }
 
 int pvx_launch_synth_v1(const SynthParams& p_in, hipStream_t s);
@@ -630,11 +766,12 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         q.vr = q.edgsam > 0 ? cos(kPi / (double)q.edgsam) : 1.0;
         q.vi = q.edgsam > 0 ? sin(kPi / (double)q.edgsam) : 0.0;
     }
-    static const int run_env = [] { const char* e = getenv("PVX_SYNTH_RUN"); return e ? atoi(e) : 0; }();
+    const int run_env = [] { const char* e = getenv("PVX_SYNTH_RUN"); return e ? atoi(e) : 0; }();           // tests
     // samples per thread: 32 (two sincos per 32 samples); a short waveform takes runs of 16 so that more of the chip works
     int R = (nseg_all * ((h + 31) / 32) < 256 * 64) ? 16 : 32;
     if (run_env == 16 || run_env == 32) R = run_env;
     SampK k;
+    bool irregular = false;
     {
         // where the pieces of fsig / msig change inside a segment: np.interp's breakpoints are h (dfr + .5 + j) and h (dfr + j)
         // (PVAnalysis.py:701-702), i.e. at ceil(h frac(dfr + .5)) and ceil(h frac(dfr)) for every contribution that has a
@@ -643,7 +780,11 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         auto brk = [&](double off) { const double fr = off - floor(off); return fr == 0.0 ? h : (int)ceil((double)h * fr); };
         int b1 = brk(q.offf), b2 = brk(q.dfr);
         if (b1 > b2) { const int t = b1; b1 = b2; b2 = t; }
-        if (getenv("PVX_SYNTH_NO_CUTS")) { b1 = b2 = h; }                   // tests: the pieces change inside runs -> k_synth_extras
+        // can a contribution's own break differ from these?  Not when h (off + j) is exact for every j: off with few
+        // fractional bits (dfr = 1, 2, 4, 1.5 ...: every power-of-two nfft / hop); otherwise the rounding of the product decides
+        auto dyadic = [&](double off) { const double t = ldexp(off, 20); return t == floor(t) && off < 1024.0; };
+        irregular = !(dyadic(q.offf) && dyadic(q.dfr) && h < (1 << 20));
+        if (getenv("PVX_SYNTH_NO_CUTS")) { b1 = b2 = h; irregular = true; } // tests: the pieces change inside runs -> k_synth_extras<, true>
         k.c1 = b1; k.c2 = b2;
         k.n0 = (b1 + R - 1) / R; k.n1 = (b2 - b1 + R - 1) / R;
         k.rps = k.n0 + k.n1 + (h - b2 + R - 1) / R;
@@ -652,7 +793,8 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     q.rps = k.rps;
     constexpr int RX = 16;                                                   // k_synth_extras' runs
 
-    const WsLayout L = ws_layout(p.F, p.K, p.P, q.EF);
+    if (nseg_all > p.F + 2 + q.EF + 2) { pvx_set_error("waveform of %lld samples is longer than %lld frames can give", (long long)p.wlen, (long long)p.F); return PVX_ERR_SIZE; }
+    const WsLayout L = ws_layout(p.F, p.K, p.P, q.EF, p.F + 2 + q.EF + 2);
     char* base = (char*)p.ws;
     if (!base) {
         std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -669,6 +811,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         return PVX_ERR_SIZE;
     }
     q.cursor = (unsigned long long*)(base + L.cursor);
+    q.segflag = (int*)(base + L.segflag); q.nseg_all = nseg_all;
     q.off = (long long*)(base + L.off);
     q.cf = (double*)(base + L.cf); q.cm = (double*)(base + L.cm); q.cr = (double*)(base + L.cr);
     q.body = (BodyRec*)(base + L.body); q.att = (EdgeRec*)(base + L.att); q.rel = (EdgeRec*)(base + L.rel);
@@ -679,13 +822,13 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     if (!p.skip_prepare) {
         PVX_HIP_CHECK(hipMemsetAsync(q.cursor, 0, 8, s));
         hipLaunchKernelGGL(k_synth_alloc, dim3((unsigned)((p.P + 255) / 256)), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(k_synth_scatter, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(k_synth_scatter, dim3((unsigned)(((q.N > nseg_all ? q.N : nseg_all) + 255) / 256)), dim3(256), 0, s, q);
     }
     // a slice of the segments (p.seg_count > 0: pvx_synth_resident launches the waveform in slices whose DMA to the host
     // runs under the next slice's kernel)
     if (p.seg0 < 0 || p.seg0 > nseg_all) { pvx_set_error("bad segment slice"); return PVX_ERR_INVALID; }
     const int64_t seg_end = (p.seg_count > 0 && p.seg0 + p.seg_count < nseg_all) ? p.seg0 + p.seg_count : nseg_all;
-    static const int64_t slice_env = [] { const char* e = getenv("PVX_SYNTH_SLICE"); return e ? atoll(e) : 0LL; }();   // tests: more slices
+    const int64_t slice_env = [] { const char* e = getenv("PVX_SYNTH_SLICE"); return e ? atoll(e) : 0LL; }();   // tests: more slices
     const int64_t slice = (slice_env >= 1 && slice_env < L.slice_segs) ? slice_env : L.slice_segs;
     for (int64_t s0 = p.seg0; s0 < seg_end; s0 += slice) {
         const int64_t s1 = s0 + slice < seg_end ? s0 + slice : seg_end;
@@ -697,15 +840,25 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         if (nloc > 0) hipLaunchKernelGGL(k_synth_params, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, s, q);
         k.body = q.body; k.att = q.att; k.rel = q.rel; k.bbits = q.bbits; k.xbits = q.xbits; k.abits = q.abits; k.rbits = q.rbits;
         k.w = q.w; k.wlen = q.wlen; k.seg0 = s0; k.nthreads = q.nseg * k.rps;
+        const int64_t grid_blocks = (k.nthreads + 255) / 256;
+        k.segflag = q.segflag;
         k.fx0 = (int)q.fx0; k.fx1 = (int)q.fx1; k.fb0 = (int)q.fb0; k.fb1 = (int)q.fb1;
         k.K = p.K; k.h = h; k.EF = q.EF; k.edgsam = q.edgsam; k.vr = q.vr; k.vi = q.vi;
-        const dim3 grid((unsigned)((k.nthreads + 255) / 256));
-        if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
-        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(256), 0, s, k);
+        // attacks and releases (and irregular bodies) first, into the flagged segments of w; k_synth_bodies starts from them
+        // (the other way round, the few threads with something to add would wait for the other XCDs' L2s to give up what
+        // k_synth_bodies wrote: ~8 us with nothing to hide behind; here those waits disappear among the bodies' work)
         SampK kx = k;
         kx.rps = (h + RX - 1) / RX;
         kx.nthreads = q.nseg * kx.rps;
-        hipLaunchKernelGGL(k_synth_extras<RX>, dim3((unsigned)((kx.nthreads + 255) / 256)), dim3(256), 0, s, kx);
+        kx.nseg = q.nseg;
+        // (three workgroups per CU fill the chip at this kernel's registers; a workgroup takes 16 segments at a time)
+        const int64_t nchunks = (q.nseg + 15) / 16;
+        const int64_t xgrid = nchunks < 768 ? nchunks : 768;
+        hipLaunchKernelGGL((k_synth_extras<RX, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        if (irregular) hipLaunchKernelGGL((k_synth_extras<RX, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        const dim3 grid((unsigned)grid_blocks);
+        if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(256), 0, s, k);
     }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;

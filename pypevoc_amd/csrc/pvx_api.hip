@@ -186,6 +186,8 @@ struct pvx_plan {
     int64_t res_P = -1, res_maxend = -1;
     double* d_w = nullptr;                 // resynthesised waveform
     size_t w_cap = 0;
+    void* d_sws = nullptr;                 // resynthesis workspace (k_synth.hip)
+    size_t sws_cap = 0;
     void* d_desc = nullptr;                // descriptor outputs (f0 / harmonic power)
     size_t desc_cap = 0;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
@@ -233,6 +235,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_pln) (void)hipFree(p->d_pln);
     if (p->d_tws) (void)hipFree(p->d_tws);
     if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_sws) (void)hipFree(p->d_sws);
     if (p->d_desc) (void)hipFree(p->d_desc);
     if (p->s_host) (void)hipStreamDestroy(p->s_host);
     if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
@@ -1283,7 +1286,8 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analysis, int hop_synth, double edge);
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
-                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first);
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
+                       void* ws, size_t ws_bytes);
 
 // ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
 extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
@@ -1336,6 +1340,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
     const int64_t need = pvx_synth_len(p->res_maxend, p->nfft, p->hop, hop_synth, edge);
     if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
     HostTrace tr("synth");
+    if ((rc = grow_dev(&p->d_sws, &p->sws_cap, pvx_synth_ws_bytes(p->res_F, p->npks, p->res_P, p->nfft, p->hop, hop_synth, edge))) != PVX_OK) return rc;
     const HostOut all = block_ptrs(p->d_res, p->res_F, p->npks);
     const size_t bytes = (size_t)wlen * 8;
     hipPointerAttribute_t attr;
@@ -1346,8 +1351,8 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         // the caller's array is page-locked (pvx_host_alloc) and small: the kernel stores its segments straight into
         // it (posted writes over PCIe, spread over the kernel's run time as workgroups finish) -- no copy operation
         // behind the kernel at all
-        rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                                 p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0);
+        rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
+                         p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap);
         if (rc != PVX_OK) return rc;
         tr.mark("kernel issued");
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
@@ -1367,7 +1372,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
             if (s0 >= nseg) break;
             const int64_t cnt = nseg - s0 < per ? nseg - s0 : per;
             rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft, p->hop, hop_synth,
-                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0);
+                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0, p->d_sws, p->sws_cap);
             if (rc != PVX_OK) return rc;
             PVX_HIP_CHECK(hipEventRecord(p->ev_ring[i], p->s_host));
             PVX_HIP_CHECK(hipStreamWaitEvent(p->s_copy, p->ev_ring[i], 0));
@@ -1380,8 +1385,8 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         tr.mark("here");
         return PVX_OK;
     }
-    rc = pvx_synth_dev_flags(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                             p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0);
+    rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
+                     p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap);
     if (rc != PVX_OK) return rc;
     if (pinned) {
         // the caller's array is page-locked: the DMA lands in it, nothing to stage or copy
@@ -1800,9 +1805,11 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 // one slice of the waveform's segments (internal: pvx_synth_resident overlaps the slices' kernels with their copies)
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
-                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first) {
+                       double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
+                       void* ws, size_t ws_bytes) {
     SynthParams sp;
     sp.skip_prepare = first ? 0 : 1;          // the partial-major copy of the analysis arrays is made with the first slice
+    sp.ws = ws; sp.ws_bytes = ws_bytes;
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;

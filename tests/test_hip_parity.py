@@ -206,37 +206,40 @@ def test_synth_matches_reference(amd, name):
         assert np.abs(w32 - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
-def test_synth_workgroup_shapes_and_result_arrays(amd, monkeypatch):
-    """k_synth_ola with one and two groups of contributions per segment (64 .. 256 / 512 threads; the sums of two
-    groups associate differently, float64 round-off apart), batches smaller than a segment's contributions, and the page-locked result arrays of the resident chain: writable,
-    and a later result does not touch an earlier one that is still alive."""
+def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
+    """The resynthesis kernels' launch shapes -- runs of 16 / 32 samples per thread, the waveform in slices of a few segments,
+    the pieces of fsig changing inside runs (no cuts: every body through k_synth_extras' predicated loop) -- and the
+    page-locked result arrays of the resident chain: writable, and a later result does not touch an earlier one that is
+    still alive."""
     g = load_golden("G7_perlman")
     h = int(g["hop"])
     ref = g["w_hop%d" % h].astype(np.float64)
     p = run_golden(amd, g, 32)
     ss = p.toSinSum()
     ws = {}
-    for nt in ("64", "128", "256", "512"):
-        monkeypatch.setenv("PVX_SYNTH_THREADS", nt)
-        ws[nt] = ss.synth(g["sr"], h)
-        assert np.abs(ws[nt] - ref).max() <= 1e-4 * np.abs(ref).max()
-    # one group of contributions per segment (<= 256 threads): the same additions in the same order, whatever the
-    # workgroup -- also when a segment's contributions take several rounds of a small batch
-    assert np.array_equal(ws["64"], ws["256"]) and np.array_equal(ws["128"], ws["256"])
-    monkeypatch.setenv("PVX_SYNTH_THREADS", "128")
-    monkeypatch.setenv("PVX_SYNTH_NB", "8")
-    assert np.array_equal(ss.synth(g["sr"], h), ws["256"])
-    monkeypatch.delenv("PVX_SYNTH_NB")
-    monkeypatch.delenv("PVX_SYNTH_THREADS")
-    assert np.abs(ws["256"] - ws["512"]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
-    keep = ws["512"].copy()
+    for run in ("16", "32"):
+        monkeypatch.setenv("PVX_SYNTH_RUN", run)
+        ws[run] = ss.synth(g["sr"], h)
+        assert np.abs(ws[run] - ref).max() <= 1e-4 * np.abs(ref).max()
+        # the same additions in the same order whatever the slices (each slice recomputes the records it needs)
+        monkeypatch.setenv("PVX_SYNTH_SLICE", "7")
+        assert np.array_equal(ss.synth(g["sr"], h), ws[run])
+        monkeypatch.delenv("PVX_SYNTH_SLICE")
+        # ... and float64 round-off apart when every body takes the general path
+        monkeypatch.setenv("PVX_SYNTH_NO_CUTS", "1")
+        wx = ss.synth(g["sr"], h)
+        monkeypatch.delenv("PVX_SYNTH_NO_CUTS")
+        assert np.abs(wx - ws[run]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    monkeypatch.delenv("PVX_SYNTH_RUN")
+    assert np.abs(ws["16"] - ws["32"]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    keep = ws["32"].copy()
     w3 = ss.synth(g["sr"], h)                      # a third buffer of the same size while two are alive
-    assert ws["512"].flags.writeable and np.array_equal(ws["512"], keep)
+    assert ws["32"].flags.writeable and np.array_equal(ws["32"], keep)
     w3 += 1.0
-    assert np.array_equal(ws["512"], keep)
+    assert np.array_equal(ws["32"], keep)
     del ws, w3
     w4 = ss.synth(g["sr"], h)                      # reuses a returned buffer
-    assert np.array_equal(w4, keep)
+    assert np.abs(w4 - keep).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
 def test_float64_signal_is_narrowed_like_the_kernels_do(amd):

@@ -59,6 +59,9 @@ def run(name, x, hop_s, check_frames=1500):
     e1.record(stream)
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / reps
+    if os.environ.get("SYNTH_TIME_NOCHECK"):
+        print(json.dumps(dict(signal=name, frames=F, partials=P, hop_s=hop_s, ms=round(ms, 4))), flush=True)
+        return
     FC = min(F, check_frames)
     hf, hm, hr = p.f[:FC], p.mag[:FC], p.realph[:FC]
     cpid, cst, cln = pvoracle.track(hf, hm)
@@ -72,5 +75,7 @@ def run(name, x, hop_s, check_frames=1500):
 
 x = c2_signal(secs)
 run("harmonic", x, 512)
+if os.environ.get("SYNTH_TIME_ONLY") == "harmonic":
+    sys.exit(0)
 run("harmonic_stretch700", x[: len(x) // 4], 700)
 run("white_noise", (0.1 * np.random.default_rng(7).standard_normal(len(x) // 2)).astype(np.float32), 512)
