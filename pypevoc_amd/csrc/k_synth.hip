@@ -80,14 +80,43 @@ __device__ __forceinline__ void fsincos(double x, double& s, double& c) {
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
 }
-// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702)
-__device__ inline double interp_w(double x, double h, double off, int nfr, const double* fp) {
+// a / b for a launch-wide b with rb = 1 / b correctly rounded (computed on the host): the quotient estimate, its exact
+// residual and one correction -- the correctly rounded quotient (Markstein), i.e. what the reference's division gives, in
+// three instructions instead of the ~35 of the general routine (no scaling or special cases needed: b is a hop, a sample
+// rate or a bin width, a a frequency or a phase)
+__device__ __forceinline__ double div_const(double a, double b, double rb) {
+    const double q = a * rb;
+    return __builtin_fma(__builtin_fma(-q, b, a), rb, q);
+}
+// the slope of a piece of np.interp: the breakpoints are h apart (exactly, unless the products h (off + j) round)
+__device__ __forceinline__ double slope_of(double num, double den, double h, double rh) {
+    return den == h ? div_const(num, h, rh) : num / den;
+}
+
+// exp(i x) - 1.  x is the change of a partial's phase increment from one sample to the next -- 2 pi / sr times a frequency
+// slope per sample: 1e-3 at the very most -- so the series do it (|x| < 2^-6: next terms x^10 / 10!, x^9 / 9!, below 1e-22);
+// anything larger: (-2 sin^2(x/2), 2 sin(x/2) cos(x/2))
+__device__ __forceinline__ void expm1i(double x, double& re, double& im) {
+    if (fabs(x) < 0.015625) {
+        const double z = x * x;
+        re = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
+        im = x * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    } else {
+        double s2, c2;
+        fsincos(0.5 * x, s2, c2);
+        re = -2.0 * s2 * s2;
+        im = 2.0 * s2 * c2;
+    }
+}
+
+// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); rh = 1 / h
+__device__ inline double interp_w(double x, double h, double rh, double off, int nfr, const double* fp) {
     if (nfr == 1) return fp[0];
     const double xlast = h * (off + (double)(nfr - 1));
     const double xfirst = h * (off + 0.0);
     if (x > xlast) return fp[nfr - 1];
     if (x < xfirst) return fp[0];
-    int j = (int)floor(x / h - off);
+    int j = (int)floor(x * rh - off);                          // (a guess: settled below)
     if (j < 0) j = 0;
     if (j > nfr - 1) j = nfr - 1;
     // settle on xp[j] <= x < xp[j+1] with the same xp values numpy compares against
@@ -97,7 +126,7 @@ __device__ inline double interp_w(double x, double h, double off, int nfr, const
     const double xj = h * (off + (double)j);
     if (xj == x) return fp[j];
     const double xj1 = h * (off + (double)(j + 1));
-    const double slope = (fp[j + 1] - fp[j]) / (xj1 - xj);
+    const double slope = slope_of(fp[j + 1] - fp[j], xj1 - xj, h, rh);
     return slope * (x - xj) + fp[j];
 }
 
@@ -107,29 +136,29 @@ __device__ inline double interp_w(double x, double h, double off, int nfr, const
 // evaluation formula as interp_w / numpy, hence the same values.
 struct Piece2 { double b1, xa, fa, sa, xb, fb, sb; };
 
-__device__ inline void piece_of(int j, double h, double off, int nfr, const double* fp, double& xj, double& fj, double& sj) {
+__device__ inline void piece_of(int j, double h, double rh, double off, int nfr, const double* fp, double& xj, double& fj, double& sj) {
     if (j < 0) { xj = 0.0; fj = fp[0]; sj = 0.0; return; }                          // left of xp[0]: fp[0]
     if (j >= nfr - 1) { xj = 0.0; fj = fp[nfr - 1]; sj = 0.0; return; }             // at / right of xp[last]
     xj = h * (off + (double)j);
     const double xj1 = h * (off + (double)(j + 1));
     fj = fp[j];
-    sj = (fp[j + 1] - fp[j]) / (xj1 - xj);
+    sj = slope_of(fp[j + 1] - fp[j], xj1 - xj, h, rh);
 }
 
-__device__ inline Piece2 make_piece2(double x0, double h, double off, int nfr, const double* fp) {
+__device__ inline Piece2 make_piece2(double x0, double h, double rh, double off, int nfr, const double* fp) {
     Piece2 q;
     int j;
     if (nfr == 1 || x0 < h * (off + 0.0)) j = -1;
     else {
-        j = (int)floor(x0 / h - off);
+        j = (int)floor(x0 * rh - off);
         if (j < 0) j = 0;
         if (j > nfr - 1) j = nfr - 1;
         while (j > 0 && x0 < h * (off + (double)j)) j--;
         while (j < nfr - 1 && x0 >= h * (off + (double)(j + 1))) j++;
     }
     if (nfr == 1) j = nfr;                                       // constant everywhere
-    piece_of(j, h, off, nfr, fp, q.xa, q.fa, q.sa);
-    piece_of(j + 1, h, off, nfr, fp, q.xb, q.fb, q.sb);
+    piece_of(j, h, rh, off, nfr, fp, q.xa, q.fa, q.sa);
+    piece_of(j + 1, h, rh, off, nfr, fp, q.xb, q.fb, q.sb);
     q.b1 = (j + 1 <= nfr - 1 && nfr > 1) ? h * (off + (double)(j + 1)) : INFINITY;
     return q;
 }
@@ -163,6 +192,7 @@ struct SynthK {
     int K, h, minframes, no_phcor, edgsam, EF, rps;
     int64_t edgsamp;
     double sr, dh, fstep, dfr, offf, sc, vr, vi;     // (vr, vi) = exp(i pi / edgsam)
+    double rsr, rdh, rfstep;                         // 1 / sr, 1 / dh, 1 / fstep, correctly rounded (div_const)
     // workspace
     unsigned long long* cursor;
     int* segflag;                    // [output segments]: 1 where k_synth_extras has something to add (k_synth_scatter zeroes, k_synth_params sets)
@@ -244,9 +274,9 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                     // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amplitude msig[0]
                     EdgeRec e;
                     e.o0 = (long long)st * h - q.edgsam;
-                    e.cfr = pf[0] * 1.0 / q.sr;
+                    e.cfr = div_const(pf[0] * 1.0, q.sr, q.rsr);
                     e.ph0 = pr[0];
-                    e.ah = interp_w(0.0, dh, offm, nfr, pm) / 2.;
+                    e.ah = interp_w(0.0, dh, q.rdh, offm, nfr, pm) / 2.;
                     fsincos(kPi2 * e.cfr, e.wi, e.wr);
                     e.pad0 = e.pad1 = 0;
                     q.att[li] = e;
@@ -259,25 +289,25 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                     BodyRec c;
                     const double nbase = dh * (double)ii;
                     // fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729)
-                    const double fs0 = interp_w(nbase, dh, offf, nfr, pf);
-                    const double fs1 = interp_w(nbase + dh, dh, offf, nfr, pf);
+                    const double fs1 = interp_w(nbase + dh, dh, q.rdh, offf, nfr, pf);
                     // fsig(nbase + m) = fa0 + fsa m for m < fmb, fb0 + fsb m beyond; msig likewise
                     {
-                        const Piece2 p2 = make_piece2(nbase, dh, offf, nfr, pf);
+                        const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offf, nfr, pf);
                         c.fa0 = p2.sa * (nbase - p2.xa) + p2.fa; c.fsa = p2.sa;
                         c.fb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.fsb = p2.sb;
                         const double d = ceil(p2.b1 - nbase);
                         c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
                     }
                     {
-                        const Piece2 p2 = make_piece2(nbase, dh, offm, nfr, pm);
+                        const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offm, nfr, pm);
                         c.ma0 = p2.sa * (nbase - p2.xa) + p2.fa; c.msa = p2.sa;
                         c.mb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.msb = p2.sb;
                         const double d = ceil(p2.b1 - nbase);
                         c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
                     }
                     // phase corrections, PVAnalysis.py:710-715
-                    const double phcor = q.no_phcor ? 0.0 : kPi * (fs1 - fs0) / q.fstep / 2.;
+                    const double fs0 = c.fa0;                                 // fsig(nbase): the first piece at m = 0, the same expression as np.interp's
+                    const double phcor = q.no_phcor ? 0.0 : div_const(kPi * (fs1 - fs0), q.fstep, q.rfstep) / 2.;
                     c.ph0 = pr[ii] + phcor;                                   // PVAnalysis.py:721
                     const double tmb = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
                     c.smb = c.fa0 * (double)c.fmb + c.fsa * tmb;              // sum of the first fmb terms
@@ -289,25 +319,25 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                         const double tm = 0.5 * (double)m * (double)(m - 1);
                         lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
                     }
-                    const double lastph = kPi2 * (lastsum / q.sr) + c.ph0;
+                    const double lastph = kPi2 * div_const(lastsum, q.sr, q.rsr) + c.ph0;
                     c.step = 0.0;
                     if (ii < nfr - 1) {
                         // discontinuity ramp towards the next point, PVAnalysis.py:724-729
-                        const double fs2 = interp_w(nbase + 2.0 * dh, dh, offf, nfr, pf);
-                        const double phcornext = q.no_phcor ? 0.0 : kPi * (fs2 - fs1) / q.fstep / 2.;
-                        const double phend = lastph + kPi2 * fs1 / q.sr;
+                        const double fs2 = interp_w(nbase + 2.0 * dh, dh, q.rdh, offf, nfr, pf);
+                        const double phcornext = q.no_phcor ? 0.0 : div_const(kPi * (fs2 - fs1), q.fstep, q.rfstep) / 2.;
+                        const double phend = lastph + div_const(kPi2 * fs1, q.sr, q.rsr);
                         const double arg = pr[ii + 1] + phcornext - phend + kPi;
                         double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
                         if (md != 0.0 && md < 0.0) md += kPi2;
-                        c.step = (md - kPi) / dh;                             // np.linspace(0, dph, h+1)[:-1]
+                        c.step = div_const(md - kPi, dh, q.rdh);              // np.linspace(0, dph, h+1)[:-1]
                     }
                     if (isr) {
                         // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amplitude msig[hop*nfr]
                         EdgeRec e;
                         e.o0 = ((long long)st + nfr) * h;
-                        e.cfr = pf[nfr - 1] * 1.0 / q.sr;
+                        e.cfr = div_const(pf[nfr - 1] * 1.0, q.sr, q.rsr);
                         e.ph0 = lastph;
-                        e.ah = interp_w(dh * (double)nfr, dh, offm, nfr, pm) / 2.;
+                        e.ah = interp_w(dh * (double)nfr, dh, q.rdh, offm, nfr, pm) / 2.;
                         fsincos(kPi2 * e.cfr, e.wi, e.wr);
                         e.pad0 = e.pad1 = 0;
                         q.rel[li] = e;
@@ -318,9 +348,8 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                         const double sc = q.sc;
                         c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
                         // rotations of the increment: exp(i x) - 1 = (-2 sin^2(x/2), 2 sin(x/2) cos(x/2)) -- x is tiny
-                        double s2, c2;
-                        fsincos(0.5 * c.fsa, s2, c2); c.dar = -2.0 * s2 * s2; c.dai = 2.0 * s2 * c2;
-                        fsincos(0.5 * c.fsb, s2, c2); c.dbr = -2.0 * s2 * s2; c.dbi = 2.0 * s2 * c2;
+                        expm1i(c.fsa, c.dar, c.dai);
+                        expm1i(c.fsb, c.dbr, c.dbi);
                         const double xb = c.step + __builtin_fma(c.fsb, (double)c.fmb, c.fb0);
                         fsincos(xb, c.wbi, c.wbr);
                         c.pad0 = c.pad1 = 0;
@@ -457,11 +486,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
     s_o[tid] = (int64_t)seg * h + s;
     s_len[tid] = live ? (flagged ? -len : len) : 0;
     __builtin_amdgcn_wave_barrier();
-    long long oo[4];
-    int ll[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { oo[i] = s_o[wbase + 16 * i + (lane >> 2)]; ll[i] = s_len[wbase + 16 * i + (lane >> 2)]; }
     if (__ballot(flagged) != 0ull) {
+        long long oo[4];
+        int ll[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { oo[i] = s_o[wbase + 16 * i + (lane >> 2)]; ll[i] = s_len[wbase + 16 * i + (lane >> 2)]; }
 #pragma unroll
         for (int c8 = 0; c8 < R / 8; c8++) {
 #pragma unroll
@@ -491,8 +520,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
 #pragma unroll
         for (int k = 0; k < R; k++) a[k] = 0.0;
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) ll[i] = ll[i] < 0 ? -ll[i] : ll[i];
     const bool mine = live && seg >= q.fb0 && seg < q.fb1;
     const int m0 = (seg - q.fx0) * K, m1 = m0 + K;                          // (a slice holds at most 2^20 + 2 EF K nodes)
     // the wave's segments and their body nodes (slice-local indices; wave-uniform)
@@ -520,10 +547,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
                     const BodyRec* c = (const BodyRec*)lds + (li - tile);
                     // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
                     const bool fa = s < c->fmb, ma = s < c->mmb;
-#ifdef PVX_AB_REP
-#pragma unroll 1
-                    for (int rep_ = 0; rep_ < PVX_AB_REP; rep_++) {
-#endif
                     PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
 #pragma unroll
                     for (int k = 0; k < R; k++) {
@@ -532,20 +555,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
                         PVX_CROT(wr, wi, dr, di);
                         ms += dms;
                     }
-#ifdef PVX_AB_REP
-                    }
-#endif
                 });
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // ---- the sums leave the same way
-#ifdef PVX_AB_NOSTORE
+    // ---- the sums leave the same way (the runs' places are fetched again: twelve registers not kept through the loop above)
+    long long oo[4];
+    int ll[4];
 #pragma unroll
-    for (int k = 0; k < R; k++) asm volatile("" :: "v"(a[k]));
-    if (q.wlen < 0)
-#endif
+    for (int i = 0; i < 4; i++) { oo[i] = s_o[wbase + 16 * i + (lane >> 2)]; const int l_ = s_len[wbase + 16 * i + (lane >> 2)]; ll[i] = l_ < 0 ? -l_ : l_; }
 #pragma unroll
     for (int c8 = 0; c8 < R / 8; c8++) {
 #pragma unroll
@@ -557,13 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
             const int k = 8 * c8 + 2 * (lane & 3);
             const long long o = oo[i] + k;
             const bool v0 = k < ll[i] && o < q.wlen, v1 = k + 1 < ll[i] && o + 1 < q.wlen;
-#ifdef PVX_AB_SC1
-            if (v0 && v1 && (o & 1) == 0) { typedef double d2_ __attribute__((ext_vector_type(2))); const d2_ vv = {v.x, v.y}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q.w + o), "v"(vv) : "memory"); }
-#elif defined(PVX_AB_NT)
-            if (v0 && v1 && (o & 1) == 0) { typedef double d2_ __attribute__((ext_vector_type(2))); const d2_ vv = {v.x, v.y}; __builtin_nontemporal_store(vv, (d2_*)(q.w + o)); }
-#else
             if (v0 && v1 && (o & 1) == 0) *(double2*)(q.w + o) = v;
-#endif
             else {
                 if (v0) q.w[o] = v.x;
                 if (v1) q.w[o + 1] = v.y;
@@ -738,12 +751,8 @@ size_t pvx_synth_ws_bytes(int64_t F, int K, int64_t P, int nfft, int hop_a, int 
     return ws_layout(F, K, P, EF, F + 2 + EF + 2).total;     // (segments of the longest waveform these frames can give)
 }
 
-int pvx_launch_synth_v1(const SynthParams& p_in, hipStream_t s);
-
 int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     if (p.wlen <= 0) return PVX_OK;
-    static const bool v1 = getenv("PVX_SYNTH_V1") != nullptr;
-    if (v1) return pvx_launch_synth_v1(p, s);
     const int h = p.hop_s;
     const int64_t nseg_all = (p.wlen + h - 1) / h;
     if (nseg_all > 0x7fffffffLL) { pvx_set_error("too many output segments"); return PVX_ERR_INVALID; }
@@ -759,6 +768,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         q.dfr = 1. / overlap / 2.;                                    // PVAnalysis.py:687
         q.offf = q.dfr + .5;
         q.sc = kPi2 / p.sr;
+        q.rsr = 1.0 / q.sr; q.rdh = 1.0 / q.dh; q.rfstep = 1.0 / q.fstep;
         q.edgsam = (int)(q.dfr * h * p.edge);                         // PVAnalysis.py:740
         const double dfr_s = (double)p.nfft / (double)p.hop_a / 2.;   // PVAnalysis.py:1055
         q.edgsamp = (int64_t)(p.edge * h * dfr_s);                    // PVAnalysis.py:1056

@@ -1798,7 +1798,7 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
-    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr; sp.no_phcor = (flags & PVX_SYNTH_NO_PHCOR) ? 1 : 0;
+    sp.w = d_w; sp.wlen = wlen; sp.no_phcor = (flags & PVX_SYNTH_NO_PHCOR) ? 1 : 0;
     return pvx_launch_synth(sp, (hipStream_t)stream);
 }
 
@@ -1813,7 +1813,7 @@ static int synth_slice(const double* d_f, const double* d_mag, const double* d_r
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
-    sp.w = d_w; sp.wlen = wlen; sp.slot_of = nullptr; sp.no_phcor = 0; sp.seg0 = seg0; sp.seg_count = seg_count;
+    sp.w = d_w; sp.wlen = wlen; sp.no_phcor = 0; sp.seg0 = seg0; sp.seg_count = seg_count;
     return pvx_launch_synth(sp, stream);
 }
 

@@ -165,17 +165,9 @@ struct SynthParams {
     int nfft, hop_a, hop_s, minframes;
     double* w;
     int64_t wlen;
-    int32_t* slot_of;     // workspace [F][K]... see k_synth.hip
     int no_phcor;         // PVX_SYNTH_NO_PHCOR: fstep=None partials (PV.py:710-713)
-    int nbatch;           // contributions gathered per round (set by pvx_launch_synth from the LDS budget)
     int64_t seg0 = 0;     // first output segment (hop) of this launch ...
     int64_t seg_count = 0;   // ... and how many (0: all from seg0 on)
-    // launch-wide constants, derived once by pvx_launch_synth with the reference's own expressions (as kernel arguments
-    // they live in scalar registers; derived in the kernel they were float64 vector arithmetic, i.e. a register pair each
-    // across the whole kernel)
-    double c_dh, c_fstep, c_dfr, c_offf, c_sc;
-    int c_edgsam, c_EF, c_WB, c_WL, c_htbits;
-    int64_t c_edgsamp;
     // device workspace of pvx_synth_ws_bytes() bytes (nullptr: a grow-only buffer per stream, owned by the library);
     // skip_prepare: the partial-major copy of the analysis arrays is already in `ws` (a later slice of the same waveform)
     void* ws = nullptr;
