@@ -373,6 +373,226 @@ __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
     PVX_STAMP(fb + wid == 1 && lane == 0, 3);
 }
 
+// ---- npks <= 8: a frame per LANE --------------------------------------------------------------------------------
+// A frame of 8 peaks keeps 8 of a wave's 64 lanes busy in k_track_links and still pays every wave-wide step of the loop
+// (1 200 wave instructions per frame: the tracker took longer than the analysis it follows).  With rows this short a lane
+// does a whole frame by itself -- both rows in registers, every loop unrolled over the 8 slots, no cross-lane step at all:
+// 64 frames per wave in ~2 500 instructions.  fc / fp is the correctly rounded quotient through the previous peak's
+// reciprocal (one division per previous peak instead of one per pair; Markstein: estimate, exact residual, one correction).
+// A workgroup is a chunk of 256 consecutive frames: it leaves the frames' links, the chunk-local creation ranks
+// (newbase[fr] = new partials of the chunk's earlier frames; the chunk's total in chunktot[c]) and every node's root as far
+// as the chunk knows it (pointer doubling in LDS, 8 rounds at most).
+constexpr int KL = 8;        // slots per frame in registers
+constexpr int CLL = 256;     // frames per workgroup = chunk
+__global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
+    __shared__ int R[CLL * KL];
+    __shared__ int wtot[CLL / 64], wamb[CLL / 64], wlast[CLL / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, K = p.K;
+    const int64_t fb = (int64_t)blockIdx.x * CLL, fr = fb + tid;
+    const bool live = fr < p.F;
+    double cf[KL], cm[KL], pf[KL], pm[KL];
+#pragma unroll
+    for (int s = 0; s < KL; s++) {
+        cf[s] = cm[s] = pf[s] = pm[s] = 0.0;
+        if (live && s < K) {
+            cf[s] = p.f[fr * K + s]; cm[s] = p.mag[fr * K + s];
+            if (fr > 0) { pf[s] = p.f[(fr - 1) * K + s]; pm[s] = p.mag[(fr - 1) * K + s]; }
+        }
+    }
+    // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first
+    // (np.argsort(mag)[::-1] / sorted(zip(pmag, pidx), reverse=True): see the header)
+    bool vc[KL], vp[KL];
+    int rc[KL], rp[KL], nc = 0, np_ = 0;
+#pragma unroll
+    for (int s = 0; s < KL; s++) { vc[s] = cf[s] > 0.0 && cm[s] > 0.0; vp[s] = pf[s] > 0.0 && pm[s] > 0.0; nc += vc[s]; np_ += vp[s]; }
+#pragma unroll
+    for (int s = 0; s < KL; s++) {
+        int a = 0, b = 0;
+#pragma unroll
+        for (int j = 0; j < KL; j++) {
+            if (j == s) continue;
+            a += vc[j] && (j > s ? cm[j] >= cm[s] : cm[j] > cm[s]);
+            b += vp[j] && (j > s ? pm[j] >= pm[s] : pm[j] > pm[s]);
+        }
+        rc[s] = vc[s] ? a : KL;
+        rp[s] = vp[s] ? b : KL;
+    }
+    // by rank: the new peaks' frequency and slot; the previous peaks' frequency, reciprocal, magnitude and slot
+    double cfs[KL], pfr[KL], rpf[KL], pmr[KL];
+    int csl[KL], psl[KL];
+    bool amb_any_pre = false;
+#pragma unroll
+    for (int c = 0; c < KL; c++) {
+        cfs[c] = 0.0; pfr[c] = 1.0; pmr[c] = 0.0; csl[c] = 0; psl[c] = 0;
+#pragma unroll
+        for (int s = 0; s < KL; s++) {
+            if (rc[s] == c) { cfs[c] = cf[s]; csl[c] = s; }
+            if (rp[s] == c) { pfr[c] = pf[s]; pmr[c] = pm[s]; psl[c] = s; }
+        }
+        rpf[c] = 1.0 / pfr[c];
+        // (a frequency whose reciprocal or quotients could leave the normal range: let the exact loop build the table)
+        if (c < np_ && !(pfr[c] > 1e-290 && pfr[c] < 1e290)) amb_any_pre = true;
+    }
+    // the assignment loop (PVAnalysis.py:903-957)
+    int link[KL], nrk[KL];
+#pragma unroll
+    for (int s = 0; s < KL; s++) { link[s] = -2; nrk[s] = -1; }
+    unsigned used = 0u, succ = 0u;
+    int nnew = 0;
+    bool amb_any = amb_any_pre;
+#pragma unroll
+    for (int c = 0; c < KL; c++) {
+        if (c < nc) {
+            const double fcur = cfs[c];
+            double st[KL], best = INFINITY, wm = 0.0;
+            int bi = -1, wo = 0;
+#pragma unroll
+            for (int i = 0; i < KL; i++) {
+                // fcur / pfr[i], correctly rounded; then dpitch2st, PVAnalysis.py:62-68, 914
+                const double q0 = fcur * rpf[i];
+                const double q = __builtin_fma(__builtin_fma(-q0, pfr[i], fcur), rpf[i], q0);
+                st[i] = (i < np_ && !((used >> i) & 1u)) ? fabs(17.312 * (q - 1.0)) : INFINITY;
+                if (st[i] < best) { best = st[i]; bi = i; wm = pmr[i]; wo = psl[i]; }       // first minimum: np.argmin, PVAnalysis.py:920
+            }
+            if (bi >= 0 && best < p.maxjmp) {                       // PVAnalysis.py:923
+                // another unused previous partial exactly as near AND exactly as strong as the winner: the reference would
+                // let the partial index decide (see the header)
+                int same = 0;
+#pragma unroll
+                for (int i = 0; i < KL; i++) same += (st[i] == best && pmr[i] == wm);
+                amb_any = amb_any || same > 1;
+                used |= 1u << bi;
+                succ |= 1u << wo;
+#pragma unroll
+                for (int s = 0; s < KL; s++) if (csl[c] == s) link[s] = wo;
+            } else {
+#pragma unroll
+                for (int s = 0; s < KL; s++) if (csl[c] == s) { link[s] = -1; nrk[s] = nnew; }     // add_empty_partial
+                nnew++;
+            }
+        }
+    }
+    // ---- the frame's rows of the table's workspace
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KL; s++) {
+            if (s < K) {
+                p.link[fr * K + s] = link[s] >= 0 ? link[s] : (link[s] == -2 ? -1 : -(nrk[s] + 2));   // the table's code (pvx_internal.h)
+                if (fr > 0) p.succ[(fr - 1) * K + s] = (unsigned char)((succ >> s) & 1u);
+                if (fr == p.F - 1) p.succ[fr * K + s] = 0;
+            }
+        }
+        p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0) | (nc > 0 ? kHasBit : 0);
+    }
+    // ---- creation ranks inside the chunk, the chunk's totals
+    const int mine = live ? nnew : 0;
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    const unsigned long long bamb = __ballot(live && amb_any), bhas = __ballot(live && nc > 0);
+    if (lane == 63) wtot[wid] = inc;
+    if (lane == 0) { wamb[wid] = bamb != 0ull; wlast[wid] = bhas ? (int)(fb + wid * 64 + 63 - __builtin_clzll(bhas)) : -1; }
+    // ---- roots: a new partial's root is its own node, a continued peak starts at its predecessor's node; pointer doubling
+    // until every node of the chunk names a root or a node of the frame before the chunk
+    const int nbase = (int)(fb * K);
+#pragma unroll
+    for (int s = 0; s < KL; s++)
+        R[tid * KL + s] = (!live || s >= K || link[s] == -2) ? -1 : (link[s] == -1 ? (int)(fr * K + s) : (int)((fr - 1) * K + link[s]));
+    __syncthreads();
+    if (live) {
+        int64_t before = 0;
+        for (int w = 0; w < wid; w++) before += wtot[w];
+        p.newbase[fr] = before + inc - mine;
+    }
+    if (tid == 0) {
+        int tot = 0, amb = 0, last = -1;
+        for (int w = 0; w < CLL / 64; w++) { tot += wtot[w]; amb |= wamb[w]; last = wlast[w] > last ? wlast[w] : last; }
+        p.chunktot[blockIdx.x] = tot | (amb ? kAmbBit : 0);
+        p.chunklast[blockIdx.x] = last;
+    }
+    for (int round = 0; round < 8; round++) {
+        int moved = 0;
+#pragma unroll
+        for (int s = 0; s < KL; s++) {
+            const int me = (int)(fr * K + s);
+            const int r = R[tid * KL + s];
+            if (r >= nbase && r != me) {                          // a node of this chunk that is not me: where does it point?
+                const int lr = r - nbase, lf = lr / K;
+                const int rr = R[lf * KL + (lr - lf * K)];
+                if (rr != r) { R[tid * KL + s] = rr; moved = 1; }
+            }
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KL; s++) if (s < K) p.root[fr * K + s] = R[tid * KL + s];
+    }
+}
+
+// The scan over the chunks' totals and the roots of the chunks' LAST frames, as k_track_boundaries does for k_track_links:
+// one workgroup; chunkbase[c] = new partials before chunk c.
+__global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    __shared__ int amb_s, last_s;
+    int32_t* rb = (int32_t*)smem;                                // [NCH][K]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int K = p.K;
+    const int64_t F = p.F;
+    const int NCH = (int)((F + CLL - 1) / CLL);
+    const int items = NCH * K;
+    auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) * CLL; return (e < F ? e : F) - 1; };
+    for (int w = tid; w < items; w += 1024) { const int c = w / K; rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
+    if (tid == 0) { carry_s = 0; amb_s = 0; last_s = -1; }
+    __syncthreads();
+    bool amb = false;
+    int last = -1;
+    for (int base = 0; base < NCH; base += 1024) {
+        const int c = base + tid;
+        const int raw = c < NCH ? p.chunktot[c] : 0;
+        amb = amb || (raw & kAmbBit);
+        if (c < NCH) { const int l = p.chunklast[c]; last = l > last ? l : last; }
+        const long long v = raw & (kAmbBit - 1);
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        long long run = carry_s + inc - v;
+        for (int w = 0; w < wid; w++) run += wsum[w];
+        if (c < NCH) p.chunkbase[c] = run;
+        __syncthreads();
+        if (tid == 1023) carry_s = run + v;
+        __syncthreads();
+    }
+    if (amb) amb_s = 1;
+    if (last >= 0) atomicMax(&last_s, last);
+    __syncthreads();
+    if (tid == 0) { p.chunkbase[NCH] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
+    for (int r = 0; (1 << r) < NCH; r++) {
+        int moved = 0;
+        for (int w = tid; w < items; w += 1024) {
+            const int v = rb[w];
+            if (v < 0) continue;                                  // empty slot
+            const int fv = v / K, cv = fv / CLL;                  // the frame and chunk v names
+            if (cv >= w / K) continue;                            // a root inside this item's own chunk: final
+            if (((fv + 1) & (CLL - 1)) != 0) continue;            // a root that is not on a chunk's last frame: final
+            const int nv = rb[cv * K + (v - fv * K)];
+            if (nv != v) { rb[w] = nv; moved = 1; }
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    for (int w = tid; w < items; w += 1024) { const int c = w / K; p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+}
+
 // The reference's loop as it stands (PVAnalysis.py:871-957), one wave, frames in order, partial indices at
 // hand: previous partials ordered by (magnitude, partial index) descending.  Only launched when
 // k_track_links met an exact double tie (see the header); O(F K) steps of one wave.
@@ -566,7 +786,7 @@ __global__ __launch_bounds__(256) void k_assign_chunked(TrackParams p) {
     const int64_t ifr = i / p.K;
     if ((int64_t)r < (ifr / p.chunk) * p.chunk * p.K) r = p.root[r];     // before the chunk: a last-frame node, final by now
     const int64_t rfr = r / p.K;
-    const int64_t pid = p.newbase[rfr] + (-(p.link[r] + 2));         // creation order, PVAnalysis.py:826
+    const int64_t pid = p.newbase[rfr] + (p.chunkbase ? p.chunkbase[rfr / p.chunk] : 0) + (-(p.link[r] + 2));   // creation order, PVAnalysis.py:826
     p.partial_id[i] = (int32_t)pid;
     const bool last = !p.succ[i];
     if (pid < p.cap) {
@@ -624,6 +844,24 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     if (p.F <= 0) return PVX_OK;
     const int64_t n = p.F * (int64_t)p.K;
     if (n >= 0x7fffffffLL) { pvx_set_error("F*K = %lld does not fit the 32-bit node index", (long long)n); return PVX_ERR_UNSUPPORTED; }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    {
+        // npks <= 8: a frame per lane (k_track_links_lane), while the last-frame rows of its chunks fit one workgroup's LDS
+        const int64_t nchl = (p.F + CLL - 1) / CLL;
+        const size_t blds = (size_t)nchl * p.K * 4;
+        if (p.K <= KL && blds <= 150 * 1024 && p.chunkbase && !getenv("PVX_TRACK_CHUNK") && !getenv("PVX_TRACK_GENERIC") && !getenv("PVX_TRACK_LARGE") &&
+            !getenv("PVX_TRACK_FPW") && !getenv("PVX_TRACK_WAVES")) {
+            p.chunk = CLL;
+            hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
+            if (blds > 48 * 1024)
+                PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+            hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);
+            hipLaunchKernelGGL(k_assign_chunked, dim3(nb), dim3(256), 0, s, p);
+            PVX_HIP_CHECK(hipGetLastError());
+            return PVX_OK;
+        }
+        p.chunkbase = nullptr;
+    }
     const int kp = (p.K + 1) & ~1;
     const size_t per_wave = WaveLds::bytes(kp);
     if (per_wave > 160 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
@@ -653,7 +891,6 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     else if (p.K <= 128) PVX_LINKS(2);
     else PVX_LINKS(4);
 #undef PVX_LINKS
-    const unsigned nb = (unsigned)((n + 255) / 256);
     const int64_t nch = (p.F + p.chunk - 1) / p.chunk;
     const size_t blds = (size_t)nch * p.K * 4;
     if (blds <= 150 * 1024 && !getenv("PVX_TRACK_LARGE")) {

@@ -1221,7 +1221,10 @@ static size_t track_ws_bytes(int64_t F, int K) {
     // link, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials, ambiguous, maxend int64; succ [F*K]
     size_t off = n * 4 * 2 + (size_t)F * 4;
     off = (off + 7) & ~(size_t)7;
-    return off + ((size_t)F + 1) * 8 + 24 + n;
+    off += ((size_t)F + 1) * 8 + 24 + n;
+    off = (off + 7) & ~(size_t)7;
+    const size_t nch = (size_t)(F + 255) / 256;                  // k_track_links_lane: chunkbase int64 [nch + 1], chunktot / chunklast int32 [nch]
+    return off + (nch + 1) * 8 + nch * 8;
 }
 
 // the tracker on device arrays with a caller-provided workspace of track_ws_bytes(F, K); returns P
@@ -1237,6 +1240,10 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
     tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
     tp.link = (int32_t*)(w + off_link); tp.root = (int32_t*)(w + off_root);
     tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
+    {
+        const size_t nch = (size_t)(F + 255) / 256, off_cb = (off_succ + n + 7) & ~(size_t)7;
+        tp.chunkbase = (int64_t*)(w + off_cb); tp.chunktot = (int32_t*)(w + off_cb + (nch + 1) * 8); tp.chunklast = tp.chunktot + nch;
+    }
     // { partials, exact double tie met, last frame with a point }: three single stores by the kernels.  In page-locked
     // host memory when the caller has some (the resident chain): the host reads them after the one synchronisation,
     // no copy operation behind the kernels.

@@ -149,6 +149,11 @@ struct TrackParams {
     int64_t* maxend;      // [1]  last frame that holds a point of any partial = max(SinSum.end) (PV.py:1059)
     int chunk, fpw;       // frames per k_track_links workgroup = chunk length of the root step (a power of two), and
                           // frames a wave takes in turn (set by pvx_launch_track)
+    // k_track_links_lane (npks <= 8): per chunk of 256 frames the partials it creates (flag bits as newcount), the last
+    // frame with a peak, and the scan of the totals; nullptr: newbase holds the scan over all frames
+    int32_t* chunktot = nullptr;     // [ceil(F / 256)]
+    int32_t* chunklast = nullptr;    // [ceil(F / 256)]
+    int64_t* chunkbase = nullptr;    // [ceil(F / 256) + 1]
     int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
                           //      the previous partials would decide an assignment (k_track.hip header)
 };
