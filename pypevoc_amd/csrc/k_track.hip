@@ -402,9 +402,9 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
     // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first
     // (np.argsort(mag)[::-1] / sorted(zip(pmag, pidx), reverse=True): see the header)
     bool vc[KL], vp[KL];
-    int rc[KL], rp[KL], nc = 0, np_ = 0;
+    int rc[KL], rp[KL], nc = 0;
 #pragma unroll
-    for (int s = 0; s < KL; s++) { vc[s] = cf[s] > 0.0 && cm[s] > 0.0; vp[s] = pf[s] > 0.0 && pm[s] > 0.0; nc += vc[s]; np_ += vp[s]; }
+    for (int s = 0; s < KL; s++) { vc[s] = cf[s] > 0.0 && cm[s] > 0.0; vp[s] = pf[s] > 0.0 && pm[s] > 0.0; nc += vc[s]; }
 #pragma unroll
     for (int s = 0; s < KL; s++) {
         int a = 0, b = 0;
@@ -417,52 +417,50 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
         rc[s] = vc[s] ? a : KL;
         rp[s] = vp[s] ? b : KL;
     }
-    // by rank: the new peaks' frequency and slot; the previous peaks' frequency, reciprocal, magnitude and slot
-    double cfs[KL], pfr[KL], rpf[KL], pmr[KL];
-    int csl[KL], psl[KL];
-    bool amb_any_pre = false;
+    // the new peaks by rank (frequency, slot); the previous peaks stay in their slots, with their reciprocals and ranks
+    double cfs[KL], rpf[KL];
+    int csl[KL];
+    bool amb_any = false;
 #pragma unroll
     for (int c = 0; c < KL; c++) {
-        cfs[c] = 0.0; pfr[c] = 1.0; pmr[c] = 0.0; csl[c] = 0; psl[c] = 0;
+        cfs[c] = 0.0; csl[c] = 0;
 #pragma unroll
-        for (int s = 0; s < KL; s++) {
+        for (int s = 0; s < KL; s++)
             if (rc[s] == c) { cfs[c] = cf[s]; csl[c] = s; }
-            if (rp[s] == c) { pfr[c] = pf[s]; pmr[c] = pm[s]; psl[c] = s; }
-        }
-        rpf[c] = 1.0 / pfr[c];
+        const double pfc = vp[c] ? pf[c] : 1.0;
+        rpf[c] = 1.0 / pfc;
         // (a frequency whose reciprocal or quotients could leave the normal range: let the exact loop build the table)
-        if (c < np_ && !(pfr[c] > 1e-290 && pfr[c] < 1e290)) amb_any_pre = true;
+        if (vp[c] && !(pfc > 1e-290 && pfc < 1e290)) amb_any = true;
     }
     // the assignment loop (PVAnalysis.py:903-957)
     int link[KL], nrk[KL];
 #pragma unroll
     for (int s = 0; s < KL; s++) { link[s] = -2; nrk[s] = -1; }
-    unsigned used = 0u, succ = 0u;
+    unsigned used = 0u;
     int nnew = 0;
-    bool amb_any = amb_any_pre;
 #pragma unroll
     for (int c = 0; c < KL; c++) {
         if (c < nc) {
             const double fcur = cfs[c];
             double st[KL], best = INFINITY, wm = 0.0;
-            int bi = -1, wo = 0;
+            int wo = -1, wr = KL;
 #pragma unroll
             for (int i = 0; i < KL; i++) {
-                // fcur / pfr[i], correctly rounded; then dpitch2st, PVAnalysis.py:62-68, 914
+                // fcur / pf[i], correctly rounded; then dpitch2st, PVAnalysis.py:62-68, 914
                 const double q0 = fcur * rpf[i];
-                const double q = __builtin_fma(__builtin_fma(-q0, pfr[i], fcur), rpf[i], q0);
-                st[i] = (i < np_ && !((used >> i) & 1u)) ? fabs(17.312 * (q - 1.0)) : INFINITY;
-                if (st[i] < best) { best = st[i]; bi = i; wm = pmr[i]; wo = psl[i]; }       // first minimum: np.argmin, PVAnalysis.py:920
+                const double q = __builtin_fma(__builtin_fma(-q0, pf[i], fcur), rpf[i], q0);
+                st[i] = (vp[i] && !((used >> i) & 1u)) ? fabs(17.312 * (q - 1.0)) : INFINITY;
+                // the first minimum in the order of the previous partials (np.argmin over the sorted list, PVAnalysis.py:893, 920)
+                if (st[i] < best || (st[i] == best && rp[i] < wr)) { best = st[i]; wm = pm[i]; wo = i; wr = rp[i]; }
             }
-            if (bi >= 0 && best < p.maxjmp) {                       // PVAnalysis.py:923
+            if (wo >= 0 && best < p.maxjmp) {                       // PVAnalysis.py:923
                 // another unused previous partial exactly as near AND exactly as strong as the winner: the reference would
                 // let the partial index decide (see the header)
                 int same = 0;
 #pragma unroll
-                for (int i = 0; i < KL; i++) same += (st[i] == best && pmr[i] == wm);
+                for (int i = 0; i < KL; i++) same += (st[i] == best && pm[i] == wm);
                 amb_any = amb_any || same > 1;
-                used |= 1u << bi;
-                succ |= 1u << wo;
+                used |= 1u << wo;
 #pragma unroll
                 for (int s = 0; s < KL; s++) if (csl[c] == s) link[s] = wo;
             } else {
@@ -472,6 +470,7 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
             }
         }
     }
+    const unsigned succ = used;                                      // by slot of frame fr-1: continued
     // ---- the frame's rows of the table's workspace
     if (live) {
 #pragma unroll
@@ -496,11 +495,12 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
     if (lane == 63) wtot[wid] = inc;
     if (lane == 0) { wamb[wid] = bamb != 0ull; wlast[wid] = bhas ? (int)(fb + wid * 64 + 63 - __builtin_clzll(bhas)) : -1; }
     // ---- roots: a new partial's root is its own node, a continued peak starts at its predecessor's node; pointer doubling
-    // until every node of the chunk names a root or a node of the frame before the chunk
-    const int nbase = (int)(fb * K);
+    // until every node of the chunk names a root or a node of the frame before the chunk.  In LDS a node is its index in
+    // the chunk (frame * 8 + slot), a node of the frame before the chunk kOut + its slot, an empty slot -1.
+    constexpr int kOut = 1 << 20;
 #pragma unroll
     for (int s = 0; s < KL; s++)
-        R[tid * KL + s] = (!live || s >= K || link[s] == -2) ? -1 : (link[s] == -1 ? (int)(fr * K + s) : (int)((fr - 1) * K + link[s]));
+        R[tid * KL + s] = (!live || s >= K || link[s] == -2) ? -1 : (link[s] == -1 ? tid * KL + s : (tid == 0 ? kOut + link[s] : (tid - 1) * KL + link[s]));
     __syncthreads();
     if (live) {
         int64_t before = 0;
@@ -517,11 +517,9 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
         int moved = 0;
 #pragma unroll
         for (int s = 0; s < KL; s++) {
-            const int me = (int)(fr * K + s);
             const int r = R[tid * KL + s];
-            if (r >= nbase && r != me) {                          // a node of this chunk that is not me: where does it point?
-                const int lr = r - nbase, lf = lr / K;
-                const int rr = R[lf * KL + (lr - lf * K)];
+            if (r >= 0 && r < kOut && r != tid * KL + s) {        // a node of this chunk that is not me: where does it point?
+                const int rr = R[r];
                 if (rr != r) { R[tid * KL + s] = rr; moved = 1; }
             }
         }
@@ -529,7 +527,12 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
     }
     if (live) {
 #pragma unroll
-        for (int s = 0; s < KL; s++) if (s < K) p.root[fr * K + s] = R[tid * KL + s];
+        for (int s = 0; s < KL; s++) {
+            if (s < K) {
+                const int r = R[tid * KL + s];
+                p.root[fr * K + s] = r < 0 ? -1 : (r >= kOut ? (int)((fb - 1) * K + (r - kOut)) : (int)((fb + (r >> 3)) * K + (r & 7)));
+            }
+        }
     }
 }
 

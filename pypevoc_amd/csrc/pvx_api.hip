@@ -1281,9 +1281,11 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     static std::mutex mu;
     static char* ws = nullptr;
     static size_t ws_cap = 0;
-    std::lock_guard<std::mutex> lk(mu);
+    static int64_t* pin3 = nullptr;         // { partials, exact double tie, last frame with a point } in page-locked memory:
+    std::lock_guard<std::mutex> lk(mu);     // the kernel's three stores are what the host waits for, no copy behind them
+    if (!pin3 && hipHostMalloc((void**)&pin3, 64, hipHostMallocDefault) != hipSuccess) { pin3 = nullptr; (void)hipGetLastError(); }
     if ((rc = grow_dev(&ws, &ws_cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
-    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, ws, (hipStream_t)stream, nullptr);
+    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, ws, (hipStream_t)stream, nullptr, pin3);
 }
 
 extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
