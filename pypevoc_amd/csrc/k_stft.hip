@@ -177,14 +177,17 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
 // straight to global memory.  nfft 4096: a workgroup of three teams (6 waves per CU, window table in LDS); nfft 8192: one
 // team (4 waves per CU).  One wave per frame with all S regions to itself held 4 / 2 waves per CU.  Window, join and untangle twiddles come
 // from global memory (L2-resident tables), the sub-transform tables stay in LDS.
-template <int R, int S, typename T> struct SplitGeo {
+// WIDE: float64 samples into the float64 transform -- the next row's samples wait in 2 R register pairs instead of 2 R
+// registers, so the window stays in LDS also at S = 4 (64 KB beside the 87 KB of regions and tables) and S = 2 runs two
+// teams per workgroup (512 registers per wave) instead of three: no register of these kernels lives in scratch.
+template <int R, int S, typename T, bool WIDE = false> struct SplitGeo {
     using G1 = StftGeo<R, T>;
     static constexpr int M1 = G1::M, M = M1 * S, N = 2 * M, LOGM1 = ilog2(M1);
     static constexpr int BUFC = G1::BUFC;                                                    // one region (complex)
     // S = 2: three teams (6 waves, 256 registers each) with the window in LDS; S = 4: one team (4 waves, up to 512
     // registers each: the window values of the next row are prefetched with its samples)
-    static constexpr bool WL = (S == 2);
-    static constexpr int TEAMS = WL ? 3 : 1;
+    static constexpr bool WL = (S == 2) || WIDE;
+    static constexpr int TEAMS = (S == 2) ? (WIDE ? 2 : 3) : 1;
     static constexpr size_t OFF_WIN = 0;                                                     // T [N]  window / wfact (WL)
     static constexpr size_t OFF_T1 = OFF_WIN + (WL ? (size_t)N * sizeof(T) : 0);             // cx [R][64]  W_M1^(l q)
     static constexpr size_t OFF_T2 = OFF_T1 + (size_t)R * 64 * 2 * sizeof(T);                // cx [R][P]   W_64^(l1 t2)
@@ -197,8 +200,8 @@ template <int R, int S, typename T> struct SplitGeo {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, int S, typename T, typename InT, bool CAND>
-__global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p) {
-    using G = SplitGeo<R, S, T>;
+__global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ? 384 : 256) void k_stft_split(StftParams p) {
+    using G = SplitGeo<R, S, T, (sizeof(T) == 8 && sizeof(InT) == 8)>;
     using G1 = StftGeo<R, T>;
     constexpr int M1 = G::M1, M = G::M, P = G1::P, PITCH = G1::PITCH;
     constexpr int NMASK = G::N - 1;
@@ -459,8 +462,13 @@ __global__ __launch_bounds__(S == 2 ? 384 : 256) void k_stft_split(StftParams p)
     }
 }
 
+template <int R, int S, typename T, bool WIDE> int launch_stft_split_g(const StftParams& p, int x_dtype, hipStream_t s);
 template <int R, int S, typename T> int launch_stft_split(const StftParams& p, int x_dtype, hipStream_t s) {
-    using G = SplitGeo<R, S, T>;
+    if (sizeof(T) == 8 && x_dtype == PVX_F64) return launch_stft_split_g<R, S, T, sizeof(T) == 8>(p, x_dtype, s);
+    return launch_stft_split_g<R, S, T, false>(p, x_dtype, s);
+}
+template <int R, int S, typename T, bool WIDE> int launch_stft_split_g(const StftParams& p, int x_dtype, hipStream_t s) {
+    using G = SplitGeo<R, S, T, WIDE>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;

@@ -459,7 +459,17 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     const void* fn = nullptr;
     switch (x_dtype) {
         case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4> : H ? (const void*)k_stft_pv<R, T, float, R / 2> : (const void*)k_stft_pv<R, T, float, 0>; break;
-        case PVX_F64: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : H ? (const void*)k_stft_pv<R, T, double, R / 2> : (const void*)k_stft_pv<R, T, double, 0>; break;
+        case PVX_F64:
+            if constexpr (sizeof(T) == 8 && R == 16) {
+                // float64 samples into the float64 transform at nfft 2048 with a hop that does not slide the window: the whole
+                // next row would wait in 64 registers beside the transform -- pvx_stft_pv_takes() sends that plan through
+                // k_stft + k_phase_peaks instead
+                if (H == 0) { pvx_set_error("k_stft_pv does not take float64 samples at nfft 2048 with hop %d", a.s.hop); return PVX_ERR_UNSUPPORTED; }
+                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : (const void*)k_stft_pv<R, T, double, R / 2>;
+            } else {
+                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : H ? (const void*)k_stft_pv<R, T, double, R / 2> : (const void*)k_stft_pv<R, T, double, 0>;
+            }
+            break;
         case PVX_I16: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4> : H ? (const void*)k_stft_pv<R, T, int16_t, R / 2> : (const void*)k_stft_pv<R, T, int16_t, 0>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
@@ -485,6 +495,12 @@ template <int R, typename T> bool pv_fits(int K) {
 }
 
 }  // namespace
+
+// does the one-launch kernel take this call?  (pvx_stft_pv_supported says whether the plan's shape fits at all)
+int pvx_stft_pv_takes(int nfft, int precision, int x_dtype, int hop) {
+    if (nfft == 2048 && precision == 64 && x_dtype == PVX_F64 && hop != 512 && hop != 1024) return 0;
+    return 1;
+}
 
 int pvx_stft_pv_supported(int nfft, int precision, int K) {
     if (precision != 64 && precision != 32) return 0;

@@ -616,7 +616,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
             fp.cand_y = p->d_cand_y; fp.cand_bin = p->d_cand_bin; fp.cand_stats = p->d_cand_stats; fp.cand_cap = p->cand_cap; fp.cand_thr = p->pkthresh;
             pp.cand_y = p->d_cand_y; pp.cand_bin = p->d_cand_bin; pp.cand_stats = p->d_cand_stats; pp.cand_cap = p->cand_cap;
         }
-        if (p->use_stft && p->use_stft_pv) {
+        if (p->use_stft && p->use_stft_pv && pvx_stft_pv_takes(p->nfft, p->precision, x_dtype, p->hop)) {
             // window + FFT + untangle + peaks of every row in one kernel (k_stft_pv.hip); the spectrum rows still land in
             // the workspace
             if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;

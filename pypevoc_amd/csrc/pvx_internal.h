@@ -123,6 +123,7 @@ int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* 
 int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
 // k_stft_pv.hip: k_stft + k_phase_peaks in one launch (nfft 512..2048 while the peak search fits the transform buffer)
 int pvx_stft_pv_supported(int nfft, int precision, int K);
+int pvx_stft_pv_takes(int nfft, int precision, int x_dtype, int hop);
 int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec, int64_t ldo, const void* twiddle, int x_dtype,
                        int precision, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);

@@ -317,6 +317,9 @@ CASES = [  # (seed, nsamp, nfft, hop, npks, pkthresh)
     (4, 20000, 1001, 333, 7, 0.005), (5, 7000, 256, 64, 70, 0.0), (6, 40000, 4096, 1024, 33, 0.001),
     (7, 5000, 128, 32, 64, 0.005), (8, 5000, 128, 100, 65, 0.3), (9, 70000, 16384, 4096, 9, 0.005),
     (10, 3000, 2048, 512, 8, 0.005),
+    # float64 samples at precision=64 where the next row's samples no longer fit beside the transform: nfft 2048 with a hop
+    # that does not slide the window (k_stft + k_phase_peaks), nfft 4096 / 8192 (k_stft_split with the window in LDS)
+    (11, 30000, 2048, 300, 8, 0.005), (12, 70000, 8192, 2048, 8, 0.005), (13, 40000, 4096, 700, 6, 0.005),
 ]
 
 
