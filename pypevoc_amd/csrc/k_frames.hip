@@ -90,3 +90,31 @@ int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStrea
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
 }
+
+// dst[i] = (float) src[i]: a device-resident float64 signal for the fused float32 kernels (pvx_api.hip, analyze_rows).
+// Streaming, 32 bytes in and 16 out per lane and trip; bound by HBM (12 bytes per sample).
+namespace {
+__global__ __launch_bounds__(256) void k_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const double2 a = ((const double2*)src)[2 * i], b = ((const double2*)src)[2 * i + 1];
+        ((float4*)dst)[i] = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (float)src[(n4 << 2) + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_narrow_any(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+}  // namespace
+
+int pvx_launch_narrow(const double* src, float* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return PVX_OK;
+    const int64_t want = (n / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+    if (((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0) hipLaunchKernelGGL(k_narrow, dim3(grid), dim3(256), 0, s, src, dst, n);
+    else hipLaunchKernelGGL(k_narrow_any, dim3(grid), dim3(256), 0, s, src, dst, n);
+    PVX_HIP_CHECK(hipGetLastError());
+    return PVX_OK;
+}

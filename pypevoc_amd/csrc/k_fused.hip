@@ -408,9 +408,8 @@ template <int R> int launch_fused_r(const FusedParams& p, int x_dtype, hipStream
     const void* fn = nullptr;
     switch (x_dtype) {
         case PVX_F32: fn = al2 ? (const void*)k_fused_pv<R, float, true> : (const void*)k_fused_pv<R, float, false>; break;
-        case PVX_F64: fn = (const void*)k_fused_pv<R, double, false>; break;
         case PVX_I16: fn = (const void*)k_fused_pv<R, int16_t, false>; break;
-        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+        default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // resident workgroups per CU: what LDS and registers admit (at most 2 waves per SIMD)
@@ -430,7 +429,6 @@ template <int R> int launch_fused_r(const FusedParams& p, int x_dtype, hipStream
             if (al2) hipLaunchKernelGGL((k_fused_pv<R, float, true>), grid, block, lds, s, p);
             else hipLaunchKernelGGL((k_fused_pv<R, float, false>), grid, block, lds, s, p);
             break;
-        case PVX_F64: hipLaunchKernelGGL((k_fused_pv<R, double, false>), grid, block, lds, s, p); break;
         default: hipLaunchKernelGGL((k_fused_pv<R, int16_t, false>), grid, block, lds, s, p); break;
     }
     PVX_HIP_CHECK(hipGetLastError());

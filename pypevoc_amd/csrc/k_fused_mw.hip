@@ -479,9 +479,8 @@ template <int R, int W> int launch_mw(const FusedParams& p, int x_dtype, hipStre
     const void* fn = nullptr;
     switch (x_dtype) {
         case PVX_F32: fn = al2 ? (const void*)k_fused_mw<R, W, float, true> : (const void*)k_fused_mw<R, W, float, false>; break;
-        case PVX_F64: fn = (const void*)k_fused_mw<R, W, double, false>; break;
         case PVX_I16: fn = (const void*)k_fused_mw<R, W, int16_t, false>; break;
-        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+        default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = 0;
@@ -501,7 +500,6 @@ template <int R, int W> int launch_mw(const FusedParams& p, int x_dtype, hipStre
             if (al2) hipLaunchKernelGGL((k_fused_mw<R, W, float, true>), grid, block, lds, s, p);
             else hipLaunchKernelGGL((k_fused_mw<R, W, float, false>), grid, block, lds, s, p);
             break;
-        case PVX_F64: hipLaunchKernelGGL((k_fused_mw<R, W, double, false>), grid, block, lds, s, p); break;
         default: hipLaunchKernelGGL((k_fused_mw<R, W, int16_t, false>), grid, block, lds, s, p); break;
     }
     PVX_HIP_CHECK(hipGetLastError());

@@ -492,9 +492,8 @@ template <int S> int launch_team(const FusedParams& p, int x_dtype, hipStream_t 
 #define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4> : H ? (const void*)k_fused_team<S, INT, AL, R / 2> : (const void*)k_fused_team<S, INT, AL, 0>)
     switch (x_dtype) {
         case PVX_F32: fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); break;
-        case PVX_F64: fn = PVX_TEAM_PICK(double, false); break;
         case PVX_I16: fn = PVX_TEAM_PICK(int16_t, false); break;
-        default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+        default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
 #undef PVX_TEAM_PICK
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

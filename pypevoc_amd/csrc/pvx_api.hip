@@ -188,6 +188,8 @@ struct pvx_plan {
     size_t w_cap = 0;
     void* d_sws = nullptr;                 // resynthesis workspace (k_synth.hip)
     size_t sws_cap = 0;
+    float* d_x32 = nullptr;                // a device-resident float64 signal narrowed for the fused float32 kernels
+    size_t x32_cap = 0;
     void* d_desc = nullptr;                // descriptor outputs (f0 / harmonic power)
     size_t desc_cap = 0;
     // optional stage timing (bench): events[4*i..4*i+3] bracket the three stages of chunk i
@@ -236,6 +238,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_tws) (void)hipFree(p->d_tws);
     if (p->d_w) (void)hipFree(p->d_w);
     if (p->d_sws) (void)hipFree(p->d_sws);
+    if (p->d_x32) (void)hipFree(p->d_x32);
     if (p->d_desc) (void)hipFree(p->d_desc);
     if (p->s_host) (void)hipStreamDestroy(p->s_host);
     if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
@@ -567,6 +570,7 @@ extern "C" int pvx_plan_get_timing(pvx_plan* plan, double* ms, int64_t* launches
 }
 
 // ---- run_pv ---------------------------------------------------------------------------------
+template <typename T> static int grow_dev(T** p, size_t* cap, size_t need);
 static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                         int64_t F, double* d_f, double* d_mag, double* d_ph, double* d_realph, double* d_binno,
                         double* d_t, double* d_totalmag, const double* d_prev0, hipStream_t s,
@@ -575,6 +579,15 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
     int rc;
     if (p->fft_mode >= 1 && p->fft_mode <= 5) {
         // one launch: window + FFT + peaks, no intermediate arrays (k_fused.hip / k_fused_mw.hip)
+        if (x_dtype == PVX_F64) {
+            // float64 samples already in HBM (the host entry points narrow while they stage): the fused kernels' first step
+            // is (float) x[n] -- done here in one pass, so that they exist for float32 and int16 samples only (a float64
+            // sample pair per lane and row cost them registers they do not have)
+            const size_t nel = (size_t)((nsig - 1) * sig_stride + nsamp);
+            if ((rc = grow_dev(&p->d_x32, &p->x32_cap, nel * 4)) != PVX_OK) return rc;
+            if ((rc = pvx_launch_narrow((const double*)d_x, p->d_x32, (int64_t)nel, s)) != PVX_OK) return rc;
+            d_x = p->d_x32; x_dtype = PVX_F32;
+        }
         FusedParams fp;
         fp.x = d_x; fp.sig_stride = sig_stride; fp.F = F; fp.total_rows = total_rows;
         fp.hop = p->hop; fp.K = p->npks; fp.rad = 5;                                     // PV.py:177
@@ -733,7 +746,10 @@ static int stage_ring(StageRing r) {
 }
 static int stage_ring(pvx_plan* p) { return stage_ring(StageRing{&p->h_ring, p->ev_ring}); }
 
-static int staged_copy(StageRing p_, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s) {
+// narrow: `host` holds float64 samples and the device gets them as float32 (`bytes` counts the float32 bytes): every
+// precision-32 kernel's first step is (float) x[n], so the staging threads do it while they copy -- the same rounding, half
+// the bytes over the link.
+static int staged_copy(StageRing p_, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s, bool narrow = false) {
     int rc = stage_ring(p_);
     if (rc != PVX_OK) return rc;
     struct { void* h_ring; hipEvent_t* ev_ring; } pp = {*p_.h_ring, p_.ev_ring}, *p = &pp;
@@ -741,23 +757,26 @@ static int staged_copy(StageRing p_, void* dev, void* host, size_t bytes, bool t
     (void)hipGetDevice(&devid);
     const size_t npieces = (bytes + kStagePiece - 1) / kStagePiece;
     int err[kStageMaxThreads] = {0};
-    auto worker = [&](int t) {
+    auto worker = [&](int t, int nthreads) {
         if (hipSetDevice(devid) != hipSuccess) { err[t] = 1; return; }
         size_t k = 0;
-        for (size_t i = (size_t)t; i < npieces; i += kStageThreads, k++) {
+        for (size_t i = (size_t)t; i < npieces; i += nthreads, k++) {
             const int slot = 2 * t + (int)(k & 1);
             char* pin = (char*)p->h_ring + (size_t)slot * kStagePiece;
             const size_t o = i * kStagePiece, c = bytes - o < kStagePiece ? bytes - o : kStagePiece;
             if (to_device) {
-                if (k >= 2 && hipEventSynchronize(p->ev_ring[slot]) != hipSuccess) { err[t] = 1; return; }    // the slot's previous DMA has read it
-                memcpy(pin, (const char*)host + o, c);
+                // the slot's previous DMA has read it -- of this call or of an earlier one on the same ring (nothing orders
+                // the host against those but this event; on an event never recorded the wait returns at once)
+                if (hipEventSynchronize(p->ev_ring[slot]) != hipSuccess) { err[t] = 1; return; }
+                if (narrow) narrow_f64_f32((const double*)host + o / 4, (float*)pin, c / 4);
+                else memcpy(pin, (const char*)host + o, c);
                 if (hipMemcpyAsync((char*)dev + o, pin, c, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(p->ev_ring[slot], s) != hipSuccess) { err[t] = 1; return; }
             } else {
                 // two DMAs of this thread in flight: piece k+1 lands while piece k is copied out
                 if (k == 0) {
                     if (hipMemcpyAsync(pin, (const char*)dev + o, c, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(p->ev_ring[slot], s) != hipSuccess) { err[t] = 1; return; }
                 }
-                const size_t in = i + kStageThreads;
+                const size_t in = i + nthreads;
                 if (in < npieces) {
                     const int ns = 2 * t + (int)((k + 1) & 1);
                     const size_t no = in * kStagePiece, nc = bytes - no < kStagePiece ? bytes - no : kStagePiece;
@@ -769,17 +788,27 @@ static int staged_copy(StageRing p_, void* dev, void* host, size_t bytes, bool t
             }
         }
     };
+    // (a thread that cannot be created must not take the process down through the C ABI: the copy then runs on this thread)
+    const bool one_thread = getenv("PVX_NO_STAGE_THREADS") != nullptr;
+    int nthreads = one_thread ? 1 : kStageThreads;
     std::thread th[kStageMaxThreads];
-    for (int t = 1; t < kStageThreads; t++) th[t] = std::thread(worker, t);
-    worker(0);
-    for (int t = 1; t < kStageThreads; t++) th[t].join();
-    for (int t = 0; t < kStageThreads; t++)
-        if (err[t]) { pvx_set_error("staged host transfer failed (%s)", hipGetErrorString(hipGetLastError())); return PVX_ERR_HIP; }
+    int started = 1;
+    try {
+        for (int t = 1; t < nthreads; t++) { th[t] = std::thread(worker, t, nthreads); started = t + 1; }
+    } catch (...) {
+        for (int t = 1; t < started; t++) th[t].join();
+        if (started > 1) { (void)hipStreamSynchronize(s); pvx_set_error("staged host transfer: could not start its threads"); return PVX_ERR_HIP; }
+        nthreads = 1;
+    }
+    worker(0, nthreads);
+    for (int t = 1; t < (started > 1 ? nthreads : 1); t++) th[t].join();
+    for (int t = 0; t < nthreads; t++)
+        if (err[t]) { (void)hipStreamSynchronize(s); pvx_set_error("staged host transfer failed (%s)", hipGetErrorString(hipGetLastError())); return PVX_ERR_HIP; }
     return PVX_OK;
 }
 
-static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s) {
-    return staged_copy(StageRing{&p->h_ring, p->ev_ring}, dev, host, bytes, to_device, s);
+static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to_device, hipStream_t s, bool narrow = false) {
+    return staged_copy(StageRing{&p->h_ring, p->ev_ring}, dev, host, bytes, to_device, s, narrow);
 }
 // Transfers between the CALLER's arrays and device memory.  A hipMemcpy of a pageable array of 1 MB or more makes the
 // runtime register (pin in place) that memory; when the caller frees the array -- result arrays: every call -- the next
@@ -918,10 +947,11 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     const size_t total_in = (size_t)((nsig - 1) * sig_stride + nsamp) * es;
     const size_t total_out = (size_t)nsig * F * per_frame_out;
     const bool small = nchunks == 1 && total_in + (keep ? 0 : total_out) <= kSmallCall;
-    // a float64 signal analysed at precision 32: every kernel's first step is (float)x[n], so the small-call path
-    // narrows while it stages (same rounding, half the bytes over PCIe, the aligned float loads on the device)
+    // a float64 signal analysed at precision 32: every kernel's first step is (float)x[n], so the host side narrows while it
+    // stages (same rounding, half the bytes over PCIe, the aligned float loads on the device) -- on the small-call path and
+    // in the staging threads of the large one
     const size_t spec_pin = (size_t)(p->N2 > 0 ? p->N2 : 1) * 16 + 256;       // the last spectrum lands behind the staged data
-    const bool narrow = small && p->precision == 32 && x_dtype == PVX_F64;
+    const bool narrow = p->precision == 32 && x_dtype == PVX_F64;
     const int dev_dtype = narrow ? PVX_F32 : x_dtype;
     const size_t des = narrow ? 4 : es;
 
@@ -990,8 +1020,8 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
         } else {
             // pageable: concurrent with the kernels of chunk c-1 on the plan's stream; large chunks through the threaded ring
             const bool threaded = getenv("PVX_NO_STAGE_THREADS") == nullptr;
-            if (threaded && in_bytes >= kStageMin) {
-                if ((rc = staged_copy(p, p->d_in[b], (void*)((const char*)x + in_off), in_bytes, true, s)) != PVX_OK) { p->progress_live = false; return rc; }
+            if (narrow || (threaded && in_bytes >= kStageMin)) {
+                if ((rc = staged_copy(p, p->d_in[b], (void*)((const char*)x + in_off), narrow ? in_bytes / 2 : in_bytes, true, s, narrow)) != PVX_OK) { p->progress_live = false; return rc; }
             } else {
                 if ((rc = host_to_device(p->d_in[b], (const char*)x + in_off, in_bytes)) != PVX_OK) { p->progress_live = false; return rc; }
             }

@@ -119,6 +119,7 @@ struct FrameParams;
 
 // launchers (defined in the .hip files)
 int pvx_launch_frames(const FrameParams& p, int x_dtype, int precision, hipStream_t s);
+int pvx_launch_narrow(const double* src, float* dst, int64_t n, hipStream_t s);   // dst[i] = (float) src[i]
 int pvx_launch_stft(const FrameParams& fp, void* spec, int64_t ldo, const void* twiddle, int x_dtype, int precision, hipStream_t s);
 int pvx_launch_phase_peaks(const PeaksParams& p, int precision, hipStream_t s);
 // k_stft_pv.hip: k_stft + k_phase_peaks in one launch (nfft 512..2048 while the peak search fits the transform buffer)

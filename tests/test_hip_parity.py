@@ -1428,6 +1428,33 @@ def test_large_host_transfers_through_the_threaded_ring(amd, monkeypatch):
     assert np.array_equal(w2, res["threads"][3]) and np.array_equal(w3, res["threads"][3])
 
 
+def test_chunks_of_a_large_signal_share_the_staging_ring(amd, monkeypatch):
+    """A resident run (PV.run_pv: nothing is fetched between chunks) whose input takes three chunks of 16 MB and more: every
+    chunk goes through the same page-locked ring, so a slot may only be refilled once the DMA of the chunk BEFORE has read
+    it (the wait of staged_copy on the slot's event).  Bit for bit the single-threaded transfer -- float32 samples, and
+    float64 samples, which the staging threads narrow on the way (the kernels' own first step: the float32 cast's numbers)."""
+    sr = 44100
+    n = 14 * 1024 * 1024 + 777
+    rng = np.random.default_rng(9)
+    t = np.arange(n) / float(sr)
+    x32 = (0.3 * np.sin(2 * np.pi * 330.0 * t * (1 + 0.01 * np.sin(2 * np.pi * 0.7 * t))) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    monkeypatch.setenv("PVX_MAX_DEVICE_BYTES", str(22 << 20))        # three chunks of ~18 MB of float32 samples (+ their results)
+    out = {}
+    for tag, x in (("f32", x32), ("f64", x32.astype(np.float64))):
+        for mode in ("threads", "plain"):
+            if mode == "plain":
+                monkeypatch.setenv("PVX_NO_STAGE_THREADS", "1")
+            p = run_pv(amd, x, sr, 2048, 512, 8, precision=32)
+            out[tag, mode] = (np.array(p.f), np.array(p.mag), np.array(p.realph), np.array(p.binno))
+            monkeypatch.delenv("PVX_NO_STAGE_THREADS", raising=False)
+    monkeypatch.delenv("PVX_MAX_DEVICE_BYTES")
+    whole = run_pv(amd, x32, sr, 2048, 512, 8, precision=32)
+    ref = (np.array(whole.f), np.array(whole.mag), np.array(whole.realph), np.array(whole.binno))
+    for key, got in out.items():
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), key
+
+
 def test_in_place_edit_of_a_fetched_result_leaves_the_resident_chain(amd):
     """The reference's f / mag / ph / realph are plain ndarrays that toSinSum (PVAnalysis.py:319) and calc_f0
     (PVAnalysis.py:379) read when they are called, so `pv.mag[pv.f > 2000] = 0` before tracking takes effect there.
