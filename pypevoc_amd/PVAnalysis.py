@@ -62,13 +62,18 @@ class _Result(object):
 
 
 try:
-    from xxhash import xxh3_64_intdigest as _digest
+    from xxhash import xxh3_64_intdigest as _digest          # optional: ~10 GB/s
 except ImportError:                                          # pragma: no cover
-    from zlib import crc32 as _digest
+    import hashlib
+
+    def _digest(buf):                                        # standard library: ~1 GB/s, 64 bits
+        return hashlib.blake2b(buf, digest_size=8).digest()
 
 
 def _fingerprint(a):
-    """Cheap content hash of a fetched result array (a few GB/s; only arrays the caller has read exist on the host)."""
+    """Content hash (64 bits) of a fetched result array: only arrays the caller has read exist on the host, and only they
+    are hashed again when toSinSum / synth / calc_f0 decide whether the results in HBM still are the results.  The
+    `totalmag` list is not tracked: nothing on the device-resident chain reads it."""
     return _digest(memoryview(np.ascontiguousarray(a)).cast("B"))
 
 

@@ -112,6 +112,9 @@ class PVBatch(object):
             # batch of short signals); the results leave for the host inside the call, so the plan is handed back at once
             self._plan = _Plan.acquire(self, self.sr, self.nfft, self.hop, K, self.peakthresh, self.win, self.precision,
                                        max_rows=B * (F + 1))
+            # (the pool is shared with PV: a plan last used by a PV with progress output still has that PV's callback)
+            _lib.check(lib.pvx_plan_set_progress(self._plan.handle, _lib.PROGRESS_FN(), None), "pvx_plan_set_progress")
+            self._plan.progress_owner = None
             if self._xdev is not None:
                 n = B * F * K
 

@@ -602,6 +602,10 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
            : (p->fft_mode == 2) ? pvx_launch_fused_mw(fp, p->nfft, x_dtype, s)
            : (p->fft_mode == 3) ? pvx_launch_fused_ring(fp, p->nfft, x_dtype, s)
            : (p->fft_mode == 5) ? pvx_launch_fused_team(fp, p->nfft, x_dtype, s) : pvx_launch_fused_rev(fp, p->nfft, x_dtype, s);
+        // (what the plan could not know when it chose the team kernel -- a salience radius beyond its fetch, a row count
+        // beyond 32 bits -- goes to the kernel of several waves per frame instead of failing the call)
+        if (rc == PVX_ERR_UNSUPPORTED && p->fft_mode == 5 && pvx_fused_mw_supported(p->nfft, p->precision, p->npks))
+            rc = pvx_launch_fused_mw(fp, p->nfft, x_dtype, s);
         if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }
