@@ -100,13 +100,13 @@ def alg_bytes(nfft=NFFT, hop=HOP, npks=NPKS, s=4, c=8):
 
 
 def csrc_sha16():
-    """Fingerprint of the kernel sources this library was built from (profiles taken with other sources are not quoted)."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "pypevoc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pypevoc_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Fingerprint of the kernel sources this library was built from (profiles taken with other sources are not quoted):
+    what the loaded library says about itself -- pypevoc_amd/_lib.py has refused it if the sources beside it differ."""
+    from pypevoc_amd import _lib
+    try:
+        return _lib.load().pvx_build_fingerprint().decode()
+    except Exception:
+        return _lib.source_fingerprint()
 
 
 def committed_traffic(kernel):

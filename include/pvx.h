@@ -49,6 +49,10 @@ typedef enum { PVX_F32 = 0, PVX_F64 = 1, PVX_I16 = 2 } pvx_dtype;
 int pvx_init(int device);
 const char* pvx_last_error(void);
 int pvx_version(void);
+/* Fingerprint of the kernel sources the library was built from: the first 16 hex digits of the sha256 over
+ * the .hip and .h files of pypevoc_amd/csrc in name order (pypevoc_amd/_lib.py refuses a library that does not match its sources;
+ * bench.py quotes committed profiles only when they carry the same fingerprint). */
+const char* pvx_build_fingerprint(void);
 /* Name of the device the library is bound to ("" before pvx_init). */
 const char* pvx_device_name(void);
 /* HIP device index the library is bound to (-1 before pvx_init) */

@@ -25,6 +25,7 @@ SIGNATURES = {
     "pvx_init": (ctypes.c_int, [ctypes.c_int]),
     "pvx_last_error": (ctypes.c_char_p, []),
     "pvx_version": (ctypes.c_int, []),
+    "pvx_build_fingerprint": (ctypes.c_char_p, []),
     "pvx_device_name": (ctypes.c_char_p, []),
     "pvx_device": (ctypes.c_int, []),
     "pvx_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
@@ -149,8 +150,30 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    want = source_fingerprint()
+    have = lib.pvx_build_fingerprint().decode()
+    if want is not None and have != want and not os.environ.get("PVX_ALLOW_STALE_LIB"):
+        raise ImportError(
+            "pypevoc_amd: %s was built from other sources (fingerprint %s, pypevoc_amd/csrc is %s) -- rebuild it with "
+            "`make -C pypevoc_amd/csrc` (PVX_ALLOW_STALE_LIB=1 loads it anyway)." % (LIB_PATH, have, want))
     _LIB = lib
     return lib
+
+
+def source_fingerprint():
+    """sha256 over pypevoc_amd/csrc/*.hip and *.h in name order, first 16 hex digits (the Makefile's build_sha.inc, the
+    library's pvx_build_fingerprint()); None when the sources are not beside the package."""
+    import glob
+    import hashlib
+    d = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")))
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, what="pvx call"):

@@ -245,6 +245,9 @@ static void plan_free(pvx_plan* p) {
     delete p;
 }
 
+#include "build_sha.inc"
+extern "C" const char* pvx_build_fingerprint(void) { return PVX_BUILD_SHA; }
+
 extern "C" int pvx_plan_destroy(pvx_plan* plan) {
     plan_free(plan);
     return PVX_OK;
