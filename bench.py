@@ -245,6 +245,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=tuple(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f64 / noise / violin lines (N = 1 only anyway)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the `config5` object (BASELINE config 5: the nfft x hop sweep at 96 kHz)")
+    ap.add_argument("--c5-seconds", type=int, default=3600, help="length of config 5's 96 kHz signal (BASELINE: 60 min = 1.38 GB of float32 in HBM)")
     ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: general path; 1 ... 5: fused kernels")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: consecutive steps alternate between two streams (hides the launch gap and the kernel tail; "
@@ -550,7 +552,7 @@ def main():
         self_check = cpu = None
         checks_failed = []
 
-        def check_block(h, o, F_, K_, nfft, hop, precision, what, well_conditioned=True):
+        def check_block(h, o, F_, K_, nfft, hop, precision, what, well_conditioned=True, sr=sr):
             """A timed result block (host copy, the reference's layout) against the oracle's result on the same signal,
             every frame; the tolerances of tests/test_hip_parity.py.  `well_conditioned=False` (noise, recordings at float32:
             thousands of peaks a float32 ulp apart in magnitude): the normalised errors only, and the share of frames whose
@@ -636,7 +638,7 @@ def main():
             h = out.cpu().numpy()
             return np.concatenate([h[: 5 * Fq * K], h[5 * Fq * K + Fq:], h[5 * Fq * K: 5 * Fq * K + Fq]])
 
-        f64 = workloads = other_nfft = chain = None
+        f64 = workloads = other_nfft = chain = config5 = None
         if extras_ok:
             from oracle import pvoracle
             pvoracle.build()
@@ -810,6 +812,55 @@ def main():
                         if not (same_tab and okw):
                             sys.stderr.write("bench.py: the tracker / resynthesis of the headline results differ from the oracle: %s\n" % json.dumps(chain))
                             checks_failed.append("chain")
+            # ---- BASELINE config 5: nfft {512 .. 8192} x hop {nfft/4, nfft/2} on a 60-min 96 kHz signal (345.6 M samples, 1.38 GB
+            # of float32 generated in HBM), every point timed with HIP events on the launch stream and the leading 60 s of its
+            # result checked against the oracle on the same samples
+            if not args.no_config5:
+                sr5, n5 = 96000, 96000 * args.c5_seconds
+                x5 = torch.empty(n5, dtype=torch.float32, device=dev)
+                g5 = torch.Generator(device=dev)
+                g5.manual_seed(1234)
+                for a5 in range(0, n5, 1 << 24):                      # the G4 generator (c2_signal) in float64 pieces on the device
+                    b5 = min(n5, a5 + (1 << 24))
+                    t5 = torch.arange(a5, b5, device=dev, dtype=torch.float64) / sr5
+                    ph5 = 2 * np.pi * 220.0 * (t5 - 0.01 / (2 * np.pi * 5.0) * torch.cos(2 * np.pi * 5.0 * t5))
+                    s5 = 0.001 * torch.randn(b5 - a5, generator=g5, device=dev, dtype=torch.float64)
+                    for hh in range(1, 9):
+                        s5 += 0.3 / hh * torch.sin(hh * ph5)
+                    x5[a5:b5] = s5.to(torch.float32)
+                del t5, ph5, s5
+                n60 = min(n5, 60 * sr5)
+                x60 = x5[:n60].cpu().numpy().astype(np.float64) if checks else None
+                points = []
+                for nf in (512, 1024, 2048, 4096, 8192):
+                    for hp in (nf // 4, nf // 2):
+                        pl = ctypes.c_void_p()
+                        wn = np.hanning(nf)
+                        _lib.check(lib.pvx_plan_create(ctypes.byref(pl), float(sr5), nf, hp, K, 0.005, _lib.dptr(wn), 32, 0), "pvx_plan_create")
+                        F5, ms5, out5 = quick(pl, x5, 3, nfft=nf, hop=hp)
+                        pt = dict(nfft=nf, hop=hp, frames=F5, ms_per_step=round(ms5, 4), value=round(F5 / ms5 * 1e3, 1), unit="frames/s",
+                                  fft_mode=int(lib.pvx_plan_get_fft_mode(pl)),
+                                  contract_target=round(0.6 * HBM_PEAK / alg_bytes(nfft=nf, hop=hp)["contract"], 1),
+                                  frac_of_hbm_at_fused_bytes=round(F5 / ms5 * 1e3 * alg_bytes(nfft=nf, hop=hp)["fused"] / HBM_PEAK, 4))
+                        pt["vs_contract_target"] = round(pt["value"] / pt["contract_target"], 3)
+                        if checks:
+                            o5 = pvoracle.analyze(x60, sr5, nf, hp, K)
+                            F60 = len(o5["t"])
+                            nk5 = F5 * K
+                            h5 = torch.cat([out5[i * nk5: i * nk5 + F60 * K] for i in range(5)] +
+                                           [out5[5 * nk5 + F5: 5 * nk5 + F5 + F60], out5[5 * nk5: 5 * nk5 + F60]]).cpu().numpy()
+                            ck = check_block(h5, o5, F60, K, nf, hp, 32, "config5 %d/%d" % (nf, hp), sr=sr5)
+                            ck["against"] = "oracle/pvoracle.c on the leading %d s of the same signal (%d frames)" % (n60 // sr5, F60)
+                            pt["self_check"] = ck
+                        points.append(pt)
+                        lib.pvx_plan_destroy(pl)
+                        del out5
+                        torch.cuda.empty_cache()
+                config5 = dict(signal="G4 generator at 96 kHz, %d s, %d samples of float32 resident in HBM, npks %d" % (args.c5_seconds, n5, K),
+                               timing="HIP events on the launch stream over 3 launches per point, after 2 untimed launches and <= 100 ms of clock ramp",
+                               points=points)
+                del x5
+                torch.cuda.empty_cache()
         if checks_failed or gather_check_failed:
             rc = 3
 
@@ -842,6 +893,8 @@ def main():
             line["other_nfft"] = other_nfft
         if chain:
             line["chain"] = chain
+        if config5:
+            line["config5"] = config5
         if gather_info:
             gather_info["ms_per_step_kernels_only"] = stage["step_ms_hip_events"]
             gather_info["exposed_ms_per_step"] = round(max(0.0, elapsed / args.steps * 1e3 - stage["step_ms_hip_events"]), 4)

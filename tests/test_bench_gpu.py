@@ -40,7 +40,7 @@ def test_bench_line_and_self_check():
 def test_bench_extras_are_all_checked_against_the_oracle():
     """The default line's extra objects on a short signal: float64, the other material, nfft 4096 / 8192, and the rest of
     the path (tracker + resynthesis on the headline results) -- every one of them carries an oracle check that passed."""
-    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "30"])
+    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "30", "--c5-seconds", "20"])
     assert rc == 0 and j is not None, err[-2000:]
     assert j["f64"]["self_check"]["ok"] and j["f64"]["white_noise"]["self_check"]["ok"]
     assert all(w["self_check"]["ok"] for w in j["workloads"].values())
@@ -48,6 +48,14 @@ def test_bench_extras_are_all_checked_against_the_oracle():
     c = j["chain"]
     assert c["tracker"]["check"]["ok"] and c["tracker"]["partials"] > 0 and c["tracker"]["value"] > 0
     assert c["resynthesis"]["check"]["ok"] and c["resynthesis"]["check"]["max_abs_err"] <= 1e-9 and c["resynthesis"]["value"] > 0
+    assert c["total"]["ms"] >= c["tracker"]["ms"] + c["resynthesis"]["ms"] and c["total_ms"] == c["total"]["ms"]
+    # BASELINE config 5 (here on a 20-s signal): all ten (nfft, hop) points, each timed, priced against the contract
+    # target and checked against the oracle
+    pts = j["config5"]["points"]
+    assert sorted((p["nfft"], p["hop"]) for p in pts) == sorted((n, h) for n in (512, 1024, 2048, 4096, 8192) for h in (n // 4, n // 2))
+    for p in pts:
+        assert p["self_check"]["ok"] and p["self_check"]["bad_peaks"] == 0 and p["self_check"]["ref_peaks"] > 0, p
+        assert p["value"] > 0 and p["contract_target"] > 0 and p["fft_mode"] in (4, 5)
 
 
 def test_bench_forced_gather_exercises_rccl():
