@@ -156,10 +156,12 @@ class _Plan(object):
 class PV(object):
     """Phase vocoder (pypevoc.PVAnalysis.PV, PVAnalysis.py:71-417) on an MI355X.
 
-    NOTE -- one behavioural difference from the reference if you only switch the import: the default `precision=32`
-    runs the transform in float32 on the device (results are float64 arrays of float32-FFT accuracy: same peak bins,
-    |df| <= 1e-3 Hz, |dmag|/mag <= 1e-5, |dph| <= 2e-5 rad, waveform <= 1e-4 max|w|).  Pass
-    `precision=64` for the reference's own float64 arithmetic end to end (|df| <= 1e-9 Hz, identical partial tables).
+    Precision follows the samples unless it is given: a float64 signal (what the reference's users hand over) is analysed in
+    the reference's own float64 arithmetic end to end (`precision=64`: |df| <= 1e-9 Hz, identical partial tables), a float32
+    or int16 signal in float32 on the device (`precision=32`, 2.7 x the frames per second: results are float64 arrays of
+    float32-FFT accuracy -- the same peak bins, and on the fixtures |df| <= 1e-3 Hz, |dmag|/mag <= 1e-5, |dph| <= 2e-5 rad,
+    waveform <= 1e-4 max|w|; on ill-conditioned material the bounds are the normalised ones of DESIGN.md section 4).  So
+    switching the import alone reproduces the reference; `precision=32` on float64 samples buys the speed.
 
     Everything else follows the reference: constructor arguments, attributes (`f, mag, ph, realph, binno, t, totalmag,
     nframes, win, wfact, fstep, dt, fbin, wfbin, oldfft, ...`), array layouts, `run_pv() / toSinSum() / calc_f0() /
@@ -174,7 +176,7 @@ class PV(object):
     totalmag = _Result("totalmag", 6)
 
     def __init__(self, x, sr, nfft=1024, hop=None, npks=20,
-                 pkthresh=0.005, wind=np.hanning, progress=True, precision=32):
+                 pkthresh=0.005, wind=np.hanning, progress=True, precision=None):
         '''
         Phase vocoder object (PVAnalysis.py:72-131).
         Arguments:
@@ -184,8 +186,9 @@ class PV(object):
             * npks = Maximum number of peaks at each frame
             * pkthresh = Threshold of peak amplitude relative of maximum
         Extra (not in the reference):
-            * precision = 32: float32 frames/spectra on the device (outputs float64, tolerances in
-                          DESIGN.md); 64: float64 end to end
+            * precision = 64: float64 end to end (the reference's arithmetic); 32: float32 frames/spectra on the
+                          device (outputs float64, tolerances in DESIGN.md); None: 64 for float64 samples, 32 for
+                          float32 / int16 samples
         '''
         self._xdev = None
         self._resident = False          # run_pv results are in the plan's resident block
@@ -212,6 +215,9 @@ class PV(object):
         self.peakthresh = pkthresh
         self.npeaks = npks
         self.nframes = 0
+        if precision is None:
+            dt_ = self._xdev.dtype if self._xdev is not None else self.x.dtype
+            precision = 32 if np.dtype(dt_) in (np.dtype(np.float32), np.dtype(np.int16)) else 64
         self.precision = precision
 
         # numpy's own windows are functions of nfft alone: their array and the sums below are kept per (function, nfft);

@@ -245,6 +245,7 @@ class DeviceSignal(object):
         self.ptr = int(cai["data"][0])
         self.shape = tuple(int(v) for v in cai["shape"])
         self.dtype_code = {"<f4": PVX_F32, "<f8": PVX_F64, "<i2": PVX_I16}[ts]
+        self.dtype = np.dtype(ts)
 
 
 def is_device_array(x):

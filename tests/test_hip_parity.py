@@ -18,12 +18,15 @@ precision=32 (float32 frames + spectra, float64 per-peak arithmetic): a float32 
 Measured values on MI355X (bench.py self_check) are 5-100x inside these bounds.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
 
 from .conftest import GOLDEN, golden_names, load_golden
 from .parity import compare_analysis, pv_result
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -343,6 +346,29 @@ def test_run_pv_matches_oracle_seeded(amd, oracle, case, precision):
                 w = ss.synth(22050.0, h)
                 ow = oracle.synth(p.f, p.mag, p.realph, opid, ost, oln, 22050.0, nfft, hop, h)
                 assert w.shape == ow.shape and np.abs(w - ow).max() <= 1e-10
+
+
+def test_precision_follows_the_samples_and_the_plateau_case_is_exact_at_64(amd, oracle):
+    """precision=None: float64 samples -> the reference's float64 arithmetic (a pure import switch reproduces the reference),
+    float32 / int16 samples -> float32 on the device.  And the one fuzz case tools/fuzz.py excuses at precision 32 (seed 91,
+    case 9632: a chirp's plateau at nfft 8192, |X| of neighbouring bins 7e-9 apart, which a float32 transform cannot
+    order) must come out EXACTLY at precision 64: every peak bin of the oracle's, |df| <= 1e-9 Hz."""
+    x = _rand_signal(3, 9000)
+    assert amd.PV(x, 22050.0, nfft=512, progress=False).precision == 64
+    assert amd.PV(x.astype(np.float32), 22050.0, nfft=512, progress=False).precision == 32
+    assert amd.PV((x * 20000).astype(np.int16), 22050.0, nfft=512, progress=False).precision == 32
+    assert amd.PV(x, 22050.0, nfft=512, progress=False, precision=32).precision == 32
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz
+    c = fuzz.make_case(91, 9632)
+    assert c["nfft"] == 8192
+    p = amd.PV(c["x"], c["sr"], nfft=c["nfft"], hop=c["hop"], npks=c["K"], pkthresh=c["thr"], progress=False)    # float64 samples: precision 64
+    assert p.precision == 64
+    p.run_pv()
+    o = oracle.analyze(c["x"], c["sr"], c["nfft"], c["hop"], c["K"], c["thr"])
+    cc = compare_analysis(pv_result(p), o, c["nfft"], c["hop"], c["sr"])
+    assert cc["bad_peaks"] == 0 and cc["frames_diff"] == 0
+    assert_f64(cc)
 
 
 def test_empty_and_minimal_inputs(amd, oracle):
