@@ -295,9 +295,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         }
         }
         const double lsum = (double)ls0 + (double)ls1;
-        maxe = wave_max(lmax);
-        mine = wave_min(lmin);
-        tot = wave_sum(lsum);
+        wave_max_min_sum_nn(lmax, lmin, lsum, maxe, mine, tot);
         wave_sync();
     };
 

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             join4_untangle<1024, F4::BUF, 256>(xz, Ly, twv, lt, Xa4IA(), lmax, lmin, ls0, ls1);
         }
         {
-            const float wm = wave_max(lmax), wn = wave_min(lmin);
-            const double wsum = wave_sum((double)ls0 + (double)ls1);
+            float wm, wn;
+            double wsum;
+            wave_max_min_sum_nn(lmax, lmin, (double)ls0 + (double)ls1, wm, wn, wsum);
             if (lane == 0) { Lpmax[wid] = wm; Lpmin[wid] = wn; Lpsum[wid] = wsum; }
         }
         team_sync();                                                // ---- B2: X, |X|^2 and the partial reductions

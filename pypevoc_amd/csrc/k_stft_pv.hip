@@ -307,7 +307,11 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
             wave_sync();                                              // dz is free: the magnitude row goes there
             if constexpr (LATE) { __builtin_amdgcn_sched_barrier(0); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3); __builtin_amdgcn_sched_barrier(0); }
             join4_emit<T>(in, tw3, lu, [&](int k, cx<T> x) {
+#ifndef PVX_AB_NO_ROWSTORE      // tools/ab: timing-only build without the spectrum rows in HBM (the peaks then read stale rows)
                 out[k] = x;
+#else
+                if (p.ldo < 0) out[k] = x;
+#endif
                 if (with_peaks) y[k] = x.x * x.x + x.y * x.y;
             });
         } else {

@@ -86,6 +86,43 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
 
+// The same reductions for the three quantities every spectrum row ends with -- max |X|^2, min |X|^2 (non-negative floats:
+// their bit patterns order like the values, so the steps are integer maxima / minima that the compiler folds into ONE
+// DPP-modified instruction each, v_max_u32_dpp, instead of v_mov_dpp + a canonicalising v_max + v_max) and the float64
+// energy -- with the rows joined by two row-broadcast steps (rows 1, 3 take row 0 / 2's lane 15, rows 2, 3 take lane 31)
+// and ONE readlane of lane 63 instead of four readlanes and a max3 per quantity.  Written as one function so that the
+// three dependent chains interleave: each fills the others' DPP hazard slots (s_nop before) and issue stalls.
+// The sum associates exactly as wave_sum does: xor 1, xor 2, half mirror, mirror, (row 0 + row 1) + (row 2 + row 3).
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL, int ROWS> __device__ __forceinline__ unsigned dpp_keep_u(unsigned v) {      // rows not in ROWS keep v
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ double dpp_keep_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, ROWS, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ void wave_max_min_sum_nn(float lmax, float lmin, double lsum, float& mx, float& mn, double& sm) {
+    unsigned a = __float_as_uint(lmax), b = __float_as_uint(lmin);
+    double s = lsum;
+#define PVX_STEP3(CTRL) a = umax_(a, dpp_u<CTRL>(a)); b = umin_(b, dpp_u<CTRL>(b)); s = s + dpp_d<CTRL>(s);
+    PVX_STEP3(0xB1) PVX_STEP3(0x4E) PVX_STEP3(0x141) PVX_STEP3(0x140)
+#undef PVX_STEP3
+    // rows 1 and 3 take the row before them, then rows 2 and 3 the first half: lane 63 holds everything
+    a = umax_(a, dpp_keep_u<0x142, 0xa>(a)); b = umin_(b, dpp_keep_u<0x142, 0xa>(b));
+    const double s1 = dpp_keep_d<0x142, 0xa>(s);
+    s = s + s1;                                                      // (rows 0 and 2 add themselves: never read)
+    a = umax_(a, dpp_keep_u<0x143, 0xc>(a)); b = umin_(b, dpp_keep_u<0x143, 0xc>(b));
+    const double s2 = dpp_keep_d<0x143, 0xc>(s);
+    s = s + s2;
+    mx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)a, 63));
+    mn = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)b, 63));
+    sm = rl_d(s, 63);
+}
+
 template <typename T> struct Key;
 template <> struct Key<float> {
     using type = unsigned int;
