@@ -109,25 +109,26 @@ __device__ __forceinline__ void expm1i(double x, double& re, double& im) {
     }
 }
 
-// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); rh = 1 / h
-__device__ inline double interp_w(double x, double h, double rh, double off, int nfr, const double* fp) {
-    if (nfr == 1) return fp[0];
+// np.interp(x, xp, fp) with xp[j] = h * (off + j), j < nfr (PVAnalysis.py:701-702); rh = 1 / h.  fp(j): point j of the partial
+// (an accessor: the points come from the partial-major copy, or straight from the analysis rows staged in LDS)
+template <class A> __device__ inline double interp_w(double x, double h, double rh, double off, int nfr, const A& fp) {
+    if (nfr == 1) return fp(0);
     const double xlast = h * (off + (double)(nfr - 1));
     const double xfirst = h * (off + 0.0);
-    if (x > xlast) return fp[nfr - 1];
-    if (x < xfirst) return fp[0];
+    if (x > xlast) return fp(nfr - 1);
+    if (x < xfirst) return fp(0);
     int j = (int)floor(x * rh - off);                          // (a guess: settled below)
     if (j < 0) j = 0;
     if (j > nfr - 1) j = nfr - 1;
     // settle on xp[j] <= x < xp[j+1] with the same xp values numpy compares against
     while (j > 0 && x < h * (off + (double)j)) j--;
     while (j < nfr - 1 && x >= h * (off + (double)(j + 1))) j++;
-    if (j == nfr - 1) return fp[j];
+    if (j == nfr - 1) return fp(j);
     const double xj = h * (off + (double)j);
-    if (xj == x) return fp[j];
+    if (xj == x) return fp(j);
     const double xj1 = h * (off + (double)(j + 1));
-    const double slope = slope_of(fp[j + 1] - fp[j], xj1 - xj, h, rh);
-    return slope * (x - xj) + fp[j];
+    const double slope = slope_of(fp(j + 1) - fp(j), xj1 - xj, h, rh);
+    return slope * (x - xj) + fp(j);
 }
 
 // np.interp restricted to a run of fewer than h consecutive sample positions x0, x0+1, ...: the
@@ -136,16 +137,16 @@ __device__ inline double interp_w(double x, double h, double rh, double off, int
 // evaluation formula as interp_w / numpy, hence the same values.
 struct Piece2 { double b1, xa, fa, sa, xb, fb, sb; };
 
-__device__ inline void piece_of(int j, double h, double rh, double off, int nfr, const double* fp, double& xj, double& fj, double& sj) {
-    if (j < 0) { xj = 0.0; fj = fp[0]; sj = 0.0; return; }                          // left of xp[0]: fp[0]
-    if (j >= nfr - 1) { xj = 0.0; fj = fp[nfr - 1]; sj = 0.0; return; }             // at / right of xp[last]
+template <class A> __device__ inline void piece_of(int j, double h, double rh, double off, int nfr, const A& fp, double& xj, double& fj, double& sj) {
+    if (j < 0) { xj = 0.0; fj = fp(0); sj = 0.0; return; }                          // left of xp[0]: fp(0)
+    if (j >= nfr - 1) { xj = 0.0; fj = fp(nfr - 1); sj = 0.0; return; }             // at / right of xp[last]
     xj = h * (off + (double)j);
     const double xj1 = h * (off + (double)(j + 1));
-    fj = fp[j];
-    sj = slope_of(fp[j + 1] - fp[j], xj1 - xj, h, rh);
+    fj = fp(j);
+    sj = slope_of(fp(j + 1) - fp(j), xj1 - xj, h, rh);
 }
 
-__device__ inline Piece2 make_piece2(double x0, double h, double rh, double off, int nfr, const double* fp) {
+template <class A> __device__ inline Piece2 make_piece2(double x0, double h, double rh, double off, int nfr, const A& fp) {
     Piece2 q;
     int j;
     if (nfr == 1 || x0 < h * (off + 0.0)) j = -1;
@@ -195,7 +196,8 @@ struct SynthK {
     double rsr, rdh, rfstep;                         // 1 / sr, 1 / dh, 1 / fstep, correctly rounded (div_const)
     // workspace
     unsigned long long* cursor;
-    int* segflag;                    // [output segments]: 1 where k_synth_extras has something to add (k_synth_scatter zeroes, k_synth_params sets)
+    int* segflag;                    // [output segments]: == gen where k_synth_extras has something to add (set by k_synth_params;
+    int gen;                         //  gen is the call's number on this workspace: nothing has to be cleared between calls)
     int64_t nseg_all;
     long long* off;                  // [P]  first point of the partial in the partial-major arrays; -1: it does not sound
     double *cf, *cm, *cr;            // [N]  partial-major f / mag / realph
@@ -237,7 +239,6 @@ __global__ __launch_bounds__(256) void k_synth_alloc(SynthK q) {
 
 __global__ __launch_bounds__(256) void k_synth_scatter(SynthK q) {
     const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (node < q.nseg_all) q.segflag[node] = 0;
     if (node >= q.N) return;
     const int pid = q.pid[node];
     if (pid < 0 || pid >= q.P) return;
@@ -251,10 +252,121 @@ __global__ __launch_bounds__(256) void k_synth_scatter(SynthK q) {
     q.cr[off + ii] = q.realph[node];
 }
 
+// The closed forms of node (fr, slot) -- point ii of a partial of nfr points starting at frame st, its points through the
+// accessors pf / pm / pr (f, mag, realph) -- into the slice's records; what it found: body / irregular body / attack / release
+struct NodeKinds { bool isb, isx, isa, isr; };
+template <class AF, class AM, class AR>
+__device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, int64_t node, int64_t fr, int st, int nfr, int ii_, const AF& pf, const AM& pm, const AR& pr) {
+    bool isb = false, isx = false, isa = false, isr = false;
+    const int ii = ii_, h = q.h;
+    const double dh = q.dh;
+    const double offf = q.offf, offm = q.dfr;                       // dfr + .5, dfr: PVAnalysis.py:701-702
+    if (ii == 0) {
+        // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amplitude msig[0]
+        EdgeRec e;
+        e.o0 = (long long)st * h - q.edgsam;
+        e.cfr = div_const(pf(0) * 1.0, q.sr, q.rsr);
+        e.ph0 = pr(0);
+        e.ah = interp_w(0.0, dh, q.rdh, offm, nfr, pm) / 2.;
+        fsincos(kPi2 * e.cfr, e.wi, e.wr);
+        e.pad0 = e.pad1 = 0;
+        q.att[li] = e;
+        isa = true;
+        for (int64_t sg = fr - q.EF; sg < fr; sg++) if (sg >= 0 && sg < q.nseg_all) q.segflag[sg] = q.gen;
+    }
+    const bool wantb = fr >= q.fb0 && fr < q.fb1;
+    isr = (ii == nfr - 1);
+    if (wantb || isr) {
+        BodyRec c;
+        const double nbase = dh * (double)ii;
+        // fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729)
+        const double fs1 = interp_w(nbase + dh, dh, q.rdh, offf, nfr, pf);
+        // fsig(nbase + m) = fa0 + fsa m for m < fmb, fb0 + fsb m beyond; msig likewise
+        {
+            const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offf, nfr, pf);
+            c.fa0 = p2.sa * (nbase - p2.xa) + p2.fa; c.fsa = p2.sa;
+            c.fb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.fsb = p2.sb;
+            const double d = ceil(p2.b1 - nbase);
+            c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+        }
+        {
+            const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offm, nfr, pm);
+            c.ma0 = p2.sa * (nbase - p2.xa) + p2.fa; c.msa = p2.sa;
+            c.mb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.msb = p2.sb;
+            const double d = ceil(p2.b1 - nbase);
+            c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
+        }
+        // phase corrections, PVAnalysis.py:710-715
+        const double fs0 = c.fa0;                                 // fsig(nbase): the first piece at m = 0, the same expression as np.interp's
+        const double phcor = q.no_phcor ? 0.0 : div_const(kPi * (fs1 - fs0), q.fstep, q.rfstep) / 2.;
+        c.ph0 = pr(ii) + phcor;                                   // PVAnalysis.py:721
+        const double tmb = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
+        c.smb = c.fa0 * (double)c.fmb + c.fsa * tmb;              // sum of the first fmb terms
+        c.tmb = tmb;
+        // ph[h-1] + ph0 (before the discontinuity ramp): prefix over the h - 1 terms fsig(nbase + 0 .. h-2)
+        double lastsum;
+        {
+            const int m = h - 1;
+            const double tm = 0.5 * (double)m * (double)(m - 1);
+            lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
+        }
+        const double lastph = kPi2 * div_const(lastsum, q.sr, q.rsr) + c.ph0;
+        c.step = 0.0;
+        if (ii < nfr - 1) {
+            // discontinuity ramp towards the next point, PVAnalysis.py:724-729
+            const double fs2 = interp_w(nbase + 2.0 * dh, dh, q.rdh, offf, nfr, pf);
+            const double phcornext = q.no_phcor ? 0.0 : div_const(kPi * (fs2 - fs1), q.fstep, q.rfstep) / 2.;
+            const double phend = lastph + div_const(kPi2 * fs1, q.sr, q.rsr);
+            const double arg = pr(ii + 1) + phcornext - phend + kPi;
+            double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
+            if (md != 0.0 && md < 0.0) md += kPi2;
+            c.step = div_const(md - kPi, dh, q.rdh);              // np.linspace(0, dph, h+1)[:-1]
+        }
+        if (isr) {
+            // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amplitude msig[hop*nfr]
+            EdgeRec e;
+            e.o0 = ((long long)st + nfr) * h;
+            e.cfr = div_const(pf(nfr - 1) * 1.0, q.sr, q.rsr);
+            e.ph0 = lastph;
+            e.ah = interp_w(dh * (double)nfr, dh, q.rdh, offm, nfr, pm) / 2.;
+            fsincos(kPi2 * e.cfr, e.wi, e.wr);
+            e.pad0 = e.pad1 = 0;
+            q.rel[li] = e;
+            for (int64_t sg = fr + 1; sg <= fr + q.EF; sg++) if (sg < q.nseg_all) q.segflag[sg] = q.gen;
+        }
+        if (wantb) {
+            // 2 pi / sr folded into the two-piece phase polynomial
+            const double sc = q.sc;
+            c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
+            // rotations of the increment: exp(i x) - 1 = (-2 sin^2(x/2), 2 sin(x/2) cos(x/2)) -- x is tiny
+            expm1i(c.fsa, c.dar, c.dai);
+            expm1i(c.fsb, c.dbr, c.dbi);
+            const double xb = c.step + __builtin_fma(c.fsb, (double)c.fmb, c.fb0);
+            fsincos(xb, c.wbi, c.wbr);
+            c.pad0 = c.pad1 = 0;
+            q.body[(fr - q.fb0) * q.K + (node - fr * q.K)] = c;
+            // does every run of k_synth_bodies lie on one piece of fsig and one of msig?  (a change at position x
+            // is harmless at 0, h, a cut, or a multiple of R past the cut before it)
+            auto on_edge = [&](int x) {
+                if (x <= 0 || x >= h || x == q.c1 || x == q.c2) return true;
+                const int base = x > q.c2 ? q.c2 : (x > q.c1 ? q.c1 : 0);
+                return (x - base) % q.R == 0;
+            };
+            isb = on_edge(c.fmb) && on_edge(c.mmb);
+            isx = !isb;
+            if (isx && fr < q.nseg_all) q.segflag[fr] = q.gen;
+        }
+    }
+    NodeKinds k;
+    k.isb = isb; k.isx = isx; k.isa = isa; k.isr = isr;
+    return k;
+}
+
 __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
     const int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nloc = (q.fx1 - q.fx0) * q.K;
-    bool isb = false, isx = false, isa = false, isr = false;
+    NodeKinds kd;
+    kd.isb = kd.isx = kd.isa = kd.isr = false;
     if (li < nloc) {
         const int64_t node = q.fx0 * q.K + li;
         const int64_t fr = node / q.K;
@@ -264,113 +376,87 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
             const int st = q.pst[pid], nfr = q.pln[pid];
             const int64_t ii64 = fr - st;
             if (off >= 0 && ii64 >= 0 && ii64 < nfr) {
-                const int ii = (int)ii64, h = q.h;
-                const double dh = q.dh;
-                const double* pf = q.cf + off;
-                const double* pm = q.cm + off;
-                const double* pr = q.cr + off;
-                const double offf = q.offf, offm = q.dfr;                       // dfr + .5, dfr: PVAnalysis.py:701-702
-                if (ii == 0) {
-                    // attack, PVAnalysis.py:742-745: output index st*h - edgsam + j, j < edgsam; amplitude msig[0]
-                    EdgeRec e;
-                    e.o0 = (long long)st * h - q.edgsam;
-                    e.cfr = div_const(pf[0] * 1.0, q.sr, q.rsr);
-                    e.ph0 = pr[0];
-                    e.ah = interp_w(0.0, dh, q.rdh, offm, nfr, pm) / 2.;
-                    fsincos(kPi2 * e.cfr, e.wi, e.wr);
-                    e.pad0 = e.pad1 = 0;
-                    q.att[li] = e;
-                    isa = true;
-                    for (int64_t sg = fr - q.EF; sg < fr; sg++) if (sg >= 0 && sg < q.nseg_all) q.segflag[sg] = 1;
-                }
-                const bool wantb = fr >= q.fb0 && fr < q.fb1;
-                isr = (ii == nfr - 1);
-                if (wantb || isr) {
-                    BodyRec c;
-                    const double nbase = dh * (double)ii;
-                    // fsig at nbase, nbase + h, nbase + 2 h (PVAnalysis.py:711-718, 724-729)
-                    const double fs1 = interp_w(nbase + dh, dh, q.rdh, offf, nfr, pf);
-                    // fsig(nbase + m) = fa0 + fsa m for m < fmb, fb0 + fsb m beyond; msig likewise
-                    {
-                        const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offf, nfr, pf);
-                        c.fa0 = p2.sa * (nbase - p2.xa) + p2.fa; c.fsa = p2.sa;
-                        c.fb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.fsb = p2.sb;
-                        const double d = ceil(p2.b1 - nbase);
-                        c.fmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
-                    }
-                    {
-                        const Piece2 p2 = make_piece2(nbase, dh, q.rdh, offm, nfr, pm);
-                        c.ma0 = p2.sa * (nbase - p2.xa) + p2.fa; c.msa = p2.sa;
-                        c.mb0 = p2.sb * (nbase - p2.xb) + p2.fb; c.msb = p2.sb;
-                        const double d = ceil(p2.b1 - nbase);
-                        c.mmb = d < 0.0 ? 0 : (d > dh ? h : (int)d);
-                    }
-                    // phase corrections, PVAnalysis.py:710-715
-                    const double fs0 = c.fa0;                                 // fsig(nbase): the first piece at m = 0, the same expression as np.interp's
-                    const double phcor = q.no_phcor ? 0.0 : div_const(kPi * (fs1 - fs0), q.fstep, q.rfstep) / 2.;
-                    c.ph0 = pr[ii] + phcor;                                   // PVAnalysis.py:721
-                    const double tmb = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
-                    c.smb = c.fa0 * (double)c.fmb + c.fsa * tmb;              // sum of the first fmb terms
-                    c.tmb = tmb;
-                    // ph[h-1] + ph0 (before the discontinuity ramp): prefix over the h - 1 terms fsig(nbase + 0 .. h-2)
-                    double lastsum;
-                    {
-                        const int m = h - 1;
-                        const double tm = 0.5 * (double)m * (double)(m - 1);
-                        lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
-                    }
-                    const double lastph = kPi2 * div_const(lastsum, q.sr, q.rsr) + c.ph0;
-                    c.step = 0.0;
-                    if (ii < nfr - 1) {
-                        // discontinuity ramp towards the next point, PVAnalysis.py:724-729
-                        const double fs2 = interp_w(nbase + 2.0 * dh, dh, q.rdh, offf, nfr, pf);
-                        const double phcornext = q.no_phcor ? 0.0 : div_const(kPi * (fs2 - fs1), q.fstep, q.rfstep) / 2.;
-                        const double phend = lastph + div_const(kPi2 * fs1, q.sr, q.rsr);
-                        const double arg = pr[ii + 1] + phcornext - phend + kPi;
-                        double md = fmod(arg, kPi2);                          // np.mod: sign of the divisor
-                        if (md != 0.0 && md < 0.0) md += kPi2;
-                        c.step = div_const(md - kPi, dh, q.rdh);              // np.linspace(0, dph, h+1)[:-1]
-                    }
-                    if (isr) {
-                        // release, PVAnalysis.py:748-751: output index (st+nfr)*h + j, j < edgsam; amplitude msig[hop*nfr]
-                        EdgeRec e;
-                        e.o0 = ((long long)st + nfr) * h;
-                        e.cfr = div_const(pf[nfr - 1] * 1.0, q.sr, q.rsr);
-                        e.ph0 = lastph;
-                        e.ah = interp_w(dh * (double)nfr, dh, q.rdh, offm, nfr, pm) / 2.;
-                        fsincos(kPi2 * e.cfr, e.wi, e.wr);
-                        e.pad0 = e.pad1 = 0;
-                        q.rel[li] = e;
-                        for (int64_t sg = fr + 1; sg <= fr + q.EF; sg++) if (sg < q.nseg_all) q.segflag[sg] = 1;
-                    }
-                    if (wantb) {
-                        // 2 pi / sr folded into the two-piece phase polynomial
-                        const double sc = q.sc;
-                        c.fa0 *= sc; c.fsa *= sc; c.fb0 *= sc; c.fsb *= sc; c.smb *= sc;
-                        // rotations of the increment: exp(i x) - 1 = (-2 sin^2(x/2), 2 sin(x/2) cos(x/2)) -- x is tiny
-                        expm1i(c.fsa, c.dar, c.dai);
-                        expm1i(c.fsb, c.dbr, c.dbi);
-                        const double xb = c.step + __builtin_fma(c.fsb, (double)c.fmb, c.fb0);
-                        fsincos(xb, c.wbi, c.wbr);
-                        c.pad0 = c.pad1 = 0;
-                        q.body[(fr - q.fb0) * q.K + (node - fr * q.K)] = c;
-                        // does every run of k_synth_bodies lie on one piece of fsig and one of msig?  (a change at position x
-                        // is harmless at 0, h, a cut, or a multiple of R past the cut before it)
-                        auto on_edge = [&](int x) {
-                            if (x <= 0 || x >= h || x == q.c1 || x == q.c2) return true;
-                            const int base = x > q.c2 ? q.c2 : (x > q.c1 ? q.c1 : 0);
-                            return (x - base) % q.R == 0;
-                        };
-                        isb = on_edge(c.fmb) && on_edge(c.mmb);
-                        isx = !isb;
-                        if (isx && fr < q.nseg_all) q.segflag[fr] = 1;
-                    }
-                }
+                const double* cf = q.cf + off;
+                const double* cm = q.cm + off;
+                const double* cr = q.cr + off;
+                kd = node_params(q, li, node, fr, st, nfr, (int)ii64, [&](int j) { return cf[j]; }, [&](int j) { return cm[j]; }, [&](int j) { return cr[j]; });
             }
         }
     }
-    const unsigned long long bb = __ballot(isb), bx = __ballot(isx), ba = __ballot(isa), br = __ballot(isr);
+    const unsigned long long bb = __ballot(kd.isb), bx = __ballot(kd.isx), ba = __ballot(kd.isa), br = __ballot(kd.isr);
     if ((threadIdx.x & 63) == 0) {
+        const int64_t w = li >> 6;
+        q.bbits[w] = bb; q.xbits[w] = bx; q.abits[w] = ba; q.rbits[w] = br;
+    }
+}
+
+// The same without the partial-major copy, for rows of at most 16 peaks: a workgroup's 256 nodes are consecutive, so the
+// frames their partials' points can sit in -- WB before the first, 3 behind the last -- are a short run of analysis rows:
+// partial_id, f, mag and realph of those rows are staged in LDS (one coalesced pass), a node finds the slots of its
+// partial's points by scanning the staged partial_id rows (a nibble per point in a 64-bit word) and reads the values where
+// they are.  No k_synth_alloc / k_synth_scatter, no second copy of the analysis arrays.
+constexpr int kDirectMaxK = 16, kDirectMaxWL = 16;
+__global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int K = q.K, tid = threadIdx.x;
+    const int64_t li0 = (int64_t)blockIdx.x * 256, li = li0 + tid;
+    const int64_t nloc = (q.fx1 - q.fx0) * K;
+    // frames of this workgroup's nodes and the rows staged around them
+    const int64_t nodeA = q.fx0 * K + li0, nodeB = q.fx0 * K + (li0 + 255 < nloc - 1 ? li0 + 255 : nloc - 1);
+    int64_t frow0 = nodeA / K - WB, frow1 = nodeB / K + 3 + 1;
+    if (frow0 < 0) frow0 = 0;
+    if (frow1 > q.F) frow1 = q.F;
+    const int nrows = (int)(frow1 - frow0);                          // <= rows_cap (host)
+    double* Lf = (double*)dsm;
+    double* Lm = Lf + (size_t)rows_cap * K;
+    double* Lr = Lm + (size_t)rows_cap * K;
+    int* Lp = (int*)(Lr + (size_t)rows_cap * K);
+    for (int i = tid; i < nrows * K; i += 256) {
+        const int64_t g = frow0 * K + i;
+        Lp[i] = q.pid[g]; Lf[i] = q.f[g]; Lm[i] = q.mag[g]; Lr[i] = q.realph[g];
+    }
+    __syncthreads();
+    NodeKinds kd;
+    kd.isb = kd.isx = kd.isa = kd.isr = false;
+    if (li < nloc) {
+        const int64_t node = q.fx0 * K + li;
+        const int64_t fr = node / K;
+        const int pid = Lp[(int)(node - frow0 * K)];
+        if (pid >= 0 && pid < q.P) {
+            const int st = q.pst[pid], nfr = q.pln[pid];
+            const int64_t ii64 = fr - st;
+            if (sounds(q, st, nfr) && ii64 >= 0 && ii64 < nfr) {
+                const int ii = (int)ii64;
+                // the slots of points j0 .. j1 of the partial (what the closed forms can touch: k_synth_params' window)
+                const int j0 = ii - WB > 0 ? ii - WB : 0, j1 = ii + 3 < nfr - 1 ? ii + 3 : nfr - 1;
+                unsigned long long slots = 0ull;
+                for (int j = j0; j <= j1; j++) {
+                    const int64_t f2 = (int64_t)st + j;
+                    unsigned key = 0x100u;                            // (different ? 256 : 0) + slot, minimum over the row
+                    if (f2 >= frow0 && f2 < frow1) {
+                        const int* row = Lp + (int)(f2 - frow0) * K;
+#pragma unroll
+                        for (int s2 = 0; s2 < kDirectMaxK; s2++) {
+                            if (s2 < K) {
+                                const unsigned d = (unsigned)(row[s2] ^ pid);
+                                const unsigned k2 = ((d < 1u ? d : 1u) << 8) | (unsigned)s2;     // (integer minima: no compare + select)
+                                key = k2 < key ? k2 : key;
+                            }
+                        }
+                    }
+                    slots |= (unsigned long long)(key & 15u) << (4 * (j - j0));
+                }
+                const int rbase = (int)((int64_t)st - frow0) * K;    // (row of point j: rbase / K + j)
+                auto at = [&](const double* L, int j) {
+                    int jj = j < j0 ? j0 : (j > j1 ? j1 : j);          // (never outside for a consistent table)
+                    return L[rbase + jj * K + (int)((slots >> (4 * (jj - j0))) & 15ull)];
+                };
+                kd = node_params(q, li, node, fr, st, nfr, ii, [&](int j) { return at(Lf, j); }, [&](int j) { return at(Lm, j); }, [&](int j) { return at(Lr, j); });
+            }
+        }
+    }
+    const unsigned long long bb = __ballot(kd.isb), bx = __ballot(kd.isx), ba = __ballot(kd.isa), br = __ballot(kd.isr);
+    if ((tid & 63) == 0) {
         const int64_t w = li >> 6;
         q.bbits[w] = bb; q.xbits[w] = bx; q.abits[w] = ba; q.rbits[w] = br;
     }
@@ -396,7 +482,8 @@ struct SampK {
     const BodyRec* body;                 // [(fb1 - fb0) K]
     const EdgeRec *att, *rel;            // [(fx1 - fx0) K]
     const unsigned long long *bbits, *xbits, *abits, *rbits;
-    const int* segflag;                  // per output segment: k_synth_extras has something to add (set by k_synth_params)
+    const int* segflag;                  // per output segment: == gen where k_synth_extras has something to add (set by k_synth_params)
+    int gen;
     double* w;
     int64_t wlen, seg0, nseg, nthreads;
     int fx0, fx1, fb0, fb1;              // frames whose edges / bodies the slice holds
@@ -482,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
     double a[R];
     // where this thread's run goes, for the lanes that move it between memory and the wave's staging rows (four lanes per
     // run, 8 doubles at a time: an instruction then touches the 64 contiguous bytes of 16 runs)
-    const bool flagged = live && q.segflag[seg] != 0;      // k_synth_extras has left this segment's attacks / releases in w
+    const bool flagged = live && q.segflag[seg] == q.gen;      // k_synth_extras has left this segment's attacks / releases in w
     s_o[tid] = (int64_t)seg * h + s;
     s_len[tid] = live ? (flagged ? -len : len) : 0;
     __builtin_amdgcn_wave_barrier();
@@ -609,7 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_
         // thread (i, j): segment j of chunk c0 + i gridDim.x
         const int i = tid_ >> 4, j = tid_ & 15;
         const int64_t ch = c0 + (int64_t)i * gridDim.x, sl_ = ch * 16 + j;
-        const bool f = ch < nchunks && sl_ < q.nseg && q.segflag[q.seg0 + sl_] != 0;
+        const bool f = ch < nchunks && sl_ < q.nseg && q.segflag[q.seg0 + sl_] == q.gen;
         // (lanes 16 i' .. 16 i' + 15 of a wave are one chunk: its flagged segments in ascending order)
         const unsigned long long bal = __ballot(f);
         const unsigned m16 = (unsigned)(bal >> ((tid_ & 63) & ~15)) & 0xffffu;
@@ -738,7 +825,7 @@ WsLayout ws_layout(int64_t F, int K, int64_t P, int EF, int64_t nseg_all) {
 
 // calls without a caller-owned workspace (pvx_synth_dev / pvx_synth): one grow-only buffer per stream -- calls on one
 // stream are ordered by the stream, calls on different streams must not share
-struct StreamWs { void* p = nullptr; size_t cap = 0; };
+struct StreamWs { void* p = nullptr; size_t cap = 0; unsigned gen = 0; };
 std::mutex g_ws_mu;
 std::map<hipStream_t, StreamWs> g_ws;
 
@@ -806,20 +893,31 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     if (nseg_all > p.F + 2 + q.EF + 2) { pvx_set_error("waveform of %lld samples is longer than %lld frames can give", (long long)p.wlen, (long long)p.F); return PVX_ERR_SIZE; }
     const WsLayout L = ws_layout(p.F, p.K, p.P, q.EF, p.F + 2 + q.EF + 2);
     char* base = (char*)p.ws;
+    unsigned* genp = p.ws_gen;                                        // the workspace's call counter (0: never used since it was allocated)
     if (!base) {
         std::lock_guard<std::mutex> lk(g_ws_mu);
         StreamWs& w = g_ws[s];
         if (w.cap < L.total) {
             if (w.p) (void)hipFree(w.p);                              // (synchronises with the device: no kernel still uses it)
-            w.p = nullptr; w.cap = 0;
+            w.p = nullptr; w.cap = 0; w.gen = 0;
             if (hipMalloc(&w.p, L.total) != hipSuccess) { pvx_set_error("hipMalloc(%zu) of the resynthesis workspace failed", L.total); w.p = nullptr; return PVX_ERR_ALLOC; }
             w.cap = L.total;
         }
         base = (char*)w.p;
-    } else if (p.ws_bytes < L.total) {
-        pvx_set_error("resynthesis workspace of %zu bytes, %zu needed", p.ws_bytes, L.total);
+        genp = &w.gen;
+    } else if (p.ws_bytes < L.total || !genp) {
+        pvx_set_error("resynthesis workspace of %zu bytes, %zu needed (and its call counter)", p.ws_bytes, L.total);
         return PVX_ERR_SIZE;
     }
+    // segment flags carry the number of the call that set them: a fresh workspace is cleared once, then never again
+    if (!p.skip_prepare) {
+        if (*genp == 0 || *genp >= 0x7ffffff0u) {
+            PVX_HIP_CHECK(hipMemsetAsync(base + L.segflag, 0, (size_t)(p.F + 2 + q.EF + 2 + 16) * 4, s));
+            *genp = 0;
+        }
+        ++*genp;
+    }
+    q.gen = (int)*genp;
     q.cursor = (unsigned long long*)(base + L.cursor);
     q.segflag = (int*)(base + L.segflag); q.nseg_all = nseg_all;
     q.off = (long long*)(base + L.off);
@@ -829,10 +927,18 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     q.w = p.w; q.wlen = p.wlen;
     q.fx0 = q.fx1 = q.fb0 = q.fb1 = 0; q.seg0 = 0; q.nseg = 0;
 
+    // rows of at most 16 peaks: the closed forms straight from the analysis rows (k_synth_params_direct); wider rows through
+    // the partial-major copy (searching a partial's slot in rows of 100 peaks costs more than copying its points once)
+    const int WB = (int)ceil(q.dfr + 0.5) + 2;                        // points a closed form can need behind its node
+    const bool direct = p.K <= kDirectMaxK && WB + 4 <= kDirectMaxWL && getenv("PVX_SYNTH_CSR") == nullptr;
+    const int rows_cap = 256 / p.K + 2 + WB + 4;
+    const size_t direct_lds = (size_t)rows_cap * p.K * 28;
     if (!p.skip_prepare) {
-        PVX_HIP_CHECK(hipMemsetAsync(q.cursor, 0, 8, s));
-        hipLaunchKernelGGL(k_synth_alloc, dim3((unsigned)((p.P + 255) / 256)), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(k_synth_scatter, dim3((unsigned)(((q.N > nseg_all ? q.N : nseg_all) + 255) / 256)), dim3(256), 0, s, q);
+        if (!direct) {
+            PVX_HIP_CHECK(hipMemsetAsync(q.cursor, 0, 8, s));
+            hipLaunchKernelGGL(k_synth_alloc, dim3((unsigned)((p.P + 255) / 256)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL(k_synth_scatter, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, s, q);
+        }
     }
     // a slice of the segments (p.seg_count > 0: pvx_synth_resident launches the waveform in slices whose DMA to the host
     // runs under the next slice's kernel)
@@ -847,11 +953,14 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         q.fx0 = s0 - q.EF > 0 ? s0 - q.EF : 0; if (q.fx0 > p.F) q.fx0 = p.F;
         q.fx1 = s1 + q.EF < p.F ? s1 + q.EF : p.F;
         const int64_t nloc = (q.fx1 - q.fx0) * p.K;
-        if (nloc > 0) hipLaunchKernelGGL(k_synth_params, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, s, q);
+        if (nloc > 0) {
+            if (direct) hipLaunchKernelGGL(k_synth_params_direct, dim3((unsigned)((nloc + 255) / 256)), dim3(256), direct_lds, s, q, WB, rows_cap);
+            else hipLaunchKernelGGL(k_synth_params, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, s, q);
+        }
         k.body = q.body; k.att = q.att; k.rel = q.rel; k.bbits = q.bbits; k.xbits = q.xbits; k.abits = q.abits; k.rbits = q.rbits;
         k.w = q.w; k.wlen = q.wlen; k.seg0 = s0; k.nthreads = q.nseg * k.rps;
         const int64_t grid_blocks = (k.nthreads + 255) / 256;
-        k.segflag = q.segflag;
+        k.segflag = q.segflag; k.gen = q.gen;
         k.fx0 = (int)q.fx0; k.fx1 = (int)q.fx1; k.fb0 = (int)q.fb0; k.fb1 = (int)q.fb1;
         k.K = p.K; k.h = h; k.EF = q.EF; k.edgsam = q.edgsam; k.vr = q.vr; k.vi = q.vi;
         // attacks and releases (and irregular bodies) first, into the flagged segments of w; k_synth_bodies starts from them

@@ -188,6 +188,7 @@ struct pvx_plan {
     size_t w_cap = 0;
     void* d_sws = nullptr;                 // resynthesis workspace (k_synth.hip)
     size_t sws_cap = 0;
+    unsigned sws_gen = 0;                  // calls on this workspace since it was allocated
     float* d_x32 = nullptr;                // a device-resident float64 signal narrowed for the fused float32 kernels
     size_t x32_cap = 0;
     void* d_desc = nullptr;                // descriptor outputs (f0 / harmonic power)
@@ -1333,7 +1334,7 @@ extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analys
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
                        double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
-                       void* ws, size_t ws_bytes);
+                       void* ws, size_t ws_bytes, unsigned* ws_gen);
 
 // ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
 extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
@@ -1386,7 +1387,12 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
     const int64_t need = pvx_synth_len(p->res_maxend, p->nfft, p->hop, hop_synth, edge);
     if (need < 0 || need != wlen) { pvx_set_error("output length %lld, expected %lld", (long long)wlen, (long long)need); return PVX_ERR_SIZE; }
     HostTrace tr("synth");
-    if ((rc = grow_dev(&p->d_sws, &p->sws_cap, pvx_synth_ws_bytes(p->res_F, p->npks, p->res_P, p->nfft, p->hop, hop_synth, edge))) != PVX_OK) return rc;
+    {
+        const void* before = p->d_sws;
+        const size_t cap_before = p->sws_cap;
+        if ((rc = grow_dev(&p->d_sws, &p->sws_cap, pvx_synth_ws_bytes(p->res_F, p->npks, p->res_P, p->nfft, p->hop, hop_synth, edge))) != PVX_OK) return rc;
+        if (p->d_sws != before || p->sws_cap != cap_before) p->sws_gen = 0;           // a new buffer: its flags are cleared on first use
+    }
     const HostOut all = block_ptrs(p->d_res, p->res_F, p->npks);
     const size_t bytes = (size_t)wlen * 8;
     hipPointerAttribute_t attr;
@@ -1398,7 +1404,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         // it (posted writes over PCIe, spread over the kernel's run time as workgroups finish) -- no copy operation
         // behind the kernel at all
         rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                         p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap);
+                         p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen);
         if (rc != PVX_OK) return rc;
         tr.mark("kernel issued");
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
@@ -1418,7 +1424,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
             if (s0 >= nseg) break;
             const int64_t cnt = nseg - s0 < per ? nseg - s0 : per;
             rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft, p->hop, hop_synth,
-                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0, p->d_sws, p->sws_cap);
+                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0, p->d_sws, p->sws_cap, &p->sws_gen);
             if (rc != PVX_OK) return rc;
             PVX_HIP_CHECK(hipEventRecord(p->ev_ring[i], p->s_host));
             PVX_HIP_CHECK(hipStreamWaitEvent(p->s_copy, p->ev_ring[i], 0));
@@ -1432,7 +1438,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         return PVX_OK;
     }
     rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                     p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap);
+                     p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen);
     if (rc != PVX_OK) return rc;
     if (pinned) {
         // the caller's array is page-locked: the DMA lands in it, nothing to stage or copy
@@ -1852,10 +1858,10 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
                        double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
-                       void* ws, size_t ws_bytes) {
+                       void* ws, size_t ws_bytes, unsigned* ws_gen) {
     SynthParams sp;
     sp.skip_prepare = first ? 0 : 1;          // the partial-major copy of the analysis arrays is made with the first slice
-    sp.ws = ws; sp.ws_bytes = ws_bytes;
+    sp.ws = ws; sp.ws_bytes = ws_bytes; sp.ws_gen = ws_gen;
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;

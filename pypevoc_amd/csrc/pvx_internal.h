@@ -179,6 +179,7 @@ struct SynthParams {
     // skip_prepare: the partial-major copy of the analysis arrays is already in `ws` (a later slice of the same waveform)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    unsigned* ws_gen = nullptr;   // with ws: the owner's call counter for it, 0 after every (re)allocation (k_synth.hip: segment flags)
     int skip_prepare = 0;
 };
 int pvx_launch_synth(const SynthParams& p, hipStream_t s);

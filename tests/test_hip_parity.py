@@ -245,6 +245,23 @@ def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
     assert np.abs(w4 - keep).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name", ["G4_harm8_vibrato", "G6_silence_gaps", "G12_hop_eighth", "G2_readme_defaulthop"])
+def test_synth_closed_forms_from_the_rows_equal_the_partial_major_copy(amd, name, monkeypatch):
+    """Rows of at most 16 peaks: k_synth_params_direct reads a partial's points where the analysis left them (rows staged in
+    LDS, the slots found by scanning partial_id); PVX_SYNTH_CSR=1 takes them through the partial-major copy instead
+    (k_synth_alloc / k_synth_scatter / k_synth_params: what wider rows always use).  The same arithmetic on the same
+    numbers: bit for bit the same waveform, at the analysis hop and time-stretched."""
+    g = load_golden(name)
+    ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    for h in (int(g["hop"]), int(g["hop"]) * 3 // 2 + 1):
+        w_direct = np.array(ss.synth(g["sr"], h))
+        monkeypatch.setenv("PVX_SYNTH_CSR", "1")
+        w_csr = np.array(ss.synth(g["sr"], h))
+        monkeypatch.delenv("PVX_SYNTH_CSR")
+        assert np.array_equal(w_direct, w_csr) and np.abs(w_direct).max() > 0
+
+
 def test_float64_signal_is_narrowed_like_the_kernels_do(amd):
     """precision=32 takes a float64 signal through float32 staging on the small-call path: the same numbers as
     handing over the float32 cast, and as the device-resident float64 signal."""
