@@ -512,6 +512,21 @@ template <class Fn> __device__ __forceinline__ void for_bits(const unsigned long
     }
 }
 
+// the same with the words wdA and wdB of the array already in registers
+template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned long long* bits, int n0, int n1, int wdA, unsigned long long wA,
+                                                                 int wdB, unsigned long long wB, Fn&& fn) {
+    for (int wd = n0 >> 6; wd <= ((n1 - 1) >> 6); wd++) {
+        unsigned long long mb = wd == wdA ? wA : (wd == wdB ? wB : bits[wd]);
+        if (wd == (n0 >> 6)) mb &= ~0ull << (n0 & 63);
+        if (wd == ((n1 - 1) >> 6) && (n1 & 63)) mb &= (1ull << (n1 & 63)) - 1ull;
+        while (mb) {
+            const int li = (wd << 6) + __builtin_ctzll(mb);
+            mb &= mb - 1ull;
+            fn(li);
+        }
+    }
+}
+
 // seeds of a body at sample s on the pieces (fa, ma): z = exp(i phase(s)), w = exp(i (phase(s+1) - phase(s))), amplitude
 #define PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)                                                                        \
     double ph_, dl_;                                                                                                \
@@ -609,6 +624,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
     }
     const bool mine = live && seg >= q.fb0 && seg < q.fb1;
     const int m0 = (seg - q.fx0) * K, m1 = m0 + K;                          // (a slice holds at most 2^20 + 2 EF K nodes)
+    // (the words of the body bits this run will walk, fetched now: their latency passes under the record tiles' copy)
+    const int wdA = m0 >> 6, wdB = (m1 - 1) >> 6;
+    unsigned long long wA = 0ull, wB = 0ull;
+    if (mine) { wA = q.bbits[wdA]; wB = q.bbits[wdB]; }
     // the wave's segments and their body nodes (slice-local indices; wave-uniform)
     {
         const int64_t gfirst = gid0 + wbase, glast = gfirst + 63 < q.nthreads - 1 ? gfirst + 63 : q.nthreads - 1;
@@ -630,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
             __builtin_amdgcn_wave_barrier();
             const int a0 = m0 > tile ? m0 : tile, a1 = m1 < tile + cnt ? m1 : tile + cnt;
             if (mine && a1 > a0) {
-                for_bits(q.bbits, a0, a1, [&](const int li) {
+                for_bits_pre(q.bbits, a0, a1, wdA, wA, wdB, wB, [&](const int li) {
                     const BodyRec* c = (const BodyRec*)lds + (li - tile);
                     // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
                     const bool fa = s < c->fmb, ma = s < c->mmb;
