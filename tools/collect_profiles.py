@@ -34,7 +34,7 @@ def short_name(k):
 
 # ---- SQ counters: every summary.json under gpurun_out/sq_<tag>*/
 sq = {"_csrc_sha16": SHA, "_tag": tag, "_frames_per_launch": FRAMES,
-      "_method": ("rocprofv3 --pmc <8 SQ counters per pass> -- python3 tools/run_mode.py -1 harmonic 8 4 [precision] | tools/run_chain.py "
+      "_method": ("rocprofv3 --pmc <8 SQ counters per pass> -- python3 tools/run_mode.py -1 harmonic 8 4 [precision] | tools/synth_time.py "
                   "(tools/prof_sq.sh): BASELINE config 2 signal, plan default fft mode; values are means over the kernel's launches; "
                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_BUSY_CU_CYCLES and "
                   "SQ_LDS_IDX_ACTIVE cycles summed over CUs")}
@@ -73,7 +73,7 @@ for d in sorted(glob.glob(os.path.join(G, "traffic_%s*" % tag))):
                          frames_per_launch=FRAMES, symbol=k, csrc_sha16=SHA, tag=tag, fetch_calibration_factor=round(factor, 4),
                          write_calibration_factor=round(wfactor, 4), launches=int(v["FETCH_SIZE"]["n"]))
 out["_method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_traffic.sh) over tools/run_mode.py / "
-                  "tools/run_chain.py on BASELINE config 2; FETCH_SIZE calibrated on tools/fetch_calib (1 GiB streamed with 8-byte-per-lane "
+                  "tools/synth_time.py on BASELINE config 2; FETCH_SIZE calibrated on tools/fetch_calib (1 GiB streamed with 8-byte-per-lane "
                   "loads reports half of the bytes on gfx950), WRITE_SIZE reads exact; earlier rounds: git log -- profiles/traffic_latest.json")
 json.dump(out, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
 json.dump(raw, open(os.path.join(P, "%s_traffic_pmc.json" % tag), "w"), indent=1)

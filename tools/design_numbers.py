@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerate the measured-numbers block of DESIGN.md (between the NUMBERS markers) from the committed profiles, so that the
-prose cannot drift from the evidence:   python tools/design_numbers.py [tag]        (default tag: r03)"""
+prose cannot drift from the evidence:   python tools/design_numbers.py [tag]        (default tag: r04)"""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 prev = "r%02d" % (int(tag[1:]) - 1)
 
 
@@ -74,14 +74,28 @@ if b:
         L.append("| `chain.tracker` (`k_track.hip`) | %s | %.3f ms (wall time of `pvx_track_dev`), %d partials; table identical to the oracle's: %s |" %
                  (M(t_["value"]), t_["ms"], t_["partials"], (t_.get("check") or {}).get("ok")))
         if r_:
-            L.append("| `chain.resynthesis` (`k_synth_ola`) | %s | %.3f ms per launch, %.1f M samples out (%.0f GB/s written); first 3000 frames against the oracle: ok = %s, \\|Δw\\| ≤ %.1e |" %
+            L.append("| `chain.resynthesis` (`k_synth.hip`) | %s | %.3f ms per call, %.1f M samples out (%.0f GB/s written); first 3000 frames against the oracle: ok = %s, \\|Δw\\| ≤ %.1e |" %
                      (M(r_["value"]), r_["ms"], r_["samples_out"] / 1e6, r_["output_GBps"], (r_.get("check") or {}).get("ok"), (r_.get("check") or {}).get("max_abs_err", 0)))
+        if ch.get("total"):
+            L.append("| `chain.total` | %s | **%.3f ms**: one analysis step + `pvx_track_dev` + `pvx_synth_dev` back to back on the resident signal, wall clock (goal %.2f ms) |" %
+                     (M(ch["total"]["value"]), ch["total"]["ms"], ch["total"].get("goal_ms", 0.55)))
     c = b.get("cpu_baseline")
     if c:
         L.append("| `cpu_baseline` | %s on %d threads | one thread %s; the Python reference %s (BASELINE.md) |" %
                  (M(c["value"]), c["cores"], M(c["single_thread"]["value"]), M(c["reference_python"]["value"])))
     L.append("")
 
+c5 = (b or {}).get("config5")
+if c5:
+    L.append("**BASELINE config 5 on the bench line (`config5`: %s; every point HIP-event timed and its leading 60 s checked against the oracle).**" % c5["signal"])
+    L.append("")
+    L.append("| nfft / hop | fft mode | frames/s | vs contract target | frac of HBM at the fused bytes | oracle check (peaks, missed, \\|Δf\\| Hz) |")
+    L.append("|---|---|---|---|---|---|")
+    for d in c5["points"]:
+        sc = d.get("self_check") or {}
+        L.append("| %d / %d | %d | %s | %.2f × | %.3f | ok = %s (%d, %d, %.1e) |" % (d["nfft"], d["hop"], d["fft_mode"], M(d["value"]), d["vs_contract_target"],
+                                                                                   d["frac_of_hbm_at_fused_bytes"], sc.get("ok"), sc.get("ref_peaks", 0), sc.get("bad_peaks", 0), sc.get("f_abs_Hz", 0)))
+    L.append("")
 sw, swp = jl("%s_config5_sweep.jsonl" % tag), jl("%s_config5_sweep.jsonl" % prev)
 if sw:
     pm = {(d["nfft"], d["hop"]): d for d in swp}
@@ -144,9 +158,6 @@ try:
         per = F if ("fused" in name or "stft" in name or "phase" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
         if per is None:
             continue
-        ms = re.search(r"k_synth_ola<(\d+)>", name)
-        if ms:                                    # launched in slices as well as whole: per output segment = per workgroup
-            per = g("SQ_WAVES") / (int(ms.group(1)) / 64.0)
         rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.3f | %.2f |" % (
             what, short.group(1)[:44] if short else name[:44], g("SQ_INSTS_VALU") / per, g("SQ_INSTS_SALU") / per, g("SQ_INSTS_LDS") / per,
             g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),

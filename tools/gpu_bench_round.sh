@@ -1,14 +1,16 @@
 # one GPU-box pass for a round: SQ counters, HBM traffic, kernel-trace stats, then the bench lines (which quote the
 # traffic / SQ profiles just taken: collect_profiles.py runs on the box first), the other BASELINE configs.
-# Outputs under gpurun_out/; afterwards, here: python tools/collect_profiles.py r03 && python tools/design_numbers.py r03
-T=r03
+# Outputs under gpurun_out/; afterwards, here: python tools/collect_profiles.py r04 && python tools/design_numbers.py r04
+T=r04
 bash tools/prof_sq.sh gpurun_out/sq_${T} -1; rm -rf gpurun_out/sq_${T}/g*/
 bash tools/prof_sq.sh gpurun_out/sq_${T}_f64 -1 harmonic 8 64; rm -rf gpurun_out/sq_${T}_f64/g*/
 PVX_RUN_NFFT=4096 bash tools/prof_sq.sh gpurun_out/sq_${T}_nfft4096 -1; rm -rf gpurun_out/sq_${T}_nfft4096/g*/
 PVX_RUN_NFFT=8192 bash tools/prof_sq.sh gpurun_out/sq_${T}_nfft8192 -1; rm -rf gpurun_out/sq_${T}_nfft8192/g*/
-PVX_PROF_PROG="tools/run_chain.py 2" bash tools/prof_sq.sh gpurun_out/sq_${T}_chain -1; rm -rf gpurun_out/sq_${T}_chain/g*/
+# the rest of the path, device to device, whole launches: tools/synth_time.py (analysis, pvx_track_dev, pvx_synth_dev x 3 on the C2 signal)
+SYNTH_TIME_NOCHECK=1 SYNTH_TIME_ONLY=harmonic PVX_PROF_PROG="tools/synth_time.py 600 3" bash tools/prof_sq.sh gpurun_out/sq_${T}_chain -1; rm -rf gpurun_out/sq_${T}_chain/g*/
 bash tools/prof_traffic.sh gpurun_out/traffic_${T}; rm -rf gpurun_out/traffic_${T}/*_SIZE/
 bash tools/prof_traffic.sh gpurun_out/traffic_${T}_f64 -1 harmonic 8 64; rm -rf gpurun_out/traffic_${T}_f64/*_SIZE/
+SYNTH_TIME_NOCHECK=1 SYNTH_TIME_ONLY=harmonic PVX_PROF_PROG="tools/synth_time.py 600 3" bash tools/prof_traffic.sh gpurun_out/traffic_${T}_chain; rm -rf gpurun_out/traffic_${T}_chain/*_SIZE/
 cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/stats_${T} -o r --output-format csv -- python3 /root/repo/bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > /root/repo/gpurun_out/stats_${T}.log 2>&1; cd /root/repo; ls gpurun_out/stats_${T}
 python tools/collect_profiles.py ${T} > gpurun_out/collect_${T}.log 2>&1; echo "collect rc=$?"
 python bench.py > gpurun_out/bench_${T}a.json 2> gpurun_out/bench_${T}a.err; echo "bench rc=$?"; tail -c 400 gpurun_out/bench_${T}a.err
