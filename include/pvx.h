@@ -178,8 +178,8 @@ int64_t pvx_track_resident(pvx_plan* plan, double maxpitchjmp, int64_t* max_end_
 int pvx_resident_fetch_table(pvx_plan* plan, int32_t* partial_id, int32_t* part_start, int32_t* part_len);
 int pvx_synth_resident(pvx_plan* plan, double sr, int hop_synth, double edge, int minframes, double* w, int64_t wlen);
 /* Page-locked host memory for result arrays.  pvx_synth_resident recognises such a destination: the waveform
- * (SinSum.synth's return value, PV.py:1070) is written straight into it -- by the kernel's own stores for a small
- * call (up to 4 MB; PVX_SYNTH_NO_ZEROCOPY disables that), by the DMA engine otherwise; any other pointer goes through
+ * (SinSum.synth's return value, PV.py:1070) is written straight into it by the DMA engine (with PVX_SYNTH_ZEROCOPY=1, up
+ * to 4 MB, by the kernels' own stores); any other pointer goes through
  * the plan's pinned staging block and one more host copy.  NULL (and pvx_last_error) on failure. */
 void* pvx_host_alloc(size_t bytes);
 void pvx_host_free(void* p);

@@ -488,6 +488,7 @@ struct SampK {
     int64_t wlen, seg0, nseg, nthreads;
     int fx0, fx1, fb0, fb1;              // frames whose edges / bodies the slice holds
     int K, h, EF, edgsam, rps;
+    int xcs;                             // k_synth_extras: log2 of its chunk of segments
     int c1, c2, n0, n1;                  // k_synth_bodies: the cuts of a segment's runs (RunCuts)
     double vr, vi;                       // k_synth_extras: exp(i pi / edgsam)
 };
@@ -495,7 +496,7 @@ struct SampK {
 // Waves per SIMD the register allocation aims at (R sums = 2 R registers + the recurrences' state; the compiler fills
 // whatever it is given with samples in flight)
 #ifndef PVX_SYNTH_WAVES
-#define PVX_SYNTH_WAVES(R) ((R) <= 16 ? 4 : 3)
+#define PVX_SYNTH_WAVES(R) ((R) <= 8 ? 5 : ((R) <= 16 ? 4 : 3))
 #endif
 
 // the set bits [n0, n1) of a bit array, in ascending order
@@ -701,36 +702,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_W
 // differ from the launch-wide one: pvx_launch_synth)
 template <int R, bool XB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_WAVES, PVX_EXTRAS_WAVES))) void k_synth_extras(SampK q) {
-    // The slice's segments in chunks of 16; workgroup b takes chunks b, b + gridDim.x, ...  The flags of 16 chunks are
-    // fetched in one go (k_synth_params wrote them long ago: a launch without work costs one load), the flagged segments
-    // of a chunk are listed in LDS and their runs dealt to the threads.
-    __shared__ int s_list[16][16];
-    __shared__ int s_n[16];
+    // The slice's segments in chunks of CS = 2^xcs (16 on a long waveform; fewer on a short one, so that its few segments
+    // still spread over the chip); workgroup b takes chunks b, b + gridDim.x, ...  The flags of 256 / CS chunks are fetched
+    // in one go (k_synth_params wrote them long ago: a launch without work costs one load), the flagged segments of a
+    // chunk are listed in LDS and their runs dealt to the threads.
+    __shared__ int s_list[256];
+    __shared__ int s_n[256];
     const int tid_ = threadIdx.x;
-    const int64_t nchunks = (q.nseg + 15) >> 4;
+    const int cs = q.xcs, CS = 1 << cs, NCF = 256 >> cs;              // chunk size, chunks per fetch
+    const int64_t nchunks = (q.nseg + CS - 1) >> cs;
 #pragma unroll 1
-    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += (int64_t)gridDim.x * 16) {
+    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += (int64_t)gridDim.x * NCF) {
     __syncthreads();
     {
         // thread (i, j): segment j of chunk c0 + i gridDim.x
-        const int i = tid_ >> 4, j = tid_ & 15;
-        const int64_t ch = c0 + (int64_t)i * gridDim.x, sl_ = ch * 16 + j;
+        const int i = tid_ >> cs, j = tid_ & (CS - 1);
+        const int64_t ch = c0 + (int64_t)i * gridDim.x, sl_ = (ch << cs) + j;
         const bool f = ch < nchunks && sl_ < q.nseg && q.segflag[q.seg0 + sl_] == q.gen;
-        // (lanes 16 i' .. 16 i' + 15 of a wave are one chunk: its flagged segments in ascending order)
+        // (lanes CS i' .. CS i' + CS - 1 of a wave are one chunk: its flagged segments in ascending order)
         const unsigned long long bal = __ballot(f);
-        const unsigned m16 = (unsigned)(bal >> ((tid_ & 63) & ~15)) & 0xffffu;
-        if (f) s_list[i][__popc(m16 & ((1u << j) - 1u))] = (int)(q.seg0 + sl_);
-        if (j == 0) s_n[i] = __popc(m16);
+        const unsigned mcs = (unsigned)(bal >> ((tid_ & 63) & ~(CS - 1))) & ((1u << CS) - 1u);
+        if (f) s_list[(i << cs) + __popc(mcs & ((1u << j) - 1u))] = (int)(q.seg0 + sl_);
+        if (j == 0) s_n[i] = __popc(mcs);
     }
     __syncthreads();
 #pragma unroll 1
-    for (int ic = 0; ic < 16; ic++) {
+    for (int ic = 0; ic < NCF; ic++) {
     const int total = s_n[ic] * q.rps;
 #pragma unroll 1
     for (int t = tid_; t < total; t += 256) {
     const int segl = t / q.rps;
     const int run = t - segl * q.rps;
-    const int seg = s_list[ic][segl];
+    const int seg = s_list[(ic << cs) + segl];
     const int h = q.h, K = q.K;
     const int s = run * R;
     const int len = h - s < R ? h - s : R;
@@ -741,20 +744,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_
     // (the attack / release launch leaves EVERY run of a flagged segment, zeros included: k_synth_bodies starts from them)
 #pragma unroll
     for (int k = 0; k < R; k++) a[k] = (XB && k < len && o + k < q.wlen) ? dst[k] : 0.0;
-#pragma unroll 1
-    for (int kind = XB ? 0 : 1; kind < (XB ? 1 : 3); kind++) {
-        // kind 0: bodies of frame seg; 1: attacks of partials starting at frames seg+1 .. seg+EF; 2: releases of partials
-        // whose last frame is seg-EF .. seg-1
-        int f0 = kind == 0 ? seg : (kind == 1 ? seg + 1 : seg - q.EF);
-        int f1 = kind == 0 ? seg + 1 : (kind == 1 ? seg + q.EF + 1 : seg);
-        const int lo = kind == 0 ? q.fb0 : q.fx0, hi = kind == 0 ? q.fb1 : q.fx1;
-        if (f0 < lo) f0 = lo;
-        if (f1 > hi) f1 = hi;
-        if (f1 <= f0) continue;
-        const unsigned long long* bits = kind == 0 ? q.xbits : (kind == 1 ? q.abits : q.rbits);
-        const int n0 = (f0 - q.fx0) * K, n1 = (f1 - q.fx0) * K;
-        for_bits(bits, n0, n1, [&](const int li) {
-            if constexpr (XB) {
+    if constexpr (XB) {
+        // the bodies of frame seg whose pieces change inside a run
+        int f0 = seg, f1 = seg + 1;
+        if (f0 < q.fb0) f0 = q.fb0;
+        if (f1 > q.fb1) f1 = q.fb1;
+        if (f1 > f0) {
+            const int n0 = (f0 - q.fx0) * K, n1 = (f1 - q.fx0) * K;
+            for_bits(q.xbits, n0, n1, [&](const int li) {
                 const BodyRec* c = q.body + (li - (q.fb0 - q.fx0) * K);
                 // leading samples of the run on the first piece of fsig (samples m < fmb; m = fmb sits on both) / of msig
                 int nfa = c->fmb - s, nma = c->mmb - s;
@@ -778,8 +775,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_
                         ms += dms;
                     }
                 }
-            } else {
-                const EdgeRec* e = (kind == 1 ? q.att : q.rel) + li;
+            });
+        }
+    } else {
+        // attacks of partials starting at frames seg+1 .. seg+EF (kind 1), then releases of partials whose last frame is
+        // seg-EF .. seg-1 (kind 2).  The record of the NEXT edge is fetched before the current one is worked on: on a short
+        // waveform a workgroup is one wave with nothing else to hide a load behind, and every edge would cost a round trip.
+        int kind = 0, wd = 0, wend = -1, n0 = 0, n1 = 0;
+        unsigned long long mb = 0ull;
+        auto masked = [&](const unsigned long long* bits, int w) {
+            unsigned long long m = bits[w];
+            if (w == (n0 >> 6)) m &= ~0ull << (n0 & 63);
+            if (w == ((n1 - 1) >> 6) && (n1 & 63)) m &= (1ull << (n1 & 63)) - 1ull;
+            return m;
+        };
+        auto advance = [&]() -> int {                                 // the next edge's node (kind set), or -1
+            for (;;) {
+                if (mb) { const int b = __builtin_ctzll(mb); mb &= mb - 1ull; return (wd << 6) + b; }
+                if (wd < wend) { wd++; mb = masked(kind == 1 ? q.abits : q.rbits, wd); continue; }
+                if (kind >= 2) return -1;
+                kind++;
+                int f0 = kind == 1 ? seg + 1 : seg - q.EF, f1 = kind == 1 ? seg + q.EF + 1 : seg;
+                if (f0 < q.fx0) f0 = q.fx0;
+                if (f1 > q.fx1) f1 = q.fx1;
+                wend = -1; wd = 0;
+                if (f1 <= f0) continue;
+                n0 = (f0 - q.fx0) * K; n1 = (f1 - q.fx0) * K;
+                wd = n0 >> 6; wend = (n1 - 1) >> 6;
+                mb = masked(kind == 1 ? q.abits : q.rbits, wd);
+            }
+        };
+        auto process = [&](const int kind, const EdgeRec& er) {
+            const EdgeRec* e = &er;
                 const long long j0l = (long long)seg * h + s - e->o0;
                 if (j0l + R <= 0 || j0l >= q.edgsam) return;
                 const int j0 = (int)j0l;
@@ -799,8 +826,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_
                     PVX_CMUL(zr, zi, ewr, ewi);
                     PVX_CMUL(ur, ui, q.vr, q.vi);
                 }
-            }
-        });
+        };
+        int li = advance(), ck = kind;
+        EdgeRec rec;
+        if (li >= 0) rec = (ck == 1 ? q.att : q.rel)[li];
+        while (li >= 0) {
+            const int lj = advance(), nk = kind;
+            EdgeRec nxt;
+            if (lj >= 0) nxt = (nk == 1 ? q.att : q.rel)[lj];
+            process(ck, rec);
+            rec = nxt; li = lj; ck = nk;
+        }
     }
 #pragma unroll
     for (int k = 0; k < R; k++)
@@ -883,9 +919,9 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         q.vi = q.edgsam > 0 ? sin(kPi / (double)q.edgsam) : 0.0;
     }
     const int run_env = [] { const char* e = getenv("PVX_SYNTH_RUN"); return e ? atoi(e) : 0; }();           // tests
-    // samples per thread: 32 (two sincos per 32 samples); a short waveform takes runs of 16 so that more of the chip works
-    int R = (nseg_all * ((h + 31) / 32) < 256 * 64) ? 16 : 32;
-    if (run_env == 16 || run_env == 32) R = run_env;
+    // samples per thread: 32 (two sincos per 32 samples); a short waveform takes runs of 16 or 8 so that more of the chip works
+    int R = (nseg_all * ((h + 31) / 32) >= 256 * 64) ? 32 : ((nseg_all * ((h + 15) / 16) >= 256 * 64) ? 16 : 8);
+    if (run_env == 8 || run_env == 16 || run_env == 32) R = run_env;
     SampK k;
     bool irregular = false;
     {
@@ -907,7 +943,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         q.c1 = b1; q.c2 = b2; q.R = R;
     }
     q.rps = k.rps;
-    constexpr int RX = 16;                                                   // k_synth_extras' runs
+    const int RX = (R == 8) ? 8 : 16;                                         // k_synth_extras' runs (8 on a very short waveform, like k_synth_bodies)
 
     if (nseg_all > p.F + 2 + q.EF + 2) { pvx_set_error("waveform of %lld samples is longer than %lld frames can give", (long long)p.wlen, (long long)p.F); return PVX_ERR_SIZE; }
     const WsLayout L = ws_layout(p.F, p.K, p.P, q.EF, p.F + 2 + q.EF + 2);
@@ -989,13 +1025,22 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         kx.rps = (h + RX - 1) / RX;
         kx.nthreads = q.nseg * kx.rps;
         kx.nseg = q.nseg;
-        // (three workgroups per CU fill the chip at this kernel's registers; a workgroup takes 16 segments at a time)
-        const int64_t nchunks = (q.nseg + 15) / 16;
+        // (three workgroups per CU fill the chip at this kernel's registers; a workgroup takes 16 segments at a time, fewer
+        // when that would leave most of the chip without a chunk)
+        int xcs = 4;
+        while (xcs > 0 && (q.nseg >> xcs) < 512) xcs--;
+        kx.xcs = xcs;
+        const int64_t nchunks = (q.nseg + (1 << xcs) - 1) >> xcs;
         const int64_t xgrid = nchunks < 768 ? nchunks : 768;
-        hipLaunchKernelGGL((k_synth_extras<RX, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
-        if (irregular) hipLaunchKernelGGL((k_synth_extras<RX, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        if (RX == 8) hipLaunchKernelGGL((k_synth_extras<8, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        else hipLaunchKernelGGL((k_synth_extras<16, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        if (irregular) {
+            if (RX == 8) hipLaunchKernelGGL((k_synth_extras<8, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+            else hipLaunchKernelGGL((k_synth_extras<16, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        }
         const dim3 grid((unsigned)grid_blocks);
-        if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
+        if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(256), 0, s, k);
+        else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
         else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(256), 0, s, k);
     }
     PVX_HIP_CHECK(hipGetLastError());

@@ -1398,7 +1398,9 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
     hipPointerAttribute_t attr;
     const bool pinned = hipPointerGetAttributes(&attr, w) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!pinned) (void)hipGetLastError();                        // an ordinary pointer is reported as an error
-    static const bool zero_copy = getenv("PVX_SYNTH_NO_ZEROCOPY") == nullptr;
+    // (off by default since the attacks / releases reach the waveform in a launch of their own and k_synth_bodies reads them
+    // back: over PCIe that costs more than the DMA it saves -- config 3: 0.21 ms against 0.17 ms)
+    static const bool zero_copy = getenv("PVX_SYNTH_ZEROCOPY") != nullptr;
     if (pinned && zero_copy && bytes <= kSmallCall) {
         // the caller's array is page-locked (pvx_host_alloc) and small: the kernel stores its segments straight into
         // it (posted writes over PCIe, spread over the kernel's run time as workgroups finish) -- no copy operation

@@ -220,7 +220,7 @@ def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
     p = run_golden(amd, g, 32)
     ss = p.toSinSum()
     ws = {}
-    for run in ("16", "32"):
+    for run in ("8", "16", "32"):
         monkeypatch.setenv("PVX_SYNTH_RUN", run)
         ws[run] = ss.synth(g["sr"], h)
         assert np.abs(ws[run] - ref).max() <= 1e-4 * np.abs(ref).max()
