@@ -177,6 +177,38 @@ const double* pvx_resident_ptr(pvx_plan* plan, int which);
 int64_t pvx_track_resident(pvx_plan* plan, double maxpitchjmp, int64_t* max_end_frame);
 int pvx_resident_fetch_table(pvx_plan* plan, int32_t* partial_id, int32_t* part_start, int32_t* part_len);
 int pvx_synth_resident(pvx_plan* plan, double sr, int hop_synth, double edge, int minframes, double* w, int64_t wlen);
+/*
+ * run_pv on many independent signals of any lengths, from host buffers, over one or more GPUs of THIS process -- the C-level
+ * batch / multi-GPU entry (SURVEY.md 8(b) `pvx_analyze_batch`; the reference's equivalent is a Python loop over PV objects,
+ * PV.py:213-264).  The path shards by signal and has no exchange step: the devices never talk to each
+ * other, each worker (workers_per_device host threads per device, 0 = 4, each with its own plan and stream so one signal's
+ * transfers run under another's kernels) takes the next signal off one queue, longest first, and its results go straight
+ * into the caller's arrays.  Every signal's arrays are bit-identical to pvx_analyze of that signal alone.
+ *   devices / ndev : the HIP devices to use (an entry may repeat); ndev = 0: the device of pvx_init
+ *   items[i]       : x / nsamp in; f .. binno float64 [F, npks] and t, totalmag float64 [F] (either may be NULL) out, caller-
+ *                    allocated with F = pvx_nframes(nsamp, nfft, hop); nframes = F or that signal's negative status;
+ *                    device = the device that analysed it
+ * pvx_batch_run returns the frames analysed (sum of F) or the first negative status (pvx_last_error names the signal); it
+ * may be called again and again on one pvx_batch -- the plans and their buffers are kept -- but not concurrently.
+ * pvx_analyze_batch = create + run + destroy.
+ */
+typedef struct pvx_batch pvx_batch;
+typedef struct pvx_batch_item {
+    const void* x;
+    int64_t nsamp;
+    double *f, *mag, *ph, *realph, *binno;
+    double *t, *totalmag;
+    int64_t nframes;
+    int32_t device;
+    int32_t reserved;
+} pvx_batch_item;
+int pvx_batch_create(pvx_batch** batch, double sr, int nfft, int hop, int npks, double pkthresh, const double* win /*nfft or NULL = hanning*/,
+                     int precision, const int* devices, int ndev, int workers_per_device);
+int64_t pvx_batch_run(pvx_batch* batch, int x_dtype, pvx_batch_item* items, int64_t nitems);
+int pvx_batch_destroy(pvx_batch* batch);
+int64_t pvx_analyze_batch(double sr, int nfft, int hop, int npks, double pkthresh, const double* win, int precision, int x_dtype,
+                          pvx_batch_item* items, int64_t nitems, const int* devices, int ndev);
+
 /* Page-locked host memory for result arrays.  pvx_synth_resident recognises such a destination: the waveform
  * (SinSum.synth's return value, PV.py:1070) is written straight into it by the DMA engine (with PVX_SYNTH_ZEROCOPY=1, up
  * to 4 MB, by the kernels' own stores); any other pointer goes through

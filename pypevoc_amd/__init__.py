@@ -9,7 +9,7 @@ ctypes; see include/pvx.h, DESIGN.md and INTEGRATION.md.
 """
 from .PVAnalysis import PV, SinSum, RegPartial, PVHarmonic  # noqa: F401  (pypevoc/__init__.py:1 exports PV, SinSum)
 from .PeakFinder import PeakFinder  # noqa: F401
-from .batch import PVBatch  # noqa: F401
+from .batch import PVBatch, PVMany  # noqa: F401
 from ._lib import PvxError  # noqa: F401
 
-__all__ = ["PV", "PVHarmonic", "SinSum", "RegPartial", "PeakFinder", "PVBatch", "PvxError"]
+__all__ = ["PV", "PVHarmonic", "SinSum", "RegPartial", "PeakFinder", "PVBatch", "PVMany", "PvxError"]

@@ -99,9 +99,23 @@ SIGNATURES = {
                                             ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_plan_set_progress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_wire_bytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
+    "pvx_batch_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, c_double_p, ctypes.c_int, c_int32_p, ctypes.c_int, ctypes.c_int]),
+    "pvx_batch_run": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
+    "pvx_batch_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pvx_analyze_batch": (ctypes.c_int64, [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, c_int32_p, ctypes.c_int]),
     "pvx_pack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 7),
     "pvx_unpack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8),
 }
+
+
+class BatchItem(ctypes.Structure):
+    """pvx_batch_item of include/pvx.h."""
+    _fields_ = [("x", ctypes.c_void_p), ("nsamp", ctypes.c_int64),
+                ("f", c_double_p), ("mag", c_double_p), ("ph", c_double_p), ("realph", c_double_p), ("binno", c_double_p),
+                ("t", c_double_p), ("totalmag", c_double_p),
+                ("nframes", ctypes.c_int64), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)

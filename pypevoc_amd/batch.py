@@ -152,6 +152,91 @@ class PVBatch(object):
         pass
 
 
+class PVMany(object):
+    """run_pv for signals of ANY lengths over the GPUs of this process: the mirror of pvx_batch_* (include/pvx.h; SURVEY.md
+    8(b) `pvx_analyze_batch`).  The reference's equivalent is `[PV(x, sr, ...).run_pv() for x in signals]`
+    (pypevoc/PVAnalysis.py:213-264); here every device takes the next signal off one queue (longest first) and the
+    devices never exchange anything.
+
+        many = PVMany(sr, nfft=2048, hop=512, npks=8, devices=[0, 1, 2, 3])
+        results = many.run(signals)          # list of dicts: f, mag, ph, realph, binno (F, npks); t, totalmag (F,); device
+
+    Signals must share a sample type (float64, float32 or int16).  precision=None follows it as PV does."""
+
+    def __init__(self, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, wind=np.hanning, precision=None, devices=None,
+                 workers_per_device=0):
+        self.sr, self.nfft = sr, int(nfft)
+        self.hop = int(self.nfft / 2) if hop is None else int(hop)
+        self.npeaks, self.peakthresh = int(npks), pkthresh
+        self.win = np.ascontiguousarray(wind(self.nfft), dtype=np.float64)
+        self.precision = precision
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.workers_per_device = int(workers_per_device)
+        self._handle = None
+        self._handle_precision = None
+
+    def _batch(self, precision):
+        lib = _lib.load()
+        if self._handle is not None and self._handle_precision != precision:
+            self.close()
+        if self._handle is None:
+            h = ctypes.c_void_p()
+            dev = None
+            nd = 0
+            if self.devices:
+                dev = (ctypes.c_int32 * len(self.devices))(*self.devices)
+                nd = len(self.devices)
+            _lib.check(lib.pvx_batch_create(ctypes.byref(h), float(self.sr), self.nfft, self.hop, self.npeaks, float(self.peakthresh),
+                                            _lib.dptr(self.win), precision, dev, nd, self.workers_per_device), "pvx_batch_create")
+            self._handle, self._handle_precision = h, precision
+        return self._handle
+
+    def run(self, signals):
+        lib = _lib.load()
+        sigs = []
+        code = None
+        for x in signals:
+            a, c = _lib.as_signal(np.asarray(x).reshape(-1))
+            if code is None:
+                code = c
+            elif c != code:
+                raise TypeError("the signals of one PVMany.run call must share a sample type")
+            sigs.append(a)
+        if not sigs:
+            return []
+        precision = self.precision if self.precision is not None else (64 if code == _lib.PVX_F64 else 32)
+        K = self.npeaks
+        items = (_lib.BatchItem * len(sigs))()
+        out = []
+        for i, a in enumerate(sigs):
+            F = _lib.nframes_host(len(a), self.nfft, self.hop)
+            r = {k: np.zeros((F, K)) for k in FIELDS}
+            r["t"] = np.zeros(F)
+            r["totalmag"] = np.zeros(F)
+            it = items[i]
+            it.x, it.nsamp = a.ctypes.data, len(a)
+            for k in FIELDS + ("t", "totalmag"):
+                setattr(it, k, _lib.dptr(r[k]))
+            out.append(r)
+        total = lib.pvx_batch_run(self._batch(precision), code, ctypes.cast(items, ctypes.c_void_p), len(sigs))
+        _lib.check(total, "pvx_batch_run")
+        for i, r in enumerate(out):
+            r["device"] = int(items[i].device)
+            r["nframes"] = int(items[i].nframes)
+        return out
+
+    def close(self):
+        if self._handle is not None:
+            _lib.load().pvx_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def gather_results(local, nitems, group=None, dst=0):
     """Gather per-rank result blocks to rank `dst` with ONE collective per call.
 

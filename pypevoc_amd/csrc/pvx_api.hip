@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -66,6 +68,7 @@ extern "C" int pvx_version(void) { return PVX_VERSION; }
 // ---- device ---------------------------------------------------------------------------------
 static std::mutex g_mu;
 static int g_device = -1;
+static thread_local int t_device = -1;   // a worker thread of pvx_batch_run is bound to its own device (the process default stays g_device)
 static bool g_fft_setup = false;
 static char g_devname[256] = "";
 
@@ -102,9 +105,10 @@ extern "C" const char* pvx_device_name(void) { return g_devname; }
 extern "C" int pvx_device(void) { return g_device; }
 
 int pvx_require_device() {
-    if (g_device >= 0) {
+    const int d = t_device >= 0 ? t_device : g_device;
+    if (d >= 0) {
         // the calling thread may be new: bind it
-        if (hipSetDevice(g_device) != hipSuccess) { pvx_set_error("hipSetDevice(%d) failed", g_device); return PVX_ERR_NO_DEVICE; }
+        if (hipSetDevice(d) != hipSuccess) { pvx_set_error("hipSetDevice(%d) failed", d); return PVX_ERR_NO_DEVICE; }
         return PVX_OK;
     }
     return pvx_init(-1);
@@ -824,9 +828,9 @@ static int staged_copy(pvx_plan* p, void* dev, void* host, size_t bytes, bool to
 // call).  So nothing of the caller's above kDirectMax is ever handed to hipMemcpy: page-locked arrays go straight, large
 // pageable ones through the threaded ring, the ones in between bounce through the process-wide ring's memory.
 static const size_t kDirectMax = (size_t)512 << 10;
-static void* g_ring = nullptr;
-static hipEvent_t g_ring_ev[16] = {};
-static std::mutex g_ring_mu;
+static const int kMaxDevices = 16;
+struct DevRing { void* ring = nullptr; hipEvent_t ev[16] = {}; std::mutex mu; };   // one per device: its events belong to that device
+static DevRing g_rings[kMaxDevices];
 static bool host_is_pinned(const void* host) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, host) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -839,8 +843,12 @@ static int user_copy(void* dev, void* host, size_t bytes, bool to_device) {
         PVX_HIP_CHECK(to_device ? hipMemcpy(dev, host, bytes, kind) : hipMemcpy(host, dev, bytes, kind));
         return PVX_OK;
     }
-    std::lock_guard<std::mutex> lk(g_ring_mu);
-    const StageRing ring{&g_ring, g_ring_ev};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    DevRing& dr = g_rings[devid >= 0 && devid < kMaxDevices ? devid : 0];
+    std::lock_guard<std::mutex> lk(dr.mu);
+    void*& g_ring = dr.ring;
+    const StageRing ring{&dr.ring, dr.ev};
     if (bytes >= kStageMin && getenv("PVX_NO_STAGE_THREADS") == nullptr) {
         const int rc = staged_copy(ring, dev, host, bytes, to_device, nullptr);
         if (rc != PVX_OK) return rc;
@@ -877,6 +885,10 @@ static HostOut block_ptrs(double* base, int64_t rows, int K) {
 }
 
 static const size_t kSmallCall = (size_t)4 << 20;     // calls up to this size go through pinned staging, one sync
+// ... and analyses up to the size where the threaded ring takes over (kStageMin): the plan's own pinned block, the DMA of
+// piece i under the host copy of piece i+1, one result copy, one synchronisation -- and no lock shared with other plans
+// (pvx_batch_run's workers; the process-wide bounce ring in between cost a 30-s signal 0.45 ms alone and serialised them)
+static const size_t kSmallAnalyze = kStageMin;
 
 // spectrum of the last row of the launch that just ran on `s` -> p->d_prev (float64 [N2][2])
 static int carry_spectrum(pvx_plan* p, int64_t rows_in_call, hipStream_t s) {
@@ -954,7 +966,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     const int64_t nchunks = (units + per_chunk - 1) / per_chunk;
     const size_t total_in = (size_t)((nsig - 1) * sig_stride + nsamp) * es;
     const size_t total_out = (size_t)nsig * F * per_frame_out;
-    const bool small = nchunks == 1 && total_in + (keep ? 0 : total_out) <= kSmallCall;
+    const bool small = nchunks == 1 && total_in + (keep ? 0 : total_out) <= kSmallAnalyze;
     // a float64 signal analysed at precision 32: every kernel's first step is (float)x[n], so the host side narrows while it
     // stages (same rounding, half the bytes over PCIe, the aligned float loads on the device) -- on the small-call path and
     // in the staging threads of the large one
@@ -1138,6 +1150,135 @@ extern "C" int64_t pvx_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t 
                                double* totalmag, const double* prev0, double* last_spec) {
     HostOut ho = {f, mag, ph, realph, binno, t, totalmag};
     return analyze_host(p, x, x_dtype, nsamp, nsig, sig_stride, &ho, prev0, last_spec, false);
+}
+
+// ---- many independent signals over the GPUs of this process (SURVEY.md 8(b) pvx_analyze_batch, 8(e)) ------------------
+// The path shards by signal and has no exchange step: every device analyses whole signals and its results go straight to
+// the caller's arrays, so the devices never talk to each other (no RCCL here: that is for callers that live in separate
+// processes, pypevoc_amd/batch.py).  One queue, longest signal first; `workers` host threads per device, each with its own
+// plan and stream, so one signal's transfers run under another's kernels; a worker takes the next signal when it is free,
+// which balances ragged batches and unequal devices without a schedule.
+static_assert(sizeof(pvx_batch_item) == 88, "pvx_batch_item is part of the C ABI");
+struct pvx_batch {
+    double sr = 0, pkthresh = 0;
+    int nfft = 0, hop = 0, npks = 0, precision = 32, workers = 4;
+    std::vector<double> win;
+    std::vector<int> devices;
+    std::vector<pvx_plan*> plans;          // [device slot][worker], created by the worker on its first signal
+};
+
+extern "C" int pvx_batch_create(pvx_batch** out, double sr, int nfft, int hop, int npks, double pkthresh, const double* win,
+                                int precision, const int* devices, int ndev, int workers_per_device) {
+    if (!out) { pvx_set_error("null batch pointer"); return PVX_ERR_INVALID; }
+    *out = nullptr;
+    if (nfft < 4 || hop <= 0 || npks <= 0 || !(sr > 0) || (precision != 32 && precision != 64) || ndev < 0 || (ndev > 0 && !devices) ||
+        workers_per_device < 0 || workers_per_device > 8) {
+        pvx_set_error("invalid batch parameters (sr=%g nfft=%d hop=%d npks=%d precision=%d ndev=%d workers=%d)", sr, nfft, hop, npks, precision, ndev, workers_per_device);
+        return PVX_ERR_INVALID;
+    }
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    int ndevices = 0;
+    PVX_HIP_CHECK(hipGetDeviceCount(&ndevices));
+    pvx_batch* b = new pvx_batch();
+    b->sr = sr; b->nfft = nfft; b->hop = hop; b->npks = npks; b->pkthresh = pkthresh; b->precision = precision;
+    b->workers = workers_per_device > 0 ? workers_per_device : 4;
+    if (win) b->win.assign(win, win + nfft);
+    if (ndev == 0) b->devices.push_back(t_device >= 0 ? t_device : g_device);
+    for (int i = 0; i < ndev; i++) {
+        const int d = devices[i];
+        if (d < 0 || d >= ndevices || d >= kMaxDevices) { pvx_set_error("device %d out of range (%d devices)", d, ndevices); delete b; return PVX_ERR_INVALID; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            pvx_set_error("device %d is not a gfx950 (MI355X) device; libpvx_hip carries gfx950 code objects only", d);
+            delete b;
+            return PVX_ERR_NO_DEVICE;
+        }
+        b->devices.push_back(d);
+    }
+    b->plans.assign(b->devices.size() * (size_t)b->workers, nullptr);
+    *out = b;
+    return PVX_OK;
+}
+
+extern "C" int pvx_batch_destroy(pvx_batch* b) {
+    if (!b) return PVX_OK;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (size_t i = 0; i < b->plans.size(); i++)
+        if (b->plans[i]) { (void)hipSetDevice(b->devices[i / b->workers]); plan_free(b->plans[i]); }
+    if (have) (void)hipSetDevice(cur);
+    delete b;
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_batch_run(pvx_batch* b, int x_dtype, pvx_batch_item* items, int64_t nitems) {
+    if (!b || nitems < 0 || (nitems > 0 && !items)) { pvx_set_error("invalid batch arguments"); return PVX_ERR_INVALID; }
+    if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("unknown sample type %d", x_dtype); return PVX_ERR_INVALID; }
+    if (nitems == 0) return 0;
+    std::vector<int64_t> order((size_t)nitems);
+    for (int64_t i = 0; i < nitems; i++) { order[(size_t)i] = i; items[i].nframes = 0; items[i].device = -1; }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return items[a].nsamp > items[c].nsamp; });
+    std::atomic<int64_t> next(0);
+    std::atomic<int> first_rc(PVX_OK);
+    std::mutex err_mu;
+    char err_text[512] = "";
+    const int nw = (int)b->plans.size();
+    auto worker = [&](int w) {
+        const int dev = b->devices[(size_t)(w / b->workers)];
+        t_device = dev;
+        auto fail = [&](int64_t item, int rc) {
+            if (item >= 0) items[item].nframes = rc;
+            int expect = PVX_OK;
+            if (first_rc.compare_exchange_strong(expect, rc)) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                snprintf(err_text, sizeof(err_text), "signal %lld on device %d: %s", (long long)item, dev, g_err);
+            }
+        };
+        for (;;) {
+            const int64_t q = next.fetch_add(1);
+            if (q >= nitems) break;
+            const int64_t i = order[(size_t)q];
+            pvx_batch_item& it = items[i];
+            it.device = dev;
+            if (!b->plans[(size_t)w]) {
+                const int rc = pvx_plan_create(&b->plans[(size_t)w], b->sr, b->nfft, b->hop, b->npks, b->pkthresh, b->win.empty() ? nullptr : b->win.data(), b->precision, 0);
+                if (rc != PVX_OK) { fail(i, rc); continue; }
+            }
+            const int64_t F = pvx_analyze(b->plans[(size_t)w], it.x, x_dtype, it.nsamp, 1, it.nsamp, it.f, it.mag, it.ph, it.realph, it.binno, it.t, it.totalmag, nullptr, nullptr);
+            if (F < 0) { fail(i, (int)F); continue; }
+            it.nframes = F;
+        }
+        t_device = -1;
+    };
+    std::vector<std::thread> th;
+    const int nthreads = (int64_t)nw < nitems ? nw : (int)nitems;
+    // workers are dealt to the devices in turn (worker w -> slot w % ndev's next worker), so a batch smaller than the pool
+    // still spreads over the devices
+    const int nd = (int)b->devices.size();
+    auto slot_of = [&](int k) { return (k % nd) * b->workers + k / nd; };
+    const int saved = t_device;
+    try {
+        for (int k = 1; k < nthreads; k++) th.emplace_back(worker, slot_of(k));
+    } catch (...) { /* the threads that started and this one share the queue */ }
+    worker(slot_of(0));
+    t_device = saved;
+    for (auto& t : th) t.join();
+    (void)pvx_require_device();            // this thread served a device: back to the caller's
+    if (first_rc.load() != PVX_OK) { pvx_set_error("%s", err_text); return first_rc.load(); }
+    int64_t total = 0;
+    for (int64_t i = 0; i < nitems; i++) total += items[i].nframes;
+    return total;
+}
+
+extern "C" int64_t pvx_analyze_batch(double sr, int nfft, int hop, int npks, double pkthresh, const double* win, int precision,
+                                     int x_dtype, pvx_batch_item* items, int64_t nitems, const int* devices, int ndev) {
+    pvx_batch* b = nullptr;
+    const int rc = pvx_batch_create(&b, sr, nfft, hop, npks, pkthresh, win, precision, devices, ndev, 0);
+    if (rc != PVX_OK) return rc;
+    const int64_t r = pvx_batch_run(b, x_dtype, items, nitems);
+    pvx_batch_destroy(b);
+    return r;
 }
 
 // ---- page-locked host arrays for results (the DMA engine writes them directly) ------------------------

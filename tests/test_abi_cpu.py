@@ -56,6 +56,23 @@ def test_no_gpu_means_loud_failure():
     assert "no CPU fallback" in str(e.value)
     with pytest.raises(pypevoc_amd.PvxError):
         pypevoc_amd.PeakFinder(np.arange(10.0))
+    with pytest.raises(pypevoc_amd.PvxError) as e:
+        pypevoc_amd.PVMany(44100, nfft=1024, hop=512, npks=4).run([np.zeros(4096), np.zeros(9000)])
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_batch_item_layout_is_the_headers():
+    """pvx_batch_item (include/pvx.h): two 8-byte inputs, seven pointers, nframes, device, reserved -- 88 bytes, the ctypes
+    mirror field for field."""
+    import ctypes
+    from pypevoc_amd import _lib
+    assert ctypes.sizeof(_lib.BatchItem) == 88
+    names = [f[0] for f in _lib.BatchItem._fields_]
+    src = open(os.path.join(ROOT, "include", "pvx.h")).read()
+    body = src[src.index("typedef struct pvx_batch_item {"):src.index("} pvx_batch_item;")]
+    import re
+    decl = re.findall(r"[*\s]([a-z_0-9]+)\s*[,;]", body)
+    assert decl == names, (decl, names)
 
 
 def test_product_never_imports_the_oracle():

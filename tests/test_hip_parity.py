@@ -979,6 +979,70 @@ def test_config4_shard_shape_batch(amd):
         assert np.median(np.abs(mid / f0 - 1.0)) < 0.02
 
 
+def test_c_level_batch_of_ragged_signals_over_a_device_list(amd, oracle):
+    """pvx_batch_* / PVMany (SURVEY 8(b) pvx_analyze_batch): signals of any lengths, one queue, worker threads per entry of the
+    device list.  Every signal's arrays are bit-identical to its own PV(...).run_pv(), whatever the list is ([0] or [0, 0, 0]:
+    the same device three times exercises three sets of workers, plans and streams side by side -- all this box has), a signal
+    too short for a frame gives empty arrays, the first signals are checked against the oracle, a second run on the same handle
+    reuses the plans, and a broken item fails with its index while the others finish."""
+    import ctypes
+    from pypevoc_amd import _lib
+    sr, nfft, hop, K = 22050.0, 1024, 256, 6
+    lens = [30000, 1024, 200000, 5000, 77777, 1025, 30000, 123456, 2049, 9000, 64000, 500, 3_000_000]
+    sigs = [_rand_signal(100 + i, n, sr) for i, n in enumerate(lens)]
+    for precision, devices in ((64, None), (32, [0, 0, 0])):
+        many = amd.PVMany(sr, nfft=nfft, hop=hop, npks=K, devices=devices, precision=precision, workers_per_device=2)
+        for rep in range(2):
+            res = many.run(sigs)
+            assert len(res) == len(sigs)
+            for i, (x, r) in enumerate(zip(sigs, res)):
+                p = run_pv(amd, x, sr, nfft, hop, K, precision=precision)
+                assert r["nframes"] == p.nframes and r["device"] == 0, (i, r["nframes"], r["device"])
+                if p.nframes == 0:                  # (the reference leaves one-dimensional empty arrays, PV.py:256-264)
+                    assert all(r[k].size == 0 for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag")), i
+                    continue
+                for k in ("f", "mag", "ph", "realph", "binno", "t"):
+                    assert np.array_equal(r[k], getattr(p, k)), (precision, rep, i, k)
+                assert np.array_equal(r["totalmag"], np.asarray(p.totalmag, dtype=np.float64)), (i, "totalmag")
+        for i in (0, 3):
+            c = compare_analysis(res[i], oracle.analyze(sigs[i], sr, nfft, hop, K, 0.005), nfft, hop, sr)
+            (assert_f64 if precision == 64 else lambda cc: assert_f32(cc, absolute=False))(c)
+        many.close()
+    # float32 samples follow precision 32 by themselves; mixed sample types are refused
+    many = amd.PVMany(sr, nfft=nfft, hop=hop, npks=K)
+    csigs = [sigs[0], sigs[2], sigs[3]]
+    r32 = many.run([s.astype(np.float32) for s in csigs])
+    for x, r in zip(csigs, r32):
+        p = run_pv(amd, x.astype(np.float32), sr, nfft, hop, K)
+        assert np.array_equal(r["f"], p.f) and np.array_equal(r["mag"], p.mag)
+    with pytest.raises(TypeError):
+        many.run([sigs[0], sigs[1].astype(np.float32)])
+    many.close()
+    # the C entry itself: one item has no output arrays -> its status, the call's status and the error text name it; the
+    # other items are complete
+    lib = _lib.load()
+    items = (_lib.BatchItem * 3)()
+    keep = []
+    for i in range(3):
+        x = csigs[i]
+        F = _lib.nframes_host(len(x), nfft, hop)
+        arrs = [np.zeros((F, K)) for _ in range(5)] + [np.zeros(F), np.zeros(F)]
+        keep.append((x, arrs))
+        items[i].x, items[i].nsamp = x.ctypes.data, len(x)
+        if i != 2:
+            for name, a in zip(("f", "mag", "ph", "realph", "binno", "t", "totalmag"), arrs):
+                setattr(items[i], name, _lib.dptr(a))
+    rc = lib.pvx_analyze_batch(sr, nfft, hop, K, 0.005, None, 64, _lib.PVX_F64, ctypes.cast(items, ctypes.c_void_p), 3, None, 0)
+    assert rc == -2 and items[2].nframes == -2 and b"signal 2" in lib.pvx_last_error(), (rc, lib.pvx_last_error())
+    for i in (0, 1):
+        p = run_pv(amd, csigs[i], sr, nfft, hop, K, precision=64)
+        assert items[i].nframes == p.nframes and np.array_equal(keep[i][1][0], p.f)
+    bad = (ctypes.c_int32 * 1)(99)
+    h = ctypes.c_void_p()
+    assert lib.pvx_batch_create(ctypes.byref(h), sr, nfft, hop, K, 0.005, None, 32, bad, 1, 0) < 0
+    assert b"out of range" in lib.pvx_last_error()
+
+
 def test_multiwave_kernel_batch_and_streaming(amd, oracle):
     """fft mode 2 (nfft 4096): batch of signals = loop, and frame-by-frame streaming = run_pv."""
     sr, nfft, hop, K = 22050.0, 4096, 1024, 6
