@@ -37,13 +37,14 @@ template <int R> struct RevGeo {
     static constexpr size_t OFF_T1 = 0;                              // v2f [R][64] W_M^(l q)   | X4: [16][16] W_256^(l q)
     static constexpr size_t OFF_T2 = OFF_T1 + (X4 ? (size_t)256 * 8 : (size_t)R * 64 * 8);    // v2f [R][P] W_64^(l1 t2) | X4: none
     static constexpr size_t OFF_TW3 = OFF_T2 + (X4 ? 0 : 64 * 8);    // v2f [TW3N] W_nfft^k     | X4: [2][4][64] join / untangle twiddles of the lane
-    static constexpr size_t OFF_WAVE = OFF_TW3 + (size_t)TW3N * 8;
+    static constexpr size_t OFF_WIN = OFF_TW3 + (size_t)TW3N * 8;    // X4: v2f [R][64] the window, lane-ordered | else: none (registers)
+    static constexpr size_t OFF_WAVE = OFF_WIN + (X4 ? (size_t)R * 64 * 8 : 0);
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFR);
         size_t b = (size_t)G::BUFC * 8                               // the wave's spectrum buffer
                  + GFR * 8 * 2                                       // orow | tot
-                 + (size_t)(G::M + 4 * R) * 4                        // y (padded, ymap<1>)
+                 + (X4 ? 0 : (size_t)(G::M + 4 * R) * 4)             // y (padded, ymap<1>) | X4: none, |X|^2 is recomputed (YofX4)
                  + gs * kpad * 5 * 4                                 // sval
                  + kpad * 4 + gs * kpad * 4                          // sel | sbin
                  + GFR * 4 * 2                                       // cnt | frm
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     float2* const cur = (float2*)wb;                                // X of the row at hand
     long long* const Lorow = (long long*)(cur + G::BUFC);
     double* const Ltot = (double*)(Lorow + GFR);
-    float* const Ly = (float*)(Ltot + GFR);
-    int* const Lcnt = (int*)(Ly + M + 4 * R);
+    float* const Ly = (float*)(Ltot + GFR);                          // (X4: no such row)
+    int* const Lcnt = (int*)(Ly + (X4 ? 0 : M + 4 * R));
     int* const Lfrm = Lcnt + GFR;
     u16* const Lci = (u16*)(Lfrm + GFR);
     int* const Lsel = (int*)(Lci + G::CAP + 64);
@@ -98,6 +99,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             for (int i = threadIdx.x; i < 512; i += 64 * NW) {      // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
                 const int ln = i & 63, u = (i >> 6) & 3, k1 = ln + 64 * (i >> 8);
                 tw3[i] = tab[(u == 0 ? k1 : 2 * u * k1) & NMASK];
+            }
+            v2f* const wl = (v2f*)(smem + RG::OFF_WIN);             // [r / 2][lane][r & 1]: the pair 4 l + u + 64 r of lane 16 u + l
+            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+                const int r = ((i >> 7) << 1) | (i & 1), ln = (i >> 1) & 63;
+                wl[i] = ((const v2f*)p.win)[lofs4(ln) / 2 + 64 * r];
             }
         } else {
             for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
@@ -131,11 +137,16 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     for (int b = 0; b < G::LOGP; b++) if (L1 & (1 << b)) t1v |= 1 << (G::LOGP - 1 - b);
     // the window stays in registers (there is room below 256): read from LDS it costs 16 reads that all
     // waves of the workgroup issue at the same moment, right after the barrier
-    v2f wv[R];
+    // (nfft 2048: from LDS, lane-ordered -- 16 conflict-free reads per frame; its 32 registers are what stands between
+    // two and three waves per SIMD there)
+    v2f wv[X4 ? 1 : R];
+    const v2f* const winL = (const v2f*)(smem + RG::OFF_WIN) + 2 * lane;      // two register pairs per 16-byte read
+    if constexpr (!X4) {
 #pragma unroll
-    for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[(X4 ? lofs4(lane) / 2 : lane) + 64 * r];
+        for (int r = 0; r < R; r++) wv[r] = ((const v2f*)p.win)[lane + 64 * r];
 #pragma unroll
-    for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
+        for (int r = 0; r < R; r++) asm volatile("" : "+v"(wv[r]));
+    }
 
     auto XA = [](int k) -> int { if constexpr (X4) return xa4(k); else return zpad<R>(k); };      // slot of bin k in `cur`
 
@@ -187,7 +198,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         v2f z[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            z[r] = raw[r] * wv[r];
+            if constexpr (X4) z[r] = raw[r] * winL[128 * (r >> 1) + (r & 1)];
+            else z[r] = raw[r] * wv[r];
             asm volatile("" : "+v"(z[r]));                          // the multiply stays above the loads
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) tw[j][u] = tw3[(j * 4 + u) * 64 + lane];
             wave_sync();
-            join4_untangle<256, F4::RP, 64>(dz, Ly, tw, lane, IdentityIA(), lmax, lmin, ls0, ls1);
+            join4_untangle<256, F4::RP, 64, IdentityIA, false>(dz, nullptr, tw, lane, IdentityIA(), lmax, lmin, ls0, ls1);
         } else {
         dft_regs<R>(z);                                             // stage 1
         __builtin_amdgcn_sched_barrier(0);
@@ -302,10 +314,13 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     // per-peak pass over this wave's staged frames [0, ng)
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
-    const int gl = lane / LPF, e0 = lane - gl * LPF;
-    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
+        // (the lane's group and its ballot mask are worked out here, once per 8 frames: as loop invariants they are four
+        // registers held through the frame loop, and at three waves per SIMD the loop has none to spare)
+        const int lnf = fresh_lane();
+        const int gl = lnf / LPF, e0 = lnf - gl * LPF;
+        const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
         kargs_t q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             }
             const unsigned long long bal = __ballot(valid) & gmask;
             if (valid) {
-                const int oi = nout + __popcll(bal & ((1ull << lane) - 1ull));
+                const int oi = nout + __popcll(bal & ((1ull << lnf) - 1ull));
                 ob[oi] = (double)nbin;
                 of[oi] = o.freq;
                 om[oi] = o.mag;
@@ -407,7 +422,9 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
             int nk = 0;
             // candidate list (ascending bins) -> Lci
-            const int C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
+            int C;
+            if constexpr (X4) C = peak_scan_x4_thin<u16>(cur, mine, th, Lci, G::CAP, lane, K);
+            else C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
             wave_sync();
             if (C <= 64 && p.rad <= 5 && !(th < 0.0 && C < K)) {
                 // ---- at most one candidate per lane (every frame of music): lane c owns candidate c and fetches
@@ -422,19 +439,36 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 const int lo = pb - rad > 1 ? pb - rad : 1;
                 int hi = pb + rad < M ? pb + rad : M;
                 hi = hi > M - 1 ? M - 1 : hi;
-                const float v = Ly[ymap<1>(pb)];
-                float nb[10];
-#pragma unroll
-                for (int d = 1; d <= 5; d++) {
-                    const int dd = d > rad ? rad : d;
-                    int j0 = pb - dd, j1 = pb + dd;
-                    j0 = j0 < lo ? lo : j0;
-                    j1 = j1 > hi ? hi : j1;
-                    nb[2 * d - 2] = Ly[ymap<1>(j0)];
-                    nb[2 * d - 1] = Ly[ymap<1>(j1)];
-                }
                 const float2 c = cur[XA(pb)];
                 const float2 vm = cur[XA(pb - 1)], vp = cur[XA(pb + 1)];
+                float v;
+                float nb[10];
+                if constexpr (X4) {
+                    float2 nx[10];
+#pragma unroll
+                    for (int d = 1; d <= 5; d++) {
+                        const int dd = d > rad ? rad : d;
+                        int j0 = pb - dd, j1 = pb + dd;
+                        j0 = j0 < lo ? lo : j0;
+                        j1 = j1 > hi ? hi : j1;
+                        nx[2 * d - 2] = cur[xa4(j0)];
+                        nx[2 * d - 1] = cur[xa4(j1)];
+                    }
+                    v = norm2(c);
+#pragma unroll
+                    for (int d = 0; d < 10; d++) nb[d] = norm2(nx[d]);
+                } else {
+                    v = Ly[ymap<1>(pb)];
+#pragma unroll
+                    for (int d = 1; d <= 5; d++) {
+                        const int dd = d > rad ? rad : d;
+                        int j0 = pb - dd, j1 = pb + dd;
+                        j0 = j0 < lo ? lo : j0;
+                        j1 = j1 > hi ? hi : j1;
+                        nb[2 * d - 2] = Ly[ymap<1>(j0)];
+                        nb[2 * d - 1] = Ly[ymap<1>(j1)];
+                    }
+                }
                 int bad = 0;
 #pragma unroll
                 for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
@@ -470,13 +504,18 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 nk = __popcll(bal);
             } else {
             // radix select inlined: the call of the out-of-line version saves / restores ~100 scalar registers per frame
-            const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, C, th, mine, lane);
+            int nsel;
+            if constexpr (X4) nsel = peak_pick_regs<R / 2, 0, u16, true>(YofX4{cur}, Lci, Lsel, M, K, C, th, mine, lane);
+            else nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, C, th, mine, lane);
             for (int eb = 0; eb < nsel; eb += 64) {
                 const int e = eb + lane;
                 int pb = 0;
                 if (e < nsel) pb = Lsel[e];
-                const bool keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, eb, nsel, p.rad, lane)
-                                               : ((e < nsel) && salient<float, 1>(Ly, M, pb, p.rad));
+                bool keep;
+                if constexpr (X4) keep = (p.rad <= 8) ? salient_groups<0>(YofX4{cur}, M, Lsel, eb, nsel, p.rad, lane)
+                                                      : ((e < nsel) && salient<float, 0>(YofX4{cur}, M, pb, p.rad));
+                else keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, eb, nsel, p.rad, lane)
+                                         : ((e < nsel) && salient<float, 1>(Ly, M, pb, p.rad));
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     const int sl = ng * kpad + nk + lane_prefix(bal);
@@ -560,8 +599,12 @@ int pvx_fused_rev_supported(int nfft, int precision, int K) {
 int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
-        case 2048: return launch_rev<16, 8>(p, x_dtype, s);
-        case 1024: return launch_rev<8, 12>(p, x_dtype, s);
+        // three waves per SIMD when the waves' buffers fit (npks up to ~90), else two
+        case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s) : launch_rev<16, 8>(p, x_dtype, s);
+#ifndef PVX_REV_NW1024
+#define PVX_REV_NW1024 12
+#endif
+        case 1024: return launch_rev<8, PVX_REV_NW1024>(p, x_dtype, s);
         case 512: return launch_rev<4, 12>(p, x_dtype, s);
         default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }

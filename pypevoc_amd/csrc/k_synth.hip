@@ -559,16 +559,20 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
 // leave through LDS as well, so that a store instruction writes 64-byte pieces instead of 16 bytes per 256.
 constexpr int kTile = 32;                        // records per wave and LDS tile (32 x 160 B = 5 KB = the wave's store staging)
 constexpr int kLaneB = 80;                       // bytes per lane in the store staging: 64 + 16 (conflict-free 16-byte rows)
+#ifndef PVX_BODIES_TB
+#define PVX_BODIES_TB 256
+#endif
+constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_synth_bodies (its waves never meet)
 template <int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
+__global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
     // everything is per wave (a wave's 64 runs are consecutive, so are the records of their segments): no workgroup barrier
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][kTile * sizeof(BodyRec)];
-    __shared__ long long s_o[256];
-    __shared__ int s_len[256];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kBodiesTB / 64][kTile * sizeof(BodyRec)];
+    __shared__ long long s_o[kBodiesTB];
+    __shared__ int s_len[kBodiesTB];
     static_assert(kTile * sizeof(BodyRec) == 64 * kLaneB, "store staging = record tile");
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     unsigned char* lds = lds_all[tid >> 6];
-    const int64_t gid0 = (int64_t)blockIdx.x * 256, gid = gid0 + tid;
+    const int64_t gid0 = (int64_t)blockIdx.x * kBodiesTB, gid = gid0 + tid;
     const bool live = gid < q.nthreads;
     const int64_t g = live ? gid : q.nthreads - 1;
     const int64_t segl = g / q.rps;
@@ -1014,7 +1018,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         }
         k.body = q.body; k.att = q.att; k.rel = q.rel; k.bbits = q.bbits; k.xbits = q.xbits; k.abits = q.abits; k.rbits = q.rbits;
         k.w = q.w; k.wlen = q.wlen; k.seg0 = s0; k.nthreads = q.nseg * k.rps;
-        const int64_t grid_blocks = (k.nthreads + 255) / 256;
+        const int64_t grid_blocks = (k.nthreads + kBodiesTB - 1) / kBodiesTB;
         k.segflag = q.segflag; k.gen = q.gen;
         k.fx0 = (int)q.fx0; k.fx1 = (int)q.fx1; k.fb0 = (int)q.fb0; k.fb1 = (int)q.fb1;
         k.K = p.K; k.h = h; k.EF = q.EF; k.edgsam = q.edgsam; k.vr = q.vr; k.vi = q.vi;
@@ -1039,9 +1043,9 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
             else hipLaunchKernelGGL((k_synth_extras<16, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
         }
         const dim3 grid((unsigned)grid_blocks);
-        if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(256), 0, s, k);
-        else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(256), 0, s, k);
-        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(256), 0, s, k);
+        if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(kBodiesTB), 0, s, k);
+        else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(kBodiesTB), 0, s, k);
+        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(kBodiesTB), 0, s, k);
     }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;

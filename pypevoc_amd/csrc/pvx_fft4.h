@@ -38,6 +38,118 @@ __device__ __forceinline__ int lofs4(int lane) { return 8 * (lane & 15) + 2 * (l
 struct IdentityIA { __device__ __forceinline__ int operator()(int i) const { return i; } };
 struct Xa4IA { __device__ __forceinline__ int operator()(int i) const { return xa4(i); } };
 
+// |X|^2 of bin k from a wave's spectrum in the natural-order quarter layout -- the expression join4_untangle uses for the
+// row's maximum / minimum / energy, on the very values it stored: bit-identical to the |X|^2 row the other kernels keep.
+// (k_fused_rev at nfft 2048 keeps no such row: 4.3 KB per wave, the difference between two and three waves per SIMD.)
+// (as two plain instructions: left to itself the compiler pairs the bins of a 16-byte read into packed multiplies -- x^2 it
+// does not need, two moves to line the operands up, and packed float32 issues at half rate: 8 issue slots per two bins
+// instead of 4)
+__device__ __forceinline__ float norm2(float2 v) {
+    float t, e;
+    asm("v_mul_f32 %0, %1, %1" : "=v"(t) : "v"(v.y));
+    asm("v_fma_f32 %0, %1, %1, %2" : "=v"(e) : "v"(v.x), "v"(t));
+    return e;
+}
+struct YofX4 {
+    const float2* x;
+    __device__ __forceinline__ float operator[](int k) const { return norm2(x[xa4(k)]); }
+};
+
+// peak_scan_block_thin (pvx_wave.h) for a 1024-bin row that exists only as the spectrum X (quarter layout): the candidate
+// list (ascending bins) of the row's interior maxima above the threshold, thinned when there are more than 192 of them.
+// Lane l owns FOUR consecutive bins of EVERY quarter, 256 j + 4 l + i: its 32 contiguous bytes per quarter are two 16-byte
+// reads on a 32-byte lane stride (16 consecutive bins per lane would put every lane of an instruction on the same banks:
+// their 128-byte blocks are half the bank array apart).  Neighbours across lanes come by DPP wave shifts (lane 0 / 63: the
+// value from the quarter before / after, through a broadcast).  List order = quarter, lane, bin: two count bits per
+// quarter (four consecutive bins hold at most two maxima).
+template <typename CI>
+__device__ __forceinline__ int peak_scan_x4_thin(const float2* X, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
+    const float thf = __double2float_rd(th);                         // see peak_scan (pvx_wave.h)
+    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
+    float v[16];                                                     // v[4 j + i] = |X[256 j + 4 lane + i]|^2
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float4 a = *(const float4*)(X + j * F4::RP + 4 * lane);
+        const float4 b = *(const float4*)(X + j * F4::RP + 4 * lane + 2);
+        v[4 * j] = norm2(make_float2(a.x, a.y)); v[4 * j + 1] = norm2(make_float2(a.z, a.w));
+        v[4 * j + 2] = norm2(make_float2(b.x, b.y)); v[4 * j + 3] = norm2(make_float2(b.z, b.w));
+    }
+    // rise[j][i], sign bit set: y[k-1] < y[k] at k = 256 j + 4 lane + i; rise[j][4] = the next lane's rise[j][0]
+    int rise[4][5];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // the bin to the left of the lane's first: the lane before's last (lane 0: lane 63's last of the quarter before; bin 0
+        // has itself there and never rises)
+        const int old = (j == 0) ? __float_as_int(v[0]) : __builtin_amdgcn_readlane(__float_as_int(v[4 * j - 1]), 63);
+        const int left = __builtin_amdgcn_update_dpp(old, __float_as_int(v[4 * j + 3]), 0x138, 0xf, 0xf, false);   // wave_shr:1
+        rise[j][0] = left - __float_as_int(v[4 * j]);
+#pragma unroll
+        for (int i = 1; i < 4; i++) rise[j][i] = __float_as_int(v[4 * j + i - 1]) - __float_as_int(v[4 * j + i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int old = (j == 3) ? 0 : __builtin_amdgcn_readlane(rise[j + 1][0], 0);     // (bin 1023 is not interior: cleared below)
+        rise[j][4] = __builtin_amdgcn_update_dpp(old, rise[j][0], 0x130, 0xf, 0xf, false);                          // wave_shl:1
+    }
+    unsigned m = 0;                                                  // bit 4 j + i
+    float sc[16];                                                    // scores y - miny (>= 0)
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            sc[4 * j + i] = v[4 * j + i] - miny;
+            const int above = thb - __float_as_int(sc[4 * j + i]);   // sign bit set: score > thf
+            const unsigned t = (unsigned)(rise[j][i] & ~rise[j][i + 1] & above);
+            m = (m << 1) | (t >> 31);
+        }
+    }
+    if (lane == 63) m &= ~(1u << 15);                                // bin 1023
+    // list positions of the lane's candidates, per quarter
+    unsigned pk01, pk23;
+    auto count = [&](unsigned mm) -> int {
+        int C = 0;
+        unsigned pos[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int cnt = __popc((mm >> (4 * j)) & 15u);           // 0, 1 or 2
+            const unsigned long long b0 = __ballot((cnt & 1) != 0), b1 = __ballot((cnt & 2) != 0);
+            pos[j] = (unsigned)(C + pvxw::lane_prefix(b0) + 2 * pvxw::lane_prefix(b1));
+            C += __popcll(b0) + 2 * __popcll(b1);
+        }
+        pk01 = pos[0] | (pos[1] << 16); pk23 = pos[2] | (pos[3] << 16);
+        return C;
+    };
+    int C = count(m);
+    if (C > 192 && npeaks <= 16) {                                   // wave-uniform; see peak_scan_block_thin
+        float best = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
+        const float T = pvxw::thin_bound(best, npeaks);
+        unsigned keep = 0u;
+#pragma unroll
+        for (int i = 15; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
+        m &= keep;
+        C = count(m);
+    }
+    // one round per candidate of the busiest lane: every lane pops its lowest set bit (lanes that have run out write to
+    // their trash slot)
+    const int tr = trash + lane;
+    while (__ballot(m != 0u) != 0ull) {                              // wave-uniform
+        const bool has = m != 0u;
+        const int b = __ffs((int)m) - 1;                             // 4 j + i
+        const bool hi = (b & 8) != 0;
+        const unsigned sh = (unsigned)(b & 4) << 2;                  // 16 (j & 1)
+        const unsigned pk = hi ? pk23 : pk01;
+        const int pos = (int)((pk >> sh) & 0xffffu);
+        ci[has ? pos : tr] = (CI)(((b >> 2) << 8) + 4 * lane + (b & 3));
+        const unsigned inc = has ? (1u << sh) : 0u;
+        pk23 += hi ? inc : 0u;
+        pk01 += hi ? 0u : inc;
+        m &= m - 1u;
+    }
+    return C;
+}
+
 constexpr float kC16 = 0.92387953251128673848f;   // cos(pi/8)
 constexpr float kS16 = 0.38268343236508978178f;   // sin(pi/8)
 constexpr float kH8 = 0.70710678118654752440f;    // sqrt(1/2)
@@ -88,7 +200,8 @@ __device__ __forceinline__ void special4(const v2f (&c)[4], v2f (&spv)[4]) {
 // LQ: points per quarter; T lanes (lt = this one) share the LQ/2 sets, NPS = LQ / (2 T) per lane; tw[j] = {W_N^k1,
 // W_M^k1, W_M^(2 k1), W_M^(3 k1)} of k1 = lt + T j (M = 4 LQ, N = 2 M).  |X|^2 of every bin -> Ly (padded layout);
 // lmax / lmin / ls0 / ls1 accumulate the lane's max, min and sums of |X|^2.
-template <int LQ, int QP, int T, typename IA>
+// WY = false: no |X|^2 row is written (k_fused_rev at nfft 2048: the peak search recomputes it from the spectrum, YofX4).
+template <int LQ, int QP, int T, typename IA, bool WY = true>
 __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&tw)[LQ / (2 * T)][4], int lt, IA ia,
                                                float& lmax, float& lmin, float& ls0, float& ls1) {
     constexpr int NPS = LQ / (2 * T);
@@ -130,8 +243,10 @@ __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&t
             const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
             xz[t * QP + sa] = x0[t];                                // X[k1 + LQ t]
             xz[(3 - t) * QP + sb] = x1[t];                          // X[kbb + LQ (3 - t)]
-            Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
-            Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
+            if constexpr (WY) {
+                Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
+                Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
+            }
             lmax = pvxw::max3f(lmax, e0, e1); lmin = pvxw::min3f(lmin, e0, e1); ls0 += e0; ls1 += e1;
         }
     }

@@ -633,8 +633,8 @@ __device__ __forceinline__ int peak_scan_seg_thin(const float* y, int kbase, int
 // The dense-candidate branch of peak_pick_regs, kept out of line: it runs on noise-like frames only, and
 // inlined its NCH-wide register arrays and unrolled loops weigh on the register allocation and code
 // layout of the common path (measured: -4 % on harmonic input in the multi-wave kernels).
-template <int NCH, int YP, typename CI>
-__device__ __forceinline__ int peak_radix_body(const float* y, const CI* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI, typename Y = const float*>
+__device__ __forceinline__ int peak_radix_body(Y y, const CI* ci, int* out, int npeaks, int C,
                                                float miny, int lane) {
     int cb[NCH];
     unsigned key[NCH];
@@ -704,24 +704,24 @@ __device__ __forceinline__ int peak_radix_body(const float* y, const CI* ci, int
     return cnt;
 }
 
-template <int NCH, int YP, typename CI>
-__device__ __attribute__((noinline)) int peak_radix_out(const float* y, const CI* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI, typename Y = const float*>
+__device__ __attribute__((noinline)) int peak_radix_out(Y y, const CI* ci, int* out, int npeaks, int C,
                                                         float miny, int lane) {
-    return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
+    return peak_radix_body<NCH, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane);
 }
 // out of line only where the arrays are big (NCH > 4: nfft >= 2048); the small kernels inline it -- a
 // call makes them reserve stack / callee registers, which costs the 2-waves-per-SIMD variants ~4 %
-template <int NCH, int YP, typename CI, bool INL = false>
-__device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int* out, int npeaks, int C,
+template <int NCH, int YP, typename CI, bool INL = false, typename Y = const float*>
+__device__ __forceinline__ int peak_radix_regs(Y y, const CI* ci, int* out, int npeaks, int C,
                                                float miny, int lane) {
     // the select's cost is its register arrays' width (3 compares + ballots per 64 list entries and round, whether
     // the entries exist or not): a recording's frames have 80-200 candidates, white noise ~280 of the 512 the list
     // can hold at nfft 2048 -- take the narrowest instantiation that covers C
-    if constexpr (NCH > 2) { if (C <= 128) return peak_radix_body<2, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
-    if constexpr (NCH > 3) { if (C <= 192) return peak_radix_body<3, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
-    if constexpr (NCH > 5) { if (C <= 320) return peak_radix_body<5, YP, CI>(y, ci, out, npeaks, C, miny, lane); }
-    if constexpr (NCH <= 4 || INL) return peak_radix_body<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
-    else return peak_radix_out<NCH, YP, CI>(y, ci, out, npeaks, C, miny, lane);
+    if constexpr (NCH > 2) { if (C <= 128) return peak_radix_body<2, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane); }
+    if constexpr (NCH > 3) { if (C <= 192) return peak_radix_body<3, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane); }
+    if constexpr (NCH > 5) { if (C <= 320) return peak_radix_body<5, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane); }
+    if constexpr (NCH <= 4 || INL) return peak_radix_body<NCH, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane);
+    else return peak_radix_out<NCH, YP, CI, Y>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // peak_pick with the candidate scores and bins in REGISTERS: lane owns list entries c = lane + 64 j,
@@ -729,8 +729,8 @@ __device__ __forceinline__ int peak_radix_regs(const float* y, const CI* ci, int
 // (noise-like frames: hundreds of maxima above the threshold) is a radix select on register keys --
 // 31 rounds of NCH compares + scalar popcounts, no LDS in the loop -- where the LDS-resident version
 // paid a memory round trip per bit.
-template <int NCH, int YP, typename CI, bool INL = false>
-__device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int* out, int n, int npeaks, int C,
+template <int NCH, int YP, typename CI, bool INL = false, typename Y = const float*>
+__device__ __forceinline__ int peak_pick_regs(Y y, const CI* ci, int* out, int n, int npeaks, int C,
                                               double th, float miny, int lane) {
     if (C <= npeaks) {
         if (th < 0.0 && C < npeaks) {
@@ -785,7 +785,7 @@ __device__ __forceinline__ int peak_pick_regs(const float* y, const CI* ci, int*
         wave_sync();
         return __popcll(bk);
     }
-    return peak_radix_regs<NCH, YP, CI, INL>(y, ci, out, npeaks, C, miny, lane);
+    return peak_radix_regs<NCH, YP, CI, INL, Y>(y, ci, out, npeaks, C, miny, lane);
 }
 
 // `th`: a bin qualifies when y - miny > th (the caller derives it from PF.py:60, 69-70; y may be any
@@ -833,8 +833,8 @@ template <typename T, int YP = 0, typename Y> __device__ __forceinline__ bool sa
 // group tests the two neighbours at distance min(o + 1, rad) (rad <= 8; indices clamped into the window
 // like `salient` does), one ballot per pass of 8 peaks.  `pb`/`mine`: this lane's own peak (list entry
 // eb + lane) and whether it exists; returns its keep flag.  sel[] = the selected bins.
-template <int YP>
-__device__ __forceinline__ bool salient_groups(const float* y, int n, const int* sel, int eb, int nsel, int rad, int lane) {
+template <int YP, typename Y = const float*>
+__device__ __forceinline__ bool salient_groups(Y y, int n, const int* sel, int eb, int nsel, int rad, int lane) {
     const int e = eb + lane;
     if (rad < 0) return e < nsel;
     bool keep = false;
