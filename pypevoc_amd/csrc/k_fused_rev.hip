@@ -38,7 +38,8 @@ template <int R> struct RevGeo {
     static constexpr size_t OFF_T2 = OFF_T1 + (X4 ? (size_t)256 * 8 : (size_t)R * 64 * 8);    // v2f [R][P] W_64^(l1 t2) | X4: none
     static constexpr size_t OFF_TW3 = OFF_T2 + (X4 ? 0 : 64 * 8);    // v2f [TW3N] W_nfft^k     | X4: [2][4][64] join / untangle twiddles of the lane
     static constexpr size_t OFF_WIN = OFF_TW3 + (size_t)TW3N * 8;    // X4: v2f [R][64] the window, lane-ordered | else: none (registers)
-    static constexpr size_t OFF_WAVE = OFF_WIN + (X4 ? (size_t)R * 64 * 8 : 0);
+    static constexpr size_t OFF_FLAG = OFF_WIN + (X4 ? (size_t)R * 64 * 8 : 0);     // int [16]: wave w has left its first spectrum in the stash
+    static constexpr size_t OFF_WAVE = OFF_FLAG + 64;
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFR);
@@ -114,6 +115,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
         }
     }
+    int* const Lflag = (int*)(smem + RG::OFF_FLAG);
+    if (threadIdx.x < 16) Lflag[threadIdx.x] = 0;
     __syncthreads();
 
     // ---- lane constants
@@ -157,11 +160,24 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     // ~25 rows on BASELINE config 2: one row is 4 % of a SIMD's work; +2 % there over an even split by wave index)
     const int NB = (int)gridDim.x;
     const int R0 = (int)(p.total_rows * (int64_t)blockIdx.x / NB), R1 = (int)(p.total_rows * ((int64_t)blockIdx.x + 1) / NB);
-    const int nwg = R1 - R0, base = nwg / NW, extra = nwg - base * NW;
-    const int r0 = R0 + wid * base + (wid < extra ? wid : extra), r1 = r0 + base + (wid < extra ? 1 : 0);
+    // (with the hand-over below only wave 0 still transforms the row under its range: it is charged one row for it, so
+    // that no wave of the workgroup runs one transform longer than the others)
+    const bool chained = p.stash != nullptr;
+    const int nwg = R1 - R0, units = nwg + ((chained && nwg >= NW) ? 1 : 0), base = units / NW, extra = units - base * NW;
+    const int dec = (chained && nwg >= NW) ? 1 : 0;                 // wave 0's share, in rows, is one less than in units
+    const int r0 = R0 + wid * base + (wid < extra ? wid : extra) - (wid > 0 ? dec : 0), r1 = R0 + (wid + 1) * base + (wid + 1 < extra ? wid + 1 : extra) - dec;
     if (r0 >= r1) return;
     const int Fi = (int)p.F;
     const int rows1 = Fi + 1;                                       // rows per signal
+    // ---- the row below a wave's range (the previous spectrum of its last frame) is the FIRST row of the wave below it in the
+    // workgroup: that wave leaves its spectrum in global memory (8 KB, once per launch) and raises a flag in LDS when the
+    // stores have landed; this wave, 16 or 25 frames later, picks its last frame's few bins up there instead of running one
+    // more transform (6 % of a wave's transforms at nfft 2048 -- and the frames a wave has are 16 or 17, not 17 or 18).
+    // Same CU, so the same L2; the flag follows `s_waitcnt vmcnt(0)` behind the stores.  Not across workgroups (their wave
+    // 0 computes the row as before), not into a zero row (nothing to fetch).
+    const bool chain_out = p.stash != nullptr && wid + 1 < NW && r1 < R1 && ((r1 - 1) % rows1) != 0;
+    const bool chain_in = p.stash != nullptr && wid > 0 && r0 > R0 && ((r0 - 1) % rows1) != 0;       // (r0 == R0: wave 0 was left without rows)
+    const int glast = chain_in ? r0 : r0 - 1;                       // last row this wave transforms
 
     // (see k_fused_ring.hip: the flush-only kernel arguments are re-read from the kernel argument segment)
     // (in the CONSTANT address space: scalar loads.  As a generic pointer these were flat loads, and the result stores below
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
     // samples of global row gn = (bn, qn): nullptr when there is nothing to load
     auto row_src = [&](int gn, int bn, int qn) -> const InT* {
-        if (gn < r0 - 1 || gn < 0 || qn == 0) return nullptr;
+        if (gn < glast || gn < 0 || qn == 0) return nullptr;
         return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
     };
     auto load_pair = [&](const InT* src, int r) {
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     // per-peak pass over this wave's staged frames [0, ng)
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
-    auto flush = [&](int ng) {
+    auto flush = [&](int gbeg, int ng) {                           // groups [gbeg, ng)
         wave_sync();
         // (the lane's group and its ballot mask are worked out here, once per 8 frames: as loop invariants they are four
         // registers held through the frame loop, and at three waves per SIMD the loop has none to spare)
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
         pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
-        const int g = gl;
+        const int g = gbeg + gl;
         const bool gvalid = g < ng;
         const int cnt = gvalid ? Lcnt[g] : -1;
         const int64_t orow = gvalid ? (int64_t)Lorow[g] : 0;
@@ -378,7 +394,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     bool pend = false, pend_prev0 = false, pend_own = false;        // the frame staged last still waits for its previous spectrum
     int pend_nk = 0, own_sl = -1, own_pb = 1;
     bool prev_zero = false;                                         // (H > 0) the row above was a zero row
-    for (; g >= r0 - 1; --g) {
+    int stash_state = chain_out ? 0 : 2;                            // 0: to be written, 1: written, flag due, 2: done
+    for (; g >= glast; --g) {
         int bn = gb, qn = gq - 1;                                   // (b, q) of row g - 1
         if (qn < 0) { qn = Fi; bn -= 1; }
         const bool zero_row = (g < 0) || (gq == 0);
@@ -390,6 +407,25 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
         spectrum(zero_row, row_src(g - 1, bn, qn), maxe, mine, tot);
+        if (stash_state == 1) {
+            // (one row after the stores: they have long landed, the wait is for form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile int*)(Lflag + wid) = 1;
+            stash_state = 2;
+        } else if (stash_state == 0) {
+            // (four bins per lane at a time: sixteen at once are 32 registers nobody has here)
+            float2* const so = (float2*)kargs->stash + ((size_t)(blockIdx.x * NW + wid) * M + fresh_lane());
+#pragma unroll
+            for (int j = 0; j < R; j += 4) {
+                float2 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) t[u] = cur[XA(lane + 64 * (j + u))];
+#pragma unroll
+                for (int u = 0; u < 4; u++) so[64 * (j + u)] = t[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stash_state = 1;
+        }
         if (pend) {
             // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
             if (pend_own && !pend_prev0) {
@@ -410,7 +446,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 Lsval[(size_t)sl * 5 + 3] = pv.y;
             }
             pend = false;
-            if (ng == gs) { flush(ng); ng = 0; }
+            if (ng == gs) { flush(0, ng); ng = 0; }
         }
         if (!zero_row && g >= r0) {
             bool own = false;                                       // every kept peak is remembered by the lane that staged it
@@ -546,10 +582,47 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         wave_sync();                                                // cur / Ly / lists are read: free for the row below
         gb = bn; gq = qn;
     }
-    if (ng > 0) flush(ng);
+    if (stash_state == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) *(volatile int*)(Lflag + wid) = 1;
+    }
+    // ---- tail.  With the hand-over, the last frame's previous spectrum comes from the stash of the wave below: the loads are
+    // issued, the groups before the last are flushed while they fly, then the last group follows.
+    int f1 = ng;
+    unsigned long long pv64 = 0ull;
+    bool late = false;
+    if (chain_in && pend) {
+        while (*(volatile int*)(Lflag + wid - 1) == 0) __builtin_amdgcn_s_sleep(4);
+        asm volatile("" ::: "memory");                              // nothing of the stash is read before the flag
+        // (same CU as the writer: same L2; this launch has read nothing of the stash before, so no older copy sits in the L1)
+        const float2* st = (const float2*)kargs->stash + (size_t)(blockIdx.x * NW + wid - 1) * M;
+        if (pend_own) {
+            if (own_sl >= 0) pv64 = __builtin_nontemporal_load((const unsigned long long*)(st + own_pb));
+            late = true; f1 = ng - 1;
+        } else
+        for (int e = lane; e < pend_nk; e += 64) {
+            const int sl = (ng - 1) * kpad + e;
+            unsigned long long v;
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(st + Lsbin[sl]) : "memory");
+            Lsval[(size_t)sl * 5 + 2] = __uint_as_float((unsigned)v);
+            Lsval[(size_t)sl * 5 + 3] = __uint_as_float((unsigned)(v >> 32));
+        }
+    }
+    int f0 = 0;
+    for (int pass = 0; pass < 2; pass++) {                          // (one copy of the flush code for both parts)
+        if (pass == 1) {
+            if (!late) break;
+            if (own_sl >= 0) {
+                Lsval[(size_t)own_sl * 5 + 2] = __uint_as_float((unsigned)pv64);
+                Lsval[(size_t)own_sl * 5 + 3] = __uint_as_float((unsigned)(pv64 >> 32));
+            }
+            f0 = ng - 1; f1 = ng;
+        }
+        if (f1 > f0) flush(f0, f1);
+    }
 }
 
-template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipStream_t s) {
+template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipStream_t s, size_t* stash_need = nullptr) {
     using RG = RevGeo<R>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -579,6 +652,8 @@ template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipSt
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     dim3 grid((unsigned)nblocks), block(64 * NW);
     FusedParams arg = p;
+    if (stash_need) { *stash_need = (size_t)nblocks * NW * Geo<R>::M * sizeof(float2); return PVX_OK; }
+    if (arg.stash_bytes < (size_t)nblocks * NW * Geo<R>::M * sizeof(float2) || getenv("PVX_REV_NO_CHAIN") != nullptr) arg.stash = nullptr;
     void* args[] = {&arg};
     PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     return PVX_OK;
@@ -596,16 +671,24 @@ int pvx_fused_rev_supported(int nfft, int precision, int K) {
     }
 }
 
-int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
+static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need);
+int pvx_launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) { return launch_fused_rev(p, nfft, x_dtype, s, nullptr); }
+size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft) {
+    size_t need = 0;
+    if (launch_fused_rev(p, nfft, PVX_F32, nullptr, &need) != PVX_OK) return 0;
+    return need;
+}
+static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need) {
+    if (stash_need) *stash_need = 0;
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
         // three waves per SIMD when the waves' buffers fit (npks up to ~90), else two
-        case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s) : launch_rev<16, 8>(p, x_dtype, s);
+        case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s, stash_need) : launch_rev<16, 8>(p, x_dtype, s, stash_need);
 #ifndef PVX_REV_NW1024
 #define PVX_REV_NW1024 12
 #endif
-        case 1024: return launch_rev<8, PVX_REV_NW1024>(p, x_dtype, s);
-        case 512: return launch_rev<4, 12>(p, x_dtype, s);
+        case 1024: return launch_rev<8, PVX_REV_NW1024>(p, x_dtype, s, stash_need);
+        case 512: return launch_rev<4, 12>(p, x_dtype, s, stash_need);
         default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

@@ -560,9 +560,10 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
 constexpr int kTile = 32;                        // records per wave and LDS tile (32 x 160 B = 5 KB = the wave's store staging)
 constexpr int kLaneB = 80;                       // bytes per lane in the store staging: 64 + 16 (conflict-free 16-byte rows)
 #ifndef PVX_BODIES_TB
-#define PVX_BODIES_TB 256
+#define PVX_BODIES_TB 64
 #endif
-constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_synth_bodies (its waves never meet)
+constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_synth_bodies: its waves never meet, and one-wave workgroups
+                                                 // start as soon as ANY wave slot is free (four-wave ones wait for four: 124 against 129 us)
 template <int R>
 __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
     // everything is per wave (a wave's 64 runs are consecutive, so are the records of their segments): no workgroup barrier

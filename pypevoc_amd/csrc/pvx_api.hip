@@ -193,6 +193,8 @@ struct pvx_plan {
     void* d_sws = nullptr;                 // resynthesis workspace (k_synth.hip)
     size_t sws_cap = 0;
     unsigned sws_gen = 0;                  // calls on this workspace since it was allocated
+    void* d_stash = nullptr;               // k_fused_rev: first spectra of its waves, for the waves below them (FusedParams::stash)
+    size_t stash_cap = 0;
     float* d_x32 = nullptr;                // a device-resident float64 signal narrowed for the fused float32 kernels
     size_t x32_cap = 0;
     void* d_desc = nullptr;                // descriptor outputs (f0 / harmonic power)
@@ -223,6 +225,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_twiddle64) (void)hipFree(p->d_twiddle64);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_specrow) (void)hipFree(p->d_specrow);
+    if (p->d_stash) (void)hipFree(p->d_stash);
     if (p->d_hf0) (void)hipFree(p->d_hf0);
     if (p->d_hx) (void)hipFree(p->d_hx);
     if (p->d_hprev) (void)hipFree(p->d_hprev);
@@ -605,6 +608,18 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.t = d_t; fp.totalmag = d_totalmag; fp.win = p->d_win; fp.twiddle = p->d_twiddle;
         fp.spec_out = spec_row >= 0 ? (p->spec_host ? p->spec_host : p->d_specrow) : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
+        fp.stash = nullptr; fp.stash_bytes = 0;
+        if (p->fft_mode == 4) {
+            // k_fused_rev: the block where its waves hand a spectrum to the wave below them (sized once, for a full grid)
+            if (!p->d_stash) {
+                FusedParams q = fp;
+                q.total_rows = (int64_t)1 << 30;
+                const size_t need = pvx_fused_rev_stash_bytes(q, p->nfft);
+                if (need > 0 && hipMalloc(&p->d_stash, need) == hipSuccess) p->stash_cap = need;
+                else { p->d_stash = nullptr; p->stash_cap = 0; (void)hipGetLastError(); }     // (without it the waves compute that row themselves)
+            }
+            fp.stash = p->d_stash; fp.stash_bytes = p->stash_cap;
+        }
         if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
         rc = (p->fft_mode == 1) ? pvx_launch_fused(fp, p->nfft, x_dtype, s)
            : (p->fft_mode == 2) ? pvx_launch_fused_mw(fp, p->nfft, x_dtype, s)

@@ -99,7 +99,13 @@ struct FusedParams {      // k_fused.hip: window + FFT + untangle + peaks in one
     float* spec_out;      // optional: half spectrum (nfft/2 complex) of global row spec_row
     int64_t spec_row;
     int64_t blocks_override;
+    // k_fused_rev.hip: where a wave leaves the first spectrum it computes for the wave below it in its workgroup (whose last
+    // frame needs it as its previous spectrum): float2 [workgroups x waves][nfft / 2], or NULL -- every wave then computes
+    // the row below its range itself.  pvx_fused_rev_stash_bytes: what the launch of these parameters would use.
+    void* stash;
+    size_t stash_bytes;
 };
+size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft);
 int pvx_fused_supported(int nfft, int precision, int K);
 int pvx_launch_fused(const FusedParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_fused_mw_supported(int nfft, int precision, int K);     // k_fused_mw.hip: several waves per frame
