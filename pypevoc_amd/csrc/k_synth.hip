@@ -19,7 +19,7 @@
 //                    (np.interp of the partial's f / mag, PVAnalysis.py:701-702) are piecewise linear with
 //                    breakpoints one hop apart, so inside a segment each is two linear pieces and the cumulative
 //                    phase (PVAnalysis.py:705-708) is a quadratic in the sample index; attack / release are pure
-//                    sinusoids under a raised cosine.  One 160-byte record per body, 64 bytes per edge, and one bit
+//                    sinusoids under a raised cosine.  One 128-byte record per body, 64 bytes per edge, and one bit
 //                    per node and kind (the wave's ballot) saying which records exist.
 //   k_synth_samples  one thread per RUN of R consecutive output samples: walks the set bits of its segment,
 //                    and for each contribution seeds exp(i phase) and exp(i phase increment) exactly (two sincos)
@@ -28,7 +28,7 @@
 //                    float64 instructions per sample instead of a forty-instruction cosine.  The recurrence is
 //                    re-seeded every run, so its error stays below R^2 * 1e-16.  R sums live in registers across
 //                    all contributions and are stored once.
-// Bound: float64 VALU issue (sample loop).  HBM: 8*h bytes written per segment, 160 B per body record
+// Bound: float64 VALU issue (sample loop).  HBM: 8*h bytes written per segment, 128 B per body record
 // written and read once (cache-resident between the two launches).
 // All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
 #include <math.h>
@@ -169,14 +169,16 @@ template <class A> __device__ inline Piece2 make_piece2(double x0, double h, dou
 //   phase(m) = ph0 + step m + [m <= fmb: fa0 m + fsa T(m) | smb + fb0 (m - fmb) + fsb (T(m) - tmb)],  T(m) = m (m - 1) / 2
 //   (coefficients pre-scaled by 2 pi / sr), amplitude(m) = m < mmb ? ma0 + msa m : mb0 + msb m       (PVAnalysis.py:734-736)
 // so phase(m+1) - phase(m) = step + (m < fmb ? fa0 + fsa m : fb0 + fsb m), and its own increment is fsa, then fsb.
-// da / db = exp(i fsa) - 1, exp(i fsb) - 1; wb = exp(i (step + fb0 + fsb fmb)): the increment's rotation at the break.
+// da / db = exp(i fsa) - 1, exp(i fsb) - 1.  tmb = T(fmb) is an exact product of small integers: the readers form it.
+// One cache line per record: the records are the resynthesis' largest stream (written once, read once).
 struct __attribute__((aligned(32))) BodyRec {
-    double ph0, step, fa0, fsa, fb0, fsb, smb, tmb;
+    double ph0, step, fa0, fsa, fb0, fsb, smb;
     double ma0, msa, mb0, msb;
-    double dar, dai, dbr, dbi, wbr, wbi;
-    int fmb, mmb, pad0, pad1;
+    double dar, dai, dbr, dbi;
+    int fmb, mmb;
 };
-static_assert(sizeof(BodyRec) == 160, "BodyRec layout");
+static_assert(sizeof(BodyRec) == 128, "BodyRec layout");
+constexpr int kLaneB = 80;                       // bytes per lane in the kernels' store staging: 64 + 16 (conflict-free 16-byte rows)
 // attack: sample j of [0, edgsam) at output index o0 + j is ah (1 - cos(pi j / edgsam)) cos(ph0 - 2 pi (edgsam - j) cfr);
 // release: ah (1 + cos(pi j / edgsam)) cos(ph0 + 2 pi (j + 1) cfr)                                  (PVAnalysis.py:740-751)
 struct __attribute__((aligned(32))) EdgeRec {
@@ -255,8 +257,10 @@ __global__ __launch_bounds__(256) void k_synth_scatter(SynthK q) {
 // The closed forms of node (fr, slot) -- point ii of a partial of nfr points starting at frame st, its points through the
 // accessors pf / pm / pr (f, mag, realph) -- into the slice's records; what it found: body / irregular body / attack / release
 struct NodeKinds { bool isb, isx, isa, isr; };
-template <class AF, class AM, class AR>
-__device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, int64_t node, int64_t fr, int st, int nfr, int ii_, const AF& pf, const AM& pm, const AR& pr) {
+// store_body(c): what to do with the node's body record (its place is q.body[(fr - q.fb0) K + slot])
+template <class AF, class AM, class AR, class SB>
+__device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, int64_t node, int64_t fr, int st, int nfr, int ii_, const AF& pf, const AM& pm, const AR& pr,
+                                                 SB&& store_body) {
     bool isb = false, isx = false, isa = false, isr = false;
     const int ii = ii_, h = q.h;
     const double dh = q.dh;
@@ -302,13 +306,12 @@ __device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, in
         c.ph0 = pr(ii) + phcor;                                   // PVAnalysis.py:721
         const double tmb = 0.5 * (double)c.fmb * (double)(c.fmb - 1);
         c.smb = c.fa0 * (double)c.fmb + c.fsa * tmb;              // sum of the first fmb terms
-        c.tmb = tmb;
         // ph[h-1] + ph0 (before the discontinuity ramp): prefix over the h - 1 terms fsig(nbase + 0 .. h-2)
         double lastsum;
         {
             const int m = h - 1;
             const double tm = 0.5 * (double)m * (double)(m - 1);
-            lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - c.tmb);
+            lastsum = (m <= c.fmb) ? c.fa0 * (double)m + c.fsa * tm : c.smb + c.fb0 * (double)(m - c.fmb) + c.fsb * (tm - tmb);
         }
         const double lastph = kPi2 * div_const(lastsum, q.sr, q.rsr) + c.ph0;
         c.step = 0.0;
@@ -341,10 +344,7 @@ __device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, in
             // rotations of the increment: exp(i x) - 1 = (-2 sin^2(x/2), 2 sin(x/2) cos(x/2)) -- x is tiny
             expm1i(c.fsa, c.dar, c.dai);
             expm1i(c.fsb, c.dbr, c.dbi);
-            const double xb = c.step + __builtin_fma(c.fsb, (double)c.fmb, c.fb0);
-            fsincos(xb, c.wbi, c.wbr);
-            c.pad0 = c.pad1 = 0;
-            q.body[(fr - q.fb0) * q.K + (node - fr * q.K)] = c;
+            store_body(c);
             // does every run of k_synth_bodies lie on one piece of fsig and one of msig?  (a change at position x
             // is harmless at 0, h, a cut, or a multiple of R past the cut before it)
             auto on_edge = [&](int x) {
@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
                 const double* cf = q.cf + off;
                 const double* cm = q.cm + off;
                 const double* cr = q.cr + off;
-                kd = node_params(q, li, node, fr, st, nfr, (int)ii64, [&](int j) { return cf[j]; }, [&](int j) { return cm[j]; }, [&](int j) { return cr[j]; });
+                kd = node_params(q, li, node, fr, st, nfr, (int)ii64, [&](int j) { return cf[j]; }, [&](int j) { return cm[j]; }, [&](int j) { return cr[j]; },
+                                 [&](const BodyRec& c) { q.body[(fr - q.fb0) * q.K + (node - fr * q.K)] = c; });
             }
         }
     }
@@ -396,7 +397,11 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
 // partial's points by scanning the staged partial_id rows (a nibble per point in a 64-bit word) and reads the values where
 // they are.  No k_synth_alloc / k_synth_scatter, no second copy of the analysis arrays.
 constexpr int kDirectMaxK = 16, kDirectMaxWL = 16;
+#ifdef PVX_PARAMS_WAVES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_WAVES, PVX_PARAMS_WAVES))) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
+#else
 __global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int K = q.K, tid = threadIdx.x;
     const int64_t li0 = (int64_t)blockIdx.x * 256, li = li0 + tid;
@@ -418,6 +423,8 @@ __global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, i
     __syncthreads();
     NodeKinds kd;
     kd.isb = kd.isx = kd.isa = kd.isr = false;
+    BodyRec crec;                                                     // this node's body record, if it has one
+    bool has_body = false;
     if (li < nloc) {
         const int64_t node = q.fx0 * K + li;
         const int64_t fr = node / K;
@@ -451,7 +458,35 @@ __global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, i
                     int jj = j < j0 ? j0 : (j > j1 ? j1 : j);          // (never outside for a consistent table)
                     return L[rbase + jj * K + (int)((slots >> (4 * (jj - j0))) & 15ull)];
                 };
-                kd = node_params(q, li, node, fr, st, nfr, ii, [&](int j) { return at(Lf, j); }, [&](int j) { return at(Lm, j); }, [&](int j) { return at(Lr, j); });
+                kd = node_params(q, li, node, fr, st, nfr, ii, [&](int j) { return at(Lf, j); }, [&](int j) { return at(Lm, j); }, [&](int j) { return at(Lr, j); },
+                                 [&](const BodyRec& c) { crec = c; has_body = true; });
+            }
+        }
+    }
+    // ---- the wave's records are consecutive in memory (a node's record sits at node - fb0 K): they leave through LDS, half a
+    // record at a time, so that a store instruction writes 64 contiguous bytes of 16 records instead of 16 bytes of 64 (one
+    // 128-byte line per lane, eight instructions each)
+    {
+        __shared__ __attribute__((aligned(16))) unsigned char stg_all[4][64 * kLaneB];
+        const unsigned long long bw = __ballot(has_body);
+        if (bw != 0ull) {                                             // wave-uniform
+            unsigned char* stg = stg_all[tid >> 6];
+            const int lane = tid & 63;
+            unsigned char* const rec0 = (unsigned char*)(q.body + (li0 + (tid & ~63) + (q.fx0 - q.fb0) * K));
+            int4 pc[8];
+            __builtin_memcpy(pc, &crec, sizeof(BodyRec));
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) *(int4*)(stg + lane * kLaneB + 16 * i) = pc[4 * half + i];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int r = 16 * i + (lane >> 2);
+                    const int4 v = *(const int4*)(stg + r * kLaneB + 16 * (lane & 3));
+                    if ((bw >> r) & 1ull) *(int4*)(rec0 + (size_t)r * sizeof(BodyRec) + 64 * half + 16 * (lane & 3)) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -537,7 +572,8 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
         dl_ = __builtin_fma(fsa_, ds, fa0_);                                                                        \
     } else {                                                                                                        \
         const double fb0_ = (c)->fb0, fsb_ = (c)->fsb;                                                              \
-        ph_ = __builtin_fma(fsb_, ts - (c)->tmb, __builtin_fma(fb0_, (double)((s) - (c)->fmb), (c)->smb));          \
+        const double dfmb_ = (double)(c)->fmb;                                                                      \
+        ph_ = __builtin_fma(fsb_, ts - 0.5 * dfmb_ * (dfmb_ - 1.0), __builtin_fma(fb0_, ds - dfmb_, (c)->smb));     \
         dl_ = __builtin_fma(fsb_, ds, fb0_);                                                                        \
     }                                                                                                               \
     {                                                                                                               \
@@ -557,8 +593,7 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
 // consecutive, so the records of its segments are consecutive too: they are staged through LDS a tile at a time (one
 // coalesced round of loads per tile instead of a dependent round trip per contribution and thread), and the finished sums
 // leave through LDS as well, so that a store instruction writes 64-byte pieces instead of 16 bytes per 256.
-constexpr int kTile = 32;                        // records per wave and LDS tile (32 x 160 B = 5 KB = the wave's store staging)
-constexpr int kLaneB = 80;                       // bytes per lane in the store staging: 64 + 16 (conflict-free 16-byte rows)
+constexpr int kTile = 40;                        // records per wave and LDS tile (40 x 128 B = 5 KB = the wave's store staging)
 #ifndef PVX_BODIES_TB
 #define PVX_BODIES_TB 64
 #endif
