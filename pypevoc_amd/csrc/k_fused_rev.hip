@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             if (valid) {
                 nbin = Lsbin[g * kpad + e];
                 const float* sv = Lsval + (size_t)(g * kpad + e) * 5;
-                o = peak_math<float>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                o = peak_math<float, true>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
                 valid = o.valid;
             }
             const unsigned long long bal = __ballot(valid) & gmask;

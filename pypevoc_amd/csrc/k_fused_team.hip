@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         if (valid) {
             nbin = Lsbin[g * kpad + e0];
             const float* sv = Lsval + (size_t)(g * kpad + e0) * 5;
-            o = peak_math<float>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+            o = peak_math<float, true>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
             valid = o.valid;
         }
         const unsigned long long bal = __ballot(valid) & gmask;

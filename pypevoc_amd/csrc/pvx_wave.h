@@ -879,8 +879,18 @@ struct PeakOut {
     bool nanph;       // the phase difference is NaN (x/0 with a zero real or imaginary part)
 };
 
-template <typename T>
+// wfbin[nbin] (PV.py:114-118) as the plan's table holds it, computed on the spot: the host's own float64 sequence
+// (pvx_plan_create), so the same bits.  For the kernels whose per-peak pass would otherwise wait for a global load
+// (`WFC`): a round trip of thousands of cycles per flush against ~25 float64 instructions.
+__device__ __forceinline__ double wfbin_of(int nbin, const PeakConst& c) {
+    const double fbin = (double)nbin * c.fstep;
+    const double dthetabin = kPi2 * fbin * c.dt;
+    return __builtin_nearbyint(dthetabin / kPi2) * kPi2;
+}
+
+template <typename T, bool WFC = false>
 __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T s3, const PeakConst& c) {
+    const double wfb = WFC ? wfbin_of(nbin, c) : c.wfbin[nbin];
     PeakOut o;
     bool nanph = false;
     if constexpr (sizeof(T) == 4) {
@@ -895,7 +905,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
             nanph = (re == 0.f || im == 0.f || re != re || im != im);
             const double dphd = (re > 0.f) ? (im > 0.f ? kPi / 4 : -kPi / 4) : (im > 0.f ? 3 * kPi / 4 : -3 * kPi / 4);
             const double fb = (double)nbin * c.fstep;
-            const double w0 = dphd + c.wfbin[nbin];
+            const double w0 = dphd + wfb;
             double bestabs = 0.0;
             o.freq = 0.0; o.dfb = 0.0;
 #pragma unroll
@@ -911,7 +921,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
             // PV.py:140-147 in closed form: with cyc = nbin*hop/nfft (cycles the bin centre advances per
             // hop) and w = wfbin/2pi, candidate m has df*dt = cyc - w - dph/2pi - m; cyc - w is exact in
             // float64 and |cyc - w| <= 1/2
-            const double cw = (double)nbin * (double)c.hop / (double)c.nfft - c.wfbin[nbin] / kPi2;
+            const double cw = (double)nbin * (double)c.hop / (double)c.nfft - wfb / kPi2;
             const float u = (float)cw - dph * (float)(1.0 / kPi2);
             float best = u + 1.f, ab = fabsf(best);                      // m = -1
             if (fabsf(u) < ab) { best = u; ab = fabsf(u); }              // m = 0   (first minimum wins)
@@ -938,7 +948,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
         }
         // PV.py:140-147 literally: three unwrapping candidates, the one nearest the bin centre
         const double fb = (double)nbin * c.fstep;                    // PV.py:114
-        const double w0 = dph + c.wfbin[nbin];
+        const double w0 = dph + wfb;
         double bestabs = 0.0;
         o.freq = 0.0; o.dfb = 0.0;
 #pragma unroll

@@ -544,6 +544,54 @@ def test_fused_kernel_variants(amd, oracle):
         assert_f32(compare_analysis(pv_result(p), o, nfft, 512, sr), absolute=False)
 
 
+def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monkeypatch):
+    """k_fused_rev at nfft 2048 (fft mode 4): three waves per SIMD without an |X|^2 row (PVX_REV_NW8=1: the two-wave instantiation
+    of the same code) and the first spectrum a wave computes handed to the wave above it through global memory
+    (PVX_REV_NO_CHAIN=1: every wave transforms the row under its range itself) -- with any grid (one workgroup; a few; one
+    row per wave; more waves than rows), hop (sliding window or full reload), input type, several signals per call (zero rows
+    where nothing is handed over) and dense frames, every output is bit-identical."""
+    rng = np.random.default_rng(4077)
+    sr, nfft = 44100.0, 2048
+    n = 400000
+    t = np.arange(n) / sr
+    noise = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    harm = (sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)).astype(np.float32)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+
+    def same(a, b, what):
+        for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
+
+    variants = ((), (("PVX_REV_NO_CHAIN", "1"),), (("PVX_REV_NW8", "1"),), (("PVX_REV_NW8", "1"), ("PVX_REV_NO_CHAIN", "1")))
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("int16", np.round(harm * 20000).astype(np.int16))):
+        for K, hop, nb in ((8, 512, None), (8, 512, "1"), (8, 512, "5"), (8, 512, "64"), (8, 512, "1000"), (20, 1024, None), (3, 333, "17"), (64, 512, None)):
+            res = []
+            for env in variants:
+                for k, v in env:
+                    monkeypatch.setenv(k, v)
+                if nb:
+                    monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
+                res.append(run_pv(amd, x, sr, nfft, hop, K, precision=32))
+                for k, v in env:
+                    monkeypatch.delenv(k)
+                if nb:
+                    monkeypatch.delenv("PVX_FUSED_BLOCKS")
+            for i in range(1, len(res)):
+                same(res[0], res[i], (name, K, hop, nb, variants[i]))
+    for ns in (nfft + 1, nfft + 512 * 9 + 5, nfft + 512 * 40):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[n // 7 - 1000:n // 7 - 1000 + ns], noise[100:100 + ns]])
+        res = []
+        for env in variants:
+            for k, v in env:
+                monkeypatch.setenv(k, v)
+            res.append(amd.PVBatch(xb, sr, nfft=nfft, hop=512, npks=8).run_pv())
+            for k, v in env:
+                monkeypatch.delenv(k)
+        for i in range(1, len(res)):
+            for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+                assert np.array_equal(np.asarray(getattr(res[0], k)), np.asarray(getattr(res[i], k))), (ns, variants[i], k)
+
+
 @pytest.mark.parametrize("nfft,kmode", [(2048, 3), (1024, 3), (512, 3), (1024, 4), (512, 4)])
 def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmode):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
