@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=tuple(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f64 / noise / violin lines (N = 1 only anyway)")
+    ap.add_argument("--no-host-batch", action="store_true", help="skip the pvx_batch_run line (host signals over a device list; N = 1 only)")
     ap.add_argument("--no-config5", action="store_true", help="skip the `config5` object (BASELINE config 5: the nfft x hop sweep at 96 kHz)")
     ap.add_argument("--c5-seconds", type=int, default=3600, help="length of config 5's 96 kHz signal (BASELINE: 60 min = 1.38 GB of float32 in HBM)")
     ap.add_argument("--fft-mode", type=int, default=-1, help="-1: plan default; 0: general path; 1 ... 5: fused kernels")
@@ -638,7 +639,7 @@ def main():
             h = out.cpu().numpy()
             return np.concatenate([h[: 5 * Fq * K], h[5 * Fq * K + Fq:], h[5 * Fq * K: 5 * Fq * K + Fq]])
 
-        f64 = workloads = other_nfft = chain = config5 = None
+        f64 = workloads = other_nfft = chain = config5 = host_batch = None
         if extras_ok:
             from oracle import pvoracle
             pvoracle.build()
@@ -861,6 +862,42 @@ def main():
                                points=points)
                 del x5
                 torch.cuda.empty_cache()
+            # ---- the C-level batch entry (pvx_batch_run, include/pvx.h): ragged signals in pageable host memory over a
+            # device list inside this process, results into per-signal host arrays -- PCIe-inclusive, so never `value`; every signal
+            # compared bit for bit with its own PV(...).run_pv()
+            host_batch = None
+            if not args.no_host_batch:
+                import pypevoc_amd
+                rngb = np.random.default_rng(11)
+                nb_sig, nb_s = 48, 30
+                tb = np.arange(nb_s * 48000) / 48000.0
+                sigs = []
+                for b in range(nb_sig):
+                    f0 = 110.0 * 2 ** (b / 48.0 * 3)
+                    xb = sum(0.3 / hh * np.sin(2 * np.pi * f0 * hh * tb) for hh in range(1, 9)) + 0.001 * rngb.standard_normal(len(tb))
+                    sigs.append(xb[: int(len(tb) * (0.25 + 0.75 * ((b * 29) % nb_sig) / nb_sig))].astype(np.float32))
+                many = pypevoc_amd.PVMany(48000, nfft=NFFT, hop=HOP, npks=NPKS, devices=[local_rank], precision=32)
+                many.run(sigs)
+                tb_ = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    resb = many.run(sigs)
+                    tb_.append(time.perf_counter() - t0)
+                many.close()
+                frb = sum(r["nframes"] for r in resb)
+                same_b = True
+                for i in (0, 7, nb_sig - 1):
+                    pb_ = pypevoc_amd.PV(sigs[i], 48000, nfft=NFFT, hop=HOP, npks=NPKS, progress=False, precision=32)
+                    pb_.run_pv()
+                    same_b = same_b and all(np.array_equal(resb[i][k], getattr(pb_, k)) for k in ("f", "mag", "ph", "realph", "binno"))
+                host_batch = dict(value=round(frb / min(tb_), 1), unit="frames/s", signals=nb_sig, frames=frb, seconds=round(min(tb_), 4),
+                                  input_MB=round(sum(len(v) for v in sigs) * 4 / 1e6, 1), devices=[local_rank], workers_per_device=4, pcie_inclusive=True,
+                                  identical_to_single_signal_calls=bool(same_b),
+                                  what="pvx_batch_run: %d signals of 7.5 .. 30 s @ 48 kHz float32 in pageable host memory, results into per-signal host arrays; "
+                                       "wall clock of the call, best of 3 (the kernels are ~5 %% of it: host copies and PCIe are the rest)" % nb_sig)
+                if not same_b:
+                    sys.stderr.write("bench.py: pvx_batch_run differs from the single-signal calls\n")
+                    checks_failed.append("host_batch")
         if checks_failed or gather_check_failed:
             rc = 3
 
@@ -895,6 +932,8 @@ def main():
             line["chain"] = chain
         if config5:
             line["config5"] = config5
+        if host_batch:
+            line["host_batch"] = host_batch
         if gather_info:
             gather_info["ms_per_step_kernels_only"] = stage["step_ms_hip_events"]
             gather_info["exposed_ms_per_step"] = round(max(0.0, elapsed / args.steps * 1e3 - stage["step_ms_hip_events"]), 4)

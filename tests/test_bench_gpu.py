@@ -56,6 +56,9 @@ def test_bench_extras_are_all_checked_against_the_oracle():
     for p in pts:
         assert p["self_check"]["ok"] and p["self_check"]["bad_peaks"] == 0 and p["self_check"]["ref_peaks"] > 0, p
         assert p["value"] > 0 and p["contract_target"] > 0 and p["fft_mode"] in (4, 5)
+    # the C-level batch entry on host signals: PCIe-inclusive, never `value`; identical to the single-signal calls
+    hb = j["host_batch"]
+    assert hb["identical_to_single_signal_calls"] and hb["pcie_inclusive"] and hb["value"] > 0 and hb["frames"] > 0
 
 
 def test_bench_forced_gather_exercises_rccl():

@@ -79,6 +79,10 @@ if b:
         if ch.get("total"):
             L.append("| `chain.total` | %s | **%.3f ms**: one analysis step + `pvx_track_dev` + `pvx_synth_dev` back to back on the resident signal, wall clock (goal %.2f ms) |" %
                      (M(ch["total"]["value"]), ch["total"]["ms"], ch["total"].get("goal_ms", 0.55)))
+    hb = b.get("host_batch")
+    if hb:
+        L.append("| `host_batch` (`pvx_batch_run`) | %s | PCIe-inclusive: %d ragged host signals (%.0f MB in), %d workers on device %s, %.4f s; identical to the single-signal calls: %s |" %
+                 (M(hb["value"]), hb["signals"], hb["input_MB"], hb["workers_per_device"], hb["devices"], hb["seconds"], hb["identical_to_single_signal_calls"]))
     c = b.get("cpu_baseline")
     if c:
         L.append("| `cpu_baseline` | %s on %d threads | one thread %s; the Python reference %s (BASELINE.md) |" %
