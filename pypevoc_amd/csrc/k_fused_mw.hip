@@ -299,10 +299,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
     const int G_ = gs;                                            // frames staged per pass
-    const int gl = lane / LPF, e0 = lane - gl * LPF;
-    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
+        // (the lane's group and ballot mask per flush, not as registers held through the frame loop: k_fused_rev.hip)
+        const int lnf = fresh_lane();
+        const int gl = lnf / LPF, e0 = lnf - gl * LPF;
+        const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
         const FusedParams* q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fused_mw(FusedParams p) {
             }
             const unsigned long long bal = __ballot(valid) & gmask;
             if (valid) {
-                const int oi = nout + __popcll(bal & ((1ull << lane) - 1ull));
+                const int oi = nout + __popcll(bal & ((1ull << lnf) - 1ull));
                 ob[oi] = (double)nbin;
                 of[oi] = o.freq;
                 om[oi] = o.mag;

@@ -242,10 +242,13 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     // per-peak pass over the staged frames [0, ng): every wave its own peaks; K <= 64: one entry per lane
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
-    const int gl = lane / LPF, e0 = lane - gl * LPF;
-    const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
     auto flush = [&](int ng) {
         wave_sync();
+        // (the lane's group and ballot mask, worked out per flush: as loop invariants they are registers held through the frame
+        // loop, which has none to spare -- k_fused_rev.hip)
+        const int lnf = fresh_lane();
+        const int gl = lnf / LPF, e0 = lnf - gl * LPF;
+        const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
         kargs_t q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         gdouble* orp = (gdouble*)q->realph + orow * K;
         gdouble* ob = (gdouble*)q->binno + orow * K;
         if (valid) {
-            const int oi = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const int oi = off + __popcll(bal & ((1ull << lnf) - 1ull));
             ob[oi] = (double)nbin;
             of[oi] = o.freq;
             om[oi] = o.mag;
