@@ -209,6 +209,29 @@ def test_synth_matches_reference(amd, name):
         assert np.abs(w32 - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+def test_synth_parameters_match_reference(amd):
+    """SinSum.synth(sr, hop, edge, minframes) with the parameters the other fixtures leave at their defaults (fixture S1: edge
+    0 .. 2, minframes 1 .. 6, synthesis hops 128 / 256 / 300; partials that start and stop, one-point partials included):
+    the HIP resynthesis from the reference's analysis arrays and tracks against the reference's waveforms, <= 1e-10; and the
+    whole float64 chain (run_pv -> toSinSum -> synth) on the fixture's samples."""
+    g = load_golden("S1_synth_params")
+    ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    s64 = run_golden(amd, g, 64).toSinSum()
+    n = 0
+    for k in g:
+        if not k.startswith("w_") or k.startswith("w_hop"):
+            continue
+        h, e100, mf = (int(v) for v in k[2:].split("_"))
+        ref = g[k]
+        for src in (ss, s64):
+            w = src.synth(g["sr"], h, edge=e100 / 100.0, minframes=mf)
+            assert w.shape == ref.shape and w.dtype == np.float64, (k, w.shape, ref.shape)
+            assert np.abs(w - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (k, float(np.abs(w - ref).max()))
+        n += 1
+    assert n == 7
+
+
 def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
     """The resynthesis kernels' launch shapes -- runs of 16 / 32 samples per thread, the waveform in slices of a few segments,
     the pieces of fsig changing inside runs (no cuts: every body through k_synth_extras' predicated loop) -- and the

@@ -70,6 +70,29 @@ def test_synth_matches_reference(oracle, name):
         np.testing.assert_allclose(w, ref, rtol=0, atol=tol * max(1.0, np.abs(ref).max()))
 
 
+def _synth_param_cases(g):
+    for k in g:
+        if k.startswith("w_") and not k.startswith("w_hop"):
+            h, e100, mf = (int(v) for v in k[2:].split("_"))
+            yield k, h, e100 / 100.0, mf
+
+
+def test_synth_parameters_match_reference(oracle):
+    """SinSum.synth's other parameters (fixture S1: edge 0 .. 2, minframes 1 .. 6, synthesis hops 128 / 256 / 300 on an
+    analysis whose partials start and stop): the oracle against the reference's waveforms."""
+    g = load_golden("S1_synth_params")
+    pid, st, ln = oracle.track(g["f"], g["mag"])
+    assert np.array_equal(st, g["part_start"]) and np.array_equal(ln, g["part_len"])
+    n = 0
+    for k, h, edge, mf in _synth_param_cases(g):
+        w = oracle.synth(g["f"], g["mag"], g["realph"], pid, st, ln, g["sr"], g["nfft"], g["hop"], h, edge=edge, minframes=mf)
+        ref = g[k]
+        assert w.shape == ref.shape, (k, w.shape, ref.shape)
+        np.testing.assert_allclose(w, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()), err_msg=k)
+        n += 1
+    assert n == 7
+
+
 def test_g1_known_answer(oracle):
     """The by-eye known answer of the reference's tests/test_pypevoc.py."""
     g = load_golden("G1_two_sines")
