@@ -209,6 +209,21 @@ def test_synth_matches_reference(amd, name):
         assert np.abs(w32 - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+def test_tracker_jump_limit_matches_reference(amd, oracle):
+    """The tracker's jump limit (fixture T2: SinSum.add_frame(..., maxpitchjmp) at 0.05 / 0.5 / 1.5 / 12 semitones -- 577 / 181 / 9
+    / 5 partials): pvx_track on the reference's arrays gives the reference's table, limit by limit."""
+    g = load_golden("T2_maxpitchjmp")
+    n = 0
+    for key in sorted(k[6:] for k in g if k.startswith("start_")):
+        ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+        ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"], maxpitchjmp=int(key) / 100.0)
+        pid, st, ln = ss.partial_table()
+        assert np.array_equal(st, g["start_" + key]) and np.array_equal(ln, g["len_" + key]), key
+        assert np.array_equal(oracle.part_slots(pid, st, ln), g["slot_" + key]), key
+        n += 1
+    assert n == 4
+
+
 def test_synth_parameters_match_reference(amd):
     """SinSum.synth(sr, hop, edge, minframes) with the parameters the other fixtures leave at their defaults (fixture S1: edge
     0 .. 2, minframes 1 .. 6, synthesis hops 128 / 256 / 300; partials that start and stop, one-point partials included):

@@ -93,6 +93,19 @@ def test_synth_parameters_match_reference(oracle):
     assert n == 7
 
 
+def test_tracker_jump_limit_matches_reference(oracle):
+    """SinSum.add_frame's maxpitchjmp (fixture T2: 0.05 / 0.5 / 1.5 / 12 semitones on a gliding, vibrating signal: 577 / 181 / 9 / 5
+    partials): the oracle's table against the reference's, limit by limit."""
+    g = load_golden("T2_maxpitchjmp")
+    seen = []
+    for key in sorted(k[6:] for k in g if k.startswith("start_")):
+        pid, st, ln = oracle.track(g["f"], g["mag"], maxpitchjmp=int(key) / 100.0)
+        assert np.array_equal(st, g["start_" + key]) and np.array_equal(ln, g["len_" + key]), key
+        assert np.array_equal(oracle.part_slots(pid, st, ln), g["slot_" + key]), key
+        seen.append(len(st))
+    assert sorted(seen) == [5, 9, 181, 577]
+
+
 def test_g1_known_answer(oracle):
     """The by-eye known answer of the reference's tests/test_pypevoc.py."""
     g = load_golden("G1_two_sines")
