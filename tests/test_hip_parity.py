@@ -1167,6 +1167,24 @@ def test_fuzz_against_oracle(amd, oracle):
     assert chk > 5000 and bad <= 1e-4 * chk, (chk, bad)
 
 
+def test_fuzz_long_cases_against_oracle(amd, oracle):
+    """tools/fuzz.py's cases at 300 .. 3000 frames (PVX_FUZZ_LONG): waves with many rows and the spectra they hand to each other,
+    every flush cycle, several tracker chunks, long waveforms -- every fft mode, both precisions, tracker, resynthesis and
+    PVHarmonic against the oracle, as in test_fuzz_against_oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pvx_fuzz_long", os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails = []
+    chk = bad = 0
+    for idx in range(14):
+        f, st = fz.run_case(4242, idx, long=True)
+        fails += f
+        chk += st["chk"]; bad += st["bad"]
+    assert not fails, fails[:5]
+    assert chk > 5000 and bad <= 1e-4 * chk, (chk, bad)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_first_frame_unwrapping_ties_follow_reference(amd, oracle, mode, monkeypatch):
     """hop = nfft/8: in frame 0 (previous spectrum all zero) the phase difference is +-pi/4 or +-3pi/4

@@ -4,6 +4,8 @@
 
   python tools/fuzz.py [seconds] [seed]        run cases seed:0, seed:1, ... for `seconds`
   python tools/fuzz.py --case SEED:INDEX       re-run one case verbosely
+  PVX_FUZZ_LONG=1 ...                          cases of 300 .. 3000 frames instead of 1 .. 60 (waves with many rows, several
+                                               tracker chunks, every flush cycle; the same checks)
 
 float64 is held to the oracle strictly.  float32 is held to it on the WELL-CONDITIONED peaks
 only: a peak whose bin, in this frame and in the previous one, is within 60 dB of that frame's
@@ -47,14 +49,18 @@ def signal(rng, n, sr):
 VERBOSE = False
 
 
-def make_case(seed, idx):
+LONG = bool(os.environ.get("PVX_FUZZ_LONG"))
+
+
+def make_case(seed, idx, long=None):
+    long = LONG if long is None else long
     rng = np.random.default_rng([seed, idx])
     nfft = int(rng.choice([128, 256, 512, 1000, 1024, 2048, 2048, 4096, 8192]))
     hop = int(rng.choice([nfft // 8, nfft // 4, nfft // 2, nfft // 3 + 1, nfft - 1]))
     K = int(rng.choice([1, 3, 8, 8, 20, 64, 100]))
     thr = float(rng.choice([0.0, 0.0005, 0.005, 0.005, 0.1]))
     sr = float(rng.choice([8000, 22050, 44100, 96000]))
-    n = int(nfft + hop * rng.integers(1, 60) + rng.integers(1, hop + 1))
+    n = int(nfft + hop * (rng.integers(300, 3000) if long else rng.integers(1, 60)) + rng.integers(1, hop + 1))
     kind, x = signal(rng, n, sr)
     return dict(nfft=nfft, hop=hop, K=K, thr=thr, sr=sr, n=n, kind=kind, x=x,
                 h2=int(rng.choice([hop, max(2, hop // 2), hop + 7])), f32in=bool(rng.random() < 0.5))
@@ -187,8 +193,8 @@ def check32(p, o, c, S):
     return msgs, nchk, nbad, worst
 
 
-def run_case(seed, idx, verbose=False):
-    c = make_case(seed, idx)
+def run_case(seed, idx, verbose=False, long=None):
+    c = make_case(seed, idx, long)
     nfft, hop, K, thr, sr, x = c["nfft"], c["hop"], c["K"], c["thr"], c["sr"], c["x"]
     o = pvoracle.analyze(x, sr, nfft, hop, K, thr)
     F = len(o["t"])
