@@ -49,7 +49,7 @@ template <int R> struct RevGeo {
                  + gs * kpad * 5 * 4                                 // sval
                  + kpad * 4 + gs * kpad * 4                          // sel | sbin
                  + GFR * 4 * 2                                       // cnt | frm
-                 + (size_t)(G::CAP + 64) * 2;                        // ci (u16) + 64 trash slots
+                 + ((size_t)(G::CAP + 64) * 2 > 512 ? (size_t)(G::CAP + 64) * 2 : 512);      // ci (u16) + 64 trash slots; then the 64 ranking keys (u64)
         return (b + 15) & ~(size_t)15;
     }
     __host__ __device__ static size_t total(int K, int nw) { return OFF_WAVE + per_wave(K) * nw; }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     int* const Lcnt = (int*)(Ly + (X4 ? 0 : M + 4 * R));
     int* const Lfrm = Lcnt + GFR;
     u16* const Lci = (u16*)(Lfrm + GFR);
-    int* const Lsel = (int*)(Lci + G::CAP + 64);
+    int* const Lsel = (int*)((unsigned char*)Lci + ((size_t)(G::CAP + 64) * 2 > 512 ? (size_t)(G::CAP + 64) * 2 : 512));
     int* const Lsbin = Lsel + kpad;
     float* const Lsval = (float*)(Lsbin + gs * kpad);
 
@@ -513,14 +513,16 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                     // keys (score, 63 - lane): unique, ties go to the lower bin; scores >= 0: bits order like values
                     const unsigned mykey = has ? __float_as_uint(v - mine) : 0u;
                     const unsigned long long my64 = ((unsigned long long)mykey << 32) | (unsigned)(63 - lane);
+                    // (the keys go through LDS, where the candidate list was -- every lane has read its entry, and a wave's LDS
+                    // operations execute in order --: a 16-byte read at a wave-uniform address hands two keys to all lanes, so
+                    // an entry costs a compare and an add; broadcast by `v_readlane` it cost five vector instructions, 100+
+                    // per frame on a signal with a few more candidates than peaks wanted)
+                    unsigned long long* const Lk = (unsigned long long*)Lci;
+                    Lk[lane] = my64;                                   // (lanes from C on hold score 0: below every candidate's)
                     int rank = 0;
-                    for (int j = 0; j < C; j += 4) {                   // (lanes from C on hold key 0: below every candidate's)
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mykey, j + u);
-                            const unsigned long long k64 = ((unsigned long long)kj << 32) | (unsigned)(63 - j - u);
-                            rank += (k64 > my64) ? 1 : 0;
-                        }
+                    for (int j = 0; j < C; j += 4) {
+                        const ulonglong2 ka = *(const ulonglong2*)(Lk + j), kb = *(const ulonglong2*)(Lk + j + 2);
+                        rank += (ka.x > my64 ? 1 : 0) + (ka.y > my64 ? 1 : 0) + (kb.x > my64 ? 1 : 0) + (kb.y > my64 ? 1 : 0);
                     }
                     take = has && (rank < K);
                 }

@@ -63,8 +63,8 @@ template <int S> struct TeamGeo {
     static constexpr size_t OFF_J4 = OFF_T1 + 256 * 8;                   // v2f [4][3][64] W_1024^(u k1) (S = 4)
     static constexpr size_t OFF_X = OFF_J4 + (size_t)J4N * 8;            // float2 [S][REG]
     static constexpr size_t OFF_Y = OFF_X + (size_t)S * REG * 8;         // float [YLEN]
-    static constexpr size_t OFF_KEYS = OFF_Y + (size_t)YLEN * 4;         // u32 [S][64]; before the keys are written: the scan's trash slots
-    static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * 64 * 4;    // double [S]
+    static constexpr size_t OFF_KEYS = (OFF_Y + (size_t)YLEN * 4 + 15) & ~(size_t)15;     // u64 [S][64] (score, tie-break); before the keys are written: the scan's trash slots
+    static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * 64 * 8;    // double [S]
     static constexpr size_t OFF_MISC = OFF_PSUM + (size_t)S * 8;         // int nw[S] | float pmax[S] | float pmin[S] | int val[S][GFT]
     static constexpr size_t OFF_WAVE = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
     __host__ __device__ static size_t per_wave(int K) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     v2f* const j4L = (v2f*)(smem + TG::OFF_J4);
     float2* const X = (float2*)(smem + TG::OFF_X);
     float* const Ly = (float*)(smem + TG::OFF_Y);
-    unsigned* const Lkeys = (unsigned*)(smem + TG::OFF_KEYS);
+    unsigned long long* const Lkeys = (unsigned long long*)(smem + TG::OFF_KEYS);
     double* const Lpsum = (double*)(smem + TG::OFF_PSUM);
     int* const Lnw = (int*)(smem + TG::OFF_MISC);
     float* const Lpmax = (float*)(Lnw + S);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
 #pragma unroll
             for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
             mykey = has ? __float_as_uint(v - mine) : 0u;           // scores >= 0: bits order like values
-            Lkeys[wid * 64 + lane] = mykey;
+            Lkeys[wid * 64 + lane] = ((unsigned long long)mykey << 32) | (unsigned)(64 * (S - 1 - wid) + 63 - lane);
             if (lane == 0) Lnw[wid] = n_w;
         }
         if (p.spec_out != nullptr && g == p.spec_row) {
@@ -408,19 +408,17 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 // rank of this lane's candidate among all the team's: larger score, or equal score and lower bin -- one
                 // compare of (score, 64 (S - 1 - wave) + 63 - lane): unique keys, four list entries per trip (the lanes
                 // behind a wave's list hold score 0: below every candidate's)
+                // (the keys are read where they are: a 16-byte LDS read at a wave-uniform address hands two of them to all
+                // lanes -- a compare and an add per entry instead of a `v_readlane` broadcast and three more instructions)
                 const unsigned long long my64 = ((unsigned long long)mykey << 32) | (unsigned)(64 * (S - 1 - wid) + 63 - lane);
                 int rank = 0;
 #pragma unroll
                 for (int w = 0; w < S; w++) {
                     const int n = Lnw[w];
-                    const unsigned ko = (w == wid) ? mykey : Lkeys[w * 64 + lane];
+                    const unsigned long long* kw = Lkeys + w * 64;
                     for (int j = 0; j < n; j += 4) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)ko, j + u);
-                            const unsigned long long k64 = ((unsigned long long)kj << 32) | (unsigned)(64 * (S - 1 - w) + 63 - j - u);
-                            rank += (k64 > my64) ? 1 : 0;
-                        }
+                        const ulonglong2 ka = *(const ulonglong2*)(kw + j), kb = *(const ulonglong2*)(kw + j + 2);
+                        rank += (ka.x > my64 ? 1 : 0) + (ka.y > my64 ? 1 : 0) + (kb.x > my64 ? 1 : 0) + (kb.y > my64 ? 1 : 0);
                     }
                 }
                 take = has && (rank < K);

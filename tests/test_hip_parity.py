@@ -601,7 +601,8 @@ def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monke
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
 
     variants = ((), (("PVX_REV_NO_CHAIN", "1"),), (("PVX_REV_NW8", "1"),), (("PVX_REV_NW8", "1"), ("PVX_REV_NO_CHAIN", "1")))
-    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("int16", np.round(harm * 20000).astype(np.int16))):
+    violin = np.tile(load_golden("G7_perlman")["x"], 2)[:n].astype(np.float32)
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("int16", np.round(harm * 20000).astype(np.int16)), ("violin", violin)):
         for K, hop, nb in ((8, 512, None), (8, 512, "1"), (8, 512, "5"), (8, 512, "64"), (8, 512, "1000"), (20, 1024, None), (3, 333, "17"), (64, 512, None)):
             res = []
             for env in variants:
@@ -663,7 +664,10 @@ def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmo
         for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
             assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
 
-    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant)):
+    # (a violin recording: 20 .. 60 candidates per frame at these sizes -- more than npks, at most one per lane: the ranking path)
+    g7 = load_golden("G7_perlman")["x"]
+    violin = np.tile(g7, 2)[:n]
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant), ("violin", violin)):
         for K, thr, hop in ((8, 0.005, nfft // 4), (1, 0.005, 333 * nfft // 2048), (3, 0.0, nfft // 4), (20, 0.3, nfft - 1), (24, 0.005, nfft // 8), (8, 0.005, nfft // 2)):
             a, b = both(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
             assert _lib.load().pvx_plan_get_fft_mode(b._plan.handle) == kmode
