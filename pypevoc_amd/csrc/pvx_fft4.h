@@ -18,6 +18,9 @@
 // The same pass joins the 1024-point sub-transforms of a team of 4 waves (k_fused_team.hip, nfft 8192): quarter =
 // a wave's region, index inside a quarter through `IA`.
 #pragma once
+#ifndef PVX_THIN_FROM
+#define PVX_THIN_FROM 96    // candidates per row (segment) from which the list is thinned before it is written (peak_scan_block_thin)
+#endif
 
 #include "pvx_fft.h"
 
@@ -120,7 +123,7 @@ __device__ __forceinline__ int peak_scan_x4_thin(const float2* X, float miny, do
         return C;
     };
     int C = count(m);
-    if (C > 192 && npeaks <= 16) {                                   // wave-uniform; see peak_scan_block_thin
+    if (C > PVX_THIN_FROM && npeaks <= 16) {                                   // wave-uniform; see peak_scan_block_thin
         float best = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);

@@ -3,6 +3,9 @@
 // (pypevoc/PeakFinder.py:155-194, 113-136) and the per-peak phase-vocoder arithmetic
 // (pypevoc/PVAnalysis.py:133-148, 187-207).
 #pragma once
+#ifndef PVX_THIN_FROM
+#define PVX_THIN_FROM 96    // candidates per row (segment) from which the list is thinned before it is written (peak_scan_block_thin)
+#endif
 
 #include <float.h>
 #include <math.h>
@@ -550,10 +553,11 @@ __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, 
     int C = count(m, pos);
     // (th < 0 -- the threshold lies below the row's minimum, as on white noise -- changes nothing here: with more than 64
     // candidates the selection takes maxima only, and at least npeaks of them survive)
-    // (worth its ~150 instructions from about 200 candidates up: below that the callers' radix select over two or
-    // three keys per lane is cheaper than this plus a ranking pass over the survivors -- a violin recording's frames,
-    // ~120 candidates, ran 8 % slower with it, white noise's, ~280, 16 % faster)
-    if (C > 192 && npeaks <= 16) {                                   // wave-uniform
+    // (its ~150 instructions pay from about a hundred candidates up, PVX_THIN_FROM: below that the callers' radix select over
+    // two keys per lane is as cheap as this plus the ranking pass over the survivors.  While that pass broadcast its keys by
+    // v_readlane the break-even was near 200 -- a violin recording's frames, ~120 candidates, ran 8 % slower thinned; with
+    // the keys read from LDS they run 2 % faster at nfft 2048 / 4096, white noise at nfft 1024, ~140 candidates, 14 %)
+    if (C > PVX_THIN_FROM && npeaks <= 16) {                                   // wave-uniform
         float best = 0.f;                                            // this lane's best candidate score (0: it has none)
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
@@ -615,7 +619,7 @@ __device__ __forceinline__ int peak_scan_seg_thin(const float* y, int kbase, int
     };
     int pos;
     int C = count(m, pos);
-    if (C > 192 && npeaks <= 16) {                                   // wave-uniform (see peak_scan_block_thin)
+    if (C > PVX_THIN_FROM && npeaks <= 16) {                                   // wave-uniform (see peak_scan_block_thin)
         float best = 0.f;
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
