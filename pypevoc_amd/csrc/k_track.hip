@@ -399,6 +399,16 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
             if (fr > 0) { pf[s] = p.f[(fr - 1) * K + s]; pm[s] = p.mag[(fr - 1) * K + s]; }
         }
     }
+    // rows of more than KL slots: this kernel is right as long as the slots from KL on hold no valid peak (TrackParams::wide)
+    // (a workgroup that meets such a frame says so and leaves: the launch's result will not be used)
+    if (K > KL) {
+        bool widefr = false;
+        if (live) for (int s = KL; s < K; s++) widefr = widefr || (p.f[fr * K + s] > 0.0 && p.mag[fr * K + s] > 0.0);
+        if (__syncthreads_or(widefr)) {
+            if (tid == 0) { *p.wide = p.gen; *p.wide_dev = p.gen; }
+            return;
+        }
+    }
     // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first
     // (np.argsort(mag)[::-1] / sorted(zip(pmag, pidx), reverse=True): see the header)
     bool vc[KL], vp[KL];
@@ -481,6 +491,12 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
                 if (fr == p.F - 1) p.succ[fr * K + s] = 0;
             }
         }
+        for (int s = KL; s < K; s++) {                              // (empty slots of a wide row)
+            p.link[fr * K + s] = -1;
+            if (fr > 0) p.succ[(fr - 1) * K + s] = 0;
+            if (fr == p.F - 1) p.succ[fr * K + s] = 0;
+            p.root[fr * K + s] = -1;
+        }
         p.newcount[fr] = nnew | (amb_any ? kAmbBit : 0) | (nc > 0 ? kHasBit : 0);
     }
     // ---- creation ranks inside the chunk, the chunk's totals
@@ -540,6 +556,7 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
 // one workgroup; chunkbase[c] = new partials before chunk c.
 __global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.wide != nullptr && *(volatile unsigned*)p.wide_dev == p.gen) return;  // (k_track_links_lane has given up: TrackParams::wide)
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     __shared__ int amb_s, last_s;
@@ -781,6 +798,7 @@ __global__ __launch_bounds__(1024) void k_track_boundaries(TrackParams p) {
 }
 
 __global__ __launch_bounds__(256) void k_assign_chunked(TrackParams p) {
+    if (p.wide != nullptr && *(volatile unsigned*)p.wide_dev == p.gen) return;  // (as k_track_boundaries_lane)
     const int64_t n = p.F * (int64_t)p.K;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -848,23 +866,7 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     const int64_t n = p.F * (int64_t)p.K;
     if (n >= 0x7fffffffLL) { pvx_set_error("F*K = %lld does not fit the 32-bit node index", (long long)n); return PVX_ERR_UNSUPPORTED; }
     const unsigned nb = (unsigned)((n + 255) / 256);
-    {
-        // npks <= 8: a frame per lane (k_track_links_lane), while the last-frame rows of its chunks fit one workgroup's LDS
-        const int64_t nchl = (p.F + CLL - 1) / CLL;
-        const size_t blds = (size_t)nchl * p.K * 4;
-        if (p.K <= KL && blds <= 150 * 1024 && p.chunkbase && !getenv("PVX_TRACK_CHUNK") && !getenv("PVX_TRACK_GENERIC") && !getenv("PVX_TRACK_LARGE") &&
-            !getenv("PVX_TRACK_FPW") && !getenv("PVX_TRACK_WAVES")) {
-            p.chunk = CLL;
-            hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
-            if (blds > 48 * 1024)
-                PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
-            hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);
-            hipLaunchKernelGGL(k_assign_chunked, dim3(nb), dim3(256), 0, s, p);
-            PVX_HIP_CHECK(hipGetLastError());
-            return PVX_OK;
-        }
-        p.chunkbase = nullptr;
-    }
+    // the wave-per-frame kernels' geometry
     const int kp = (p.K + 1) & ~1;
     const size_t per_wave = WaveLds::bytes(kp);
     if (per_wave > 160 * 1024) { pvx_set_error("npks=%d too large for the tracker", p.K); return PVX_ERR_UNSUPPORTED; }
@@ -878,6 +880,28 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
     // boundary rows for k_track_boundaries' single workgroup to jump over
     int fpw = (p.K <= 16 && p.F >= 4096 && waves == 16 && per_wave * 64 <= 64 * 1024) ? 4 : 1;
     if (const char* e = getenv("PVX_TRACK_FPW")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && per_wave * waves * v <= 64 * 1024) fpw = v; }
+    {
+        // a frame per lane (k_track_links_lane): rows of npks <= 8 -- and wider rows (<= 64) in the hope that no frame has a
+        // valid peak beyond slot 7 (a tone under the reference's default npks = 20): the kernel says so in *p.wide if one
+        // has, and the caller, who waits for the result words anyway, then calls again without the word (track_on).
+        // While the last-frame rows of the chunks fit one workgroup's LDS.
+        const int64_t nchl = (p.F + CLL - 1) / CLL;
+        const size_t blds = (size_t)nchl * p.K * 4;
+        const bool hope = p.K > KL;
+        const bool fits = blds <= 150 * 1024 && (!hope || (p.K <= 64 && p.wide != nullptr && p.wide_dev != nullptr && p.gen != 0 && !getenv("PVX_TRACK_NO_LANE")));
+        if (fits && p.chunkbase && !getenv("PVX_TRACK_CHUNK") && !getenv("PVX_TRACK_GENERIC") && !getenv("PVX_TRACK_LARGE") &&
+            !getenv("PVX_TRACK_FPW") && !getenv("PVX_TRACK_WAVES")) {
+            p.chunk = CLL;
+            hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
+            if (blds > 48 * 1024)
+                PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+            hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);
+            hipLaunchKernelGGL(k_assign_chunked, dim3(nb), dim3(256), 0, s, p);
+            PVX_HIP_CHECK(hipGetLastError());
+            return PVX_OK;
+        }
+        p.chunkbase = nullptr;
+    }
     p.fpw = fpw;
     p.chunk = waves * fpw;
     const dim3 grid((unsigned)((p.F + p.chunk - 1) / p.chunk)), block(64 * waves);

@@ -1415,7 +1415,7 @@ static size_t track_ws_bytes(int64_t F, int K) {
     // link, root: int32 [F*K]; newcount int32 [F]; newbase int64 [F+1]; npartials, ambiguous, maxend int64; succ [F*K]
     size_t off = n * 4 * 2 + (size_t)F * 4;
     off = (off + 7) & ~(size_t)7;
-    off += ((size_t)F + 1) * 8 + 24 + n;
+    off += ((size_t)F + 1) * 8 + 32 + n;
     off = (off + 7) & ~(size_t)7;
     const size_t nch = (size_t)(F + 255) / 256;                  // k_track_links_lane: chunkbase int64 [nch + 1], chunktot / chunklast int32 [nch]
     return off + (nch + 1) * 8 + nch * 8;
@@ -1428,7 +1428,7 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
     const size_t n = (size_t)F * K;
     const size_t off_link = 0, off_root = off_link + n * 4, off_cnt = off_root + n * 4;
     const size_t off_base = (off_cnt + (size_t)F * 4 + 7) & ~(size_t)7;
-    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 24;
+    const size_t off_np = off_base + ((size_t)F + 1) * 8, off_succ = off_np + 32;
     TrackParams tp;
     tp.f = d_f; tp.mag = d_mag; tp.F = F; tp.K = K; tp.maxjmp = maxpitchjmp;
     tp.partial_id = d_partial_id; tp.part_start = d_part_start; tp.part_len = d_part_len; tp.cap = cap;
@@ -1441,15 +1441,31 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
     // { partials, exact double tie met, last frame with a point }: three single stores by the kernels.  In page-locked
     // host memory when the caller has some (the resident chain): the host reads them after the one synchronisation,
     // no copy operation behind the kernels.
-    int64_t pa_[3] = {0, 0, -1};
+    // (the fourth word: k_track_links_lane's report of a frame too wide for it -- the call's number, see TrackParams::wide)
+    int64_t pa_[4] = {0, 0, -1, 0};
     volatile int64_t* pa = pinned3 ? pinned3 : pa_;
     tp.npartials = pinned3 ? pinned3 : (int64_t*)(w + off_np);
     tp.ambiguous = tp.npartials + 1;
     tp.maxend = tp.npartials + 2;
+    static std::atomic<unsigned> calls{0};
+    tp.wide = (unsigned*)(tp.npartials + 3);
+    tp.wide_dev = (unsigned*)(w + off_np + 24) + 1;              // (the workspace's own copy of the words is device memory either way)
+    do { tp.gen = ++calls; } while (tp.gen == 0);
+    if (K > 8) {                                                   // (rows of at most 8 slots never use the words)
+        if (pinned3) pinned3[3] = 0;
+        PVX_HIP_CHECK(hipMemsetAsync(w + off_np + 24, 0, 8, s));
+    }
     int rc = pvx_launch_track(tp, s);
     if (rc != PVX_OK) return rc;
-    if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+    if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 32, hipMemcpyDeviceToHost, s));
     PVX_HIP_CHECK(hipStreamSynchronize(s));
+    if ((unsigned)pa[3] == tp.gen) {
+        // a frame with a valid peak beyond slot 7: the table of the wave-per-frame kernels instead
+        tp.wide = nullptr;
+        if ((rc = pvx_launch_track(tp, s)) != PVX_OK) return rc;
+        if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 24, hipMemcpyDeviceToHost, s));
+        PVX_HIP_CHECK(hipStreamSynchronize(s));
+    }
     if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
         // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
         // table with the sequential kernel, which has the partial indices at hand

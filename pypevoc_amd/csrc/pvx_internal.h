@@ -162,6 +162,12 @@ struct TrackParams {
     int32_t* chunktot = nullptr;     // [ceil(F / 256)]
     int32_t* chunklast = nullptr;    // [ceil(F / 256)]
     int64_t* chunkbase = nullptr;    // [ceil(F / 256) + 1]
+    // rows wider than 8 slots that hold at most 8 valid peaks (the reference's default npks is 20; a tone has a handful) go
+    // through k_track_links_lane too: it works on slots 0 .. 7 and stores gen into *wide when a frame has a valid peak beyond;
+    // the caller then launches again with wide = nullptr (the wave-per-frame kernels)
+    unsigned* wide = nullptr;        // [1], read by the host with the result words (page-locked host memory when the caller has some)
+    unsigned* wide_dev = nullptr;    // [1], the same in device memory: what the launch's later kernels look at
+    unsigned gen = 0;                // the call's number (never 0)
     int64_t* ambiguous;   // [1]  set by k_track_links when the reference's (magnitude, partial index) order of
                           //      the previous partials would decide an assignment (k_track.hip header)
 };

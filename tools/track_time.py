@@ -11,7 +11,7 @@ from pypevoc_amd import _lib  # noqa: E402
 from oracle import pvoracle  # noqa: E402
 from bench import c2_signal  # noqa: E402
 secs = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-SR, NFFT, HOP, K = 44100, 2048, 512, 8
+SR, NFFT, HOP, K = 44100, 2048, 512, int(os.environ.get("TRACK_TIME_NPKS", "8"))
 lib = _lib.load()
 dev = torch.device("cuda:0")
 sp = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
