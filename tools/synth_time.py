@@ -23,7 +23,7 @@ from bench import c2_signal  # noqa: E402
 
 secs = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-SR, NFFT, HOP, K = 44100, 2048, 512, 8
+SR, NFFT, HOP, K = 44100, 2048, 512, int(os.environ.get("SYNTH_TIME_NPKS", "8"))
 lib = _lib.load()
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream(dev)
