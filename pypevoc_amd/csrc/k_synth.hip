@@ -524,6 +524,7 @@ struct SampK {
     int fx0, fx1, fb0, fb1;              // frames whose edges / bodies the slice holds
     int K, h, EF, edgsam, rps;
     int xcs;                             // k_synth_extras: log2 of its chunk of segments
+    int tile;                            // k_synth_bodies: records per wave and LDS tile (>= kTile)
     int c1, c2, n0, n1;                  // k_synth_bodies: the cuts of a segment's runs (RunCuts)
     double vr, vi;                       // k_synth_extras: exp(i pi / edgsam)
 };
@@ -593,7 +594,7 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
 // consecutive, so the records of its segments are consecutive too: they are staged through LDS a tile at a time (one
 // coalesced round of loads per tile instead of a dependent round trip per contribution and thread), and the finished sums
 // leave through LDS as well, so that a store instruction writes 64-byte pieces instead of 16 bytes per 256.
-constexpr int kTile = 40;                        // records per wave and LDS tile (40 x 128 B = 5 KB = the wave's store staging)
+constexpr int kTile = 40;                        // least records per wave and LDS tile (40 x 128 B = 5 KB = the wave's store staging); SampK::tile
 #ifndef PVX_BODIES_TB
 #define PVX_BODIES_TB 64
 #endif
@@ -602,12 +603,15 @@ constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_s
 template <int R>
 __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
     // everything is per wave (a wave's 64 runs are consecutive, so are the records of their segments): no workgroup barrier
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kBodiesTB / 64][kTile * sizeof(BodyRec)];
+    // (q.tile records per wave, at least kTile: all the records a wave's 64 runs can need -- a few segments' K slots -- so that
+    // its lanes walk their segments' bodies together; with a tile shorter than that, the lanes of different segments take
+    // turns, tile by tile, and half the wave idles: rows of 20 slots cost twice the time of rows of 8 for the same bodies)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     __shared__ long long s_o[kBodiesTB];
     __shared__ int s_len[kBodiesTB];
-    static_assert(kTile * sizeof(BodyRec) == 64 * kLaneB, "store staging = record tile");
+    static_assert(kTile * sizeof(BodyRec) == 64 * kLaneB, "store staging = the least record tile");
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
-    unsigned char* lds = lds_all[tid >> 6];
+    unsigned char* lds = lds_dyn + (size_t)(tid >> 6) * q.tile * sizeof(BodyRec);
     const int64_t gid0 = (int64_t)blockIdx.x * kBodiesTB, gid = gid0 + tid;
     const bool live = gid < q.nthreads;
     const int64_t g = live ? gid : q.nthreads - 1;
@@ -678,8 +682,8 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
         if (seg_hi > q.fb1) seg_hi = q.fb1;
         const int nlo = __builtin_amdgcn_readfirstlane((seg_lo - q.fx0) * K), nhi = __builtin_amdgcn_readfirstlane((seg_hi - q.fx0) * K);
         const BodyRec* rec = q.body - (q.fb0 - q.fx0) * K;
-        for (int tile = nlo; tile < nhi; tile += kTile) {
-            const int cnt = nhi - tile < kTile ? nhi - tile : kTile;
+        for (int tile = nlo; tile < nhi; tile += q.tile) {
+            const int cnt = nhi - tile < q.tile ? nhi - tile : q.tile;
             // (LDS operations of one wave execute in order: the copy below is behind the previous tile's reads, the
             // reads behind the copy)
             {
@@ -1079,9 +1083,17 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
             else hipLaunchKernelGGL((k_synth_extras<16, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
         }
         const dim3 grid((unsigned)grid_blocks);
-        if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(kBodiesTB), 0, s, k);
-        else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(kBodiesTB), 0, s, k);
-        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(kBodiesTB), 0, s, k);
+        // a wave's 64 runs span (64 + rps - 1) / rps + 1 segments at most: the tile holds their K slots each (within 16 KB)
+        {
+            const int64_t segs = (64 + k.rps - 1) / k.rps + 1;
+            int64_t need = segs * p.K;
+            need = need < kTile ? kTile : (need > 128 ? 128 : ((need + 7) & ~(int64_t)7));
+            k.tile = (int)need;
+        }
+        const size_t blds = (size_t)k.tile * sizeof(BodyRec) * (kBodiesTB / 64);
+        if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(kBodiesTB), blds, s, k);
+        else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(kBodiesTB), blds, s, k);
+        else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(kBodiesTB), blds, s, k);
     }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
