@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) tw[j][u] = tw3[(j * 4 + u) * 64 + lane];
             wave_sync();
-            join4_untangle<256, F4::RP, 64, IdentityIA, false>(dz, nullptr, tw, lane, IdentityIA(), lmax, lmin, ls0, ls1);
+            join4_untangle<256, F4::RP, 64, IdentityIA, false, false>(dz, nullptr, tw, lane, IdentityIA(), lmax, lmin, ls0, ls1);
         } else {
         dft_regs<R>(z);                                             // stage 1
         __builtin_amdgcn_sched_barrier(0);
@@ -322,8 +322,10 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             lmax = fmaxf(lmax, fmaxf(e0, e1)); lmin = fminf(lmin, fminf(e0, e1)); ls0 += e0; ls1 += e1;
         }
         }
-        const double lsum = (double)ls0 + (double)ls1;
-        wave_max_min_sum_nn(lmax, lmin, lsum, maxe, mine, tot);
+        if constexpr (!X4) {                                        // (X4: the peak search takes them, peak_scan_x4_thin)
+            const double lsum = (double)ls0 + (double)ls1;
+            wave_max_min_sum_nn(lmax, lmin, lsum, maxe, mine, tot);
+        }
         wave_sync();
     };
 
@@ -453,14 +455,17 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             own_sl = -1;
             const int64_t orow = (int64_t)gb * Fi + (gq - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
-            const float maxy = __builtin_amdgcn_sqrtf(maxe);
-            const double minamp = (double)maxy * p.thr;             // PF.py:60
-            const double th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
+            double th = 0.0;
             int nk = 0;
             // candidate list (ascending bins) -> Lci
             int C;
-            if constexpr (X4) C = peak_scan_x4_thin<u16>(cur, mine, th, Lci, G::CAP, lane, K);
-            else C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
+            if constexpr (X4) C = peak_scan_x4_thin<u16>(cur, p.thr, maxe, mine, tot, th, Lci, G::CAP, lane, K);
+            else {
+                const float maxy = __builtin_amdgcn_sqrtf(maxe);
+                const double minamp = (double)maxy * p.thr;         // PF.py:60
+                th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
+                C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
+            }
             wave_sync();
             if (C <= 64 && p.rad <= 5 && !(th < 0.0 && C < K)) {
                 // ---- at most one candidate per lane (every frame of music): lane c owns candidate c and fetches

@@ -65,10 +65,11 @@ struct YofX4 {
 // their 128-byte blocks are half the bank array apart).  Neighbours across lanes come by DPP wave shifts (lane 0 / 63: the
 // value from the quarter before / after, through a broadcast).  List order = quarter, lane, bin: two count bits per
 // quarter (four consecutive bins hold at most two maxima).
+// It is also where the row's maximum, minimum and energy are taken (maxe, miny, tot: every |X|^2 passes through here, the
+// join forms none) and the threshold th they set (PF.py:60, 69-70; thr = PeakFinder's minrattomax).
 template <typename CI>
-__device__ __forceinline__ int peak_scan_x4_thin(const float2* X, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
-    const float thf = __double2float_rd(th);                         // see peak_scan (pvx_wave.h)
-    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
+__device__ __forceinline__ int peak_scan_x4_thin(const float2* X, double thr, float& maxe, float& miny, double& tot, double& th,
+                                                 CI* ci, int trash, int lane, int npeaks) {
     float v[16];                                                     // v[4 j + i] = |X[256 j + 4 lane + i]|^2
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -77,6 +78,20 @@ __device__ __forceinline__ int peak_scan_x4_thin(const float2* X, float miny, do
         v[4 * j] = norm2(make_float2(a.x, a.y)); v[4 * j + 1] = norm2(make_float2(a.z, a.w));
         v[4 * j + 2] = norm2(make_float2(b.x, b.y)); v[4 * j + 3] = norm2(make_float2(b.z, b.w));
     }
+    {
+        float lmax = v[0], lmin = v[0], ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            lmax = pvxw::max3f(lmax, v[i], v[i + 1]); lmin = pvxw::min3f(lmin, v[i], v[i + 1]);
+            ls0 += v[i]; ls1 += v[i + 1];
+        }
+        pvxw::wave_max_min_sum_nn(lmax, lmin, (double)ls0 + (double)ls1, maxe, miny, tot);
+        const float maxy = __builtin_amdgcn_sqrtf(maxe);
+        const double minamp = (double)maxy * thr;                   // PF.py:60
+        th = (minamp != 0.0) ? minamp * minamp - (double)miny : 0.0;
+    }
+    const float thf = __double2float_rd(th);                         // see peak_scan (pvx_wave.h)
+    const int thb = thf < 0.f ? -1 : __float_as_int(thf);
     // rise[j][i], sign bit set: y[k-1] < y[k] at k = 256 j + 4 lane + i; rise[j][4] = the next lane's rise[j][0]
     int rise[4][5];
 #pragma unroll
@@ -204,7 +219,9 @@ __device__ __forceinline__ void special4(const v2f (&c)[4], v2f (&spv)[4]) {
 // W_M^k1, W_M^(2 k1), W_M^(3 k1)} of k1 = lt + T j (M = 4 LQ, N = 2 M).  |X|^2 of every bin -> Ly (padded layout);
 // lmax / lmin / ls0 / ls1 accumulate the lane's max, min and sums of |X|^2.
 // WY = false: no |X|^2 row is written (k_fused_rev at nfft 2048: the peak search recomputes it from the spectrum, YofX4).
-template <int LQ, int QP, int T, typename IA, bool WY = true>
+// WS = false (with WY = false): no |X|^2 at all -- the row's maximum / minimum / energy come from the peak search as well
+// (peak_scan_x4_thin), which forms every |X|^2 anyway.
+template <int LQ, int QP, int T, typename IA, bool WY = true, bool WS = true>
 __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&tw)[LQ / (2 * T)][4], int lt, IA ia,
                                                float& lmax, float& lmin, float& ls0, float& ls1) {
     constexpr int NPS = LQ / (2 * T);
@@ -243,14 +260,16 @@ __device__ __forceinline__ void join4_untangle(v2f* xz, float* Ly, const v2f (&t
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
             xz[t * QP + sa] = x0[t];                                // X[k1 + LQ t]
             xz[(3 - t) * QP + sb] = x1[t];                          // X[kbb + LQ (3 - t)]
-            if constexpr (WY) {
-                Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
-                Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
+            if constexpr (WY || WS) {
+                const float e0 = __builtin_fmaf(x0[t].x, x0[t].x, x0[t].y * x0[t].y), e1 = __builtin_fmaf(x1[t].x, x1[t].x, x1[t].y * x1[t].y);
+                if constexpr (WY) {
+                    Ly[pvxw::ymap<1>(k1 + LQ * t)] = e0;
+                    Ly[pvxw::ymap<1>(kbb + LQ * (3 - t))] = e1;
+                }
+                lmax = pvxw::max3f(lmax, e0, e1); lmin = pvxw::min3f(lmin, e0, e1); ls0 += e0; ls1 += e1;
             }
-            lmax = pvxw::max3f(lmax, e0, e1); lmin = pvxw::min3f(lmin, e0, e1); ls0 += e0; ls1 += e1;
         }
     }
 }
