@@ -17,31 +17,49 @@ def _run(extra, env=None, timeout=600):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # the driver's record keeps a short tail of stdout: exactly ONE JSON line, and a small one (round 4's 20.8 KB line was lost)
+    assert len(lines) <= 1 and all(len(ln) < 2000 for ln in lines), [len(ln) for ln in lines]
     return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
 
 
+def _detail(j):
+    """The full record bench.py wrote beside the compact stdout line."""
+    assert j.get("detail"), j
+    with open(os.path.join(ROOT, j["detail"])) as fh:
+        return json.load(fh)
+
+
 def test_bench_line_and_self_check():
-    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "20", "--no-extras"])
+    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "20", "--no-extras", "--detail", "gpurun_out/test_bench_detail_a.json"])
     assert rc == 0 and j is not None, err[-2000:]
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    for k in ("metric", "value", "value_from_idle", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "self_check"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert set(j["config"]) == {"workload", "nfft", "hop", "npks", "sr", "frames_per_gpu", "signals_per_gpu", "parallelism"}
     r = j["roofline"]
     assert r["bound"] == "hbm" and 0.0 < r["frac"] <= 1.0 and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3 and r["ms_per_launch"] > 0 and r["alg_bytes_per_frame"] == 2384
     assert j["self_check"]["ok"] and j["self_check"]["bad_peaks"] == 0 and j["self_check"]["frames"] == j["config"]["frames_per_gpu"]
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"]["cores"] == 1 and c["value"] > 0
-    if (r.get("issue") or {}).get("valu_issue"):            # quoted only when profiles/sq_latest.json is of these sources
-        assert 0.0 < r["issue"]["valu_issue"]["frac"] <= 1.0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"] > 0 and c["value"] > 0
+    # everything but scalars is in the detail file; the compact line is a projection of it
+    d = _detail(j)
+    assert d["value"] == j["value"] and d["roofline"]["frac"] == r["frac"] and d["cpu_baseline"]["single_thread"]["cores"] == 1
+    assert all(not isinstance(v, (dict, list)) or k in ("config", "roofline", "cpu_baseline", "self_check", "per_rank_ms_per_step", "gather")
+               for k, v in j.items()), j
+    if (d["roofline"].get("issue") or {}).get("valu_issue"):            # quoted only when profiles/sq_latest.json is of these sources
+        assert 0.0 < d["roofline"]["issue"]["valu_issue"]["frac"] <= 1.0
 
 
 def test_bench_extras_are_all_checked_against_the_oracle():
     """The default line's extra objects on a short signal: float64, the other material, nfft 4096 / 8192, and the rest of
     the path (tracker + resynthesis on the headline results) -- every one of them carries an oracle check that passed."""
-    rc, j, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "30", "--c5-seconds", "20"])
-    assert rc == 0 and j is not None, err[-2000:]
+    rc, jc, err = _run(["--steps", "3", "--warmup", "1", "--seconds", "30", "--c5-seconds", "20", "--detail", "gpurun_out/test_bench_detail_b.json"])
+    assert rc == 0 and jc is not None, err[-2000:]
+    assert jc["extras_ok"] and jc["c5_all_ok"] and jc["f64_ok"] and jc["f64_value"] > 0 and jc["chain_total_ms"] > 0 and jc["c5_min_vs_target"] > 0
+    j = _detail(jc)
+    assert j["chain"]["total_ms"] == jc["chain_total_ms"] and j["f64"]["value"] == jc["f64_value"]
     assert j["f64"]["self_check"]["ok"] and j["f64"]["white_noise"]["self_check"]["ok"]
     assert all(w["self_check"]["ok"] for w in j["workloads"].values())
     assert all(w["self_check"]["ok"] for w in j["other_nfft"].values())

@@ -87,6 +87,10 @@ for src, dst in (("bench_%sa.json" % tag, "%s_bench.json" % tag), ("bench_c4.jso
         lines = [ln for ln in open(s).read().splitlines() if ln.startswith("{")]
         if lines:
             open(os.path.join(P, dst), "w").write(lines[-1] + "\n")
+    # the full record bench.py wrote beside its compact stdout line (--detail): one line of JSON in profiles/
+    sd = os.path.join(G, src.replace(".json", "_detail.json"))
+    if os.path.exists(sd):
+        open(os.path.join(P, dst.replace(".json", "_detail.json")), "w").write(json.dumps(json.load(open(sd))) + "\n")
 for src, dst in (("configs_%s.jsonl" % tag, "%s_configs_3_4.jsonl" % tag), ("sweep5_%s.jsonl" % tag, "%s_config5_sweep.jsonl" % tag),
                  ("sweep5_%s_f64.jsonl" % tag, "%s_config5_sweep_f64.jsonl" % tag), ("ab_nfft_%s.jsonl" % tag, "%s_nfft_harmonic_vs_noise.jsonl" % tag)):
     s = os.path.join(G, src)

@@ -31,7 +31,7 @@ def M(v):
 
 
 L = []
-b = (jl("%s_bench.json" % tag) or [None])[-1]
+b = (jl("%s_bench_detail.json" % tag) or jl("%s_bench.json" % tag) or [None])[-1]      # the full record (bench.py --detail); rounds 1-4: the stdout line
 if b:
     r = b["roofline"]
     L.append("**`bench.py`, N = 1 (`profiles/%s_bench.json`; BASELINE config 2: 10 min @ 44.1 kHz, nfft 2048, hop 512, npks 8, F = 51 676).**" % tag)
