@@ -97,6 +97,10 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);
+/* The HIP device that was current when the plan was created: its buffers, streams and events live there.  Every entry point
+ * that takes a plan fails with PVX_ERR_INVALID when the calling thread is bound to another device (pvx_init(d), or a
+ * pvx_batch worker's device) instead of running kernels on buffers of the wrong device. */
+int pvx_plan_device(const pvx_plan* plan);
 /*
  * Progress reporting: replaces Progress.update (pypevoc/ProgressDisplay.py:82-88), which the
  * reference calls once per frame (PV.py:250-254, 528).  The HOST entry points pvx_analyze and
@@ -339,6 +343,19 @@ int64_t pvx_heterodyne_dev(const double* d_x, const double* d_hetsig, int64_t n,
 int64_t pvx_rms_frames(const double* x, int64_t n, const double* wind, int wlen, int hop, double* out);
 int64_t pvx_rms_frames_dev(const double* d_x, int64_t n, const double* wind, int wlen, int hop,
                            double* d_out, void* stream);
+
+/* pvx_funcwind: SoundUtils.FuncWind(func, x, sr, nwind, nhop, power, windfunc) (pypevoc/SoundUtils.py:42-69)
+ * for the named reducers: out[i] = func(x[i*hop : i*hop+wlen] * wind) / divisor, with
+ * divisor = sum(wind**power) for power > 0, else 1 (SoundUtils.py:55-58; computed by the caller).
+ * x_complex != 0: x is complex128 [n] given as [n][2] (Heterodyn passes x * sinsig, :112): SUM and MEAN then
+ * write complex results [nfr][2], STD / VAR real ones (numpy: mean(abs(xw - mean(xw))**2)); MAX / MIN of
+ * complex frames -> PVX_ERR_UNSUPPORTED.  An arbitrary Python callable has no device form: the Python mirror
+ * raises TypeError for anything but these six.  Returns nfr or a negative status. */
+typedef enum { PVX_FW_SUM = 0, PVX_FW_MEAN = 1, PVX_FW_MAX = 2, PVX_FW_MIN = 3, PVX_FW_STD = 4, PVX_FW_VAR = 5 } pvx_funcwind_op;
+int64_t pvx_funcwind(const double* x, int x_complex, int64_t n, const double* wind, int wlen, int hop,
+                     int func, double divisor, double* out);
+int64_t pvx_funcwind_dev(const double* d_x, int x_complex, int64_t n, const double* wind, int wlen, int hop,
+                         int func, double divisor, double* d_out, void* stream);
 
 /* ---- multi-GPU result gather: compact wire format --------------------------------------
  *

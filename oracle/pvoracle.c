@@ -415,6 +415,44 @@ int64_t pvo_rms_frames(const double *x, int64_t n, const double *wind, int wlen,
     return nfr;
 }
 
+/* SoundUtils.FuncWind(func, x, sr, nwind, nhop, power, windfunc) for the named reducers (SoundUtils.py:42-69):
+ * out[i] = func(x[ist:ist+wlen] * wind) / divisor (divisor = sum(wind**power) or 1, :55-58, from the caller).
+ * func: 0 np.sum, 1 np.mean, 2 np.max, 3 np.min, 4 np.std, 5 np.var.  cpx: x is complex [n][2]; sum / mean then
+ * write [nfr][2], std / var (numpy: mean(abs(xw - mean(xw))**2), two passes) one double per frame. */
+int64_t pvo_funcwind(const double *x, int cpx, int64_t n, const double *wind, int wlen, int hop, int func, double divisor, double *out) {
+    if (wlen <= 0 || hop <= 0 || func < 0 || func > 5 || (cpx && (func == 2 || func == 3))) return -1;
+    int64_t nfr = 0;
+    for (int64_t ist = 0; ist + wlen < n; ist += hop, nfr++) {
+        double sr = 0.0, si = 0.0, mx = -INFINITY, mn = INFINITY;
+        int nan = 0;
+        for (int j = 0; j < wlen; j++) {
+            const double re = (cpx ? x[2 * (ist + j)] : x[ist + j]) * wind[j], im = cpx ? x[2 * (ist + j) + 1] * wind[j] : 0.0;
+            sr += re; si += im;
+            if (re > mx) mx = re;
+            if (re < mn) mn = re;
+            if (re != re) nan = 1;
+        }
+        double o0 = 0.0, o1 = 0.0;
+        if (func == 0) { o0 = sr; o1 = si; }
+        else if (func == 1) { o0 = sr / wlen; o1 = si / wlen; }
+        else if (func == 2) o0 = nan ? NAN : mx;
+        else if (func == 3) o0 = nan ? NAN : mn;
+        else {
+            const double mr = sr / wlen, mi = si / wlen;
+            double q = 0.0;
+            for (int j = 0; j < wlen; j++) {
+                const double dr = (cpx ? x[2 * (ist + j)] : x[ist + j]) * wind[j] - mr, di = cpx ? x[2 * (ist + j) + 1] * wind[j] - mi : 0.0;
+                q += dr * dr + di * di;
+            }
+            q /= wlen;
+            o0 = func == 4 ? sqrt(q) : q;
+        }
+        if (cpx && func <= 1) { out[2 * nfr] = o0 / divisor; out[2 * nfr + 1] = o1 / divisor; }
+        else out[nfr] = o0 / divisor;
+    }
+    return nfr;
+}
+
 /* Windowed, normalised half spectrum of frame `fr` (PV.py:150-158, 169): for checking the
  * device STFT stage in isolation.  outr/outi: nfft/2. */
 int pvo_stft_frame(const double *x, int64_t pos, int nfft, const double *win, double *outr, double *outi) {

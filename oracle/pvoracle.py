@@ -47,6 +47,8 @@ def lib():
                                      ctypes.POINTER(ctypes.c_int64)]
         L.pvo_rms_frames.restype = ctypes.c_int64
         L.pvo_rms_frames.argtypes = [_dp, ctypes.c_int64, _dp, ctypes.c_int, ctypes.c_int, _dp]
+        L.pvo_funcwind.restype = ctypes.c_int64
+        L.pvo_funcwind.argtypes = [_dp, ctypes.c_int, ctypes.c_int64, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _dp]
         L.pvo_stft_frame.restype = ctypes.c_int
         L.pvo_stft_frame.argtypes = [_dp, ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp]
         L.pvo_peakfinder.restype = ctypes.c_int
@@ -144,6 +146,26 @@ def rms_frames(x, wind, hop):
     r = lib().pvo_rms_frames(_d(x), len(x), _d(wind), len(wind), int(hop), _d(out))
     if r != nfr:
         raise RuntimeError("pvo_rms_frames: %d frames, expected %d" % (r, nfr))
+    return out
+
+
+FUNCWIND_OPS = {"sum": 0, "mean": 1, "max": 2, "min": 3, "std": 4, "var": 5}
+
+
+def funcwind(func, x, wind, hop, power=1):
+    """SoundUtils.FuncWind(np.<func>, x, nwind=len(wind), nhop=hop, power=power) values (SoundUtils.py:42-69)."""
+    x = np.asarray(x)
+    cpx = np.iscomplexobj(x)
+    x = np.ascontiguousarray(x, dtype=np.complex128 if cpx else np.float64)
+    wind = np.ascontiguousarray(wind, dtype=np.float64)
+    divisor = float(sum(wind ** power)) if power > 0 else 1.0
+    nfr = nframes(len(x), len(wind), hop)
+    op = FUNCWIND_OPS[func]
+    out = np.zeros(nfr, dtype=np.complex128 if (cpx and op <= 1) else np.float64)
+    r = lib().pvo_funcwind(x.view(np.float64).ctypes.data_as(_dp), int(cpx), len(x), _d(wind), len(wind), int(hop), op, divisor,
+                           out.view(np.float64).ctypes.data_as(_dp))
+    if r != nfr:
+        raise RuntimeError("pvo_funcwind: %d frames, expected %d" % (r, nfr))
     return out
 
 

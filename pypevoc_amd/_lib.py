@@ -38,6 +38,7 @@ SIGNATURES = {
     "pvx_plan_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
     "pvx_plan_set_fft_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pvx_plan_get_fft_mode": (ctypes.c_int, [ctypes.c_void_p]),
+    "pvx_plan_device": (ctypes.c_int, [ctypes.c_void_p]),
     "pvx_plan_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pvx_plan_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int64_p]),
     "pvx_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
@@ -95,6 +96,10 @@ SIGNATURES = {
     "pvx_heterodyne_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_double_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_rms_frames": (ctypes.c_int64, [c_double_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p]),
+    "pvx_funcwind": (ctypes.c_int64, [c_double_p, ctypes.c_int, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_double, c_double_p]),
+    "pvx_funcwind_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_rms_frames_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_plan_set_progress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -175,18 +180,27 @@ def load():
 
 
 def source_fingerprint():
-    """sha256 over pypevoc_amd/csrc/*.hip and *.h in name order, first 16 hex digits (the Makefile's build_sha.inc, the
-    library's pvx_build_fingerprint()); None when the sources are not beside the package."""
+    """What csrc/Makefile writes into build_sha.inc (the library's pvx_build_fingerprint()): sha256 over pypevoc_amd/csrc/*.hip
+    and *.h in name order, include/pvx.h and the Makefile's default CXXFLAGS, first 16 hex digits; None when the sources are
+    not beside the package."""
     import glob
     import hashlib
+    import re
     d = os.path.join(_HERE, "csrc")
-    files = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")))
+    files = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")), key=os.path.basename)
     if not files:
         return None
+    files.append(os.path.join(_HERE, "..", "include", "pvx.h"))
     h = hashlib.sha256()
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
+    with open(os.path.join(d, "Makefile")) as fh:
+        mk = fh.read()
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+    flags = re.search(r"^CXXFLAGS \?= ((?:.*\\\n)*.*)$", mk, re.M).group(1)
+    flags = re.sub(r"\s*\\\n\s*", " ", flags).replace("$(ARCH)", arch).strip()
+    h.update(flags.encode())
     return h.hexdigest()[:16]
 
 

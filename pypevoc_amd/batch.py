@@ -42,11 +42,13 @@ def frame_shard(nsamp, nfft, hop, rank, world):
     return f0, f1, a, b, f0 - h0
 
 
-def analyze_frame_shard(x, sr, nfft, hop, npks, rank, world, pkthresh=0.005, wind=np.hanning, precision=32):
+def analyze_frame_shard(x, sr, nfft, hop, npks, rank, world, pkthresh=0.005, wind=np.hanning, precision=None):
     """This rank's rows of PV(x, sr, nfft, hop, npks, pkthresh).run_pv() under `frame_shard`:
     dict(f, mag, ph, realph, binno [n, npks], t, totalmag [n], f0, f1).  Concatenating the ranks' blocks
     in rank order (e.g. with `gather_results` on padded blocks) gives the unsharded arrays; the tracker
-    (toSinSum) then runs once on the gathered (F, npks) arrays -- links only need adjacent rows."""
+    (toSinSum) then runs once on the gathered (F, npks) arrays -- links only need adjacent rows.
+    precision=None follows the samples as PV does (float64 samples: the reference's float64 arithmetic), so the shards of a
+    signal agree with PV(x).run_pv() on the same data."""
     from .PVAnalysis import PV
     f0, f1, a, b, drop = frame_shard(len(x), nfft, hop, rank, world)
     out = dict(f0=f0, f1=f1)
@@ -72,7 +74,7 @@ class PVBatch(object):
     Results: f, mag, ph, realph, binno with shape (B, F, npks); t (F,); totalmag (B, F)."""
 
     def __init__(self, x, sr, nfft=1024, hop=None, npks=20, pkthresh=0.005, wind=np.hanning,
-                 precision=32):
+                 precision=None):
         self._xdev = None
         if _lib.is_device_array(x):
             # a batch that already lives in GPU memory (e.g. a torch tensor on the GPU) is analysed in place
@@ -94,6 +96,9 @@ class PVBatch(object):
         self.npeaks = npks
         self.peakthresh = pkthresh
         self.win = wind(nfft)
+        if precision is None:
+            # as PV: float64 samples get the reference's float64 arithmetic, float32 / int16 samples the float32 transform
+            precision = 64 if self.x_dtype == _lib.PVX_F64 else 32
         self.precision = precision
         self.nframes = 0
         self._plan = None

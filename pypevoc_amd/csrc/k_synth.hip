@@ -926,7 +926,7 @@ WsLayout ws_layout(int64_t F, int K, int64_t P, int EF, int64_t nseg_all) {
 // stream are ordered by the stream, calls on different streams must not share
 struct StreamWs { void* p = nullptr; size_t cap = 0; unsigned gen = 0; };
 std::mutex g_ws_mu;
-std::map<hipStream_t, StreamWs> g_ws;
+std::map<std::pair<int, hipStream_t>, StreamWs> g_ws;               // (device, stream): the null stream of two devices is two streams
 
 }  // namespace
 
@@ -995,7 +995,9 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     unsigned* genp = p.ws_gen;                                        // the workspace's call counter (0: never used since it was allocated)
     if (!base) {
         std::lock_guard<std::mutex> lk(g_ws_mu);
-        StreamWs& w = g_ws[s];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        StreamWs& w = g_ws[std::make_pair(dev, s)];
         if (w.cap < L.total) {
             if (w.p) (void)hipFree(w.p);                              // (synchronises with the device: no kernel still uses it)
             w.p = nullptr; w.cap = 0; w.gen = 0;

@@ -377,8 +377,10 @@ __global__ __launch_bounds__(1024) void k_track_links(TrackParams p) {
 // A frame of 8 peaks keeps 8 of a wave's 64 lanes busy in k_track_links and still pays every wave-wide step of the loop
 // (1 200 wave instructions per frame: the tracker took longer than the analysis it follows).  With rows this short a lane
 // does a whole frame by itself -- both rows in registers, every loop unrolled over the 8 slots, no cross-lane step at all:
-// 64 frames per wave in ~2 500 instructions.  fc / fp is the correctly rounded quotient through the previous peak's
-// reciprocal (one division per previous peak instead of one per pair; Markstein: estimate, exact residual, one correction).
+// 64 frames per wave in ~2 500 instructions.  fc / fp goes through the previous peak's reciprocal (one division per previous
+// peak instead of one per pair: estimate, exact residual, one correction -- within one ulp of the reference's division, equal
+// to it almost always); a frame where a comparison is decided by less than that error is flagged and the table rebuilt by the
+// sequential kernel, which divides.
 // A workgroup is a chunk of 256 consecutive frames: it leaves the frames' links, the chunk-local creation ranks
 // (newbase[fr] = new partials of the chunk's earlier frames; the chunk's total in chunktot[c]) and every node's root as far
 // as the chunk knows it (pointer doubling in LDS, 8 rounds at most).
@@ -456,12 +458,28 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
             int wo = -1, wr = KL;
 #pragma unroll
             for (int i = 0; i < KL; i++) {
-                // fcur / pf[i], correctly rounded; then dpitch2st, PVAnalysis.py:62-68, 914
+                // fcur / pf[i] through the previous peak's reciprocal: estimate, exact residual, one correction step.  That is the
+                // correctly rounded quotient whenever q0 is a faithful estimate; RN(fcur RN(1 / pf)) can be 1.5 ulp off, so for rare
+                // pairs q may differ from the reference's division by one ulp -- which only matters where a comparison below is
+                // decided by less than that: those frames go to the exact sequential kernel (`near`, below).
+                // Then dpitch2st, PVAnalysis.py:62-68, 914
                 const double q0 = fcur * rpf[i];
                 const double q = __builtin_fma(__builtin_fma(-q0, pf[i], fcur), rpf[i], q0);
                 st[i] = (vp[i] && !((used >> i) & 1u)) ? fabs(17.312 * (q - 1.0)) : INFINITY;
                 // the first minimum in the order of the previous partials (np.argmin over the sorted list, PVAnalysis.py:893, 920)
                 if (st[i] < best || (st[i] == best && rp[i] < wr)) { best = st[i]; wm = pm[i]; wo = i; wr = rp[i]; }
+            }
+            // a one-ulp error of a quotient q (<= q 2^-52) moves its st by <= 17.312 q 2^-52: where the threshold test or the choice of
+            // the nearest partial hangs on less than eps (sixteen times that at q ~ 1; st >= 0.5 sets no link at the default jump),
+            // the frame is left to k_track_sequential, which divides (the table is then the reference's whatever the rounding was)
+            if (wo >= 0) {
+                const double eps = 0x1p-46 * (1.0 + best);
+                bool near = fabs(best - p.maxjmp) <= eps;
+                if (best < p.maxjmp) {
+#pragma unroll
+                    for (int i = 0; i < KL; i++) near = near || (i != wo && st[i] - best <= eps);     // (unavailable ones are at infinity)
+                }
+                amb_any = amb_any || near;
             }
             if (wo >= 0 && best < p.maxjmp) {                       // PVAnalysis.py:923
                 // another unused previous partial exactly as near AND exactly as strong as the winner: the reference would

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -114,6 +115,24 @@ int pvx_require_device() {
     return pvx_init(-1);
 }
 
+struct pvx_plan;
+static int plan_device(const pvx_plan* p);
+// entry points that take a plan: the thread is bound as above, and the plan must have been created under the device the
+// call runs on -- its buffers, streams and events live there (a worker of pvx_batch_run creates its plan under its own
+// device; anything else handing a plan of device a to a thread bound to device b is refused, not run)
+int pvx_require_plan_device(const pvx_plan* p) {
+    const int rc = pvx_require_device();
+    if (rc != PVX_OK || !p) return rc;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { pvx_set_error("hipGetDevice failed"); return PVX_ERR_HIP; }
+    if (cur != plan_device(p)) {
+        pvx_set_error("the plan was created on device %d and is used under device %d (pvx_init / the batch worker's device): create the plan under the device that runs it",
+                      plan_device(p), cur);
+        return PVX_ERR_INVALID;
+    }
+    return PVX_OK;
+}
+
 extern "C" int64_t pvx_nframes(int64_t nsamp, int nfft, int hop) {
     // PV.py:223-249: pos = 0, hop, 2 hop, ... while pos < nsamp - nfft (strict)
     const int64_t maxpos = nsamp - nfft;
@@ -123,6 +142,7 @@ extern "C" int64_t pvx_nframes(int64_t nsamp, int nfft, int hop) {
 
 // ---- plan -----------------------------------------------------------------------------------
 struct pvx_plan {
+    int device = -1;          // the HIP device current when the plan was created: every buffer / stream / event below lives there
     double sr = 0, pkthresh = 0, wfact = 0, fstep = 0, dt = 0;
     int nfft = 0, hop = 0, npks = 0, N2 = 0, precision = 32, fft_mode = 0;
     int64_t max_rows = 0;     // rows per launch (without the halo row)
@@ -205,6 +225,8 @@ struct pvx_plan {
     size_t ev_used = 0;
     std::vector<std::pair<int, size_t>> ev_spans;   // (stage, index of the start event; end = next event)
 };
+static int plan_device(const pvx_plan* p) { return p->device; }
+extern "C" int pvx_plan_device(const pvx_plan* plan) { return plan ? plan->device : PVX_ERR_INVALID; }
 
 static size_t real_size(int precision) { return precision == 32 ? 4 : 8; }
 
@@ -304,6 +326,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     }
     const int64_t rows_hint = max_rows;
     pvx_plan* p = new pvx_plan();
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; pvx_set_error("hipGetDevice failed"); return PVX_ERR_HIP; }
     p->sr = sr; p->nfft = nfft; p->hop = hop; p->npks = npks; p->pkthresh = pkthresh;
     p->precision = precision;
     p->N2 = nfft / 2;                                   // PV.py:88
@@ -699,7 +722,7 @@ extern "C" int64_t pvx_analyze_dev(pvx_plan* p, const void* d_x, int x_dtype, in
                                    int64_t sig_stride, double* d_f, double* d_mag, double* d_ph, double* d_realph,
                                    double* d_binno, double* d_t, double* d_totalmag, const double* d_prev0,
                                    void* stream) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(p);
     if (rc != PVX_OK) return rc;
     rc = check_analyze_args(p, d_x, x_dtype, nsamp, nsig, sig_stride, d_prev0);
     if (rc != PVX_OK) return rc;
@@ -926,7 +949,7 @@ static int carry_spectrum(pvx_plan* p, int64_t rows_in_call, hipStream_t s) {
 static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                             const HostOut* ho, const double* prev0, double* last_spec, bool keep) {
     HostTrace tr("analyze");
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(p);
     if (rc != PVX_OK) return rc;
     rc = check_analyze_args(p, x, x_dtype, nsamp, nsig, sig_stride, prev0);
     if (rc != PVX_OK) return rc;
@@ -1231,14 +1254,23 @@ extern "C" int64_t pvx_batch_run(pvx_batch* b, int x_dtype, pvx_batch_item* item
     if (!b || nitems < 0 || (nitems > 0 && !items)) { pvx_set_error("invalid batch arguments"); return PVX_ERR_INVALID; }
     if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("unknown sample type %d", x_dtype); return PVX_ERR_INVALID; }
     if (nitems == 0) return 0;
-    std::vector<int64_t> order((size_t)nitems);
+    // (no C++ exception may leave an extern "C" function: a bad_alloc of the two vectors, or of a worker's plan, is
+    // PVX_ERR_ALLOC; threads already started are always joined)
+    std::vector<int64_t> order;
+    std::vector<std::thread> th;
+    const int nw = (int)b->plans.size();
+    try {
+        order.resize((size_t)nitems);
+        th.reserve((size_t)nw);
+    } catch (...) { pvx_set_error("pvx_batch_run: out of host memory for %lld items", (long long)nitems); return PVX_ERR_ALLOC; }
     for (int64_t i = 0; i < nitems; i++) { order[(size_t)i] = i; items[i].nframes = 0; items[i].device = -1; }
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return items[a].nsamp > items[c].nsamp; });
+    try {
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return items[a].nsamp > items[c].nsamp; });
+    } catch (...) { pvx_set_error("pvx_batch_run: out of host memory for %lld items", (long long)nitems); return PVX_ERR_ALLOC; }
     std::atomic<int64_t> next(0);
     std::atomic<int> first_rc(PVX_OK);
     std::mutex err_mu;
     char err_text[512] = "";
-    const int nw = (int)b->plans.size();
     auto worker = [&](int w) {
         const int dev = b->devices[(size_t)(w / b->workers)];
         t_device = dev;
@@ -1255,6 +1287,7 @@ extern "C" int64_t pvx_batch_run(pvx_batch* b, int x_dtype, pvx_batch_item* item
             if (q >= nitems) break;
             const int64_t i = order[(size_t)q];
             pvx_batch_item& it = items[i];
+            try {
             it.device = dev;
             if (!b->plans[(size_t)w]) {
                 const int rc = pvx_plan_create(&b->plans[(size_t)w], b->sr, b->nfft, b->hop, b->npks, b->pkthresh, b->win.empty() ? nullptr : b->win.data(), b->precision, 0);
@@ -1263,10 +1296,10 @@ extern "C" int64_t pvx_batch_run(pvx_batch* b, int x_dtype, pvx_batch_item* item
             const int64_t F = pvx_analyze(b->plans[(size_t)w], it.x, x_dtype, it.nsamp, 1, it.nsamp, it.f, it.mag, it.ph, it.realph, it.binno, it.t, it.totalmag, nullptr, nullptr);
             if (F < 0) { fail(i, (int)F); continue; }
             it.nframes = F;
+            } catch (...) { pvx_set_error("out of host memory"); fail(i, PVX_ERR_ALLOC); }
         }
         t_device = -1;
     };
-    std::vector<std::thread> th;
     const int nthreads = (int64_t)nw < nitems ? nw : (int)nitems;
     // workers are dealt to the devices in turn (worker w -> slot w % ndev's next worker), so a batch smaller than the pool
     // still spreads over the devices
@@ -1274,7 +1307,7 @@ extern "C" int64_t pvx_batch_run(pvx_batch* b, int x_dtype, pvx_batch_item* item
     auto slot_of = [&](int k) { return (k % nd) * b->workers + k / nd; };
     const int saved = t_device;
     try {
-        for (int k = 1; k < nthreads; k++) th.emplace_back(worker, slot_of(k));
+        for (int k = 1; k < nthreads; k++) th.emplace_back(worker, slot_of(k));      // (th has its capacity: only thread creation can fail)
     } catch (...) { /* the threads that started and this one share the queue */ }
     worker(slot_of(0));
     t_device = saved;
@@ -1316,7 +1349,7 @@ extern "C" int64_t pvx_analyze_resident(pvx_plan* p, const void* x, int x_dtype,
 static int need_resident(pvx_plan* p) {
     if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     if (!p->res_valid) { pvx_set_error("the plan holds no resident results (pvx_analyze_resident first)"); return PVX_ERR_INVALID; }
-    return pvx_require_device();
+    return pvx_require_plan_device(p);
 }
 
 extern "C" int pvx_resident_fetch(pvx_plan* p, int which, double* host) {
@@ -1340,7 +1373,7 @@ extern "C" const double* pvx_resident_ptr(pvx_plan* p, int which) {
 
 extern "C" int pvx_stft_frames(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const int64_t* pos, int64_t nfr,
                                double* spec) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(p);
     if (rc != PVX_OK) return rc;
     if (!p || !x || !pos || !spec || nfr < 0) { pvx_set_error("bad argument"); return PVX_ERR_INVALID; }
     if (x_dtype != PVX_F32 && x_dtype != PVX_F64 && x_dtype != PVX_I16) { pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID; }
@@ -1488,14 +1521,19 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     if (!d_f || !d_mag || !d_partial_id || !d_part_start || !d_part_len) { pvx_set_error("null tracker array"); return PVX_ERR_INVALID; }
     // the workspace of the plan-less tracker is kept (allocating and freeing it cost as much as the kernels); the call is
     // synchronous, one at a time through it
+    // (one workspace per DEVICE: a thread bound to another device must not hand its kernels a buffer of this one; the result
+    // words are page-locked memory every device can write: hipHostMallocPortable)
+    struct DevWs { char* ws = nullptr; size_t cap = 0; };
     static std::mutex mu;
-    static char* ws = nullptr;
-    static size_t ws_cap = 0;
+    static std::map<int, DevWs> wsd;
     static int64_t* pin3 = nullptr;         // { partials, exact double tie, last frame with a point } in page-locked memory:
     std::lock_guard<std::mutex> lk(mu);     // the kernel's three stores are what the host waits for, no copy behind them
-    if (!pin3 && hipHostMalloc((void**)&pin3, 64, hipHostMallocDefault) != hipSuccess) { pin3 = nullptr; (void)hipGetLastError(); }
-    if ((rc = grow_dev(&ws, &ws_cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
-    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, ws, (hipStream_t)stream, nullptr, pin3);
+    if (!pin3 && hipHostMalloc((void**)&pin3, 64, hipHostMallocPortable) != hipSuccess) { pin3 = nullptr; (void)hipGetLastError(); }
+    int dev = 0;
+    PVX_HIP_CHECK(hipGetDevice(&dev));
+    DevWs& w = wsd[dev];
+    if ((rc = grow_dev(&w.ws, &w.cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
+    return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, w.ws, (hipStream_t)stream, nullptr, pin3);
 }
 
 extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,
@@ -1815,7 +1853,7 @@ static int check_harmonic_args(pvx_plan* p, const void* x, int x_dtype, int64_t 
 extern "C" int64_t pvx_harmonic_analyze_dev(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, const double* f0,
                                             int64_t nf0, double fmin, double* d_f, double* d_mag, double* d_ph,
                                             double* d_residual, double* d_t, const double* d_prev0, void* stream) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(p);
     if (rc != PVX_OK) return rc;
     if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
@@ -1830,7 +1868,7 @@ extern "C" int64_t pvx_harmonic_analyze_dev(pvx_plan* p, const void* d_x, int x_
 extern "C" int64_t pvx_harmonic_analyze(pvx_plan* p, const void* x, int x_dtype, int64_t nsamp, const double* f0, int64_t nf0,
                                         double fmin, double* f, double* mag, double* ph, double* residual, double* t,
                                         const double* prev0, double* last_spec) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(p);
     if (rc != PVX_OK) return rc;
     if (!p) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
@@ -1967,6 +2005,51 @@ extern "C" int64_t pvx_rms_frames(const double* x, int64_t n, const double* wind
     return nfr;
 }
 
+// FuncWind's named reducers (SoundUtils.py:42-69)
+static int funcwind_args(int x_complex, int64_t n, const double* wind, int wlen, int hop, int func, double divisor) {
+    if (n < 0 || wlen <= 0 || hop <= 0 || !wind) { pvx_set_error("bad windowed-reduction argument"); return PVX_ERR_INVALID; }
+    if (func < PVX_FW_SUM || func > PVX_FW_VAR) { pvx_set_error("pvx_funcwind: unknown reducer %d", func); return PVX_ERR_INVALID; }
+    if (!(divisor == divisor) || divisor == 0.0) { pvx_set_error("pvx_funcwind: divisor %g", divisor); return PVX_ERR_INVALID; }
+    if (x_complex && (func == PVX_FW_MAX || func == PVX_FW_MIN)) { pvx_set_error("pvx_funcwind: max / min of complex frames"); return PVX_ERR_UNSUPPORTED; }
+    return PVX_OK;
+}
+
+extern "C" int64_t pvx_funcwind_dev(const double* d_x, int x_complex, int64_t n, const double* wind, int wlen, int hop, int func, double divisor,
+                                    double* d_out, void* stream) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if ((rc = funcwind_args(x_complex, n, wind, wlen, hop, func, divisor)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!d_x || !d_out) { pvx_set_error("null funcwind array"); return PVX_ERR_INVALID; }
+    DevBuf dw;
+    if ((rc = dw.alloc((size_t)wlen * 8)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipMemcpy(dw.p, wind, (size_t)wlen * 8, hipMemcpyHostToDevice));
+    ReduceParams rp = {};
+    rp.x = d_x; rp.wind = (const double*)dw.p; rp.nfr = nfr; rp.wlen = wlen; rp.hop = hop; rp.norm = divisor; rp.out = d_out;
+    if ((rc = pvx_launch_funcwind(rp, func, x_complex != 0, (hipStream_t)stream)) != PVX_OK) return rc;
+    PVX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));            // dw is a local
+    return nfr;
+}
+
+extern "C" int64_t pvx_funcwind(const double* x, int x_complex, int64_t n, const double* wind, int wlen, int hop, int func, double divisor, double* out) {
+    int rc = pvx_require_device();
+    if (rc != PVX_OK) return rc;
+    if ((rc = funcwind_args(x_complex, n, wind, wlen, hop, func, divisor)) != PVX_OK) return rc;
+    const int64_t nfr = pvx_nframes(n, wlen, hop);
+    if (nfr == 0) return 0;
+    if (!x || !out) { pvx_set_error("null funcwind array"); return PVX_ERR_INVALID; }
+    const size_t xb = (size_t)n * (x_complex ? 16 : 8);
+    const size_t ob = (size_t)nfr * ((x_complex && (func == PVX_FW_SUM || func == PVX_FW_MEAN)) ? 16 : 8);
+    DevBuf dx, dout;
+    if ((rc = dx.alloc(xb)) != PVX_OK || (rc = dout.alloc(ob)) != PVX_OK) return rc;
+    if ((rc = host_to_device(dx.p, x, xb)) != PVX_OK) return rc;
+    const int64_t r = pvx_funcwind_dev((const double*)dx.p, x_complex, n, wind, wlen, hop, func, divisor, (double*)dout.p, nullptr);
+    if (r < 0) return r;
+    if ((rc = device_to_host(out, dout.p, ob)) != PVX_OK) return rc;
+    return nfr;
+}
+
 // ---- result wire format for the multi-GPU gather (k_wire.hip) -------------------------------
 extern "C" int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows) {
     if (!plan || rows < 0) { pvx_set_error("bad wire argument"); return PVX_ERR_INVALID; }
@@ -1977,7 +2060,7 @@ extern "C" int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows) {
 extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
                                  const double* d_ph, const double* d_binno, const double* d_totalmag, void* d_wire,
                                  void* stream) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(plan);
     if (rc != PVX_OK) return rc;
     if (pvx_wire_bytes(plan, rows) < 0) return PVX_ERR_INVALID;
     if (rows == 0) return PVX_OK;
@@ -1990,7 +2073,7 @@ extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const doubl
 
 extern "C" int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f, double* d_mag,
                                    double* d_ph, double* d_realph, double* d_binno, double* d_totalmag, void* stream) {
-    int rc = pvx_require_device();
+    int rc = pvx_require_plan_device(plan);
     if (rc != PVX_OK) return rc;
     if (pvx_wire_bytes(plan, rows) < 0) return PVX_ERR_INVALID;
     if (rows == 0) return PVX_OK;

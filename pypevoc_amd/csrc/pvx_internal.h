@@ -227,6 +227,8 @@ struct ReduceParams {
     int64_t* icent;           // [nfr] optional (heterodyne)
 };
 int pvx_launch_reduce(const ReduceParams& p, int mode, hipStream_t s);
+// FuncWind's named reducers (func: pvx_funcwind_op); x complex128 when cpx (p.x then points at [n][2])
+int pvx_launch_funcwind(const ReduceParams& p, int func, bool cpx, hipStream_t s);
 
 // result wire format for the multi-GPU gather (k_wire.hip)
 struct WireParams {

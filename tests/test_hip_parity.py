@@ -623,7 +623,7 @@ def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monke
         for env in variants:
             for k, v in env:
                 monkeypatch.setenv(k, v)
-            res.append(amd.PVBatch(xb, sr, nfft=nfft, hop=512, npks=8).run_pv())
+            res.append(amd.PVBatch(xb, sr, nfft=nfft, hop=512, npks=8, precision=32).run_pv())
             for k, v in env:
                 monkeypatch.delenv(k)
         for i in range(1, len(res)):
@@ -1001,7 +1001,7 @@ def test_full_size_config2_properties(amd, oracle, monkeypatch):
                 totalmag=np.array(p.totalmag[:F2]))
     assert_f32(compare_analysis(head, o, nfft, hop, sr))
     xb = np.stack([x[i * 10 * sr:(i + 1) * 10 * sr] for i in range(4)])
-    b = amd.PVBatch(xb, sr, nfft=nfft, hop=hop, npks=K).run_pv()
+    b = amd.PVBatch(xb, sr, nfft=nfft, hop=hop, npks=K, precision=32).run_pv()
     for i in range(4):
         r = run_pv(amd, xb[i], sr, nfft, hop, K)
         for k in ("f", "mag", "ph", "realph", "binno"):
@@ -1067,6 +1067,43 @@ def test_config4_shard_shape_batch(amd):
         f0 = 110.0 * 2 ** (b / 1024.0 * 3)
         mid = res[0, b, 10:-10, 0]
         assert np.median(np.abs(mid / f0 - 1.0)) < 0.02
+
+
+def test_plan_records_its_device_and_multi_device_batches_when_the_box_has_them(amd):
+    """A plan carries the device it was created under (pvx_plan_device); entry points refuse a plan under another device.  With
+    one GPU (this box) only the record can be checked; with two or more, a PVMany over distinct devices must give every signal the
+    single-call arrays, name the device that served it, and a plan of device 0 used by a thread bound to device 1 must fail with
+    PVX_ERR_INVALID instead of running."""
+    import ctypes
+    import torch
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    x = _rand_signal(5, 50000, 44100.0)
+    p = run_pv(amd, x, 44100.0, 1024, 256, 6)
+    assert lib.pvx_plan_device(p._plan.handle) == lib.pvx_device() == 0
+    assert lib.pvx_plan_device(None) == -2                           # PVX_ERR_INVALID
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        return
+    sigs = [_rand_signal(200 + i, 40000 + 3000 * i, 44100.0) for i in range(12)]
+    many = amd.PVMany(44100.0, nfft=1024, hop=256, npks=6, devices=list(range(min(ndev, 4))), precision=32, workers_per_device=2)
+    res = many.run(sigs)
+    many.close()
+    assert len({r["device"] for r in res}) >= 2
+    for xi, r in zip(sigs, res):
+        q = run_pv(amd, xi, 44100.0, 1024, 256, 6, precision=32)
+        for k in ("f", "mag", "ph", "realph", "binno", "t"):
+            assert np.array_equal(r[k], getattr(q, k)), k
+    try:
+        assert lib.pvx_init(1) == 0
+        F = lib.pvx_nframes(len(x), 1024, 256)
+        out = [np.zeros((F, 6)) for _ in range(5)] + [np.zeros(F), np.zeros(F)]
+        xs = np.ascontiguousarray(x, dtype=np.float64)
+        rc = lib.pvx_analyze(p._plan.handle, xs.ctypes.data_as(ctypes.c_void_p), _lib.PVX_F64, len(xs), 1, len(xs),
+                             *[_lib.dptr(a) for a in out], None, None)
+        assert rc == -2 and b"device 0" in lib.pvx_last_error()
+    finally:
+        assert lib.pvx_init(0) == 0
 
 
 def test_c_level_batch_of_ragged_signals_over_a_device_list(amd, oracle):
@@ -1137,7 +1174,7 @@ def test_multiwave_kernel_batch_and_streaming(amd, oracle):
     """fft mode 2 (nfft 4096): batch of signals = loop, and frame-by-frame streaming = run_pv."""
     sr, nfft, hop, K = 22050.0, 4096, 1024, 6
     xs = np.stack([_rand_signal(30 + i, 40000).astype(np.float32) for i in range(3)])
-    b = amd.PVBatch(xs, sr, nfft=nfft, hop=hop, npks=K).run_pv()
+    b = amd.PVBatch(xs, sr, nfft=nfft, hop=hop, npks=K, precision=32).run_pv()
     for i in range(3):
         r = run_pv(amd, xs[i], sr, nfft, hop, K)
         for k in ("f", "mag", "ph", "realph", "binno"):
@@ -1425,6 +1462,84 @@ def test_windowed_reductions_match_reference(amd, oracle):
     assert np.abs(rr - oracle.rms_frames(y, w, 1000)).max() <= 1e-13
     e, ie = heterodyne(y[:100], hs[:100], wind=np.ones(256), hop=10)
     assert len(e) == 0 and len(ie) == 0
+
+
+def test_funcwind_matches_reference(amd, oracle):
+    """SoundUtils.FuncWind with the named reducers through the Python drop-in (k_funcwind, k_reduce.hip) against values
+    captured from the reference (W2: np.sum / mean / max / min / std / var x power 0 / 1 / 2, an odd window and hop, a
+    complex signal) and against the oracle on a seeded larger case.  float64; summation order is the only difference:
+    1e-13 absolute on O(0.1) amplitudes, max / min exact.  Any other callable is a TypeError (no device form)."""
+    from pypevoc_amd import SoundUtils as su
+    g = dict(np.load(os.path.join(GOLDEN, "W2_funcwind.npz")))
+    x = g["x"].astype(np.float64)
+    sr = float(g["sr"])
+    fns = dict(sum=np.sum, mean=np.mean, max=np.max, min=np.min, std=np.std, var=np.var)
+    for name, fn in fns.items():
+        tol = 0.0 if name in ("max", "min") else 1e-13
+        for power in (0, 1, 2):
+            r, t = su.FuncWind(fn, x, sr=sr, nwind=1024, nhop=512, power=power)
+            assert np.array_equal(t, g["t"]) and r.dtype == np.float64
+            assert np.abs(r - g["%s_p%d" % (name, power)]).max() <= tol, (name, power)
+        r, t = su.FuncWind(fn, x, sr=sr, nwind=1000, nhop=333, power=1, windfunc=np.hanning)
+        assert np.array_equal(t, g["t_odd"]) and np.abs(r - g["%s_odd" % name]).max() <= tol, name
+    xc = x * np.exp(2j * np.pi * np.arange(len(x)) * 1000.0 / sr)
+    for name in ("sum", "mean"):
+        r, t = su.FuncWind(fns[name], xc, sr=sr, nwind=1024, nhop=256, power=1)
+        assert np.array_equal(t, g["t_c"]) and np.iscomplexobj(r)
+        assert np.abs(np.stack([r.real, r.imag], axis=1) - g["c_%s" % name]).max() <= 1e-13, name
+    for name in ("std", "var"):
+        r, _ = su.FuncWind(fns[name], xc, sr=sr, nwind=1024, nhop=256, power=1)
+        assert r.dtype == np.float64 and np.abs(r - g["c_%s" % name]).max() <= 1e-13, name
+    # Heterodyn is FuncWind(np.sum, x * sinsig) * 2 (SoundUtils.py:112-117): the two device routes agree
+    a, _ = su.Heterodyn(x, 1000.0, sr=sr, nwind=1024, nhop=256)
+    r, _ = su.FuncWind(np.sum, xc, sr=sr, nwind=1024, nhop=256, power=1)
+    assert np.abs(a - 2 * r).max() <= 1e-13
+    # seeded, larger, odd sizes, against the oracle; the builtins and names as aliases; NaN propagates through max
+    rng = np.random.default_rng(9)
+    y = rng.standard_normal(300001)
+    for name in fns:
+        r, _ = su.FuncWind(name, y, nwind=4097, nhop=1000, power=2, windfunc=np.hanning)
+        o = oracle.funcwind(name, y, np.hanning(4097), 1000, 2)
+        assert r.shape == o.shape and np.abs(r - o).max() <= 1e-12 * max(1.0, np.abs(o).max()), name
+    r, _ = su.FuncWind(max, y, nwind=512, nhop=256)
+    assert np.array_equal(r, oracle.funcwind("max", y, np.blackman(512), 256, 1))
+    yn = y[:5000].copy()
+    yn[700] = np.nan
+    r, _ = su.FuncWind(np.max, yn, nwind=512, nhop=256)
+    assert np.isnan(r[1]) and np.isnan(r[2]) and not np.isnan(r[0]) and not np.isnan(r[3:]).any()
+    e, te = su.FuncWind(np.sum, y[:100], nwind=256, nhop=10)
+    assert len(e) == 0 and len(te) == 0
+    with pytest.raises(TypeError):
+        su.FuncWind(lambda v: v.sum(), x)
+    with pytest.raises(TypeError):
+        su.FuncWind(np.median, x)
+    with pytest.raises(RuntimeError):
+        su.FuncWind(np.max, xc)                              # max of complex frames: PVX_ERR_UNSUPPORTED
+
+
+def test_batch_precision_follows_the_samples(amd):
+    """PVBatch / analyze_frame_shard with precision=None (the default) take the arithmetic of PV on the same samples: float64
+    samples the reference's float64 path, float32 samples the float32 transform -- a float64 batch equals the loop of PV(x)."""
+    from pypevoc_amd.batch import analyze_frame_shard
+    rng = np.random.default_rng(77)
+    n = 30000
+    t = np.arange(n) / 44100.0
+    xb = np.stack([0.3 * np.sin(2 * np.pi * (300.0 + 50.0 * i) * t) + 0.01 * rng.standard_normal(n) for i in range(3)])
+    for arr, want in ((xb, 64), (xb.astype(np.float32), 32)):
+        b = amd.PVBatch(arr, 44100, nfft=1024, hop=256, npks=6)
+        assert b.precision == want
+        b.run_pv()
+        for i in range(3):
+            p = amd.PV(arr[i], 44100, nfft=1024, hop=256, npks=6, progress=False)
+            assert p.precision == want
+            p.run_pv()
+            for k in ("f", "mag", "ph", "realph", "binno"):
+                assert np.array_equal(getattr(b, k)[i], getattr(p, k)), (want, i, k)
+        full = amd.PV(arr[0], 44100, nfft=1024, hop=256, npks=6, progress=False)
+        full.run_pv()
+        parts = [analyze_frame_shard(arr[0], 44100, 1024, 256, 6, r, 2) for r in range(2)]
+        for k in ("f", "mag", "realph"):
+            assert np.array_equal(np.concatenate([q[k] for q in parts]), getattr(full, k)), (want, k)
 
 
 # ------------------------------------------------------------------ device-resident input

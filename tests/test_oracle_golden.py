@@ -199,3 +199,24 @@ def test_windowed_reductions_match_reference(oracle):
     assert np.abs(np.stack([h2.real, h2.imag], axis=1) - g["het_rect"]).max() <= 1e-13
     assert np.abs(oracle.rms_frames(g["x"], np.blackman(1024), 512) - g["rms"]).max() <= 1e-14
     assert np.abs(oracle.rms_frames(g["x"], np.hanning(1000), 333) - g["rms_odd"]).max() <= 1e-14
+
+
+def test_funcwind_matches_reference(oracle):
+    """pvo_funcwind against SoundUtils.FuncWind of the reference with np.sum / mean / max / min / std / var (W2,
+    tests/golden/make_golden_harmonic.py funcwind): real signal x power 0 / 1 / 2 and an odd window / hop, complex signal for
+    sum / mean / std / var.  numpy sums pairwise, the oracle left to right: 1e-13 absolute on O(0.1) amplitudes; max / min exact."""
+    g = dict(np.load(os.path.join(GOLDEN, "W2_funcwind.npz")))
+    x = g["x"].astype(np.float64)
+    for name in ("sum", "mean", "max", "min", "std", "var"):
+        tol = 0.0 if name in ("max", "min") else 1e-13
+        for power in (0, 1, 2):
+            got = oracle.funcwind(name, x, np.blackman(1024), 512, power)
+            assert got.shape == g["%s_p%d" % (name, power)].shape and np.abs(got - g["%s_p%d" % (name, power)]).max() <= tol, (name, power)
+        got = oracle.funcwind(name, x, np.hanning(1000), 333, 1)
+        assert np.abs(got - g["%s_odd" % name]).max() <= tol, name
+    xc = x * np.exp(2j * np.pi * np.arange(len(x)) * 1000.0 / float(g["sr"]))
+    for name in ("sum", "mean"):
+        got = oracle.funcwind(name, xc, np.blackman(1024), 256, 1)
+        assert np.abs(np.stack([got.real, got.imag], axis=1) - g["c_%s" % name]).max() <= 1e-13, name
+    for name in ("std", "var"):
+        assert np.abs(oracle.funcwind(name, xc, np.blackman(1024), 256, 1) - g["c_%s" % name]).max() <= 1e-13, name
