@@ -91,34 +91,6 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     int* const Lsbin = Lsel + kpad;
     float* const Lsval = (float*)(Lsbin + gs * kpad);
 
-    // ---- block-shared tables
-    {
-        const v2f* tab = (const v2f*)p.twiddle;                     // W_nfft^j, j < nfft
-        constexpr int NMASK = G::N - 1;
-        if constexpr (X4) {
-            for (int i = threadIdx.x; i < 256; i += 64 * NW) t1L[i] = tab[((G::N / 256) * (i & 15) * (i >> 4)) & NMASK];     // [q][l] W_256^(l q)
-            for (int i = threadIdx.x; i < 512; i += 64 * NW) {      // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
-                const int ln = i & 63, u = (i >> 6) & 3, k1 = ln + 64 * (i >> 8);
-                tw3[i] = tab[(u == 0 ? k1 : 2 * u * k1) & NMASK];
-            }
-            v2f* const wl = (v2f*)(smem + RG::OFF_WIN);             // [r / 2][lane][r & 1]: the pair 4 l + u + 64 r of lane 16 u + l
-            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
-                const int r = ((i >> 7) << 1) | (i & 1), ln = (i >> 1) & 63;
-                wl[i] = ((const v2f*)p.win)[lofs4(ln) / 2 + 64 * r];
-            }
-        } else {
-            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
-                const int q = i >> 6, l = i & 63;
-                t1L[i] = tab[(2 * l * q) & NMASK];                  // W_M^(l q)
-            }
-            for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
-            for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
-        }
-    }
-    int* const Lflag = (int*)(smem + RG::OFF_FLAG);
-    if (threadIdx.x < 16) Lflag[threadIdx.x] = 0;
-    __syncthreads();
-
     // ---- lane constants
     const int Q = lane / P, L1 = lane % P;
     float csg[G::LOGP > 0 ? G::LOGP : 1];
@@ -166,7 +138,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     const int nwg = R1 - R0, units = nwg + ((chained && nwg >= NW) ? 1 : 0), base = units / NW, extra = units - base * NW;
     const int dec = (chained && nwg >= NW) ? 1 : 0;                 // wave 0's share, in rows, is one less than in units
     const int r0 = R0 + wid * base + (wid < extra ? wid : extra) - (wid > 0 ? dec : 0), r1 = R0 + (wid + 1) * base + (wid + 1 < extra ? wid + 1 : extra) - dec;
-    if (r0 >= r1) return;
+    const bool idle_wave = r0 >= r1;                                // (no rows: it still helps to fill the tables below)
     const int Fi = (int)p.F;
     const int rows1 = Fi + 1;                                       // rows per signal
     // ---- the row below a wave's range (the previous spectrum of its last frame) is the FIRST row of the wave below it in the
@@ -214,9 +186,26 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         v2f z[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            if constexpr (X4) z[r] = raw[r] * winL[128 * (r >> 1) + (r & 1)];
-            else z[r] = raw[r] * wv[r];
-            asm volatile("" : "+v"(z[r]));                          // the multiply stays above the loads
+            if constexpr (!X4) {
+                z[r] = raw[r] * wv[r];
+                asm volatile("" : "+v"(z[r]));                      // the multiply stays above the loads
+            }
+        }
+        if constexpr (X4) {
+            // the window from LDS: the register pairs (r, r + 1) of a lane sit side by side, so eight 16-byte reads, ALL in flight
+            // before the first multiply (read one pair at a time into one temporary -- what the compiler made of the plain loop --
+            // the frame pays sixteen LDS round trips one after the other here: the wave's longest stall)
+            pvxc::v4f wq[R / 2];
+#pragma unroll
+            for (int m = 0; m < R / 2; m++) wq[m] = *(const pvxc::v4f*)(winL + 128 * m);
+#pragma unroll
+            for (int m = 0; m < R / 2; m++) asm volatile("" : "+v"(wq[m]));     // (the reads stay together, above the multiplies)
+#pragma unroll
+            for (int m = 0; m < R / 2; m++) {
+                z[2 * m] = raw[2 * m] * pvxc::mk(wq[m].x, wq[m].y);
+                z[2 * m + 1] = raw[2 * m + 1] * pvxc::mk(wq[m].z, wq[m].w);
+                asm volatile("" : "+v"(z[2 * m]), "+v"(z[2 * m + 1]));          // the multiplies stay above the loads
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (H > 0) {
@@ -391,7 +380,38 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
 
     // ---- (signal b, row-in-signal q) of this wave's first row g = r1 - 1; rows go down by one
     int g = r1 - 1, gb = g / rows1, gq = g - gb * rows1;            // the only division
-    { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
+    if (!idle_wave) { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
+    // (the first row's samples are on their way from HBM while the workgroup fills its tables: two latencies side by side --
+    // every launch pays them once per wave, and BASELINE config 2 is one launch of 17 rows per wave)
+    // ---- block-shared tables
+    {
+        const v2f* tab = (const v2f*)p.twiddle;                     // W_nfft^j, j < nfft
+        constexpr int NMASK = G::N - 1;
+        if constexpr (X4) {
+            for (int i = threadIdx.x; i < 256; i += 64 * NW) t1L[i] = tab[((G::N / 256) * (i & 15) * (i >> 4)) & NMASK];     // [q][l] W_256^(l q)
+            for (int i = threadIdx.x; i < 512; i += 64 * NW) {      // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
+                const int ln = i & 63, u = (i >> 6) & 3, k1 = ln + 64 * (i >> 8);
+                tw3[i] = tab[(u == 0 ? k1 : 2 * u * k1) & NMASK];
+            }
+            v2f* const wl = (v2f*)(smem + RG::OFF_WIN);             // [r / 2][lane][r & 1]: the pair 4 l + u + 64 r of lane 16 u + l
+            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+                const int r = ((i >> 7) << 1) | (i & 1), ln = (i >> 1) & 63;
+                wl[i] = ((const v2f*)p.win)[lofs4(ln) / 2 + 64 * r];
+            }
+        } else {
+            for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+                const int q = i >> 6, l = i & 63;
+                t1L[i] = tab[(2 * l * q) & NMASK];                  // W_M^(l q)
+            }
+            for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
+            for (int i = threadIdx.x; i <= G::HALF; i += 64 * NW) tw3[i] = tab[i];
+        }
+    }
+    int* const Lflag = (int*)(smem + RG::OFF_FLAG);
+    if (threadIdx.x < 16) Lflag[threadIdx.x] = 0;
+    __syncthreads();
+    if (idle_wave) return;
+
     int ng = 0;
     bool pend = false, pend_prev0 = false, pend_own = false;        // the frame staged last still waits for its previous spectrum
     int pend_nk = 0, own_sl = -1, own_pb = 1;

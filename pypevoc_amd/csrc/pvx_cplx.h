@@ -17,6 +17,7 @@
 namespace pvxc {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v2f mk(float re, float im) { return (v2f){re, im}; }
 __device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
