@@ -71,12 +71,21 @@ template <typename CI>
 __device__ __forceinline__ int peak_scan_x4_thin(const float2* X, double thr, float& maxe, float& miny, double& tot, double& th,
                                                  CI* ci, int trash, int lane, int npeaks) {
     float v[16];                                                     // v[4 j + i] = |X[256 j + 4 lane + i]|^2
+    {
+        // (all eight reads in flight before the first |X|^2: a quarter at a time they are four round trips in a row)
+        pvxc::v4f xa[4], xb[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float4 a = *(const float4*)(X + j * F4::RP + 4 * lane);
-        const float4 b = *(const float4*)(X + j * F4::RP + 4 * lane + 2);
-        v[4 * j] = norm2(make_float2(a.x, a.y)); v[4 * j + 1] = norm2(make_float2(a.z, a.w));
-        v[4 * j + 2] = norm2(make_float2(b.x, b.y)); v[4 * j + 3] = norm2(make_float2(b.z, b.w));
+        for (int j = 0; j < 4; j++) {
+            xa[j] = *(const pvxc::v4f*)(X + j * F4::RP + 4 * lane);
+            xb[j] = *(const pvxc::v4f*)(X + j * F4::RP + 4 * lane + 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[4 * j] = norm2(make_float2(xa[j].x, xa[j].y)); v[4 * j + 1] = norm2(make_float2(xa[j].z, xa[j].w));
+            v[4 * j + 2] = norm2(make_float2(xb[j].x, xb[j].y)); v[4 * j + 3] = norm2(make_float2(xb[j].z, xb[j].w));
+        }
     }
     {
         float lmax = v[0], lmin = v[0], ls0 = 0.f, ls1 = 0.f;
@@ -379,11 +388,18 @@ __device__ __forceinline__ void fft4_quarters(v2f (&z)[16], v2f* dz, const v2f* 
     hook1();
     const int l = lane & 15, u = lane >> 4;
     v2f* const ew = dz + u * F4::EU + l;
-    // two rows at a time, twiddles first: adjacent so that the accesses pair into ds_read2 / ds_write2
+    // the sixteen twiddles of the lane first, ALL in flight before the first product (taken a pair at a time beside the
+    // stores -- what the compiler makes of the plain loop -- every pair is an LDS round trip of its own behind the store of
+    // the pair before: eight in a row, the longest stall of the transform); then two rows at a time, adjacent, so that the
+    // accesses pair into ds_read2 / ds_write2
+    v2f tw[16];
+#pragma unroll
+    for (int q = 1; q < 16; q++) tw[q] = t1[q * 16 + l];
+#pragma unroll
+    for (int q = 1; q < 16; q++) asm volatile("" : "+v"(tw[q]));
 #pragma unroll
     for (int q2 = 0; q2 < 16; q2 += 2) {
-        const v2f ta = t1[q2 * 16 + l], tb = t1[(q2 + 1) * 16 + l];
-        const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], ta) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tb);
+        const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], tw[q2]) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tw[q2 + 1]);
         ew[q2 * F4::EP] = pa;
         ew[(q2 + 1) * F4::EP] = pb2;
     }
