@@ -266,10 +266,24 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         const bool with_peaks = j > rel0;
         const InT* nsrc = row_src(j + 1);                             // (nullptr once the window has been slid)
         cx<T> z[R];
+        {
+            // the lane's window pairs, ALL in flight before the first product (one at a time, each behind its own wait -- what the
+            // compiler makes of the plain loop -- a frame starts with sixteen LDS round trips in a row)
+            // (float64 samples at nfft 2048 hold their rows in register pairs: two batches of eight there, or a register spills)
+            constexpr int WB = (sizeof(RawT) == 8 && sizeof(T) == 8 && R == 16) ? R / 2 : R;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            z[r] = mkc<T>((T)raw[2 * r] * winL[lofs + 128 * r], (T)raw[2 * r + 1] * winL[lofs + 128 * r + 1]);
-            asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
+            for (int r0 = 0; r0 < R; r0 += WB) {
+                cx<T> wq[WB];
+#pragma unroll
+                for (int r = 0; r < WB; r++) wq[r] = *(const cx<T>*)(winL + lofs + 128 * (r0 + r));
+#pragma unroll
+                for (int r = 0; r < WB; r++) asm volatile("" : "+v"(wq[r].x), "+v"(wq[r].y));
+#pragma unroll
+                for (int r = 0; r < WB; r++) {
+                    z[r0 + r] = mkc<T>((T)raw[2 * (r0 + r)] * wq[r].x, (T)raw[2 * (r0 + r) + 1] * wq[r].y);
+                    asm volatile("" : "+v"(z[r0 + r].x), "+v"(z[r0 + r].y));       // the multiplies stay above the next loads
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // rows j and j + 1 are consecutive frames of one signal: slide the window, fetch the hop's new samples
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
         if constexpr (X4) {
             // ---- four 256-point transforms, then the radix-4 join inside the untangle (pvx_stft4.h): bins straight to the
             // workspace row, |X|^2 of every bin to LDS where the transform buffer was
-            fft4_quartersT<T>(z, dz, t1L, lane, [&]() { prefetch_part(nsrc, 1); }, [&]() { if constexpr (!LATE) prefetch_part(nsrc, 2); },
+            fft4_quartersT<T, (LATE ? 8 : 16)>(z, dz, t1L, lane, [&]() { prefetch_part(nsrc, 1); }, [&]() { if constexpr (!LATE) prefetch_part(nsrc, 2); },
                               [&]() { if constexpr (!LATE) prefetch_part(nsrc, 3); });
             int lu = lane;
             asm volatile("" : "+v"(lu));                             // (see flush: addresses derived here, not hoisted)

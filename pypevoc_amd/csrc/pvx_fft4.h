@@ -383,20 +383,27 @@ __device__ __forceinline__ void join8_untangle(v2f* xz, float* Ly, const v2f (&t
 template <typename H1, typename H2, typename H3>
 __device__ __forceinline__ void fft4_quarters(v2f (&z)[16], v2f* dz, const v2f* t1, int lane, H1 hook1, H2 hook2, H3 hook3) {
     using pvxw::wave_sync;
+    const int l = lane & 15, u = lane >> 4;
+#ifndef PVX_TW_EARLY
+#define PVX_TW_EARLY 1
+#endif
+    v2f tw[16];
+#pragma unroll
+    for (int q = 1; q < PVX_TW_EARLY; q++) tw[q] = t1[q * 16 + l];
+#pragma unroll
+    for (int q = 1; q < PVX_TW_EARLY; q++) asm volatile("" : "+v"(tw[q]));
     dft_regs<16>(z);                                                // stage 1: radix-16 over r
     __builtin_amdgcn_sched_barrier(0);
     hook1();
-    const int l = lane & 15, u = lane >> 4;
     v2f* const ew = dz + u * F4::EU + l;
     // the sixteen twiddles of the lane first, ALL in flight before the first product (taken a pair at a time beside the
     // stores -- what the compiler makes of the plain loop -- every pair is an LDS round trip of its own behind the store of
     // the pair before: eight in a row, the longest stall of the transform); then two rows at a time, adjacent, so that the
     // accesses pair into ds_read2 / ds_write2
-    v2f tw[16];
 #pragma unroll
-    for (int q = 1; q < 16; q++) tw[q] = t1[q * 16 + l];
+    for (int q = PVX_TW_EARLY; q < 16; q++) tw[q] = t1[q * 16 + l];
 #pragma unroll
-    for (int q = 1; q < 16; q++) asm volatile("" : "+v"(tw[q]));
+    for (int q = PVX_TW_EARLY; q < 16; q++) asm volatile("" : "+v"(tw[q]));
 #pragma unroll
     for (int q2 = 0; q2 < 16; q2 += 2) {
         const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], tw[q2]) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tw[q2 + 1]);

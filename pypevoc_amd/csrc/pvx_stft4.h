@@ -29,15 +29,28 @@ template <typename T> __device__ __forceinline__ void untangleT(cx<T> za, cx<T> 
 }
 
 // stages 1 and 2 of the four quarters and the natural-order store (quarter u at u RP); t1: LDS table [16][16] W_256^(l q)
-template <typename T, typename H1, typename H2, typename H3>
+// TB: twiddles in flight at a time (16: all; 8 where the caller has no registers to spare)
+template <typename T, int TB = 16, typename H1, typename H2, typename H3>
 __device__ __forceinline__ void fft4_quartersT(cx<T> (&z)[16], cx<T>* dz, const cx<T>* t1, int lane, H1 hook1, H2 hook2, H3 hook3) {
     dftT<16, T>(z);                                                  // stage 1: radix-16 over r
     __builtin_amdgcn_sched_barrier(0);
     hook1();
     const int l = lane & 15, u = lane >> 4;
     cx<T>* const ew = dz + u * F4::EU + l;
+    {
+        // the lane's fifteen twiddles first, all in flight (a twiddle at a time between the stores, every one is an LDS round
+        // trip behind the store before it)
 #pragma unroll
-    for (int q = 0; q < 16; q++) ew[q * F4::EP] = (q > 0) ? cmulT(z[q], t1[q * 16 + l]) : z[q];
+        for (int q0 = 0; q0 < 16; q0 += TB) {
+            cx<T> tw[TB];
+#pragma unroll
+            for (int q = (q0 == 0 ? 1 : 0); q < TB; q++) tw[q] = t1[(q0 + q) * 16 + l];
+#pragma unroll
+            for (int q = (q0 == 0 ? 1 : 0); q < TB; q++) asm volatile("" : "+v"(tw[q].x), "+v"(tw[q].y));
+#pragma unroll
+            for (int q = 0; q < TB; q++) ew[(q0 + q) * F4::EP] = (q0 + q > 0) ? cmulT(z[q0 + q], tw[q]) : z[q0 + q];
+        }
+    }
     wave_sync();
     const cx<T>* const er = dz + u * F4::EU + l * F4::EP;
 #pragma unroll

@@ -4,7 +4,7 @@ OUT=$1; ROUNDS=$2; shift 2
 : > "$OUT"
 for r in $(seq 1 "$ROUNDS"); do
   for n in "$@"; do
-    PVX_ALLOW_STALE_LIB=1 PVX_LIB=tools/ab/libpvx_$n.so python tools/ab_nfft.py ${AB_NFFT:-2048} 2>/dev/null | sed "s/^{/{\"lib\": \"$n\", /" >> "$OUT"
+    PVX_ALLOW_STALE_LIB=1 PVX_LIB=tools/ab/libpvx_$n.so python tools/ab_nfft.py ${AB_NFFT:-2048} ${AB_PREC:-32} 2>/dev/null | sed "s/^{/{\"lib\": \"$n\", /" >> "$OUT"
   done
 done
 python - "$OUT" <<'PY'
