@@ -38,6 +38,7 @@ constexpr int GF = 8;                 // frames staged before the per-peak pass
 struct StftPvParams {
     StftParams s;                     // rows, input, tables, workspace
     PeaksParams p;                    // peak parameters and result arrays (p.spec / p.ldo = s.spec / s.ldo)
+    int win_symmetric = 0;            // host knowledge: the window reads the same backwards
 };
 
 // per-wave LDS behind the transform buffer: lst[GF][kpad] int | cnt[GF] int | rel[GF] int64 | tot[GF] double
@@ -58,16 +59,21 @@ template <int R, typename T> __host__ __device__ inline size_t pv_search_bytes(i
 // which is what lets a seventh wave's buffer in
 // R = 16 (nfft 2048): the four-quarter transform of pvx_stft4.h -- t1 is [16][16] W_256^(l q), there is no t2, and the
 // untangle's table becomes the lane-ordered join / untangle twiddles [2][4][64]: 28 KB of tables instead of 37 at float64
-template <int R, typename T> struct PvGeo : StftGeo<R, T> {
+// SYM (nfft 2048 at float64, a window with w[n] = w[N-1-n] -- np.hanning and its kind, checked on the host): only the first
+// half of the window is kept, the pairs of the upper half are the mirrored pairs read backwards.  8 KB less, which is what lets
+// an EIGHTH wave's buffer in: two waves on every SIMD instead of 2 + 2 + 2 + 1 (the kernel's speed follows its waves:
+// 4 / 5 / 6 / 7 waves per CU run 113 / 119 / 135 / 148 M frames/s on BASELINE config 2).
+template <int R, typename T, bool SYM = false> struct PvGeo : StftGeo<R, T> {
     static constexpr bool X4 = (R == 16);
+    static_assert(!SYM || X4, "the half window exists for the four-quarter layout");
     static constexpr int TW8N = X4 ? 512 : ((StftGeo<R, T>::HALF / 2 + 1 + 7) & ~7);
-    static constexpr size_t OFF_T1 = StftGeo<R, T>::OFF_T1;
+    static constexpr size_t OFF_T1 = SYM ? (size_t)(StftGeo<R, T>::N / 2) * sizeof(T) : StftGeo<R, T>::OFF_T1;
     static constexpr size_t OFF_T2 = X4 ? OFF_T1 + (size_t)256 * 2 * sizeof(T) : StftGeo<R, T>::OFF_T2;
     static constexpr size_t OFF_TW3 = X4 ? OFF_T2 : StftGeo<R, T>::OFF_TW3;
     static constexpr size_t OFF_BUF = OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);                          // cx [NW][BUFC]
 };
-template <int R, typename T> __host__ __device__ inline size_t pv_total_lds(int nw, int K) {
-    return PvGeo<R, T>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
+template <int R, typename T, bool SYM = false> __host__ __device__ inline size_t pv_total_lds(int nw, int K) {
+    return PvGeo<R, T, SYM>::OFF_BUF + (size_t)nw * (StftGeo<R, T>::BUFC * 2 * sizeof(T) + pv_stage_bytes(K));
 }
 
 // a value this wave stored earlier in the kernel: read it where the store went (L2), not from a vector-L1 line that
@@ -79,9 +85,9 @@ __device__ __forceinline__ float ldw(const float* q) { return __hip_atomic_load(
 // register pairs (sample 2l + 128 r + hop = 2l + 128 (r + H)): only the last H pairs are loaded -- hop*4 bytes per
 // frame from HBM instead of nfft*4 (a wave walks its rows alone: by the time it comes back for the next frame the
 // spectrum rows streaming through L2 have evicted the samples it shared with this one).
-template <int R, typename T, typename InT, int H>
-__global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
-    using G = PvGeo<R, T>;
+template <int R, typename T, typename InT, int H, bool SYM = false>
+__global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
+    using G = PvGeo<R, T, SYM>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
     constexpr bool X4 = G::X4;
     const StftParams& p = a.s;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
     {
         const cx<T>* tab = (const cx<T>*)p.twiddle;
         constexpr int NMASK = G::N - 1;
-        for (int i = threadIdx.x; i < G::N; i += blockDim.x) winL[i] = ((const T*)p.win)[i];
+        for (int i = threadIdx.x; i < (SYM ? G::N / 2 : G::N); i += blockDim.x) winL[i] = ((const T*)p.win)[i];
         if constexpr (X4) {
             for (int i = threadIdx.x; i < 256; i += blockDim.x) t1L[i] = tab[((G::N / 256) * (i & 15) * (i >> 4)) & NMASK];    // [q][l] W_256^(l q)
             for (int i = threadIdx.x; i < 512; i += blockDim.x) {   // [j][u][lane]: W_N^k1 (u = 0), W_1024^(u k1); k1 = lane + 64 j
@@ -275,12 +281,17 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
             for (int r0 = 0; r0 < R; r0 += WB) {
                 cx<T> wq[WB];
 #pragma unroll
-                for (int r = 0; r < WB; r++) wq[r] = *(const cx<T>*)(winL + lofs + 128 * (r0 + r));
+                for (int r = 0; r < WB; r++) {
+                    // (SYM: the pair n, n + 1 of the upper half is w[N-1-n], w[N-2-n]: the pair at N-2-n, read backwards)
+                    const bool up = SYM && (r0 + r) >= R / 2;
+                    wq[r] = *(const cx<T>*)(winL + (up ? G::N - 2 - (lofs + 128 * (r0 + r)) : lofs + 128 * (r0 + r)));
+                }
 #pragma unroll
                 for (int r = 0; r < WB; r++) asm volatile("" : "+v"(wq[r].x), "+v"(wq[r].y));
 #pragma unroll
                 for (int r = 0; r < WB; r++) {
-                    z[r0 + r] = mkc<T>((T)raw[2 * (r0 + r)] * wq[r].x, (T)raw[2 * (r0 + r) + 1] * wq[r].y);
+                    const bool up = SYM && (r0 + r) >= R / 2;
+                    z[r0 + r] = mkc<T>((T)raw[2 * (r0 + r)] * (up ? wq[r].y : wq[r].x), (T)raw[2 * (r0 + r) + 1] * (up ? wq[r].x : wq[r].y));
                     asm volatile("" : "+v"(z[r0 + r].x), "+v"(z[r0 + r].y));       // the multiplies stay above the next loads
                 }
             }
@@ -460,6 +471,11 @@ __global__ __launch_bounds__(448) void k_stft_pv(StftPvParams a) {
     if (ng > 0) flush(ng);
 }
 
+template <int R, typename T> size_t pv_lds(int nw, int K, bool sym) {
+    if constexpr (R == 16) { if (sym) return pv_total_lds<R, T, true>(nw, K); }
+    return pv_total_lds<R, T>(nw, K);
+}
+
 template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_dtype, hipStream_t s) {
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -469,9 +485,14 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     const int K = a.p.K;
     // float64: LDS admits 7 waves per CU at nfft 2048 (npks <= 12); float32 (<= 176 registers: two waves per SIMD): two workgroups of 4
     int nw = (sizeof(T) == 8 && R == 16) ? 7 : 4;                      // (the others hold two waves per SIMD by registers)
-    if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= 7) nw = v; }                 // tests: other workgroups
-    while (nw > 1 && pv_total_lds<R, T>(nw, K) > 160 * 1024) nw--;
-    const size_t lds = pv_total_lds<R, T>(nw, K);
+    // a symmetric window at nfft 2048 / float64: half of it in LDS, an eighth wave (PvGeo)
+    bool sym = false;
+    if constexpr (sizeof(T) == 8 && R == 16) sym = a.win_symmetric != 0 && getenv("PVX_STFT_PV_NOSYM") == nullptr && pv_lds<R, T>(8, K, true) <= 160 * 1024;
+    if (a.s.hop != 32 * R && a.s.hop != 64 * R) sym = false;           // (instantiated for the two sliding-window hops)
+    if (sym) nw = 8;
+    if (const char* e = getenv("PVX_STFT_PV_NW")) { const int v = atoi(e); if (v >= 1 && v <= (sym ? 8 : 7)) nw = v; }      // tests: other workgroups
+    while (nw > 1 && pv_lds<R, T>(nw, K, sym) > 160 * 1024) nw--;
+    const size_t lds = pv_lds<R, T>(nw, K, sym);
     // the sliding-window instantiations for the two usual hops
     const int H = (a.s.hop == 32 * R) ? R / 4 : (a.s.hop == 64 * R) ? R / 2 : 0;
     const void* fn = nullptr;
@@ -490,6 +511,15 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
             break;
         case PVX_I16: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4> : H ? (const void*)k_stft_pv<R, T, int16_t, R / 2> : (const void*)k_stft_pv<R, T, int16_t, 0>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+    }
+    if constexpr (sizeof(T) == 8 && R == 16) {
+        if (sym && H > 0) {
+            switch (x_dtype) {
+                case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4, true> : (const void*)k_stft_pv<R, T, float, R / 2, true>; break;
+                case PVX_F64: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4, true> : (const void*)k_stft_pv<R, T, double, R / 2, true>; break;
+                default: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4, true> : (const void*)k_stft_pv<R, T, int16_t, R / 2, true>; break;
+            }
+        }
     }
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((160 * 1024) / lds);                            // workgroups that fit a CU's LDS side by side
@@ -539,6 +569,7 @@ int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec,
     a.s.x = fp.x; a.s.nsamp = fp.nsamp; a.s.sig_stride = fp.sig_stride; a.s.F = fp.F; a.s.R0 = fp.R0; a.s.ws_rows = fp.ws_rows;
     a.s.total_rows = fp.total_rows; a.s.hop = fp.hop; a.s.win = fp.win; a.s.twiddle = twiddle; a.s.spec = spec; a.s.ldo = ldo;
     a.p = pp; a.p.spec = spec; a.p.ldo = ldo;
+    a.win_symmetric = fp.win_symmetric;
     if (precision == 64) {
         switch (fp.nfft) {
             case 512: return launch_stft_pv_r<4, double>(a, x_dtype, s);

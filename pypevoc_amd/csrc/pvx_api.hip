@@ -148,6 +148,7 @@ struct pvx_plan {
     int64_t max_rows = 0;     // rows per launch (without the halo row)
     int64_t ldi = 0, ldo = 0; // workspace row pitches (elements / complex elements)
     std::vector<double> win;  // caller's window
+    bool win_symmetric = false;  // win[n] == win[nfft-1-n] for every n
     void* d_win = nullptr;    // window / wfact in the working precision
     double* d_wfbin = nullptr;
     void* d_frames = nullptr; // [max_rows+1][ldi]
@@ -341,6 +342,8 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     }
     double wsum2 = 0.0;                                 // PV.py:99 (Python sum: left to right)
     for (int i = 0; i < nfft; i++) wsum2 = wsum2 + p->win[i] * p->win[i];
+    p->win_symmetric = true;
+    for (int i = 0; i < nfft / 2; i++) p->win_symmetric = p->win_symmetric && (p->win[i] == p->win[nfft - 1 - i]);
     p->wfact = sqrt(wsum2 * nfft) / 2.0;                // PV.py:102
     p->fstep = sr / (double)nfft;                       // PV.py:105
     p->dt = (double)hop / sr;                           // PV.py:108
@@ -667,7 +670,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         FrameParams fp;
         fp.x = d_x; fp.nsamp = nsamp; fp.sig_stride = sig_stride; fp.F = F; fp.R0 = R0;
         fp.ws_rows = nrows + 1; fp.total_rows = total_rows; fp.nfft = p->nfft; fp.hop = p->hop;
-        fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi;
+        fp.win = p->d_win; fp.frames = p->d_frames; fp.ldi = p->ldi; fp.win_symmetric = p->win_symmetric ? 1 : 0;
         PeaksParams pp;
         pp.spec = p->d_spec; pp.ldo = p->ldo; pp.F = F; pp.R0 = R0; pp.nrows = nrows;
         pp.nfft = p->nfft; pp.hop = p->hop; pp.N2 = p->N2; pp.K = p->npks; pp.rad = 5;   // PV.py:177

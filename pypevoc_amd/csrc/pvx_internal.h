@@ -48,6 +48,7 @@ struct FrameParams {
     int64_t total_rows;   // nsig * (F + 1)
     int nfft, hop;
     const void* win;      // window * (1/wfact), T[nfft]
+    int win_symmetric = 0; // w[n] == w[nfft-1-n] for every n (np.hanning and its kind): k_stft_pv may keep half of it
     void* frames;         // T [ws_rows][ldi]
     int64_t ldi;          // elements per workspace row
     // optional candidate output of the split transform (pvx_stft.h: StftParams)
