@@ -154,17 +154,14 @@ def _share_hip_runtime_with_torch():
         pass            # no torch, or an unusual layout: the system runtime is used
 
 
-def load():
-    """Load libpvx_hip.so and bind every entry point.  Fails loudly if the library is missing."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
+def _bind(path):
+    """dlopen `path`, bind every entry point and check that it was built from the sources beside the package."""
+    if not os.path.exists(path):
         raise ImportError(
             "pypevoc_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C pypevoc_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+            "or `make -C pypevoc_amd/csrc`.  There is no CPU fallback." % path)
     _share_hip_runtime_with_torch()
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
@@ -174,9 +171,29 @@ def load():
     if want is not None and have != want and not os.environ.get("PVX_ALLOW_STALE_LIB"):
         raise ImportError(
             "pypevoc_amd: %s was built from other sources (fingerprint %s, pypevoc_amd/csrc is %s) -- rebuild it with "
-            "`make -C pypevoc_amd/csrc` (PVX_ALLOW_STALE_LIB=1 loads it anyway)." % (LIB_PATH, have, want))
-    _LIB = lib
+            "`make -C pypevoc_amd/csrc` (PVX_ALLOW_STALE_LIB=1 loads it anyway)." % (path, have, want))
     return lib
+
+
+def load():
+    """Load libpvx_hip.so and bind every entry point.  Fails loudly if the library is missing."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _bind(LIB_PATH)
+    return _LIB
+
+
+def swap_library(lib_or_path):
+    """TESTS ONLY: make another build of the same sources (tests/libpvx_witness.so: the product plus the witness kernels of
+    fft modes 1 and 3) the library every call goes through; returns the handle it replaces, to be swapped back.  Pooled plans
+    belong to the library that made them: the pool is emptied on every swap."""
+    global _LIB, _INIT_DEVICE
+    old = load()
+    _LIB = _bind(lib_or_path) if isinstance(lib_or_path, str) else lib_or_path
+    _INIT_DEVICE = None
+    from . import PVAnalysis
+    PVAnalysis._Plan._pool.clear()
+    return old
 
 
 def source_fingerprint():

@@ -298,7 +298,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 3 && !pvx_fused_ring_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the ring kernel handles nfft in {512, 1024, 2048} at precision=32 while npks leaves it enough LDS (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
+        pvx_set_error("fft mode 3 (the ring kernel, a witness of the bit-identity tests: tests/libpvx_witness.so, not libpvx_hip.so) handles nfft in {512, 1024, 2048} at precision=32 while npks leaves it enough LDS (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 2 && !pvx_fused_mw_supported(plan->nfft, plan->precision, plan->npks)) {
@@ -306,7 +306,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 1 && !pvx_fused_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the fused kernel handles nfft in {512, 1024, 2048} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
+        pvx_set_error("fft mode 1 (one wave per frame over two buffers, a witness of the bit-identity tests: tests/libpvx_witness.so, not libpvx_hip.so) handles nfft in {512, 1024, 2048} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
         return PVX_ERR_UNSUPPORTED;
     }
     plan->fft_mode = mode;

@@ -52,3 +52,21 @@ def oracle():
     from oracle import pvoracle
     pvoracle.build()
     return pvoracle
+
+
+@pytest.fixture
+def witness():
+    """fft modes 1 and 3 (k_fused.hip, k_fused_ring.hip: the witness kernels of the bit-identity tests) are not in the product
+    library: for the duration of a test every call goes through tests/libpvx_witness.so, the product's objects plus those two
+    (`make -C pypevoc_amd/csrc witness`, which __graft_entry__.build() runs)."""
+    from pypevoc_amd import _lib
+    path = os.path.join(ROOT, "tests", "libpvx_witness.so")
+    if not os.path.exists(path):
+        pytest.fail("tests/libpvx_witness.so is missing: make -C pypevoc_amd/csrc witness")
+    old = _lib.swap_library(path)
+    _lib.init()
+    try:
+        yield path
+    finally:
+        _lib.swap_library(old)
+        _lib.init()

@@ -481,7 +481,26 @@ def test_streaming_frame_api(amd, oracle):
     assert abs(fq - (17 * p.fstep + (0.3 - 2 * np.pi * 17 * hop / nfft + 2 * np.pi * round(17 * hop / nfft)) / (2 * np.pi * p.dt))) < 1e-9
 
 
-def test_fused_kernel_variants(amd, oracle):
+def test_product_library_carries_no_witness_kernels(amd):
+    """libpvx_hip.so has fft modes 0, 2, 4 and 5; asking it for the witness kernels (modes 1 and 3: tests/libpvx_witness.so) is
+    PVX_ERR_UNSUPPORTED with a message that says where they are, and PVX_FFT_MODE=1 / 3 leave a plan on its default mode."""
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    assert os.path.basename(_lib.LIB_PATH) == "libpvx_hip.so" or os.environ.get("PVX_LIB")
+    p = run_pv(amd, _rand_signal(3, 20000), 22050.0, 2048, 512, 6)
+    assert lib.pvx_plan_get_fft_mode(p._plan.handle) == 4
+    for mode in (1, 3):
+        assert lib.pvx_plan_set_fft_mode(p._plan.handle, mode) == -5           # PVX_ERR_UNSUPPORTED
+        assert lib.pvx_plan_get_fft_mode(p._plan.handle) == 4
+        os.environ["PVX_FFT_MODE"] = str(mode)
+        try:
+            q = run_pv(amd, _rand_signal(3, 20000), 22050.0, 2048, 512, 7)
+        finally:
+            del os.environ["PVX_FFT_MODE"]
+        assert lib.pvx_plan_get_fft_mode(q._plan.handle) == 4
+
+
+def test_fused_kernel_variants(amd, oracle, witness):
     """nfft=2048 at precision=32 runs the fused kernels (fft mode 4 by default: independent waves walking their rows
     downwards; mode 3, the workgroup-ring form, and mode 1, one independent wave per frame over two buffers, on
     request: same arithmetic, bit-identical results).  Cover the
@@ -632,7 +651,7 @@ def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monke
 
 
 @pytest.mark.parametrize("nfft,kmode", [(2048, 3), (1024, 3), (512, 3), (1024, 4), (512, 4)])
-def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, nfft, kmode):
+def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, witness, nfft, kmode):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
     of spectra, hand-off through progress counters in LDS) does the arithmetic of mode 1 (k_fused.hip, which the
     other tests pin to the reference and the oracle): every output must be bit-identical, whatever the signal
@@ -978,14 +997,10 @@ def test_full_size_config2_properties(amd, oracle, monkeypatch):
     assert p.totalmag == q.totalmag
     # the fused kernels: another grid (37 workgroups instead of one per CU: other row ranges per wave,
     # other halo rows), and the one-wave-per-frame form (fft mode 1) against the workgroup-ring default
-    for env in (("PVX_FUSED_BLOCKS", "37"), ("PVX_FFT_MODE", "1")):
+    for env in (("PVX_FUSED_BLOCKS", "37"),):
         monkeypatch.setenv(*env)
         q = run_pv(amd, x, sr, nfft, hop, K)
         monkeypatch.delenv(env[0])
-        if env[0] == "PVX_FFT_MODE":
-            # (another transform since the default's four-quarter form, pvx_fft4.h: same peaks, values to float32 round-off)
-            assert np.array_equal(p.binno, q.binno) and np.abs(p.f - q.f).max() <= 1e-3 and np.abs(p.mag - q.mag).max() <= 1e-6 * p.mag.max()
-            continue
         for k in ("f", "mag", "ph", "realph", "binno", "t"):
             assert np.array_equal(getattr(p, k), getattr(q, k)), (env, k)
         assert p.totalmag == q.totalmag
@@ -1226,8 +1241,8 @@ def test_fuzz_long_cases_against_oracle(amd, oracle):
     assert chk > 5000 and bad <= 1e-4 * chk, (chk, bad)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_first_frame_unwrapping_ties_follow_reference(amd, oracle, mode, monkeypatch):
+@pytest.mark.parametrize("mode", [0, 1, 4])
+def test_first_frame_unwrapping_ties_follow_reference(amd, oracle, mode, monkeypatch, witness):
     """hop = nfft/8: in frame 0 (previous spectrum all zero) the phase difference is +-pi/4 or +-3pi/4
     exactly (PV.py:171,190) and for every other bin two unwrapping candidates are EXACTLY equidistant
     from the bin centre; which one PV.py:140-147 keeps is decided by its float64 rounding.  The float32
@@ -1245,7 +1260,7 @@ def test_first_frame_unwrapping_ties_follow_reference(amd, oracle, mode, monkeyp
 
 
 # ------------------------------------------------------------------ multi-GPU result wire format
-@pytest.mark.parametrize("precision,nfft,mode", [(32, 2048, 1), (32, 4096, 2), (32, 1000, 0), (64, 1024, 0)])
+@pytest.mark.parametrize("precision,nfft,mode", [(32, 2048, 4), (32, 4096, 2), (32, 1000, 0), (64, 1024, 0)])
 def test_result_wire_round_trip_is_bit_exact(amd, precision, nfft, mode, monkeypatch):
     """pvx_pack_rows_dev -> pvx_unpack_rows_dev (include/pvx.h: the gather's 18 / 26 B per slot format)
     gives back f, mag, ph, realph, binno, totalmag bit for bit, for every analysis kernel, including
@@ -1641,7 +1656,7 @@ def test_library_first_then_torch_in_a_fresh_process():
 
 
 # ------------------------------------------------------------------ host path: chunked input, resident chain, descriptors
-@pytest.mark.parametrize("nfft,hop,K,precision,mode", [(2048, 512, 8, 32, None), (2048, 333, 8, 32, 1), (4096, 1024, 12, 32, None),
+@pytest.mark.parametrize("nfft,hop,K,precision,mode", [(2048, 512, 8, 32, None), (2048, 333, 8, 32, 4), (4096, 1024, 12, 32, None),
                                                         (1024, 256, 8, 64, None), (1000, 250, 6, 32, None)])
 def test_chunked_host_input_is_bitwise_the_single_shot_result(amd, monkeypatch, nfft, hop, K, precision, mode):
     """pvx_analyze / pvx_analyze_resident take the input in chunks that fit PVX_MAX_DEVICE_BYTES and carry the

@@ -204,7 +204,9 @@ def run_case(seed, idx, verbose=False, long=None):
     tag = "case %d:%d nfft=%d hop=%d K=%d thr=%g sr=%g n=%d kind=%d" % (seed, idx, nfft, hop, K, thr, sr, c["n"], c["kind"])
     p64 = None
     for prec in (64, 32):
-        modes = [None] if prec == 64 else [0] + ([1] if nfft in (512, 1024, 2048) else []) + ([2] if nfft in (2048, 4096, 8192) else []) + ([3, 4] if nfft in (512, 1024, 2048) else []) + ([5] if nfft in (4096, 8192) and K <= 64 else [])
+        # (fft modes 1 and 3, the witness kernels, exist in tests/libpvx_witness.so only: PVX_LIB=tests/libpvx_witness.so python tools/fuzz.py)
+        wit = [1, 3] if "witness" in os.path.basename(os.environ.get("PVX_LIB", "")) else []
+        modes = [None] if prec == 64 else [0] + ([2] if nfft in (2048, 4096, 8192) else []) + (wit + [4] if nfft in (512, 1024, 2048) else []) + ([5] if nfft in (4096, 8192) and K <= 64 else [])
         for mode in modes:
             p = run_hip(c, prec, mode)
             stats["runs"] += 1
