@@ -246,11 +246,16 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         dft_regs<R>(z);                                             // stage 1
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
-        // two rows at a time, twiddles first: adjacent so that the accesses pair into ds_read2st64 / ds_write2
+        // the lane's twiddles first, all in flight (a pair at a time they are R / 2 LDS round trips in a row behind the stores);
+        // then two rows at a time: adjacent so that the accesses pair into ds_read2st64 / ds_write2
+        v2f tq[R];
+#pragma unroll
+        for (int q = 1; q < R; q++) tq[q] = t1L[q * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < R; q++) asm volatile("" : "+v"(tq[q]));
 #pragma unroll
         for (int q2 = 0; q2 < R; q2 += 2) {
-            const v2f ta = t1L[q2 * 64 + lane], tb = t1L[(q2 + 1) * 64 + lane];
-            const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], ta) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tb);
+            const v2f pa = (q2 > 0) ? pvxc::cmul(z[q2], tq[q2]) : z[q2], pb2 = pvxc::cmul(z[q2 + 1], tq[q2 + 1]);
             dz[q2 * PITCH + lane] = pa;
             dz[(q2 + 1) * PITCH + lane] = pb2;
         }
@@ -262,11 +267,16 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         dft_regs<R>(z);                                             // stage 2
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 3);
+        v2f t2q[R];                                                  // (likewise: the stage's twiddles before its cross-lane steps)
+#pragma unroll
+        for (int t = 1; t < R; t++) t2q[t] = t2L[t * P + L1];
+#pragma unroll
+        for (int t = 1; t < R; t++) asm volatile("" : "+v"(t2q[t]));
 #pragma unroll
         for (int t0 = 0; t0 < R; t0 += 4) {
             v2f a[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2L[(t0 + j) * P + L1]) : z[t0 + j];
+            for (int j = 0; j < 4; j++) a[j] = (t0 + j > 0) ? pvxc::cmul(z[t0 + j], t2q[t0 + j]) : z[t0 + j];
             if constexpr (G::LOGP >= 1) {
                 if constexpr (P >= 16) xstep4<8, true>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
                 if constexpr (P >= 8) xstep4<4, true>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
