@@ -100,11 +100,11 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
         const bool zero_row = row_src(j) == nullptr;
         const InT* nsrc = row_src(j + W);
         cx<T> z[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            z[r] = mkc<T>(raw[2 * r] * winL[2 * lane + 128 * r], raw[2 * r + 1] * winL[2 * lane + 128 * r + 1]);
+        // the lane's window pairs, as many in flight as the registers hold (pvx_stft.h: lds_gather_use)
+        lds_gather_use<0, R, lds_batch<R, T>(), T>((const cx<T>*)(winL + 2 * lane), 64, [&](int r, cx<T> w) {
+            z[r] = mkc<T>(raw[2 * r] * w.x, raw[2 * r + 1] * w.y);
             asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));           // the multiplies stay above the next loads
-        }
+        });
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 0);
         if (zero_row) {
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
         dftT<R, T>(z);                                                // stage 1
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
-#pragma unroll
-        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        dz[lane] = z[0];
+        lds_gather_use<1, R, lds_batch<R, T>(), T>(t1L + lane, 64, [&](int q2, cx<T> w) { dz[q2 * PITCH + lane] = cmulT(z[q2], w); });
         wave_sync();
 #pragma unroll
         for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
@@ -125,10 +125,12 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
         dftT<R, T>(z);                                                // stage 2
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 3);
+        cx<T> tq2[R];
+        if constexpr (lds_batch<R, T>() == R) lds_gather<1, R, T>(tq2, t2L + L1, P);
 #pragma unroll
         for (int t = 0; t < R; t++) {
             // twiddle W_64^(l1 t2), then stage 3: P-point DFT across the P lanes of a group (decimation in frequency)
-            cx<T> a = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+            cx<T> a = (t > 0) ? cmulT(z[t], lds_batch<R, T>() == R ? tq2[t] : t2L[t * P + L1]) : z[t];
             if constexpr (G::LOGP >= 1) {
                 if constexpr (P >= 16) a = xstepT<8, true, T>(a, csg[G::LOGP - 4], cw[G::LOGP - 4]);
                 if constexpr (P >= 8) a = xstepT<4, true, T>(a, csg[G::LOGP - 3], cw[G::LOGP - 3]);
@@ -279,23 +281,26 @@ __global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ?
         const bool real = src != nullptr;
         if (real) {
             cx<T> z[R];
+            if constexpr (G::WL) {
+                // (window in LDS: the lane's pairs, as many in flight as the registers hold)
+                lds_gather_use<0, R, lds_batch<R, T>(), T>((const cx<T>*)(winL + 2 * S * lane + 2 * sub), 64 * S, [&](int r, cx<T> w) {
+                    z[r] = mkc<T>((T)raw[2 * r] * w.x, (T)raw[2 * r + 1] * w.y);
+                    asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));   // the multiplies stay above the next loads
+                });
+            } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                if constexpr (G::WL) {
-                    const int o = 2 * S * lane + 128 * S * r + 2 * sub;
-                    z[r] = mkc<T>((T)raw[2 * r] * winL[o], (T)raw[2 * r + 1] * winL[o + 1]);
-                } else {
+                for (int r = 0; r < R; r++) {
                     z[r] = mkc<T>((T)raw[2 * r] * wn[2 * r], (T)raw[2 * r + 1] * wn[2 * r + 1]);
+                    asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));   // the multiplies stay above the next loads
                 }
-                asm volatile("" : "+v"(z[r].x), "+v"(z[r].y));       // the multiplies stay above the next loads
             }
             __builtin_amdgcn_sched_barrier(0);
             prefetch_part(nrow, 0);
             dftT<R, T>(z);                                            // stage 1
             __builtin_amdgcn_sched_barrier(0);
             prefetch_part(nrow, 1);
-#pragma unroll
-            for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+            dz[lane] = z[0];
+            lds_gather_use<1, R, lds_batch<R, T>(), T>(t1L + lane, 64, [&](int q2, cx<T> w) { dz[q2 * PITCH + lane] = cmulT(z[q2], w); });
             wave_sync();
 #pragma unroll
             for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
@@ -304,9 +309,11 @@ __global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ?
             dftT<R, T>(z);                                            // stage 2
             __builtin_amdgcn_sched_barrier(0);
             prefetch_part(nrow, 3);
+            cx<T> tq2[R];
+            if constexpr (lds_batch<R, T>() == R) lds_gather<1, R, T>(tq2, t2L + L1, P);
 #pragma unroll
             for (int t = 0; t < R; t++) {
-                cx<T> a = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+                cx<T> a = (t > 0) ? cmulT(z[t], lds_batch<R, T>() == R ? tq2[t] : t2L[t * P + L1]) : z[t];
                 if constexpr (G1::LOGP >= 1) {
                     if constexpr (P >= 16) a = xstepT<8, true, T>(a, csg[G1::LOGP - 4], cw[G1::LOGP - 4]);
                     if constexpr (P >= 8) a = xstepT<4, true, T>(a, csg[G1::LOGP - 3], cw[G1::LOGP - 3]);

@@ -343,8 +343,10 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
         dftT<R, T>(z);                                                // stage 1
         __builtin_amdgcn_sched_barrier(0);
         prefetch_part(nsrc, 1);
+        cx<T> tq1[R];
+        lds_gather<1, R, T>(tq1, t1L + lane, 64);
 #pragma unroll
-        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], t1L[q2 * 64 + lane]) : z[q2];
+        for (int q2 = 0; q2 < R; q2++) dz[q2 * PITCH + lane] = (q2 > 0) ? cmulT(z[q2], tq1[q2]) : z[q2];
         wave_sync();
 #pragma unroll
         for (int l2 = 0; l2 < R; l2++) z[l2] = dz[Q * PITCH + L1 + P * l2];
@@ -355,10 +357,12 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
         dftT<R, T>(z);                                                // stage 2
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LATE) prefetch_part(nsrc, 3);
+        cx<T> tq2[R];
+        lds_gather<1, R, T>(tq2, t2L + L1, P);
 #pragma unroll
         for (int t = 0; t < R; t++) {
             // twiddle W_64^(l1 t2), then stage 3: P-point DFT across the P lanes of a group (decimation in frequency)
-            cx<T> v = (t > 0) ? cmulT(z[t], t2L[t * P + L1]) : z[t];
+            cx<T> v = (t > 0) ? cmulT(z[t], tq2[t]) : z[t];
             if constexpr (G::LOGP >= 1) {
                 if constexpr (P >= 16) v = xstepT<8, true, T>(v, csg[G::LOGP - 4], cw[G::LOGP - 4]);
                 if constexpr (P >= 8) v = xstepT<4, true, T>(v, csg[G::LOGP - 3], cw[G::LOGP - 3]);

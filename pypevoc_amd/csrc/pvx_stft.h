@@ -112,6 +112,32 @@ template <int R, typename T> struct StftGeo {
     static constexpr size_t OFF_BUF = OFF_TW3 + (size_t)TW3N * 2 * sizeof(T);                // cx [NW][BUFC]
     __host__ __device__ static size_t total(int nw) { return OFF_BUF + (size_t)nw * BUFC * 2 * sizeof(T); }
 };
+// n strided LDS table entries of a lane, ALL in flight before the first use: read one at a time beside the stores or the
+// arithmetic that use them -- what the compiler makes of the plain loops -- every entry is an LDS round trip of its own
+// (measured on k_fused_rev / k_stft_pv: the longest stalls of the transform)
+template <int N0, int N1, typename T> __device__ __forceinline__ void lds_gather(cx<T> (&dst)[N1], const cx<T>* base, int stride) {
+#pragma unroll
+    for (int q = N0; q < N1; q++) dst[q] = base[q * stride];
+#pragma unroll
+    for (int q = N0; q < N1; q++) asm volatile("" : "+v"(dst[q].x), "+v"(dst[q].y));
+}
+
+// ... in batches of B entries where the registers do not hold them all: use(q, entry) for q in [N0, N1)
+template <int N0, int N1, int B, typename T, typename F> __device__ __forceinline__ void lds_gather_use(const cx<T>* base, int stride, F use) {
+#pragma unroll
+    for (int q0 = N0; q0 < N1; q0 += B) {
+        cx<T> t[B];
+#pragma unroll
+        for (int i = 0; i < B; i++) if (q0 + i < N1) t[i] = base[(q0 + i) * stride];
+#pragma unroll
+        for (int i = 0; i < B; i++) if (q0 + i < N1) asm volatile("" : "+v"(t[i].x), "+v"(t[i].y));
+#pragma unroll
+        for (int i = 0; i < B; i++) if (q0 + i < N1) use(q0 + i, t[i]);
+    }
+}
+// entries in flight at a time: all of them, except where 16 float64 values per lane already fill the registers
+template <int R, typename T> constexpr int lds_batch() { return (sizeof(T) == 8 && R == 16) ? 4 : R; }
+
 template <int R, typename T> __device__ __forceinline__ int zpadT(int k) { return k + StftGeo<R, T>::ZP * (k >> (2 * StftGeo<R, T>::LOGR)); }
 
 struct StftParams {
