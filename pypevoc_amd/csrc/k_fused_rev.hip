@@ -162,10 +162,13 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     v2f raw[R];
 #pragma unroll
     for (int r = 0; r < R; r++) raw[r] = pvxc::splat(0.f);
-    // samples of global row gn = (bn, qn): nullptr when there is nothing to load
-    auto row_src = [&](int gn, int bn, int qn) -> const InT* {
-        if (gn < glast || gn < 0 || qn == 0) return nullptr;
-        return (const InT*)p.x + (int64_t)bn * p.sig_stride + (int64_t)(qn - 1) * p.hop;
+    // samples of row q >= 1 of signal b, from the kernel argument segment: the frame loop carries the pointer of the row at
+    // hand and steps it down by the hop (the base pointer, the signal stride and the 64-bit products stay out of the loop's
+    // registers); only a wave's first row and the last row of the signal below a zero row come through here
+    auto row_ptr = [&](int b, int q) -> const InT* {
+        kargs_t a = kargs;
+        asm volatile("" : "+s"(a));
+        return (const InT*)a->x + (int64_t)b * a->sig_stride + (int64_t)(q - 1) * a->hop;
     };
     auto load_pair = [&](const InT* src, int r) {
         const InT* q = src + (X4 ? lofs4(lane) : 2 * lane) + 128 * r;      // X4: pair 4 l + u + 64 r of lane 16 u + l
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
 
     // spectrum of this wave's row into `cur` (zeros for a zero row) + |X|^2 -> Ly, wave-reduced max/min/energy;
     // fetches the samples of the row below (nsrc) once the raw samples have been consumed
-    auto spectrum = [&](bool zero_row, const InT* nsrc, float& maxe, float& mine, double& tot) {
+    auto spectrum = [&](bool zero_row, const InT* nsrc, const InT* safe_src, float& maxe, float& mine, double& tot) {
         float2* const dst = cur;
         v2f z[R];
 #pragma unroll
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             // waits for HBM right there, once per frame.  When the row below is not such a frame (a zero row, the end of
             // the wave's range) the loads read the start of the signal and nobody uses them: the next real row
             // reloads its whole window (`full`, below).
-            const InT* ns = (nsrc != nullptr) ? nsrc : (const InT*)p.x;
+            const InT* ns = (nsrc != nullptr) ? nsrc : safe_src;
 #pragma unroll
             for (int r = R - 1; r >= H; r--) raw[r] = raw[r - H];
 #pragma unroll
@@ -389,8 +392,18 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     };
 
     // ---- (signal b, row-in-signal q) of this wave's first row g = r1 - 1; rows go down by one
-    int g = r1 - 1, gb = g / rows1, gq = g - gb * rows1;            // the only division
-    if (!idle_wave) { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
+    // the row at hand: g (global), gq (row in its signal; 0 = the zero row), and -- valid while gq >= 1 -- its samples `csrc`
+    // and its output row `orow`.  Rows go down by one: inside a signal the pointer steps down by the hop.
+    int g = r1 - 1, gq;
+    int orow = 0;
+    const InT* csrc = (const InT*)p.x;                               // (always some address inside the input: the unused loads of the sliding window read there)
+    {
+        const int gb = g / rows1;                                    // (a division per wave, and one per signal boundary it crosses)
+        gq = g - gb * rows1;
+        if (g >= 0 && gq >= 1) { csrc = row_ptr(gb, gq); orow = gb * Fi + gq - 1; }
+    }
+    const int hopi = p.hop;
+    if (!idle_wave && g >= glast && g >= 0 && gq >= 1) { prefetch_part(csrc, 0); prefetch_part(csrc, 1); prefetch_part(csrc, 2); prefetch_part(csrc, 3); }
     // (the first row's samples are on their way from HBM while the workgroup fills its tables: two latencies side by side --
     // every launch pays them once per wave, and BASELINE config 2 is one launch of 17 rows per wave)
     // ---- block-shared tables
@@ -423,28 +436,42 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     if (idle_wave) return;
 
     int ng = 0;
-    bool pend = false, pend_prev0 = false, pend_own = false;        // the frame staged last still waits for its previous spectrum
+    // the loop's yes / no state in ONE scalar register (as separate bools each is a register, some a register pair, carried
+    // through the frame loop -- and at three waves per SIMD the loop spills what it carries):
+    //   ST_PEND   the frame staged last still waits for its previous spectrum      ST_PREV0  ... which is the caller's prev0
+    //   ST_OWN    ... and every kept peak is remembered by the lane that staged it  ST_PZ     (H > 0) the row above was a zero row
+    //   ST_STASH  two bits: 0 first spectrum to be written to the stash, 1 written, flag due, 2 done
+    constexpr unsigned ST_PEND = 1u, ST_PREV0 = 2u, ST_OWN = 4u, ST_PZ = 8u, ST_STASH = 16u;
+    unsigned st = chain_out ? 0u : 2u * ST_STASH;
     int pend_nk = 0, own_sl = -1, own_pb = 1;
-    bool prev_zero = false;                                         // (H > 0) the row above was a zero row
-    int stash_state = chain_out ? 0 : 2;                            // 0: to be written, 1: written, flag due, 2: done
+    // rows the optional arguments name, as 32-bit row numbers (no such row: a number no row has): the pointers themselves are
+    // re-read from the kernel argument segment where they are used, once per launch
+    const int prev0_g = (p.prev0 != nullptr) ? 1 : -0x7fffffff;      // output row 0 = global row 1
+    const int spec_g = (p.spec_out != nullptr && p.spec_row >= -1 && p.spec_row < 0x7fffffffLL) ? (int)p.spec_row : -0x7fffffff;
     for (; g >= glast; --g) {
-        int bn = gb, qn = gq - 1;                                   // (b, q) of row g - 1
-        if (qn < 0) { qn = Fi; bn -= 1; }
+        const int qn = gq >= 1 ? gq - 1 : Fi;                       // row g - 1 in its signal (below a zero row: the last row of the signal before)
         const bool zero_row = (g < 0) || (gq == 0);
+        // samples and output row of row g - 1 (nullptr: nothing to load -- a zero row, or below the wave's range)
+        const InT* nsrc = nullptr;
+        int norow = orow - 1;
+        if (g - 1 >= glast && g - 1 >= 0 && qn >= 1) {
+            if (gq >= 2) nsrc = csrc - hopi;
+            else { const int bn = (g - 1) / rows1; nsrc = row_ptr(bn, qn); norow = bn * Fi + qn - 1; }
+        }
         if constexpr (H > 0) {
             // the first frame below a zero row: its window did not slide in
-            if (!zero_row && prev_zero) { const InT* s1 = row_src(g, gb, gq); prefetch_part(s1, 0); prefetch_part(s1, 1); prefetch_part(s1, 2); prefetch_part(s1, 3); }
-            prev_zero = zero_row;
+            if (!zero_row && (st & ST_PZ)) { prefetch_part(csrc, 0); prefetch_part(csrc, 1); prefetch_part(csrc, 2); prefetch_part(csrc, 3); }
+            st = zero_row ? (st | ST_PZ) : (st & ~ST_PZ);
         }
         float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
-        spectrum(zero_row, row_src(g - 1, bn, qn), maxe, mine, tot);
-        if (stash_state == 1) {
+        spectrum(zero_row, nsrc, csrc, maxe, mine, tot);
+        if ((st & (3u * ST_STASH)) == ST_STASH) {
             // (one row after the stores: they have long landed, the wait is for form)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile int*)(Lflag + wid) = 1;
-            stash_state = 2;
-        } else if (stash_state == 0) {
+            st += ST_STASH;
+        } else if ((st & (3u * ST_STASH)) == 0u) {
             // (four bins per lane at a time: sixteen at once are 32 registers nobody has here)
             float2* const so = (float2*)kargs->stash + ((size_t)(blockIdx.x * NW + wid) * M + fresh_lane());
 #pragma unroll
@@ -456,11 +483,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 for (int u = 0; u < 4; u++) so[64 * (j + u)] = t[u];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            stash_state = 1;
+            st += ST_STASH;
         }
-        if (pend) {
+        if (st & ST_PEND) {
             // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
-            if (pend_own && !pend_prev0) {
+            if ((st & (ST_OWN | ST_PREV0)) == ST_OWN) {
                 // (the usual case: the lane that staged a peak kept its slot and bin -- one LDS round trip)
                 if (own_sl >= 0) {
                     const float2 pv = cur[XA(own_pb)];
@@ -472,18 +499,17 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 const int sl = (ng - 1) * kpad + e;
                 const int nbin = Lsbin[sl];
                 float2 pv;
-                if (pend_prev0) pv = make_float2((float)p.prev0[2 * nbin], (float)p.prev0[2 * nbin + 1]);
+                if (st & ST_PREV0) { const double* pz = kargs->prev0; pv = make_float2((float)pz[2 * nbin], (float)pz[2 * nbin + 1]); }
                 else pv = cur[XA(nbin)];
                 Lsval[(size_t)sl * 5 + 2] = pv.x;
                 Lsval[(size_t)sl * 5 + 3] = pv.y;
             }
-            pend = false;
+            st &= ~ST_PEND;
             if (ng == gs) { flush(0, ng); ng = 0; }
         }
         if (!zero_row && g >= r0) {
             bool own = false;                                       // every kept peak is remembered by the lane that staged it
             own_sl = -1;
-            const int64_t orow = (int64_t)gb * Fi + (gq - 1);
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
             double th = 0.0;
             int nk = 0;
@@ -604,22 +630,25 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 nk += __popcll(bal);
             }
             }
-            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = orow; Ltot[ng] = tot; }
+            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = (long long)orow; Ltot[ng] = tot; }
             ng++;
-            pend = true; pend_nk = nk; pend_prev0 = (p.prev0 != nullptr) && (orow == 0); pend_own = own;
+            pend_nk = nk;
+            st = (st & ~(ST_PREV0 | ST_OWN)) | ST_PEND | (g == prev0_g ? ST_PREV0 : 0u) | (own ? ST_OWN : 0u);
         }
-        if (p.spec_out != nullptr && g == p.spec_row) {
+        if (g == spec_g) {
+            float* const so = kargs->spec_out;
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 const float2 v = cur[XA(lane + 64 * j)];
-                p.spec_out[2 * (lane + 64 * j)] = v.x;
-                p.spec_out[2 * (lane + 64 * j) + 1] = v.y;
+                so[2 * (lane + 64 * j)] = v.x;
+                so[2 * (lane + 64 * j) + 1] = v.y;
             }
         }
         wave_sync();                                                // cur / Ly / lists are read: free for the row below
-        gb = bn; gq = qn;
+        gq = qn;
+        if (nsrc != nullptr) { csrc = nsrc; orow = norow; }
     }
-    if (stash_state == 1) {
+    if ((st & (3u * ST_STASH)) == ST_STASH) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) *(volatile int*)(Lflag + wid) = 1;
     }
@@ -628,19 +657,19 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     int f1 = ng;
     unsigned long long pv64 = 0ull;
     bool late = false;
-    if (chain_in && pend) {
+    if (chain_in && (st & ST_PEND)) {
         while (*(volatile int*)(Lflag + wid - 1) == 0) __builtin_amdgcn_s_sleep(4);
         asm volatile("" ::: "memory");                              // nothing of the stash is read before the flag
         // (same CU as the writer: same L2; this launch has read nothing of the stash before, so no older copy sits in the L1)
-        const float2* st = (const float2*)kargs->stash + (size_t)(blockIdx.x * NW + wid - 1) * M;
-        if (pend_own) {
-            if (own_sl >= 0) pv64 = __builtin_nontemporal_load((const unsigned long long*)(st + own_pb));
+        const float2* stp = (const float2*)kargs->stash + (size_t)(blockIdx.x * NW + wid - 1) * M;
+        if (st & ST_OWN) {
+            if (own_sl >= 0) pv64 = __builtin_nontemporal_load((const unsigned long long*)(stp + own_pb));
             late = true; f1 = ng - 1;
         } else
         for (int e = lane; e < pend_nk; e += 64) {
             const int sl = (ng - 1) * kpad + e;
             unsigned long long v;
-            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(st + Lsbin[sl]) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(stp + Lsbin[sl]) : "memory");
             Lsval[(size_t)sl * 5 + 2] = __uint_as_float((unsigned)v);
             Lsval[(size_t)sl * 5 + 3] = __uint_as_float((unsigned)(v >> 32));
         }
