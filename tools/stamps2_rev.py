@@ -1,5 +1,5 @@
-"""Where a wave of k_fused_rev (nfft 2048) spends its cycles: s_memtime stamps of an instrumented build.
-   bash tools/ab/buildstamp_rev.sh && PVX_LIB=tools/ab/libpvx_st.so python tools/stamps_rev.py [noise|violin]"""
+"""Where a wave of k_fused_rev (nfft 2048) spends its time: s_memtime stamps of an instrumented build (round-5 sources).
+   bash tools/ab/buildstamp2_rev.sh && PVX_ALLOW_STALE_LIB=1 PVX_LIB=tools/ab/libpvx_st.so python tools/stamps2_rev.py [noise|violin]"""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PVX_STAMPS"] = "1"
@@ -28,14 +28,15 @@ raw.pvx_debug_stamps(plan, None, 1)
 n = 5
 for _ in range(n):
     lib.pvx_analyze_dev(plan, x.data_ptr(), 0, nsamp, 1, nsamp, *ptrs, None, None)
-NS = 14
+NS = 18
 out = (ctypes.c_uint64 * NS)()
 raw.pvx_debug_stamps(plan, out, 0)
-names = ["0 loop top, row bookkeeping, window multiply", "1 slide + sample loads issued", "2 stage 1 (radix-16)", "3 twiddle + exchange write + reads issued",
-         "4 exchange reads landed + stage 2", "5 natural-order store + twiddle reads, drained", "6 join + untangle + |X|^2 stores", "7 wave reductions (max / min / sum)",
-         "8 previous-spectrum pick-up (+ flush every 8th frame)", "9 candidate scan + list", "10 fetch, rank, salience, staging", "11 loop bottom", "12 (explicit vmcnt(0) after the transform)", "13 (PVX_FUSED_BLOCKS=-5: vmcnt(0) right behind the sample loads = their raw latency)"]
+names = ["0 loop top, row bookkeeping, window reads + multiply", "1 slide + sample loads issued", "2 stage 1 (radix-16)",
+         "3 twiddle reads + products + exchange write + reads issued", "4 exchange reads landed + stage 2", "5 natural-order store + join twiddles, drained",
+         "6 join + untangle (both halves) + the row's tail", "7 stash / previous-spectrum pick-up (+ flush every 8th frame)", "8 candidate scan + list",
+         "9 fetch, rank, salience, staging", "10 loop bottom", "11 (after the loop)", "12 (of 0) loop top + window reads landed", "13 (of 0) the row's samples have arrived (vmcnt(0))", "14 (of 0) back edge: the top of the loop body", "15 (of 0) row bookkeeping + explicit vmcnt(0): samples in registers", "16 (PVX_STAMP_LAT=1) slide loads issued", "17 (PVX_STAMP_LAT=1) ... and landed: their raw latency"]
 tot = sum(out)
-frames = n * (F + 2048)          # every wave also transforms the row above its range
+frames = n * (F + 1 + 256)       # (+ the row under a workgroup's range that its wave 0 transforms)
 for i in range(NS):
-    print("%-58s %8.1f ticks/frame  %5.1f %%" % (names[i], out[i] / frames, 100.0 * out[i] / max(tot, 1)))
-print("total %.1f s_memtime ticks per frame (100 MHz ticks x clock ratio; two waves share a SIMD)" % (tot / frames))
+    print("%-62s %8.1f ticks/frame  %5.1f %%" % (names[i], out[i] / frames, 100.0 * out[i] / max(tot, 1)))
+print("total %.1f s_memtime ticks per frame and wave (100 MHz ticks; three waves share a SIMD); input: %s" % (tot / frames, what))
