@@ -26,6 +26,16 @@ using namespace pvxf;
 namespace {
 
 constexpr int GFR = 8;              // frames staged before the per-peak pass
+// issue priorities of the frame loop's phases (see the loop; -D overrides for A/B builds)
+#ifndef PVX_PRIO_T
+#define PVX_PRIO_T 2
+#endif
+#ifndef PVX_PRIO_S
+#define PVX_PRIO_S 1
+#endif
+#ifndef PVX_PRIO_C
+#define PVX_PRIO_C 0
+#endif
 
 typedef unsigned short u16;
 
@@ -465,7 +475,19 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         }
         float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
+        // ---- issue priority by phase (s_setprio): transform 2 > previous-spectrum pick-up, flush and candidate scan 1 > the
+        // candidates' fetch / ranking / staging 0.  The three waves of a SIMD run the same program; left at equal priority they
+        // take turns instruction by instruction, every wave's dense phase (the transform: packed arithmetic, 4 cycles an
+        // instruction) stretched by its neighbours' and every latency-bound phase (the peak search: short dependent steps between
+        // LDS round trips and wave reductions) queueing for issue slots behind them.  With the phases ranked, a wave in its
+        // transform runs it at the pipe's rate and the other two fit their searches into its LDS waits: the arbitration of
+        // MI355X_MICROARCH.md, "Two waves per SIMD", items 2-4, used between phases of one program instead of between roles.
+        // 441 -> 506 M frames/s at config 2, noise 373 -> 425, violin 373 -> 420; two levels (transform over everything else)
+        // give 486, the search ranked ABOVE the transform 462; splitting the transform (stages over join) loses what the third
+        // level gains (profiles/r05_ab_steps.txt).
+        __builtin_amdgcn_s_setprio(PVX_PRIO_T);
         spectrum(zero_row, nsrc, csrc, maxe, mine, tot);
+        __builtin_amdgcn_s_setprio(PVX_PRIO_S);
         if ((st & (3u * ST_STASH)) == ST_STASH) {
             // (one row after the stores: they have long landed, the wait is for form)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,6 +545,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
             }
             wave_sync();
+            __builtin_amdgcn_s_setprio(PVX_PRIO_C);
             if (C <= 64 && p.rad <= 5 && !(th < 0.0 && C < K)) {
                 // ---- at most one candidate per lane (every frame of music): lane c owns candidate c and fetches
                 // in ONE LDS round trip all that the rest of the frame needs of it -- its score, the 2*rad

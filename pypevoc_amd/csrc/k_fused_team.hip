@@ -48,6 +48,16 @@ __device__ __forceinline__ void team_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// issue priorities of the frame loop's phases (see the loop; -D overrides for A/B builds)
+#ifndef PVX_TEAM_PRIO_T
+#define PVX_TEAM_PRIO_T 2
+#endif
+#ifndef PVX_TEAM_PRIO_S
+#define PVX_TEAM_PRIO_S 1
+#endif
+#ifndef PVX_TEAM_PRIO_C
+#define PVX_TEAM_PRIO_C 0
+#endif
 template <int S> struct TeamGeo {
     static constexpr int L = 1024;                       // complex points per wave
     static constexpr int M = L * S;                      // bins 0..M-1
@@ -320,7 +330,11 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         }
         float maxe = 0.f, mine = 0.f;
         double tot = 0.0;
+        // issue priority by phase, as in k_fused_rev.hip (the teams of a CU are in different phases): transform and join 2,
+        // pick-up / flush / candidate scan 1, ranking and staging 0
+        __builtin_amdgcn_s_setprio(PVX_TEAM_PRIO_T);
         spectrum(zero_row, row_src(g - 1, bn, qn), maxe, mine, tot);
+        __builtin_amdgcn_s_setprio(PVX_TEAM_PRIO_S);
         if (pend) {
             // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
             if (!pend_prev0) {
@@ -398,6 +412,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             }
         }
         team_sync();                                                // ---- B3: keys exchanged; X and |X|^2 are free for the row below
+        __builtin_amdgcn_s_setprio(PVX_TEAM_PRIO_C);
         if (real) {
             int ctot = 0;
 #pragma unroll

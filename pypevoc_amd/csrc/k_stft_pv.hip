@@ -35,6 +35,21 @@ namespace {
 
 constexpr int GF = 8;                 // frames staged before the per-peak pass
 
+// issue priorities of the row loop's phases (k_fused_rev.hip; -D overrides for A/B builds): transform, search, selection + staging
+#ifndef PVX_PV_PRIO_T
+#define PVX_PV_PRIO_T 2
+#endif
+#ifndef PVX_PV_PRIO_S
+#define PVX_PV_PRIO_S 1
+#endif
+#ifndef PVX_PV_PRIO_C
+#define PVX_PV_PRIO_C 0
+#endif
+// (nfft 512 at float64 loses 5 % with the phases ranked -- 448 -> 427 M frames/s: its transform is a fifth of the 2048 one's and
+// the waves' phases interleave by themselves --, nfft 1024 / 2048 gain 5 / 7 %: ranked from R = 8 on)
+#ifndef PVX_PV_PRIO_MINR
+#define PVX_PV_PRIO_MINR 8
+#endif
 struct StftPvParams {
     StftParams s;                     // rows, input, tables, workspace
     PeaksParams p;                    // peak parameters and result arrays (p.spec / p.ldo = s.spec / s.ldo)
@@ -271,6 +286,7 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
         const bool zero_row = row_src(j) == nullptr;
         const bool with_peaks = j > rel0;
         const InT* nsrc = row_src(j + 1);                             // (nullptr once the window has been slid)
+        if constexpr (R >= PVX_PV_PRIO_MINR) __builtin_amdgcn_s_setprio(PVX_PV_PRIO_T);      // issue priority by phase (k_fused_rev.hip): the transform over the peak search
         cx<T> z[R];
         {
             // the lane's window pairs, ALL in flight before the first product (one at a time, each behind its own wait -- what the
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
         }
         }
         wave_sync();
+        if constexpr (R >= PVX_PV_PRIO_MINR) __builtin_amdgcn_s_setprio(PVX_PV_PRIO_S);
         if (!with_peaks) continue;
 
         // ---- extremes and energy of the row, in k_phase_peaks' order of summation (PV.py:173, 210; PF.py:60, 164)
@@ -454,6 +471,7 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
 #pragma unroll 1
         for (int kb = 0; kb < M; kb += PIECE) C += peak_scan<T, PIECE / 64>(y, kb, PIECE, M, minv, th, cs + C, ci + C, ln);
         wave_sync();
+        if constexpr (R >= PVX_PV_PRIO_MINR) __builtin_amdgcn_s_setprio(PVX_PV_PRIO_C);
         const int nsel = peak_pick<T>(y, cs, ci, sel, M, K, C, th, ln);
         int nk = 0;
         int rad = pk.rad;
