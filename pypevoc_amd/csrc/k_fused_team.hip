@@ -27,7 +27,9 @@
 // Every staged frame is flushed by all waves together (one more barrier per 8 frames): a wave does the per-peak
 // arithmetic of its own peaks, the waves exchange how many of theirs were emitted (freq > 0, PV.py:193) and write
 // them behind those of the waves below them -- rows stay left-packed in ascending bin order (PV.py:226-239).
-// npks <= 64 (one staged peak per lane); larger npks stay with k_fused_mw.hip.
+// npks <= 64: one candidate per lane (PPL = 1).  64 < npks <= 128 (BASELINE config 3: npks = 100): TWO per lane (PPL = 2) --
+// lane l owns entries l and l + 64 of its wave's list, everything a candidate carries through B3 exists twice, the key rows
+// are 128 long, the per-peak pass takes a wave's staged peaks in two rounds.  Larger npks stay with k_fused_mw.hip.
 #include <stdlib.h>
 
 #include "pvx_fft4.h"
@@ -58,7 +60,7 @@ __device__ __forceinline__ void team_sync() {
 #ifndef PVX_TEAM_PRIO_C
 #define PVX_TEAM_PRIO_C 0
 #endif
-template <int S> struct TeamGeo {
+template <int S, int PPL = 1> struct TeamGeo {
     static constexpr int L = 1024;                       // complex points per wave
     static constexpr int M = L * S;                      // bins 0..M-1
     static constexpr int N = 2 * M;                      // nfft
@@ -66,6 +68,7 @@ template <int S> struct TeamGeo {
     static constexpr int REG = F4::BUF;                  // complex slots per wave region (4 quarters of 272)
     static constexpr int YLEN = M + (M >> 6) * 4;        // |X|^2 row, padded layout (ymap<1>)
     static constexpr int CAPW = L / 2 + 4;               // candidate list capacity per wave
+    static constexpr int CW = 64 * PPL;                  // candidates a wave carries through B3 (PPL per lane)
     static constexpr int TWN = 512 * S;                  // join / untangle twiddles of the team, lane-ordered (global table)
     static constexpr int J4N = (S == 4) ? 4 * 3 * 64 : 0;   // S = 4: twiddles of the in-wave radix-4 join
     // block-shared (bytes)
@@ -73,25 +76,32 @@ template <int S> struct TeamGeo {
     static constexpr size_t OFF_J4 = OFF_T1 + 256 * 8;                   // v2f [4][3][64] W_1024^(u k1) (S = 4)
     static constexpr size_t OFF_X = OFF_J4 + (size_t)J4N * 8;            // float2 [S][REG]
     static constexpr size_t OFF_Y = OFF_X + (size_t)S * REG * 8;         // float [YLEN]
-    static constexpr size_t OFF_KEYS = (OFF_Y + (size_t)YLEN * 4 + 15) & ~(size_t)15;     // u64 [S][64] (score, tie-break); before the keys are written: the scan's trash slots
-    static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * 64 * 8;    // double [S]
+    static constexpr size_t OFF_KEYS = (OFF_Y + (size_t)YLEN * 4 + 15) & ~(size_t)15;     // u64 [S][CW] (score, tie-break); before the keys are written: the scan's trash slots
+    static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * CW * 8;    // double [S]
     static constexpr size_t OFF_MISC = OFF_PSUM + (size_t)S * 8;         // int nw[S] | float pmax[S] | float pmin[S] | int val[S][GFT]
     static constexpr size_t OFF_WAVE = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
+    // PPL = 2 stages one frame at a time (npks > 64) and flushes it before the next scan: the candidate list and the staged
+    // values are never alive together and share their bytes -- what lets two teams of nfft 8192 into a CU's LDS at npks 128
+    __host__ __device__ static size_t ci_or_sval(int K) {
+        const size_t kpad = (size_t)((K + 3) & ~3), ci = ((size_t)CAPW * 2 + 15) & ~(size_t)15, sval = (size_t)staged_frames(K, GFT) * kpad * 5 * 4;
+        return ci > sval ? ci : ((sval + 15) & ~(size_t)15);
+    }
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFT);
         size_t b = GFT * 8 + GFT * 4 * 2                                 // tot | orow | cnt
-                 + (size_t)CAPW * 2                                      // ci (u16)
-                 + kpad * 4 + gs * kpad * 4                              // sel | sbin
-                 + gs * kpad * 5 * 4;                                    // sval
+                 + kpad * 4 + gs * kpad * 4;                             // sel | sbin
+        if (PPL == 2) b += ci_or_sval(K);
+        else b += (size_t)CAPW * 2 + gs * kpad * 5 * 4;                  // ci (u16) | sval
         return (b + 15) & ~(size_t)15;
     }
     __host__ __device__ static size_t total(int K) { return OFF_WAVE + per_wave(K) * S; }
 };
 
-template <int S, typename InT, bool AL2, int H>
+template <int S, typename InT, bool AL2, int H, int PPL = 1>
 __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
-    using TG = TeamGeo<S>;
+    using TG = TeamGeo<S, PPL>;
+    constexpr int CW = TG::CW;
     constexpr int R = 16, L = TG::L, M = TG::M, T = TG::T, REG = TG::REG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -119,10 +129,11 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     int* const Lorow = (int*)(Ltot + GFT);                          // output row (the launcher checks that rows fit 32 bits)
     int* const Lcnt = Lorow + GFT;
     u16* const Lci = (u16*)(Lcnt + GFT);
-    int* const Lsel = (int*)(Lci + TG::CAPW);
+    // PPL = 1: ci | sel | sbin | sval.  PPL = 2: (ci or sval) | sel | sbin  (see per_wave)
+    int* const Lsel = (PPL == 2) ? (int*)((unsigned char*)Lci + TG::ci_or_sval(K)) : (int*)(Lci + TG::CAPW);
     int* const Lsbin = Lsel + kpad;
-    float* const Lsval = (float*)(Lsbin + gs * kpad);
-    const int trash0 = (int)(((const unsigned char*)(Lkeys + wid * 64) - (const unsigned char*)Lci) / 2);    // in u16 slots from Lci
+    float* const Lsval = (PPL == 2) ? (float*)Lci : (float*)(Lsbin + gs * kpad);
+    const int trash0 = (int)(((const unsigned char*)(Lkeys + wid * CW) - (const unsigned char*)Lci) / 2);    // in u16 slots from Lci
     unsigned xoff = (unsigned)(TG::OFF_X + (size_t)REG * 8 * wid);
     asm volatile("" : "+s"(xoff));
     float2* const cur = (float2*)(smem + xoff);                     // this wave's region: exchange matrix, then E_s
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         maxe = mx; mine = mn; tot = sm;
     };
 
-    // per-peak pass over the staged frames [0, ng): every wave its own peaks; K <= 64: one entry per lane
+    // per-peak pass over the staged frames [0, ng): every wave its own peaks; PPL entries per lane
     int LPF = 1;
     while (LPF < K && LPF < 64) LPF <<= 1;
     auto flush = [&](int ng) {
@@ -267,18 +278,28 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         const bool gvalid = g < ng;
         const int cnt = gvalid ? Lcnt[g] : -1;
         const int64_t orow = gvalid ? (int64_t)Lorow[g] : 0;
-        bool valid = (cnt >= 0) && (e0 < cnt);
-        int nbin = 0;
-        PeakOut o;
-        o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
-        if (valid) {
-            nbin = Lsbin[g * kpad + e0];
-            const float* sv = Lsval + (size_t)(g * kpad + e0) * 5;
-            o = peak_math<float, true>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
-            valid = o.valid;
+        // (PPL = 2: npks > 64, LPF = 64, one staged frame: the wave's own peaks e0 and e0 + 64, in two rounds)
+        bool valid[PPL];
+        int nbin[PPL];
+        PeakOut o[PPL];
+        unsigned long long bal[PPL];
+        int nval = 0;
+#pragma unroll
+        for (int h = 0; h < PPL; h++) {
+            const int e = e0 + 64 * h;
+            valid[h] = (cnt >= 0) && (e < cnt);
+            nbin[h] = 0;
+            o[h].freq = 0.0; o[h].dfb = 0.0; o[h].thisph = 0.0; o[h].mag = 0.0; o[h].valid = false;
+            if (valid[h]) {
+                nbin[h] = Lsbin[g * kpad + e];
+                const float* sv = Lsval + (size_t)(g * kpad + e) * 5;
+                o[h] = peak_math<float, true>(nbin[h], sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                valid[h] = o[h].valid;
+            }
+            bal[h] = __ballot(valid[h]) & gmask;
+            nval += __popcll(bal[h]);
         }
-        const unsigned long long bal = __ballot(valid) & gmask;
-        if (gvalid && e0 == 0) Lval[wid * GFT + g] = __popcll(bal);
+        if (gvalid && e0 == 0) Lval[wid * GFT + g] = nval;
         team_sync();                                                 // the waves' emitted counts
         int off = 0, tot = 0;
         if (gvalid) {
@@ -290,13 +311,17 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         gdouble* op = (gdouble*)q->ph + orow * K;
         gdouble* orp = (gdouble*)q->realph + orow * K;
         gdouble* ob = (gdouble*)q->binno + orow * K;
-        if (valid) {
-            const int oi = off + __popcll(bal & ((1ull << lnf) - 1ull));
-            ob[oi] = (double)nbin;
-            of[oi] = o.freq;
-            om[oi] = o.mag;
-            op[oi] = o.thisph;
-            orp[oi] = o.thisph + kPi * o.dfb / pc.fstep;              // PV.py:207
+#pragma unroll
+        for (int h = 0; h < PPL; h++) {
+            if (valid[h]) {
+                const int oi = off + __popcll(bal[h] & ((1ull << lnf) - 1ull));
+                ob[oi] = (double)nbin[h];
+                of[oi] = o[h].freq;
+                om[oi] = o[h].mag;
+                op[oi] = o[h].thisph;
+                orp[oi] = o[h].thisph + kPi * o[h].dfb / pc.fstep;    // PV.py:207
+            }
+            off += __popcll(bal[h]);
         }
         if (gvalid) {
             if (wid == S - 1) {
@@ -318,7 +343,9 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
     int ng = 0;
     bool pend = false, pend_prev0 = false;                          // the frame staged last still waits for its previous spectrum
-    int pend_nk = 0, own_sl = -1, own_pb = 1;
+    int pend_nk = 0, own[PPL];                                      // the lane's staged peaks: slot << 16 | bin, -1: none (one register each across the transform)
+#pragma unroll
+    for (int h = 0; h < PPL; h++) own[h] = -1;
     bool prev_zero = false;                                         // (H > 0) the row above was a zero row
     for (; g >= r0 - 1; --g) {
         int bn = gb, qn = gq - 1;                                   // (b, q) of row g - 1
@@ -338,10 +365,26 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         if (pend) {
             // ---- the frame above (staged as group ng - 1) takes its previous spectrum from this row
             if (!pend_prev0) {
-                if (own_sl >= 0) {
-                    const float2 pv = X[xa4(own_pb)];
-                    Lsval[(size_t)own_sl * 5 + 2] = pv.x;
-                    Lsval[(size_t)own_sl * 5 + 3] = pv.y;
+                if constexpr (PPL == 1) {
+                    if (own[0] >= 0) {
+                        const float2 pv = X[xa4(own[0] & 0xffff)];
+                        Lsval[(size_t)(own[0] >> 16) * 5 + 2] = pv.x;
+                        Lsval[(size_t)(own[0] >> 16) * 5 + 3] = pv.y;
+                    }
+                } else {
+                    // (two per lane: the staged bins are read back from LDS -- nothing of them is held in registers across the
+                    // transform, which has none to spare)
+                    const int ln = fresh_lane();
+#pragma unroll
+                    for (int h = 0; h < PPL; h++) {
+                        const int e = ln + 64 * h;
+                        if (e < pend_nk) {
+                            const int sl = (ng - 1) * kpad + e;
+                            const float2 pv = X[xa4(Lsbin[sl])];
+                            Lsval[(size_t)sl * 5 + 2] = pv.x;
+                            Lsval[(size_t)sl * 5 + 3] = pv.y;
+                        }
+                    }
                 }
             } else
             for (int e = fresh_lane(); e < pend_nk; e += 64) {      // (rare: the first frame of a streamed call)
@@ -354,10 +397,12 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             if (ng == gs) { flush(ng); ng = 0; }                    // team-uniform
         }
         const bool real = !zero_row && g >= r0;                     // team-uniform
-        bool has = false, slow = false;
-        int pb = 1, bad = 0, n_w = 0;
-        unsigned mykey = 0u;
-        float2 c = make_float2(0.f, 0.f), vm = c, vp = c;
+        bool has[PPL], slow = false;
+        int pb[PPL], bad[PPL], n_w = 0;
+        unsigned mykey[PPL];
+        float2 c[PPL], vm[PPL], vp[PPL];
+#pragma unroll
+        for (int h = 0; h < PPL; h++) { has[h] = false; pb[h] = 1; bad[h] = 0; mykey[h] = 0u; c[h] = make_float2(0.f, 0.f); vm[h] = c[h]; vp[h] = c[h]; }
         double th = 0.0;
         if (real) {
             // PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178); see k_fused.hip
@@ -369,38 +414,49 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             const int C_w = peak_scan_seg_thin<R, u16>(Ly, L * wid, M, mine, th, Lci, trash0, lane, K);
             wave_sync();
             n_w = C_w;
-            if (C_w > 64) {
+            if (C_w > CW) {
                 // a dense segment: its npks best first (the row's npks best are among the segments' npks best, same tie rule)
                 n_w = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, C_w, th, mine, lane);
-                has = lane < n_w;
-                pb = has ? Lsel[lane] : 1;
+#pragma unroll
+                for (int h = 0; h < PPL; h++) { has[h] = lane + 64 * h < n_w; pb[h] = has[h] ? Lsel[lane + 64 * h] : 1; }
             } else {
-                has = lane < n_w;
-                pb = has ? (int)Lci[lane] : 1;
+#pragma unroll
+                for (int h = 0; h < PPL; h++) { has[h] = lane + 64 * h < n_w; pb[h] = has[h] ? (int)Lci[lane + 64 * h] : 1; }
             }
-            // ---- lane c owns candidate c: one LDS round trip for its score, the 2*rad neighbours of the salience test
-            // (PF.py:126-134), the spectrum around it (k_fused_rev.hip)
+            // ---- lane c owns candidates c (and c + 64): one LDS round trip for their scores, the 2*rad neighbours of the
+            // salience test (PF.py:126-134), the spectrum around them (k_fused_rev.hip)
             const int rad = p.rad;
-            const int lo = pb - rad > 1 ? pb - rad : 1;
-            int hi = pb + rad < M ? pb + rad : M;
-            hi = hi > M - 1 ? M - 1 : hi;
-            const float v = Ly[ymap<1>(pb)];
-            float nb[10];
+            float v[PPL], nb[PPL][10];
 #pragma unroll
-            for (int d = 1; d <= 5; d++) {
-                const int dd = d > rad ? rad : d;
-                int j0 = pb - dd, j1 = pb + dd;
-                j0 = j0 < lo ? lo : j0;
-                j1 = j1 > hi ? hi : j1;
-                nb[2 * d - 2] = Ly[ymap<1>(j0)];
-                nb[2 * d - 1] = Ly[ymap<1>(j1)];
+            for (int h = 0; h < PPL; h++) {
+                const int lo = pb[h] - rad > 1 ? pb[h] - rad : 1;
+                int hi = pb[h] + rad < M ? pb[h] + rad : M;
+                hi = hi > M - 1 ? M - 1 : hi;
+                v[h] = Ly[ymap<1>(pb[h])];
+#pragma unroll
+                for (int d = 1; d <= 5; d++) {
+                    const int dd = d > rad ? rad : d;
+                    int j0 = pb[h] - dd, j1 = pb[h] + dd;
+                    j0 = j0 < lo ? lo : j0;
+                    j1 = j1 > hi ? hi : j1;
+                    nb[h][2 * d - 2] = Ly[ymap<1>(j0)];
+                    nb[h][2 * d - 1] = Ly[ymap<1>(j1)];
+                }
+                c[h] = X[xa4(pb[h])];
+                vm[h] = X[xa4(pb[h] - 1)]; vp[h] = X[xa4(pb[h] + 1)];
             }
-            c = X[xa4(pb)];
-            vm = X[xa4(pb - 1)]; vp = X[xa4(pb + 1)];
 #pragma unroll
-            for (int d = 0; d < 10; d++) bad |= (int)(nb[d] > v);
-            mykey = has ? __float_as_uint(v - mine) : 0u;           // scores >= 0: bits order like values
-            Lkeys[wid * 64 + lane] = ((unsigned long long)mykey << 32) | (unsigned)(64 * (S - 1 - wid) + 63 - lane);
+            for (int h = 0; h < PPL; h++) {
+                if constexpr (PPL == 2) {
+                    // (two candidates per lane: the 3-bin energy now, the same sums in the same order -- four registers less through B3 and the ranking)
+                    const float em = (pb[h] > 1) ? __builtin_fmaf(vm[h].x, vm[h].x, vm[h].y * vm[h].y) : 0.f;
+                    vm[h].x = (em + __builtin_fmaf(c[h].x, c[h].x, c[h].y * c[h].y)) + __builtin_fmaf(vp[h].x, vp[h].x, vp[h].y * vp[h].y);
+                }
+#pragma unroll
+                for (int d = 0; d < 10; d++) bad[h] |= (int)(nb[h][d] > v[h]);
+                mykey[h] = has[h] ? __float_as_uint(v[h] - mine) : 0u;      // scores >= 0: bits order like values
+                Lkeys[wid * CW + lane + 64 * h] = ((unsigned long long)mykey[h] << 32) | (unsigned)(CW * (S - 1 - wid) + CW - 1 - lane - 64 * h);
+            }
             if (lane == 0) Lnw[wid] = n_w;
         }
         if (p.spec_out != nullptr && g == p.spec_row) {
@@ -418,67 +474,91 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
 #pragma unroll
             for (int w = 0; w < S; w++) ctot += Lnw[w];
             slow = (th < 0.0) && (ctot < K);                        // zeros of pkmskamp qualify too (PF.py:166-187): wave 0, below
-            bool take = has;
+            bool take[PPL];
+#pragma unroll
+            for (int h = 0; h < PPL; h++) take[h] = has[h];
             if (ctot > K) {
                 // rank of this lane's candidate among all the team's: larger score, or equal score and lower bin -- one
-                // compare of (score, 64 (S - 1 - wave) + 63 - lane): unique keys, four list entries per trip (the lanes
+                // compare of (score, CW (S - 1 - wave) + CW - 1 - entry): unique keys, four list entries per trip (the entries
                 // behind a wave's list hold score 0: below every candidate's)
                 // (the keys are read where they are: a 16-byte LDS read at a wave-uniform address hands two of them to all
                 // lanes -- a compare and an add per entry instead of a `v_readlane` broadcast and three more instructions)
-                const unsigned long long my64 = ((unsigned long long)mykey << 32) | (unsigned)(64 * (S - 1 - wid) + 63 - lane);
-                int rank = 0;
+                unsigned long long my64[PPL];
+                int rank[PPL];
+#pragma unroll
+                for (int h = 0; h < PPL; h++) { my64[h] = ((unsigned long long)mykey[h] << 32) | (unsigned)(CW * (S - 1 - wid) + CW - 1 - lane - 64 * h); rank[h] = 0; }
 #pragma unroll
                 for (int w = 0; w < S; w++) {
                     const int n = Lnw[w];
-                    const unsigned long long* kw = Lkeys + w * 64;
+                    const unsigned long long* kw = Lkeys + w * CW;
                     for (int j = 0; j < n; j += 4) {
                         const ulonglong2 ka = *(const ulonglong2*)(kw + j), kb = *(const ulonglong2*)(kw + j + 2);
-                        rank += (ka.x > my64 ? 1 : 0) + (ka.y > my64 ? 1 : 0) + (kb.x > my64 ? 1 : 0) + (kb.y > my64 ? 1 : 0);
+#pragma unroll
+                        for (int h = 0; h < PPL; h++)
+                            rank[h] += (ka.x > my64[h] ? 1 : 0) + (ka.y > my64[h] ? 1 : 0) + (kb.x > my64[h] ? 1 : 0) + (kb.y > my64[h] ? 1 : 0);
                     }
                 }
-                take = has && (rank < K);
+#pragma unroll
+                for (int h = 0; h < PPL; h++) take[h] = has[h] && (rank[h] < K);
             }
             int nk = 0;
-            own_sl = -1;
+#pragma unroll
+            for (int h = 0; h < PPL; h++) own[h] = -1;
             const int64_t orow = (int64_t)gb * Fi + (gq - 1);
             if (!slow) {
-                const bool keep = take && (p.rad < 0 || bad == 0);
-                const unsigned long long bal = __ballot(keep);
-                if (keep) {
-                    const int sl = ng * kpad + lane_prefix(bal);
-                    // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
-                    const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
-                    const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
-                    Lsbin[sl] = pb;
-                    float* sv = Lsval + (size_t)sl * 5;
-                    sv[0] = c.x; sv[1] = c.y; sv[4] = s3;           // sv[2], sv[3]: the previous spectrum, one row later
-                    own_sl = sl; own_pb = pb;
+#pragma unroll
+                for (int h = 0; h < PPL; h++) {
+                    const bool keep = take[h] && (p.rad < 0 || bad[h] == 0);
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {
+                        const int sl = ng * kpad + nk + lane_prefix(bal);       // entries l before entries l + 64: ascending bins
+                        // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
+                        float s3;
+                        if constexpr (PPL == 1) {
+                            const float em = (pb[h] > 1) ? __builtin_fmaf(vm[h].x, vm[h].x, vm[h].y * vm[h].y) : 0.f;
+                            s3 = (em + __builtin_fmaf(c[h].x, c[h].x, c[h].y * c[h].y)) + __builtin_fmaf(vp[h].x, vp[h].x, vp[h].y * vp[h].y);
+                        } else s3 = vm[h].x;                         // (formed before B3, below)
+                        Lsbin[sl] = pb[h];
+                        float* sv = Lsval + (size_t)sl * 5;
+                        sv[0] = c[h].x; sv[1] = c[h].y; sv[4] = s3;  // sv[2], sv[3]: the previous spectrum, one row later
+                        if constexpr (PPL == 1) own[h] = (sl << 16) | pb[h];
+                    }
+                    nk += __popcll(bal);
                 }
-                nk = __popcll(bal);
             } else {
                 // fewer maxima than npks under a negative threshold: all maxima, then the first non-maximum interior
                 // bins (peak_pick_regs' first branch, on the whole row) -- wave 0 alone, then one more barrier
                 if (wid == 0) {
                     const int ln = fresh_lane();
                     const int nsel = peak_pick_regs<R / 2, 1, u16, true>(Ly, Lci, Lsel, M, K, ctot, th, mine, ln);
-                    const int e = ln;
-                    int sb2 = 1;
-                    if (e < nsel) sb2 = Lsel[e];
-                    const bool keep = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, 0, nsel, p.rad, ln)
-                                                   : ((e < nsel) && salient<float, 1>(Ly, M, sb2, p.rad));
-                    const unsigned long long bal = __ballot(keep);
-                    if (keep) {
-                        const int sl = ng * kpad + lane_prefix(bal);
-                        const float2 cc = X[xa4(sb2)];
-                        const float2 cm = X[xa4(sb2 - 1)], cp = X[xa4(sb2 + 1)];
-                        const float em = (sb2 > 1) ? __builtin_fmaf(cm.x, cm.x, cm.y * cm.y) : 0.f;
-                        const float s3 = (em + __builtin_fmaf(cc.x, cc.x, cc.y * cc.y)) + __builtin_fmaf(cp.x, cp.x, cp.y * cp.y);
-                        Lsbin[sl] = sb2;
-                        float* sv = Lsval + (size_t)sl * 5;
-                        sv[0] = cc.x; sv[1] = cc.y; sv[4] = s3;
-                        own_sl = sl; own_pb = sb2;
+                    // (PPL = 2: the selected bins are read before anything is staged -- the staged values share the list's bytes,
+                    // not Lsel's, but the order keeps this branch independent of the layout)
+                    int sb2[PPL];
+                    bool keep[PPL];
+#pragma unroll
+                    for (int h = 0; h < PPL; h++) {
+                        const int e = ln + 64 * h;
+                        sb2[h] = 1;
+                        if (e < nsel) sb2[h] = Lsel[e];
+                        keep[h] = (p.rad <= 8) ? salient_groups<1>(Ly, M, Lsel, 64 * h, nsel, p.rad, ln)
+                                               : ((e < nsel) && salient<float, 1>(Ly, M, sb2[h], p.rad));
                     }
-                    nk = __popcll(bal);
+#pragma unroll
+                    for (int h = 0; h < PPL; h++) {
+                        const unsigned long long bal = __ballot(keep[h]);
+                        if (keep[h]) {
+                            const int sl = ng * kpad + nk + lane_prefix(bal);
+                            const float2 cc = X[xa4(sb2[h])];
+                            const float2 cm = X[xa4(sb2[h] - 1)], cp = X[xa4(sb2[h] + 1)];
+                            const float em = (sb2[h] > 1) ? __builtin_fmaf(cm.x, cm.x, cm.y * cm.y) : 0.f;
+                            const float s3 = (em + __builtin_fmaf(cc.x, cc.x, cc.y * cc.y)) + __builtin_fmaf(cp.x, cp.x, cp.y * cp.y);
+                            Lsbin[sl] = sb2[h];
+                            float* sv = Lsval + (size_t)sl * 5;
+                            sv[0] = cc.x; sv[1] = cc.y; sv[4] = s3;
+                            if constexpr (PPL == 1) own[h] = (sl << 16) | sb2[h];
+                        }
+                        nk += __popcll(bal);
+                    }
                 }
                 team_sync();
             }
@@ -491,24 +571,25 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     if (ng > 0) flush(ng);
 }
 
-template <int S> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
-    using TG = TeamGeo<S>;
+template <int S, int PPL> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
+    using TG = TeamGeo<S, PPL>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     if (p.total_rows >= 0x7fffff00LL) { pvx_set_error("the fused kernel indexes rows in 32 bits (%lld rows)", (long long)p.total_rows); return PVX_ERR_UNSUPPORTED; }
-    if (p.K > 64 || p.rad > 5) { pvx_set_error("the team kernel takes npks <= 64 and rad <= 5 (npks=%d rad=%d)", p.K, p.rad); return PVX_ERR_UNSUPPORTED; }
+    if (p.K > 64 * PPL || (PPL == 2 && p.K <= 64) || p.rad > 5) { pvx_set_error("the team kernel takes npks <= 128 and rad <= 5 (npks=%d rad=%d)", p.K, p.rad); return PVX_ERR_UNSUPPORTED; }
     const size_t lds = TG::total(p.K);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the team kernel", TG::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
     constexpr int R = 16;
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     const int H = (p.hop == 32 * R * S) ? R / 4 : (p.hop == 64 * R * S) ? R / 2 : 0;
     const void* fn = nullptr;
-#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4> : H ? (const void*)k_fused_team<S, INT, AL, R / 2> : (const void*)k_fused_team<S, INT, AL, 0>)
+#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4, PPL> : H ? (const void*)k_fused_team<S, INT, AL, R / 2, PPL> : (const void*)k_fused_team<S, INT, AL, 0, PPL>)
     switch (x_dtype) {
-        case PVX_F32: fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); break;
+        // (two candidates per lane: without the 8-byte sample loads' instantiations -- a row's new samples are a quarter of its loads)
+        case PVX_F32: if constexpr (PPL == 1) { fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); } else { fn = PVX_TEAM_PICK(float, false); } break;
         case PVX_I16: fn = PVX_TEAM_PICK(int16_t, false); break;
         default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
@@ -547,10 +628,10 @@ void pvx_fused_team_table(int nfft, const float* tw /* [nfft][2] */, float* out)
 }
 
 int pvx_fused_team_supported(int nfft, int precision, int K) {
-    if (precision != 32 || K > 64) return 0;
+    if (precision != 32 || K > 128) return 0;
     switch (nfft) {
-        case 4096: return TeamGeo<2>::total(K) <= 160 * 1024;
-        case 8192: return TeamGeo<4>::total(K) <= 160 * 1024;
+        case 4096: return (K > 64 ? TeamGeo<2, 2>::total(K) : TeamGeo<2>::total(K)) <= 160 * 1024;
+        case 8192: return (K > 64 ? TeamGeo<4, 2>::total(K) : TeamGeo<4>::total(K)) <= 160 * 1024;
         default: return 0;
     }
 }
@@ -558,8 +639,8 @@ int pvx_fused_team_supported(int nfft, int precision, int K) {
 int pvx_launch_fused_team(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
     switch (nfft) {
-        case 4096: return launch_team<2>(p, x_dtype, s);
-        case 8192: return launch_team<4>(p, x_dtype, s);
+        case 4096: return p.K > 64 ? launch_team<2, 2>(p, x_dtype, s) : launch_team<2, 1>(p, x_dtype, s);
+        case 8192: return p.K > 64 ? launch_team<4, 2>(p, x_dtype, s) : launch_team<4, 1>(p, x_dtype, s);
         default: pvx_set_error("the team kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

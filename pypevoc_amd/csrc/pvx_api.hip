@@ -441,7 +441,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         // default: one wave per frame where it exists (nfft <= 2048: independent waves walking their rows downwards
         // over one buffer each, k_fused_rev.hip, while npks leaves them enough LDS), several waves per frame above
-        // (nfft 4096 / 8192: teams of such waves, k_fused_team.hip, while npks <= 64; k_fused_mw.hip beyond)
+        // (nfft 4096 / 8192: teams of such waves, k_fused_team.hip, while npks <= 128; k_fused_mw.hip beyond)
         p->fft_mode = can4 ? 4 : can3 ? 3 : can1 ? 1 : can5 ? 5 : 2;
         if (const char* e = getenv("PVX_FFT_MODE")) {
             const int m = atoi(e);

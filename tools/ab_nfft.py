@@ -16,7 +16,7 @@ g7 = os.path.join(ROOT, "tests", "golden", "G7_perlman.npz")
 if os.path.exists(g7):
     xv = np.load(g7)["x"].astype(np.float32)
     inputs["violin"] = torch.from_numpy(np.tile(xv, 44100 * 600 // len(xv) + 1)[: 44100 * 600]).to(dev)
-K = 8
+K = int(os.environ.get("AB_K", "8"))                   # peaks per frame (AB_K=100: BASELINE config 3's)
 for nfft in nffts:
     hop = nfft // 4
     for name, x in inputs.items():
@@ -37,6 +37,6 @@ for nfft in nffts:
         for _ in range(reps): lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, sp)
         e1.record(s); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        print(json.dumps(dict(nfft=nfft, hop=hop, input=name, precision=prec, fft_mode=int(lib.pvx_plan_get_fft_mode(plan)), ms=round(ms, 4),
+        print(json.dumps(dict(nfft=nfft, hop=hop, input=name, precision=prec, npks=K, fft_mode=int(lib.pvx_plan_get_fft_mode(plan)), ms=round(ms, 4),
                               Mframes_per_s=round(F / ms / 1e3, 1), checksum=float(out[: F * K].sum().item()))))
         sys.stdout.flush(); lib.pvx_plan_destroy(plan)

@@ -57,7 +57,7 @@ def make_case(seed, idx, long=None):
     rng = np.random.default_rng([seed, idx])
     nfft = int(rng.choice([128, 256, 512, 1000, 1024, 2048, 2048, 4096, 8192]))
     hop = int(rng.choice([nfft // 8, nfft // 4, nfft // 2, nfft // 3 + 1, nfft - 1]))
-    K = int(rng.choice([1, 3, 8, 8, 20, 64, 100]))
+    K = int(rng.choice([1, 3, 8, 8, 20, 64, 100, 128, 70]))
     thr = float(rng.choice([0.0, 0.0005, 0.005, 0.005, 0.1]))
     sr = float(rng.choice([8000, 22050, 44100, 96000]))
     n = int(nfft + hop * (rng.integers(300, 3000) if long else rng.integers(1, 60)) + rng.integers(1, hop + 1))
@@ -206,7 +206,7 @@ def run_case(seed, idx, verbose=False, long=None):
     for prec in (64, 32):
         # (fft modes 1 and 3, the witness kernels, exist in tests/libpvx_witness.so only: PVX_LIB=tests/libpvx_witness.so python tools/fuzz.py)
         wit = [1, 3] if "witness" in os.path.basename(os.environ.get("PVX_LIB", "")) else []
-        modes = [None] if prec == 64 else [0] + ([2] if nfft in (2048, 4096, 8192) else []) + (wit + [4] if nfft in (512, 1024, 2048) else []) + ([5] if nfft in (4096, 8192) and K <= 64 else [])
+        modes = [None] if prec == 64 else [0] + ([2] if nfft in (2048, 4096, 8192) else []) + (wit + [4] if nfft in (512, 1024, 2048) else []) + ([5] if nfft in (4096, 8192) and K <= 128 else [])
         for mode in modes:
             p = run_hip(c, prec, mode)
             stats["runs"] += 1
