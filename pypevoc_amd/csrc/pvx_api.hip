@@ -290,7 +290,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
     if (mode < 0 || mode > 5) { pvx_set_error("unknown fft mode %d", mode); return PVX_ERR_INVALID; }
     if (mode == 5 && !pvx_fused_team_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the team kernel handles nfft in {4096, 8192} at precision=32 with npks <= 64 (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
+        pvx_set_error("the team kernel handles nfft in {4096, 8192} at precision=32 with npks <= 128 (this plan: nfft=%d precision=%d npks=%d)", plan->nfft, plan->precision, plan->npks);
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 4 && !pvx_fused_rev_supported(plan->nfft, plan->precision, plan->npks)) {
