@@ -37,6 +37,13 @@ for nfft in nffts:
         for _ in range(reps): lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, sp)
         e1.record(s); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        print(json.dumps(dict(nfft=nfft, hop=hop, input=name, precision=prec, npks=K, fft_mode=int(lib.pvx_plan_get_fft_mode(plan)), ms=round(ms, 4),
+        stages = None
+        if os.environ.get("AB_STAGES"):                       # the general path's stages of one more call: frames / transform, rocFFT, peaks, one-launch kernel
+            ms4 = (ctypes.c_double * 4)(); nl4 = (ctypes.c_int64 * 4)()
+            lib.pvx_plan_set_timing(plan, 1)
+            lib.pvx_analyze_dev(plan, x.data_ptr(), 0, n, 1, n, *ptrs, None, sp); torch.cuda.synchronize()
+            lib.pvx_plan_get_timing(plan, ms4, nl4); lib.pvx_plan_set_timing(plan, 0)
+            stages = dict(ms=[round(v, 4) for v in ms4], launches=[int(v) for v in nl4])
+        print(json.dumps(dict(nfft=nfft, hop=hop, input=name, precision=prec, npks=K, stages=stages, fft_mode=int(lib.pvx_plan_get_fft_mode(plan)), ms=round(ms, 4),
                               Mframes_per_s=round(F / ms / 1e3, 1), checksum=float(out[: F * K].sum().item()))))
         sys.stdout.flush(); lib.pvx_plan_destroy(plan)
