@@ -71,6 +71,13 @@ template <typename T> struct RowMag {
 // CAND: the transform kernel (k_stft_split) left every row's candidates -- bins and |X|^2 of the interior local maxima
 // above the threshold, max / min / sum of |X|^2 -- so phase A loads a few hundred bytes per row instead of streaming
 // nfft/2 complex bins: same candidates, same selection (the energy is summed in another order: totalmag to round-off).
+// (A/B: -D overrides) vector loads of a row in flight per lane; bins per piece of the candidate scan
+#ifndef PVX_PEAKS_UNROLL
+#define PVX_PEAKS_UNROLL 8
+#endif
+#ifndef PVX_PEAKS_PIECE
+#define PVX_PEAKS_PIECE 512
+#endif
 template <typename T, bool CAND>
 __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
             constexpr int CPV = Vec16<T>::CPV;
             const int nvec = N2 / CPV;
             const V* cv = (const V*)cur;
-#pragma unroll 8
+#pragma unroll PVX_PEAKS_UNROLL
             for (int i = lane; i < nvec; i += 64) {
                 const V v = cv[i];
                 if constexpr (CPV == 2) {
@@ -184,7 +191,12 @@ __global__ __launch_bounds__(256) void k_phase_peaks(PeaksParams p) {
         const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
         int nsel = 0;
         if (N2 >= 3) {
-            const int C = peak_scan<T, 0, false>((const T*)y, 0, N2, N2, minv, th, (T*)nullptr, ci, lane);
+            // the candidate scan in pieces of 512 bins, each with all of its LDS reads in flight (the loop form is a dependent
+            // round trip per 64 bins: 32 of them at nfft 4096), the rest of the row in the loop form
+            int C = 0, kb = 0;
+#pragma unroll 1
+            for (; kb + PVX_PEAKS_PIECE <= N2; kb += PVX_PEAKS_PIECE) C += peak_scan<T, PVX_PEAKS_PIECE / 64, false>((const T*)y, kb, PVX_PEAKS_PIECE, N2, minv, th, (T*)nullptr, ci + C, lane);
+            if (kb < N2) C += peak_scan<T, 0, false>((const T*)y, kb, N2 - kb, N2, minv, th, (T*)nullptr, ci + C, lane);
             wave_sync();
             nsel = peak_pick<T, 0, false, true>((const T*)y, (T*)nullptr, ci, sel, N2, K, C, th, lane, minv);
         }

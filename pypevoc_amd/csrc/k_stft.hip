@@ -201,6 +201,9 @@ template <int R, int S, typename T, bool WIDE = false> struct SplitGeo {
 // wait for the prefetched samples of the next row
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef PVX_SPLIT_SCAN_PIECE
+#define PVX_SPLIT_SCAN_PIECE 512
+#endif
 template <int R, int S, typename T, typename InT, bool CAND>
 __global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ? 384 : 256) void k_stft_split(StftParams p) {
     using G = SplitGeo<R, S, T, (sizeof(T) == 8 && sizeof(InT) == 8)>;
@@ -442,8 +445,14 @@ __global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ?
                 if constexpr (sizeof(T) == 4) minamp = (double)sqrtf((float)mx) * p.cand_thr;       // PF.py:60 (k_phase_peaks)
                 else minamp = sqrt(mx) * p.cand_thr;
                 const double th = (minamp != 0.0) ? minamp * minamp - mn : 0.0;
-                // (S = 4: up to 512 registers per wave, all of the scan's LDS reads in flight at once; S = 2 has 256: the loop form)
-                C_w = pvxw::peak_scan<T, (S == 4 ? SEG / 64 : 0), false>((const T*)yL, sub * SEG, SEG, M, (T)mn, th, (T*)nullptr, ciL, lane);
+                // (S = 4: up to 512 registers per wave, all of the scan's LDS reads in flight at once; S = 2 has 256: two pieces of
+                // 512 bins, each with its reads in flight together -- the loop form is a dependent LDS round trip per 64 bins)
+                if constexpr (S == 4) C_w = pvxw::peak_scan<T, SEG / 64, false>((const T*)yL, sub * SEG, SEG, M, (T)mn, th, (T*)nullptr, ciL, lane);
+                else {
+                    constexpr int PIECE = PVX_SPLIT_SCAN_PIECE;
+#pragma unroll 1
+                    for (int kb = 0; kb < SEG; kb += PIECE) C_w += pvxw::peak_scan<T, PIECE / 64, false>((const T*)yL, sub * SEG + kb, PIECE, M, (T)mn, th, (T*)nullptr, ciL + C_w, lane);
+                }
                 if (lane == 0) partL[sub * 4 + 3] = (double)C_w;
             }
             lds_barrier();                                            // the waves' candidate counts (and this wave's list)
