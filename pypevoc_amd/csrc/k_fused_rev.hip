@@ -38,6 +38,7 @@ constexpr int GFR = 8;              // frames staged before the per-peak pass
 #endif
 
 typedef unsigned short u16;
+constexpr int kDense = 64;               // slots of the dense staging: one per lane of the per-peak pass
 
 template <int R> struct RevGeo {
     using G = Geo<R>;
@@ -50,22 +51,30 @@ template <int R> struct RevGeo {
     static constexpr size_t OFF_WIN = OFF_TW3 + (size_t)TW3N * 8;    // X4: v2f [R][64] the window, lane-ordered | else: none (registers)
     static constexpr size_t OFF_FLAG = OFF_WIN + (X4 ? (size_t)R * 64 * 8 : 0);     // int [16]: wave w has left its first spectrum in the stash
     static constexpr size_t OFF_WAVE = OFF_FLAG + 64;
-    __host__ __device__ static size_t per_wave(int K) {
+    // dense: the kept peaks of up to GFR frames staged back to back in kDense slots (8 < npks <= 32, see the kernel's DENSE)
+    __host__ __device__ static size_t per_wave(int K, bool dense = false) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFR);
+        const size_t slots = dense ? (size_t)kDense : gs * kpad;
         size_t b = (size_t)G::BUFC * 8                               // the wave's spectrum buffer
                  + GFR * 8 * 2                                       // orow | tot
                  + (X4 ? 0 : (size_t)(G::M + 4 * R) * 4)             // y (padded, ymap<1>) | X4: none, |X|^2 is recomputed (YofX4)
-                 + gs * kpad * 5 * 4                                 // sval
-                 + kpad * 4 + gs * kpad * 4                          // sel | sbin
+                 + slots * 5 * 4                                     // sval
+                 + kpad * 4 + slots * 4                              // sel | sbin
+                 + (dense ? GFR * 4 : 0)                             // (dense) off: a frame's first slot
                  + GFR * 4 * 2                                       // cnt | frm
                  + ((size_t)(G::CAP + 64) * 2 > 512 ? (size_t)(G::CAP + 64) * 2 : 512);      // ci (u16) + 64 trash slots; then the 64 ranking keys (u64)
         return (b + 15) & ~(size_t)15;
     }
-    __host__ __device__ static size_t total(int K, int nw) { return OFF_WAVE + per_wave(K) * nw; }
+    __host__ __device__ static size_t total(int K, int nw, bool dense = false) { return OFF_WAVE + per_wave(K, dense) * nw; }
 };
 
-template <int R, int NW, typename InT, bool AL2, int H>
+// DENSE (8 < npks <= 32; the reference's default npks is 20): the per-peak pass (flush) costs what half a frame costs whether 8 or
+// 64 of its lanes hold a peak, and with a frame's peaks staged at a stride of npks it ran once per 64 / pow2(npks) frames --
+// every second frame at npks 20, on signals whose frames keep 8 peaks.  Dense: a frame's kept peaks are staged behind the
+// previous frame's, the pass runs when the next frame might not fit (staged + npks > 64) or GFR frames wait: once per 6 frames
+// there.  The running slot count rides in bits 8.. of the loop's state word.
+template <int R, int NW, typename InT, bool AL2, int H, bool DENSE = false>
 __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     using G = Geo<R>;
     using RG = RevGeo<R>;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     // immediate offsets of every access -- 16-bit fields -- and then cannot pair the 64-bit accesses of the exchange and
     // the natural-order pass into ds_write2 / ds_read2, whose two offsets have 8 bits each: 15 more LDS instructions per
     // frame than k_fused_ring.hip, whose slot address is a run-time value anyway)
-    unsigned wboff = (unsigned)(RG::OFF_WAVE + RG::per_wave(K) * wid);
+    unsigned wboff = (unsigned)(RG::OFF_WAVE + RG::per_wave(K, DENSE) * wid);
     asm volatile("" : "+s"(wboff));
     unsigned char* wb = smem + wboff;
     float2* const cur = (float2*)wb;                                // X of the row at hand
@@ -96,10 +105,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     float* const Ly = (float*)(Ltot + GFR);                          // (X4: no such row)
     int* const Lcnt = (int*)(Ly + (X4 ? 0 : M + 4 * R));
     int* const Lfrm = Lcnt + GFR;
-    u16* const Lci = (u16*)(Lfrm + GFR);
+    int* const Lsoff = Lfrm + GFR;                                  // (DENSE) [GFR]: a staged frame's first slot (16-byte aligned like Lcnt)
+    u16* const Lci = (u16*)(Lsoff + (DENSE ? GFR : 0));
     int* const Lsel = (int*)((unsigned char*)Lci + ((size_t)(G::CAP + 64) * 2 > 512 ? (size_t)(G::CAP + 64) * 2 : 512));
     int* const Lsbin = Lsel + kpad;
-    float* const Lsval = (float*)(Lsbin + gs * kpad);
+    float* const Lsval = (float*)(Lsbin + (DENSE ? kDense : gs * kpad));
 
     // ---- lane constants
     const int Q = lane / P, L1 = lane % P;
@@ -346,6 +356,76 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     while (LPF < K && LPF < 64) LPF <<= 1;
     auto flush = [&](int gbeg, int ng) {                           // groups [gbeg, ng)
         wave_sync();
+        if constexpr (DENSE) {
+            // ---- the staged peaks of frames [gbeg, ng) sit back to back: lane l takes slot base + l
+            const int lnf = fresh_lane();
+            kargs_t q = kargs;
+            asm volatile("" : "+s"(q));
+            PeakConst pc;
+            pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
+            // (the frames' first slots and counts in ONE LDS round trip, then selects: a loop over the frames with a read each is a
+            // chain of dependent round trips -- at nfft 1024 longer than the transform it sits beside)
+            static_assert(GFR == 8, "two 16-byte reads per table");
+            const int4 oa = *(const int4*)Lsoff, ob4 = *((const int4*)Lsoff + 1), ca = *(const int4*)Lcnt, cb4 = *((const int4*)Lcnt + 1);
+            const int offs[8] = {oa.x, oa.y, oa.z, oa.w, ob4.x, ob4.y, ob4.z, ob4.w}, cnts[8] = {ca.x, ca.y, ca.z, ca.w, cb4.x, cb4.y, cb4.z, cb4.w};
+            int base = 0, top = 0, cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { if (j == gbeg) { base = offs[j]; cnt = cnts[j]; } if (j == ng - 1) top = offs[j] + cnts[j]; }
+            const int ent = base + lnf;
+            bool valid = ent < top;
+            int g = gbeg, start = base;                              // the frame of this lane's slot: the last one that starts at or before it
+#pragma unroll
+            for (int j = 1; j < 8; j++) { if (j > gbeg && j < ng && offs[j] <= ent) { g = j; start = offs[j]; cnt = cnts[j]; } }
+            const int64_t orow = (int64_t)Lorow[g];
+            gdouble* of = (gdouble*)q->f + orow * K;
+            gdouble* om = (gdouble*)q->mag + orow * K;
+            gdouble* op = (gdouble*)q->ph + orow * K;
+            gdouble* orp = (gdouble*)q->realph + orow * K;
+            gdouble* ob = (gdouble*)q->binno + orow * K;
+            int nbin = 0;
+            PeakOut o;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            if (valid) {
+                nbin = Lsbin[ent];
+                const float* sv = Lsval + (size_t)ent * 5;
+                o = peak_math<float, true>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                valid = o.valid;
+            }
+            // the lanes of this frame: [start - base, start - base + cnt)
+            const unsigned long long gm = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << (start - base);
+            const unsigned long long ball = __ballot(valid);
+            if (valid) {
+                const int oi = __popcll(ball & gm & ((1ull << lnf) - 1ull));
+                ob[oi] = (double)nbin;
+                of[oi] = o.freq;
+                om[oi] = o.mag;
+                op[oi] = o.thisph;
+                orp[oi] = o.thisph + kPi * o.dfb / pc.fstep;          // PV.py:207
+            }
+            {
+                // zero padding (PV.py:226-239) and the frames' scalars: eight lanes per staged frame, lane c of a frame takes the
+                // columns nout + c, nout + c + 8, ... (a frame's own lanes may be one or two: they would pad for npks rounds)
+                const int g2 = gbeg + (lnf >> 3), c2 = lnf & 7;
+                int o2 = 0, n2 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { if (j == g2) { o2 = offs[j]; n2 = cnts[j]; } }
+                if (g2 < ng) {
+                    const unsigned long long gm2 = (n2 >= 64 ? ~0ull : ((1ull << n2) - 1ull)) << (o2 - base);
+                    const int nout2 = __popcll(ball & gm2);
+                    const int64_t orow2 = (int64_t)Lorow[g2];
+                    gdouble* of2 = (gdouble*)q->f + orow2 * K; gdouble* om2 = (gdouble*)q->mag + orow2 * K; gdouble* op2 = (gdouble*)q->ph + orow2 * K;
+                    gdouble* orp2 = (gdouble*)q->realph + orow2 * K; gdouble* ob2 = (gdouble*)q->binno + orow2 * K;
+                    for (int j = nout2 + c2; j < K; j += 8) { ob2[j] = 0.0; of2[j] = 0.0; om2[j] = 0.0; op2[j] = 0.0; orp2[j] = 0.0; }
+                    if (c2 == 0) {
+                        const int64_t fr = Lfrm[g2];
+                        if (q->totalmag) ((gdouble*)q->totalmag)[orow2] = sqrt(Ltot[g2]);                                  // PV.py:210
+                        if (q->t) ((gdouble*)q->t)[orow2] = ((double)(fr * (int64_t)pc.hop) + G::N / 2.0) / q->sr;        // PV.py:247
+                    }
+                }
+            }
+            wave_sync();
+            return;
+        }
         // (the lane's group and its ballot mask are worked out here, once per 8 frames: as loop invariants they are four
         // registers held through the frame loop, and at three waves per SIMD the loop has none to spare)
         const int lnf = fresh_lane();
@@ -452,6 +532,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     //   ST_OWN    ... and every kept peak is remembered by the lane that staged it  ST_PZ     (H > 0) the row above was a zero row
     //   ST_STASH  two bits: 0 first spectrum to be written to the stash, 1 written, flag due, 2 done
     constexpr unsigned ST_PEND = 1u, ST_PREV0 = 2u, ST_OWN = 4u, ST_PZ = 8u, ST_STASH = 16u;
+    constexpr unsigned ST_NST = 256u;                               // (DENSE) bits 8..: slots staged since the last per-peak pass
     unsigned st = chain_out ? 0u : 2u * ST_STASH;
     int pend_nk = 0, own_sl = -1, own_pb = 1;
     // rows the optional arguments name, as 32-bit row numbers (no such row: a number no row has): the pointers themselves are
@@ -518,7 +599,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 }
             } else
             for (int e = lane; e < pend_nk; e += 64) {
-                const int sl = (ng - 1) * kpad + e;
+                const int sl = (DENSE ? (int)(st / ST_NST) - pend_nk : (ng - 1) * kpad) + e;
                 const int nbin = Lsbin[sl];
                 float2 pv;
                 if (st & ST_PREV0) { const double* pz = kargs->prev0; pv = make_float2((float)pz[2 * nbin], (float)pz[2 * nbin + 1]); }
@@ -527,6 +608,9 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 Lsval[(size_t)sl * 5 + 3] = pv.y;
             }
             st &= ~ST_PEND;
+            if constexpr (DENSE) {
+                if (ng == GFR || (int)(st / ST_NST) + K > kDense) { flush(0, ng); ng = 0; st &= ST_NST - 1u; }
+            } else
             if (ng == gs) { flush(0, ng); ng = 0; }
         }
         if (!zero_row && g >= r0) {
@@ -613,7 +697,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 const bool keep = take && (rad < 0 || bad == 0);
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
-                    const int sl = ng * kpad + lane_prefix(bal);
+                    const int sl = (DENSE ? (int)(st / ST_NST) : ng * kpad) + lane_prefix(bal);
                     // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
                     const float em = (pb > 1) ? __builtin_fmaf(vm.x, vm.x, vm.y * vm.y) : 0.f;
                     const float s3 = (em + __builtin_fmaf(c.x, c.x, c.y * c.y)) + __builtin_fmaf(vp.x, vp.x, vp.y * vp.y);
@@ -640,7 +724,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                                          : ((e < nsel) && salient<float, 1>(Ly, M, pb, p.rad));
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
-                    const int sl = ng * kpad + nk + lane_prefix(bal);
+                    const int sl = (DENSE ? (int)(st / ST_NST) : ng * kpad) + nk + lane_prefix(bal);
                     const float2 c = cur[XA(pb)];
                     // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
                     const float2 vm = cur[XA(pb - 1)], vp = cur[XA(pb + 1)];
@@ -653,9 +737,10 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                 nk += __popcll(bal);
             }
             }
-            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = (long long)orow; Ltot[ng] = tot; }
+            if (lane == 0) { Lcnt[ng] = nk; Lfrm[ng] = (int)(gq - 1); Lorow[ng] = (long long)orow; Ltot[ng] = tot; if constexpr (DENSE) Lsoff[ng] = (int)(st / ST_NST); }
             ng++;
             pend_nk = nk;
+            if constexpr (DENSE) st += ST_NST * (unsigned)nk;
             st = (st & ~(ST_PREV0 | ST_OWN)) | ST_PEND | (g == prev0_g ? ST_PREV0 : 0u) | (own ? ST_OWN : 0u);
         }
         if (g == spec_g) {
@@ -690,7 +775,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             late = true; f1 = ng - 1;
         } else
         for (int e = lane; e < pend_nk; e += 64) {
-            const int sl = (ng - 1) * kpad + e;
+            const int sl = (DENSE ? (int)(st / ST_NST) - pend_nk : (ng - 1) * kpad) + e;
             unsigned long long v;
             asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(stp + Lsbin[sl]) : "memory");
             Lsval[(size_t)sl * 5 + 2] = __uint_as_float((unsigned)v);
@@ -711,7 +796,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
     }
 }
 
-template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipStream_t s, size_t* stash_need = nullptr) {
+template <int R, int NW, bool DENSE = false> int launch_rev(const FusedParams& p, int x_dtype, hipStream_t s, size_t* stash_need = nullptr) {
     using RG = RevGeo<R>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -719,14 +804,15 @@ template <int R, int NW> int launch_rev(const FusedParams& p, int x_dtype, hipSt
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     if (p.total_rows >= 0x7fffff00LL) { pvx_set_error("the fused kernel indexes rows in 32 bits (%lld rows)", (long long)p.total_rows); return PVX_ERR_UNSUPPORTED; }
-    const size_t lds = RG::total(p.K, NW);
+    const size_t lds = RG::total(p.K, NW, DENSE);
     if (lds > 160 * 1024) { pvx_set_error("nfft=%d npks=%d needs %zu bytes of LDS in the fused kernel", Geo<R>::N, p.K, lds); return PVX_ERR_UNSUPPORTED; }
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     const int H = (p.hop == 32 * R) ? R / 4 : (p.hop == 64 * R) ? R / 2 : 0;
     const void* fn = nullptr;
-#define PVX_REV_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_rev<R, NW, INT, AL, R / 4> : H ? (const void*)k_fused_rev<R, NW, INT, AL, R / 2> : (const void*)k_fused_rev<R, NW, INT, AL, 0>)
+#define PVX_REV_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_rev<R, NW, INT, AL, R / 4, DENSE> : H ? (const void*)k_fused_rev<R, NW, INT, AL, R / 2, DENSE> : (const void*)k_fused_rev<R, NW, INT, AL, 0, DENSE>)
     switch (x_dtype) {
-        case PVX_F32: fn = al2 ? PVX_REV_PICK(float, true) : PVX_REV_PICK(float, false); break;
+        // (the dense staging's instantiations do without the 8-byte sample loads: a row's new samples are a quarter of its loads)
+        case PVX_F32: if constexpr (DENSE) { fn = PVX_REV_PICK(float, false); } else { fn = al2 ? PVX_REV_PICK(float, true) : PVX_REV_PICK(float, false); } break;
         case PVX_I16: fn = PVX_REV_PICK(int16_t, false); break;
         default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
@@ -767,15 +853,25 @@ size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft) {
     if (launch_fused_rev(p, nfft, PVX_F32, nullptr, &need) != PVX_OK) return 0;
     return need;
 }
-static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need) {
-    if (stash_need) *stash_need = 0;
-    if (p.total_rows <= 0) return PVX_OK;
-    switch (nfft) {
-        // three waves per SIMD when the waves' buffers fit (npks up to ~90), else two
-        case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s, stash_need) : launch_rev<16, 8>(p, x_dtype, s, stash_need);
 #ifndef PVX_REV_NW1024
 #define PVX_REV_NW1024 12
 #endif
+static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need) {
+    if (stash_need) *stash_need = 0;
+    if (p.total_rows <= 0) return PVX_OK;
+    // 8 < npks <= 32: the kept peaks staged densely (see the kernel's DENSE); PVX_REV_NO_DENSE=1: the strided staging (A/B, tests)
+    const bool dense = p.K > 8 && p.K <= 32 && getenv("PVX_REV_NO_DENSE") == nullptr;
+    if (dense) {
+        switch (nfft) {
+            case 2048: if (getenv("PVX_REV_NW8") == nullptr) return launch_rev<16, 12, true>(p, x_dtype, s, stash_need); break;
+            case 1024: return launch_rev<8, PVX_REV_NW1024, true>(p, x_dtype, s, stash_need);
+            case 512: return launch_rev<4, 12, true>(p, x_dtype, s, stash_need);
+            default: break;
+        }
+    }
+    switch (nfft) {
+        // three waves per SIMD when the waves' buffers fit (npks up to ~90), else two
+        case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s, stash_need) : launch_rev<16, 8>(p, x_dtype, s, stash_need);
         case 1024: return launch_rev<8, PVX_REV_NW1024>(p, x_dtype, s, stash_need);
         case 512: return launch_rev<4, 12>(p, x_dtype, s, stash_need);
         default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;

@@ -650,6 +650,70 @@ def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monke
                 assert np.array_equal(np.asarray(getattr(res[0], k)), np.asarray(getattr(res[i], k))), (ns, variants[i], k)
 
 
+@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monkeypatch, nfft):
+    """k_fused_rev at 8 < npks <= 32 stages a frame's kept peaks behind the previous frame's (the per-peak pass then runs once per
+    up to eight frames instead of once per 64 / pow2(npks)); PVX_REV_NO_DENSE=1 runs the strided staging of the other npks.  Same
+    arithmetic on the same peaks: every output bit for bit -- dense and sparse frames, silence (frames that stage nothing), exact
+    ties, every npks of the range and its neighbours, hops with and without the sliding window, grids down to one row per wave,
+    several signals per call; and against the oracle."""
+    rng = np.random.default_rng(905)
+    sr = 44100.0
+    n = 60000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    quant = np.round(harm * 50) / 50
+    rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 31)) + 1e-4 * rng.standard_normal(n)     # ~30 partials: frames that fill npks
+
+    def pair(make):
+        a = make()
+        monkeypatch.setenv("PVX_REV_NO_DENSE", "1")
+        b = make()
+        monkeypatch.delenv("PVX_REV_NO_DENSE")
+        return a, b
+
+    def same(a, b, what):
+        for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (what, k)
+
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant), ("rich", rich)):
+        x = x.astype(np.float32)
+        for K, thr, hop, nb in ((20, 0.005, nfft // 4, None), (9, 0.005, nfft // 2, None), (32, 0.0005, nfft // 4, "3"), (12, 0.3, 333 * nfft // 2048, None),
+                                (17, 0.0, nfft // 4, "1000"), (24, 0.005, nfft // 8, None), (31, 0.005, nfft - 1, "1")):
+            if nb:
+                monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
+            a, b = pair(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
+            if nb:
+                monkeypatch.delenv("PVX_FUSED_BLOCKS")
+            assert _lib_mode(a) == 4
+            same(a, b, (name, K, thr, hop, nb))
+        o = oracle.analyze(x.astype(np.float64), sr, nfft, nfft // 4, 20)
+        c = compare_analysis(pv_result(run_pv(amd, x, sr, nfft, nfft // 4, 20, precision=32)), o, nfft, nfft // 4, sr)
+        if name == "gaps":
+            assert c["bad_peaks"] <= max(40, 0.06 * c["ref_peaks"]), c
+        else:
+            assert_f32(c, absolute=False)
+    # npks just outside the range take the strided staging either way
+    for K in (8, 33):
+        a, b = pair(lambda: run_pv(amd, harm.astype(np.float32), sr, nfft, nfft // 4, K, precision=32))
+        same(a, b, ("outside", K))
+    # several signals per call, down to one frame per signal; int16 samples
+    for ns in (nfft + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 30):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[n // 7 - 1000:n // 7 - 1000 + ns], rich[:ns]]).astype(np.float32)
+        a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=32).run_pv())
+        for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
+    a, b = pair(lambda: run_pv(amd, np.round(rich * 20000).astype(np.int16), sr, nfft, nfft // 4, 20, precision=32))
+    same(a, b, "int16")
+
+
+def _lib_mode(p):
+    from pypevoc_amd import _lib
+    return _lib.load().pvx_plan_get_fft_mode(p._plan.handle)
+
+
 @pytest.mark.parametrize("nfft,kmode", [(2048, 3), (1024, 3), (512, 3), (1024, 4), (512, 4)])
 def test_ring_kernel_is_bit_identical_to_wave_kernel(amd, monkeypatch, witness, nfft, kmode):
     """fft mode 3 (k_fused_ring.hip: eight waves of a workgroup walk eight consecutive frames over a shared ring
