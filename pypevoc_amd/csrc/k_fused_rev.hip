@@ -51,7 +51,7 @@ template <int R> struct RevGeo {
     static constexpr size_t OFF_WIN = OFF_TW3 + (size_t)TW3N * 8;    // X4: v2f [R][64] the window, lane-ordered | else: none (registers)
     static constexpr size_t OFF_FLAG = OFF_WIN + (X4 ? (size_t)R * 64 * 8 : 0);     // int [16]: wave w has left its first spectrum in the stash
     static constexpr size_t OFF_WAVE = OFF_FLAG + 64;
-    // dense: the kept peaks of up to GFR frames staged back to back in kDense slots (8 < npks <= 32, see the kernel's DENSE)
+    // dense: the kept peaks of up to GFR frames staged back to back in kDense slots (8 < npks <= 24, see the kernel's DENSE)
     __host__ __device__ static size_t per_wave(int K, bool dense = false) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFR);
@@ -69,7 +69,7 @@ template <int R> struct RevGeo {
     __host__ __device__ static size_t total(int K, int nw, bool dense = false) { return OFF_WAVE + per_wave(K, dense) * nw; }
 };
 
-// DENSE (8 < npks <= 32; the reference's default npks is 20): the per-peak pass (flush) costs what half a frame costs whether 8 or
+// DENSE (8 < npks <= 24; the reference's default npks is 20): the per-peak pass (flush) costs what half a frame costs whether 8 or
 // 64 of its lanes hold a peak, and with a frame's peaks staged at a stride of npks it ran once per 64 / pow2(npks) frames --
 // every second frame at npks 20, on signals whose frames keep 8 peaks.  Dense: a frame's kept peaks are staged behind the
 // previous frame's, the pass runs when the next frame might not fit (staged + npks > 64) or GFR frames wait: once per 6 frames
@@ -859,8 +859,9 @@ size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft) {
 static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need) {
     if (stash_need) *stash_need = 0;
     if (p.total_rows <= 0) return PVX_OK;
-    // 8 < npks <= 32: the kept peaks staged densely (see the kernel's DENSE); PVX_REV_NO_DENSE=1: the strided staging (A/B, tests)
-    const bool dense = p.K > 8 && p.K <= 32 && getenv("PVX_REV_NO_DENSE") == nullptr;
+    // 8 < npks <= 24: the kept peaks staged densely (see the kernel's DENSE; from 25 on two full frames are all that fit either way, and the
+    // dense pass is the dearer one: -3 % on a recording at npks 32); PVX_REV_NO_DENSE=1: the strided staging (A/B, tests)
+    const bool dense = p.K > 8 && p.K <= 24 && getenv("PVX_REV_NO_DENSE") == nullptr;
     if (dense) {
         switch (nfft) {
             case 2048: if (getenv("PVX_REV_NW8") == nullptr) return launch_rev<16, 12, true>(p, x_dtype, s, stash_need); break;

@@ -652,7 +652,7 @@ def test_rev_kernel_wave_handover_and_occupancy_do_not_change_results(amd, monke
 
 @pytest.mark.parametrize("nfft", [2048, 1024, 512])
 def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monkeypatch, nfft):
-    """k_fused_rev at 8 < npks <= 32 stages a frame's kept peaks behind the previous frame's (the per-peak pass then runs once per
+    """k_fused_rev at 8 < npks <= 24 stages a frame's kept peaks behind the previous frame's (the per-peak pass then runs once per
     up to eight frames instead of once per 64 / pow2(npks)); PVX_REV_NO_DENSE=1 runs the strided staging of the other npks.  Same
     arithmetic on the same peaks: every output bit for bit -- dense and sparse frames, silence (frames that stage nothing), exact
     ties, every npks of the range and its neighbours, hops with and without the sliding window, grids down to one row per wave,
@@ -680,8 +680,8 @@ def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monke
 
     for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("quant", quant), ("rich", rich)):
         x = x.astype(np.float32)
-        for K, thr, hop, nb in ((20, 0.005, nfft // 4, None), (9, 0.005, nfft // 2, None), (32, 0.0005, nfft // 4, "3"), (12, 0.3, 333 * nfft // 2048, None),
-                                (17, 0.0, nfft // 4, "1000"), (24, 0.005, nfft // 8, None), (31, 0.005, nfft - 1, "1")):
+        for K, thr, hop, nb in ((20, 0.005, nfft // 4, None), (9, 0.005, nfft // 2, None), (24, 0.0005, nfft // 4, "3"), (12, 0.3, 333 * nfft // 2048, None),
+                                (17, 0.0, nfft // 4, "1000"), (22, 0.005, nfft // 8, None), (23, 0.005, nfft - 1, "1")):
             if nb:
                 monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
             a, b = pair(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
@@ -696,7 +696,7 @@ def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monke
         else:
             assert_f32(c, absolute=False)
     # npks just outside the range take the strided staging either way
-    for K in (8, 33):
+    for K in (8, 25):
         a, b = pair(lambda: run_pv(amd, harm.astype(np.float32), sr, nfft, nfft // 4, K, precision=32))
         same(a, b, ("outside", K))
     # several signals per call, down to one frame per signal; int16 samples
