@@ -100,7 +100,7 @@ __device__ __forceinline__ float ldw(const float* q) { return __hip_atomic_load(
 // register pairs (sample 2l + 128 r + hop = 2l + 128 (r + H)): only the last H pairs are loaded -- hop*4 bytes per
 // frame from HBM instead of nfft*4 (a wave walks its rows alone: by the time it comes back for the next frame the
 // spectrum rows streaming through L2 have evicted the samples it shared with this one).
-template <int R, typename T, typename InT, int H, bool SYM = false>
+template <int R, typename T, typename InT, int H, bool SYM = false, bool DENSE = false>
 __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
     using G = PvGeo<R, T, SYM>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH;
@@ -211,6 +211,92 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
         // occupy -- and spill -- registers across the transform)
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        if constexpr (DENSE) {
+            // ---- DENSE: 8 < npks <= 32 at float64 (a separate instantiation: the others are the code they were) (the reference's default is 20): the staged frames' peaks taken 64 at a time ACROSS the frames instead of
+            // 64 / pow2(npks) frames at a time -- at npks 20 a pass per two frames, on signals whose frames keep 8 peaks.  A pass of
+            // this arithmetic (two float64 arctangents per peak) costs what it costs whether 16 or 64 of its lanes hold a peak.
+            // Same peaks, same arithmetic, same places: bit-identical to the loop below (PVX_PV_NO_DENSE=1, GPU test).
+            static_assert(GF == 8, "two 16-byte reads of the counts");
+            const int4 ca = *(const int4*)cntv, cb = *((const int4*)cntv + 1);
+            int cnts[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w}, offs[8], nprev[8];
+            int total = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { cnts[j] = j < ng ? cnts[j] : 0; offs[j] = total; total += cnts[j]; nprev[j] = 0; }     // (a staged frame's count is >= 0: zero rows stage nothing)
+            for (int i0 = 0; i0 < total; i0 += 64) {
+                const int i = i0 + ln;
+                bool valid = i < total;
+                int g = 0, off = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { if (cnts[j] > 0 && offs[j] <= i) { g = j; off = offs[j]; } }
+                const int e = i - off;
+                const int64_t rel = (int64_t)relv[g];
+                const int64_t gr = p.R0 + rel;
+                const int64_t b = gr / rows1;
+                const int64_t fr = gr - b * rows1 - 1;
+                const int64_t orow = b * p.F + fr;
+                const T* cur = (const T*)p.spec + (size_t)(rel + 1) * p.ldo * 2;
+                const T* prv = (const T*)p.spec + (size_t)rel * p.ldo * 2;
+                const bool use_prev0 = (pk.prev0 != nullptr) && (orow == 0);
+                int nbin = 0;
+                double freq = 0.0, dfb = 0.0, thisph = 0.0, mg = 0.0;
+                if (valid) {
+                    nbin = lst[g * kpad + e];
+                    const T re = ldw(cur + 2 * nbin), im = ldw(cur + 2 * nbin + 1);
+                    T pr, pi;
+                    if (use_prev0) { pr = (T)pk.prev0[2 * nbin]; pi = (T)pk.prev0[2 * nbin + 1]; }
+                    else { pr = ldw(prv + 2 * nbin); pi = ldw(prv + 2 * nbin + 1); }
+                    const int imin = nbin - 1 > 1 ? nbin - 1 : 1;     // PV.py:197-199: 3-bin energy, bin 0 excluded
+                    int imax = nbin + 1 < M ? nbin + 1 : M;
+                    if (imax > M - 1) imax = M - 1;
+                    T s3 = (T)0;
+                    for (int j = imin; j <= imax; j++) { const T ar = ldw(cur + 2 * j), c = ldw(cur + 2 * j + 1); s3 = s3 + (ar * ar + c * c); }
+                    const PeakOut o = peak_math<T>(nbin, re, im, pr, pi, s3, pc);
+                    freq = o.freq; dfb = o.dfb; thisph = o.thisph; mg = o.mag;
+                    valid = o.valid;
+                }
+                const unsigned long long ball = __ballot(valid);
+                // the lanes of this pass that hold frame j's peaks: [max(offs[j], i0), min(offs[j] + cnts[j], i0 + 64)) - i0
+                unsigned long long gm = 0ull;
+                int before = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    int lo = offs[j] - i0, hi = offs[j] + cnts[j] - i0;
+                    lo = lo < 0 ? 0 : lo; hi = hi > 64 ? 64 : hi;
+                    const unsigned long long mj = hi > lo ? ((hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo) : 0ull;
+                    if (j == g) { gm = mj; before = nprev[j]; }
+                    nprev[j] += __popcll(ball & mj);
+                }
+                if (valid) {
+                    const int o = before + __popcll(ball & gm & ((1ull << ln) - 1ull));
+                    pk.binno[orow * K + o] = (double)nbin;
+                    pk.f[orow * K + o] = freq;
+                    pk.mag[orow * K + o] = mg;
+                    pk.ph[orow * K + o] = thisph;
+                    pk.realph[orow * K + o] = thisph + kPi * dfb / pk.fstep;     // PV.py:207
+                }
+            }
+            {
+                // zero padding (PV.py:226-239) and the frames' scalars: eight lanes per staged frame
+                const int g2 = ln >> 3, c2 = ln & 7;
+                int n2 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { if (j == g2) n2 = nprev[j]; }
+                if (g2 < ng) {
+                    const int64_t rel = (int64_t)relv[g2];
+                    const int64_t gr = p.R0 + rel;
+                    const int64_t b = gr / rows1;
+                    const int64_t fr = gr - b * rows1 - 1;
+                    const int64_t orow = b * p.F + fr;
+                    for (int j = n2 + c2; j < K; j += 8) { pk.binno[orow * K + j] = 0.0; pk.f[orow * K + j] = 0.0; pk.mag[orow * K + j] = 0.0; pk.ph[orow * K + j] = 0.0; pk.realph[orow * K + j] = 0.0; }
+                    if (c2 == 0) {
+                        if (pk.totalmag) pk.totalmag[orow] = sqrt(totv[g2]);                                  // PV.py:210
+                        if (pk.t) pk.t[orow] = ((double)(fr * (int64_t)pk.hop) + pk.nfft / 2.0) / pk.sr;     // PV.py:247
+                    }
+                }
+            }
+            wave_sync();
+            return;
+        }
         const int gl = ln / LPF, e0 = ln - gl * LPF;
         const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
         for (int gb = 0; gb < ng; gb += fpp) {
@@ -498,7 +584,7 @@ template <int R, typename T> size_t pv_lds(int nw, int K, bool sym) {
     return pv_total_lds<R, T>(nw, K);
 }
 
-template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_dtype, hipStream_t s) {
+template <int R, typename T, bool DENSE> int launch_stft_pv_rd(const StftPvParams& a, int x_dtype, hipStream_t s) {
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -519,27 +605,27 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     const int H = (a.s.hop == 32 * R) ? R / 4 : (a.s.hop == 64 * R) ? R / 2 : 0;
     const void* fn = nullptr;
     switch (x_dtype) {
-        case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4> : H ? (const void*)k_stft_pv<R, T, float, R / 2> : (const void*)k_stft_pv<R, T, float, 0>; break;
+        case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4, false, DENSE> : H ? (const void*)k_stft_pv<R, T, float, R / 2, false, DENSE> : (const void*)k_stft_pv<R, T, float, 0, false, DENSE>; break;
         case PVX_F64:
             if constexpr (sizeof(T) == 8 && R == 16) {
                 // float64 samples into the float64 transform at nfft 2048 with a hop that does not slide the window: the whole
                 // next row would wait in 64 registers beside the transform -- pvx_stft_pv_takes() sends that plan through
                 // k_stft + k_phase_peaks instead
                 if (H == 0) { pvx_set_error("k_stft_pv does not take float64 samples at nfft 2048 with hop %d", a.s.hop); return PVX_ERR_UNSUPPORTED; }
-                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : (const void*)k_stft_pv<R, T, double, R / 2>;
+                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4, false, DENSE> : (const void*)k_stft_pv<R, T, double, R / 2, false, DENSE>;
             } else {
-                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4> : H ? (const void*)k_stft_pv<R, T, double, R / 2> : (const void*)k_stft_pv<R, T, double, 0>;
+                fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4, false, DENSE> : H ? (const void*)k_stft_pv<R, T, double, R / 2, false, DENSE> : (const void*)k_stft_pv<R, T, double, 0, false, DENSE>;
             }
             break;
-        case PVX_I16: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4> : H ? (const void*)k_stft_pv<R, T, int16_t, R / 2> : (const void*)k_stft_pv<R, T, int16_t, 0>; break;
+        case PVX_I16: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4, false, DENSE> : H ? (const void*)k_stft_pv<R, T, int16_t, R / 2, false, DENSE> : (const void*)k_stft_pv<R, T, int16_t, 0, false, DENSE>; break;
         default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
     }
     if constexpr (sizeof(T) == 8 && R == 16) {
         if (sym && H > 0) {
             switch (x_dtype) {
-                case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4, true> : (const void*)k_stft_pv<R, T, float, R / 2, true>; break;
-                case PVX_F64: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4, true> : (const void*)k_stft_pv<R, T, double, R / 2, true>; break;
-                default: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4, true> : (const void*)k_stft_pv<R, T, int16_t, R / 2, true>; break;
+                case PVX_F32: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, float, R / 4, true, DENSE> : (const void*)k_stft_pv<R, T, float, R / 2, true, DENSE>; break;
+                case PVX_F64: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, double, R / 4, true, DENSE> : (const void*)k_stft_pv<R, T, double, R / 2, true, DENSE>; break;
+                default: fn = H == R / 4 ? (const void*)k_stft_pv<R, T, int16_t, R / 4, true, DENSE> : (const void*)k_stft_pv<R, T, int16_t, R / 2, true, DENSE>; break;
             }
         }
     }
@@ -558,6 +644,15 @@ template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_d
     PVX_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, s));
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;
+}
+
+// float64 at 8 < npks <= 32: the instantiation whose per-peak pass runs across the staged frames (the kernel's DENSE); PVX_PV_NO_DENSE=1:
+// the other one (A/B, tests)
+template <int R, typename T> int launch_stft_pv_r(const StftPvParams& a, int x_dtype, hipStream_t s) {
+    if constexpr (sizeof(T) == 8) {
+        if (a.p.K > 8 && a.p.K <= 32 && getenv("PVX_PV_NO_DENSE") == nullptr) return launch_stft_pv_rd<R, T, true>(a, x_dtype, s);
+    }
+    return launch_stft_pv_rd<R, T, false>(a, x_dtype, s);
 }
 
 template <int R, typename T> bool pv_fits(int K) {

@@ -709,6 +709,46 @@ def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monke
     same(a, b, "int16")
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+def test_general_kernel_dense_peak_pass_is_bit_identical(amd, oracle, monkeypatch, nfft, precision):
+    """k_stft_pv at 8 < npks <= 32 runs its per-peak pass over the staged frames' peaks 64 at a time across the frames (a frame's peaks
+    may straddle two passes); PVX_PV_NO_DENSE=1 runs it frame group by frame group as at the other npks.  Every output bit for bit, and
+    float64 against the oracle strictly."""
+    rng = np.random.default_rng(906)
+    sr = 44100.0
+    n = 50000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 31)) + 1e-4 * rng.standard_normal(n)
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+
+    def pair(make):
+        a = make()
+        monkeypatch.setenv("PVX_PV_NO_DENSE", "1")
+        b = make()
+        monkeypatch.delenv("PVX_PV_NO_DENSE")
+        return a, b
+
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("rich", rich)):
+        for K, thr, hop in ((20, 0.005, nfft // 4), (9, 0.005, nfft // 2), (32, 0.0005, nfft // 4), (12, 0.3, 333 * nfft // 2048), (17, 0.0, nfft // 4), (27, 0.005, nfft // 4)):
+            if precision == 64 and nfft == 2048 and hop not in (nfft // 4, nfft // 2):
+                continue                                             # (float64 samples at nfft 2048: the one-launch kernel takes the sliding-window hops)
+            a, b = pair(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=precision))
+            assert _lib_mode(a) == 0
+            for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+                assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (name, K, thr, hop, k)
+        if precision == 64:
+            o = oracle.analyze(x, sr, nfft, nfft // 4, 20)
+            assert_f64(compare_analysis(pv_result(run_pv(amd, x, sr, nfft, nfft // 4, 20, precision=64)), o, nfft, nfft // 4, sr))
+    xb = np.stack([noise[:nfft * 6], harm[:nfft * 6], gaps[n // 7 - 1000:n // 7 - 1000 + nfft * 6], rich[:nfft * 6]])
+    a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=precision).run_pv())
+    for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+        assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), k
+
+
 def _lib_mode(p):
     from pypevoc_amd import _lib
     return _lib.load().pvx_plan_get_fft_mode(p._plan.handle)
