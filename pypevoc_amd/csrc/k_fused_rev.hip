@@ -621,12 +621,12 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             int nk = 0;
             // candidate list (ascending bins) -> Lci
             int C;
-            if constexpr (X4) C = peak_scan_x4_thin<u16>(cur, p.thr, maxe, mine, tot, th, Lci, G::CAP, lane, K);
+            if constexpr (X4) C = peak_scan_x4_thin<u16, (DENSE ? 24 : 16)>(cur, p.thr, maxe, mine, tot, th, Lci, G::CAP, lane, K);
             else {
                 const float maxy = __builtin_amdgcn_sqrtf(maxe);
                 const double minamp = (double)maxy * p.thr;         // PF.py:60
                 th = (minamp != 0.0) ? minamp * minamp - (double)mine : 0.0;
-                C = peak_scan_block_thin<R, u16>(Ly, mine, th, Lci, G::CAP, lane, K);
+                C = peak_scan_block_thin<R, u16, (DENSE ? 24 : 16)>(Ly, mine, th, Lci, G::CAP, lane, K);
             }
             wave_sync();
             __builtin_amdgcn_s_setprio(PVX_PRIO_C);

@@ -67,7 +67,7 @@ struct YofX4 {
 // quarter (four consecutive bins hold at most two maxima).
 // It is also where the row's maximum, minimum and energy are taken (maxe, miny, tot: every |X|^2 passes through here, the
 // join forms none) and the threshold th they set (PF.py:60, 69-70; thr = PeakFinder's minrattomax).
-template <typename CI>
+template <typename CI, int MAXK = 16>
 __device__ __forceinline__ int peak_scan_x4_thin(const float2* X, double thr, float& maxe, float& miny, double& tot, double& th,
                                                  CI* ci, int trash, int lane, int npeaks) {
     float v[16];                                                     // v[4 j + i] = |X[256 j + 4 lane + i]|^2
@@ -147,11 +147,11 @@ __device__ __forceinline__ int peak_scan_x4_thin(const float2* X, double thr, fl
         return C;
     };
     int C = count(m);
-    if (C > PVX_THIN_FROM && npeaks <= 16) {                                   // wave-uniform; see peak_scan_block_thin
+    if (C > PVX_THIN_FROM && npeaks <= MAXK) {                                 // wave-uniform; see peak_scan_block_thin
         float best = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
-        const float T = pvxw::thin_bound(best, npeaks);
+        const float T = pvxw::thin_bound<MAXK>(best, npeaks);
         unsigned keep = 0u;
 #pragma unroll
         for (int i = 15; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);

@@ -498,16 +498,26 @@ __device__ __forceinline__ int peak_scan_block(const float* y, float miny, doubl
 // (Tried: the exact npeaks-th largest of the 64 lane bests -- one more broadcast per lane at or above T -- and thinning
 // from 64 candidates on: both slower on a violin recording and on noise; a broadcast costs what ten candidates cost the
 // radix select.)
+// MAXK > 16 (k_fused_rev's instantiations for 8 < npks <= 24: the reference's default npks is 20): for 16 < npeaks <= MAXK the same
+// bound from the 32 PAIRS of lanes -- 32 different candidates, twice the broadcasts; white noise at npks 20 keeps ~50 of 280
+// candidates (+18 %; a recording 0 .. +5 %; at npks 32 the bound keeps too many to repay itself, and in the npks <= 8 kernels the
+// longer loop body costs 1 %: hence a template parameter, 16 everywhere else).
+template <int MAXK = 16>
 __device__ __forceinline__ float thin_bound(float best, int npeaks) {
-    float qb = fmaxf(best, dpp_f<0xB1>(best));
-    qb = fmaxf(qb, dpp_f<0x4E>(qb));                                 // every lane: its quad's best
-    int beaten = 0;                                                  // quads whose best beats this one's
+    float qb = fmaxf(best, dpp_f<0xB1>(best));                       // every lane: its pair's best
+    int beaten = 0;                                                  // groups whose best beats this one's
+    if (MAXK <= 16 || npeaks <= 16) {
+        qb = fmaxf(qb, dpp_f<0x4E>(qb));                             // every lane: its quad's best
 #pragma unroll
-    for (int j = 0; j < 16; j++) beaten += (rl_f(qb, 4 * j) > qb) ? 1 : 0;
+        for (int j = 0; j < 16; j++) beaten += (rl_f(qb, 4 * j) > qb) ? 1 : 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; j++) beaten += (rl_f(qb, 2 * j) > qb) ? 1 : 0;
+    }
     return wave_min(beaten < npeaks ? qb : INFINITY);
 }
 
-template <int R, typename CI>
+template <int R, typename CI, int MAXK = 16>
 __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, double th, CI* ci, int trash, int lane, int npeaks) {
     static_assert(R % 4 == 0 && R <= 16, "block scan handles 4, 8 or 16 bins per lane");
     constexpr int n = 64 * R;
@@ -557,11 +567,11 @@ __device__ __forceinline__ int peak_scan_block_thin(const float* y, float miny, 
     // two keys per lane is as cheap as this plus the ranking pass over the survivors.  While that pass broadcast its keys by
     // v_readlane the break-even was near 200 -- a violin recording's frames, ~120 candidates, ran 8 % slower thinned; with
     // the keys read from LDS they run 2 % faster at nfft 2048 / 4096, white noise at nfft 1024, ~140 candidates, 14 %)
-    if (C > PVX_THIN_FROM && npeaks <= 16) {                                   // wave-uniform
+    if (C > PVX_THIN_FROM && npeaks <= MAXK) {                                   // wave-uniform
         float best = 0.f;                                            // this lane's best candidate score (0: it has none)
 #pragma unroll
         for (int i = 0; i < R; i++) best = fmaxf(best, ((m >> i) & 1u) ? sc[i] : 0.f);
-        const float T = thin_bound(best, npeaks);
+        const float T = thin_bound<MAXK>(best, npeaks);
         unsigned keep = 0u;
 #pragma unroll
         for (int i = R - 1; i >= 0; i--) keep = (keep << 1) | (sc[i] >= T ? 1u : 0u);
