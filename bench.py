@@ -268,6 +268,8 @@ def compact_line(full, detail_path):
     if full.get("workloads"):
         out["noise_value"] = g(full, "workloads", "white_noise", "value")
         out["violin_value"] = g(full, "workloads", "violin_g7_tiled", "value")
+        out["defaults_f32_value"] = g(full, "workloads", "reference_defaults", "f32", "value")
+        out["defaults_f64_value"] = g(full, "workloads", "reference_defaults", "f64", "value")
     if full.get("other_nfft"):
         out["nfft4096_value"] = g(full, "other_nfft", "4096", "value")
         out["nfft8192_value"] = g(full, "other_nfft", "8192", "value")
@@ -676,7 +678,7 @@ def main():
             self_check = check_block(np.concatenate([h[: 5 * FT * K + FT], h[nres - FT:]]), o, FT, K, NFFT, HOP, args.precision, "headline")
             cpu = cpu_baseline(x_host, sr, o, dtc)
 
-        def quick(pl, xin, steps, nfft=NFFT, hop=HOP, ramp=True):
+        def quick(pl, xin, steps, nfft=NFFT, hop=HOP, ramp=True, K=K):
             """frames/s of `steps` passes over a [1, n] device signal on `pl` (events on the launch stream); returns the
             frame count, ms per pass and the result block of the last pass."""
             n = int(xin.numel())
@@ -704,7 +706,7 @@ def main():
             msq = a0.elapsed_time(a1) / steps
             return Fq, msq, out
 
-        def host_block(out, Fq):
+        def host_block(out, Fq, K=K):
             """quick()'s result block on the host in check_block's order: the five arrays, totalmag, t."""
             h = out.cpu().numpy()
             return np.concatenate([h[: 5 * Fq * K], h[5 * Fq * K + Fq:], h[5 * Fq * K: 5 * Fq * K + Fq]])
@@ -776,6 +778,23 @@ def main():
                                                     peaks_per_frame=round(int((outv[: Fv * K] > 0).sum().item()) / Fv, 2),
                                                     data="tests/golden/G7_perlman.npz (examples/perlmanVn.wav) tiled to 26.46 M samples",
                                                     self_check=(check_block(host_block(outv, Fv), ov, Fv, K, NFFT, HOP, 32, "violin", well_conditioned=False) if checks else None))
+            # ---- the reference's own defaults on the same material: PV(x, sr) is nfft 1024, hop nfft/2, npks 20 (PV.py:72-73), float64
+            # arithmetic for a float64 array -- both precisions, the harmonic signal (against the oracle) and the recording
+            KD, ND, HD = 20, 1024, 512
+            od = pvoracle.analyze(xs, sr, ND, HD, KD) if checks else None
+            ref_defaults = dict(config="PV(x, sr): nfft %d, hop %d, npks %d" % (ND, HD, KD))
+            for prec_d in (32, 64):
+                pd = ctypes.c_void_p()
+                _lib.check(lib.pvx_plan_create(ctypes.byref(pd), float(sr), ND, HD, KD, 0.005, _lib.dptr(np.hanning(ND)), prec_d, 0), "pvx_plan_create")
+                Fd, msd, outd = quick(pd, x, 10, nfft=ND, hop=HD, K=KD)
+                blk = dict(value=round(Fd / msd * 1e3, 1), unit="frames/s", ms_per_step=round(msd, 4), frames=Fd, fft_mode=int(lib.pvx_plan_get_fft_mode(pd)),
+                           self_check=(check_block(host_block(outd, Fd, KD), od, Fd, KD, ND, HD, prec_d, "defaults f%d" % prec_d) if checks else None))
+                if xv is not None:
+                    Fdv, msdv, _ = quick(pd, xv, 5, nfft=ND, hop=HD, K=KD)
+                    blk["violin_g7_tiled"] = dict(value=round(Fdv / msdv * 1e3, 1), unit="frames/s", ms_per_step=round(msdv, 4))
+                ref_defaults["f%d" % prec_d] = blk
+                lib.pvx_plan_destroy(pd)
+            workloads["reference_defaults"] = ref_defaults
             # ---- the larger transforms of BASELINE config 5 on the same signal (hop = nfft/4): k_fused_team.hip
             other_nfft = {}
             for nf in (4096, 8192):

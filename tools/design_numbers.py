@@ -60,6 +60,12 @@ if b:
                   M(f["white_noise"]["value"]), (f["white_noise"].get("self_check") or {}).get("ok"), f["roofline"]["frac"], f["roofline"]["stage_alg_bytes_per_frame"],
                   ("%.0f MB per launch" % (f["roofline"]["traffic"] / 1e6)) if f["roofline"].get("traffic") else "not quoted"))
     for name, w in (b.get("workloads") or {}).items():
+        if name == "reference_defaults":
+            a32, a64 = w.get("f32") or {}, w.get("f64") or {}
+            L.append("| `workloads.reference_defaults` (%s) | f32 %s, f64 %s | the recording: %s / %s; self-checks ok = %s / %s (\\|Δf\\| ≤ %.1e / %.1e Hz) |" %
+                     (w.get("config"), M(a32.get("value", 0)), M(a64.get("value", 0)), M((a32.get("violin_g7_tiled") or {}).get("value", 0)), M((a64.get("violin_g7_tiled") or {}).get("value", 0)),
+                      (a32.get("self_check") or {}).get("ok"), (a64.get("self_check") or {}).get("ok"), (a32.get("self_check") or {}).get("f_abs_Hz", 0), (a64.get("self_check") or {}).get("f_abs_Hz", 0)))
+            continue
         s = w.get("self_check") or {}
         sh = (s.get("normalised") or {}).get("share_of_peaks_within_f32_tolerance") or {}
         L.append("| `workloads.%s` | %s | %.2f peaks per frame; check ok = %s: %d of %d frames with another peak set, %.2f %% / %.2f %% of the peaks within the f / realph tolerance |" %
