@@ -506,6 +506,7 @@ template <int R, int S, typename T, bool WIDE> int launch_stft_split_g(const Stf
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu * teams * S > 8) per_cu = 8 / (teams * S) > 0 ? 8 / (teams * S) : 1;
+    { const int nb = pvx_resident_blocks(fn, 64 * teams * S, lds); if (nb >= 1 && nb < per_cu) per_cu = nb; }      // (registers: pvx_internal.h)
     int64_t nblocks = (int64_t)ncu * per_cu;
     const int64_t maxb = (p.ws_rows + teams - 1) / teams;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
@@ -537,6 +538,7 @@ template <int R, typename T> int launch_stft_r(const StftParams& p, int x_dtype,
     int per_cu = (int)((160 * 1024) / lds);                            // workgroups that fit a CU's LDS side by side
     if (per_cu < 1) per_cu = 1;
     if (per_cu * nw > 16) per_cu = 16 / nw > 0 ? 16 / nw : 1;
+    { const int nb = pvx_resident_blocks(fn, 64 * nw, lds); if (nb >= 1 && nb < per_cu) per_cu = nb; }      // (registers: pvx_internal.h)
     int64_t nblocks = (int64_t)ncu * per_cu;
     const int64_t maxb = (p.ws_rows + nw - 1) / nw;
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;

@@ -633,6 +633,7 @@ template <int R, typename T, bool DENSE> int launch_stft_pv_rd(const StftPvParam
     int per_cu = (int)((160 * 1024) / lds);                            // workgroups that fit a CU's LDS side by side
     if (per_cu < 1) per_cu = 1;
     if (per_cu * nw > 16) per_cu = 16 / nw > 0 ? 16 / nw : 1;
+    { const int nb = pvx_resident_blocks(fn, 64 * nw, lds); if (nb >= 1 && nb < per_cu) per_cu = nb; }      // (registers: pvx_internal.h)
     const int64_t nrows = a.s.ws_rows - 1;
     int64_t nblocks = (int64_t)ncu * per_cu;
     if (const char* e = getenv("PVX_STFT_PV_BLOCKS")) { const long long v = atoll(e); if (v >= 1) nblocks = v; }   // tests: other grids

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -285,6 +286,21 @@ extern "C" int pvx_plan_destroy(pvx_plan* plan) {
 }
 
 extern "C" int64_t pvx_plan_workspace_bytes(const pvx_plan* plan) { return plan ? plan->ws_bytes : 0; }
+
+int pvx_resident_blocks(const void* fn, int threads, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void*, int, size_t>, int> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const auto key = std::make_tuple(dev, fn, threads, lds);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(key);
+    if (it != seen.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    seen[key] = nb;
+    return nb;
+}
 
 extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
     if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }

@@ -32,6 +32,13 @@ void pvx_set_error(const char* fmt, ...);
 
 int pvx_require_device();  // PVX_OK or PVX_ERR_NO_DEVICE (sets the message)
 
+// workgroups of `threads` threads and `lds` bytes of dynamic LDS of kernel `fn` that are RESIDENT on a CU together, registers included
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered per (device, kernel, threads, lds)); <= 0: unknown.  The general path's
+// kernels size their grids as CUs x workgroups per CU: a grid sized by LDS alone launches workgroups that wait for a slot and
+// then run by themselves -- nfft 512 at float64 asked for four workgroups of four waves per CU where registers admit three:
+// 450 -> 505 M frames/s with the grid that fits.
+int pvx_resident_blocks(const void* fn, int threads, size_t lds);
+
 // ---- row space ------------------------------------------------------------------------------
 // The analysis works on a global "row space": every signal owns F+1 consecutive rows, row 0 of a
 // signal being an all-zero frame (the reference's initial oldfft = zeros, PV.py:121) and row q > 0
