@@ -61,7 +61,10 @@ def test_bench_extras_are_all_checked_against_the_oracle():
     j = _detail(jc)
     assert j["chain"]["total_ms"] == jc["chain_total_ms"] and j["f64"]["value"] == jc["f64_value"]
     assert j["f64"]["self_check"]["ok"] and j["f64"]["white_noise"]["self_check"]["ok"]
-    assert all(w["self_check"]["ok"] for w in j["workloads"].values())
+    assert all(w["self_check"]["ok"] for k, w in j["workloads"].items() if k != "reference_defaults")
+    rd = j["workloads"]["reference_defaults"]                       # PV(x, sr): nfft 1024, hop 512, npks 20 at both precisions
+    assert rd["f32"]["self_check"]["ok"] and rd["f64"]["self_check"]["ok"] and rd["f32"]["value"] > rd["f64"]["value"] > 0
+    assert jc["defaults_f32_value"] == rd["f32"]["value"] and jc["defaults_f64_value"] == rd["f64"]["value"]
     assert all(w["self_check"]["ok"] for w in j["other_nfft"].values())
     c = j["chain"]
     assert c["tracker"]["check"]["ok"] and c["tracker"]["partials"] > 0 and c["tracker"]["value"] > 0
