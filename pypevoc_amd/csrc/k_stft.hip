@@ -163,8 +163,8 @@ __global__ __launch_bounds__(384) void k_stft(StftParams p) {
             cx<T> x1 = mkc<T>(fmaT((T)0.5, S.x, -Pk.x), -fmaT((T)0.5, S.y, -Pk.y));
             int kk = km;
             if (j2 == 0 && lane == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = G::HALF; }      // bin 0 pairs with itself; its slot takes bin M/2
-            out[k] = x0;
-            out[kk] = x1;
+            row_store(&out[k], x0);
+            row_store(&out[kk], x1);
         }
         wave_sync();                                                  // dz is free again
     }
@@ -392,8 +392,8 @@ __global__ __launch_bounds__((S == 2 && !(sizeof(T) == 8 && sizeof(InT) == 8)) ?
                 cx<T> x1 = mkc<T>(fmaT((T)0.5, Sm.x, -Pk.x), -fmaT((T)0.5, Sm.y, -Pk.y));
                 int kk = km;
                 if (ch == 0 && j2 == 0 && lane == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = M / 2; }      // bin 0 pairs with itself; its slot takes bin M/2
-                out[k] = x0;
-                out[kk] = x1;
+                row_store(&out[k], x0);
+                row_store(&out[kk], x1);
                 if constexpr (CAND) {
                     // |X|^2 of both bins, k_phase_peaks' formula (k_peaks.hip): plain products and one sum
                     ey[2 * j2] = x0.x * x0.x + x0.y * x0.y;

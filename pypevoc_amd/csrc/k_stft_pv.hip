@@ -435,7 +435,7 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
             if constexpr (LATE) { __builtin_amdgcn_sched_barrier(0); prefetch_part(nsrc, 2); prefetch_part(nsrc, 3); __builtin_amdgcn_sched_barrier(0); }
             join4_emit<T>(in, tw3, lu, [&](int k, cx<T> x) {
 #ifndef PVX_AB_NO_ROWSTORE      // tools/ab: timing-only build without the spectrum rows in HBM (the peaks then read stale rows)
-                out[k] = x;
+                row_store(&out[k], x);
 #else
                 if (p.ldo < 0) out[k] = x;
 #endif
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(SYM ? 512 : 448) void k_stft_pv(StftPvParams a) {
             cx<T> x1 = mkc<T>(fmaT((T)0.5, S.x, -Pk.x), -fmaT((T)0.5, S.y, -Pk.y));
             int kk = km;
             if (j2 == 0 && lu == 0) { x1 = mkc<T>(zc.x, -zc.y); kk = G::HALF; }      // bin 0 pairs with itself; its slot takes bin M/2
-            out[k] = x0;
-            out[kk] = x1;
+            row_store(&out[k], x0);
+            row_store(&out[kk], x1);
             if (with_peaks) {
                 // the peak search runs on |X|^2: every test it makes (local maximum, threshold, ranking, salience) is
                 // monotone in |X| (k_peaks.hip); plain products and one sum, the same value whichever kernel computes it

@@ -9,6 +9,20 @@ using namespace pvxw;
 using namespace pvxf;
 
 template <typename T> struct cx { T x, y; };
+
+// A spectrum row's store (k_stft.hip, k_stft_pv.hip): non-temporal.  The rows stream out -- of a row's nfft/2 bins the peak pass reads
+// back the few kept ones, soon, from the L2 it went through -- and as ordinary stores they pushed everything else out of the caches on
+// their way to HBM: float64 at nfft 1024 282 -> 324 M frames/s on the harmonic signal, nfft 2048 168 -> 176 (the recording 146 -> 157),
+// nfft 512 512 -> 534 (profiles/r05_ab_steps.txt; PVX_ROWS_TEMPORAL=1 at build time: the plain store).
+template <typename T> __device__ __forceinline__ void row_store(cx<T>* q, cx<T> v) {
+#ifdef PVX_ROWS_TEMPORAL
+    *q = v;
+#else
+    typedef T v2t __attribute__((ext_vector_type(2)));
+    v2t w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, (v2t*)q);
+#endif
+}
 template <typename T> __device__ __forceinline__ cx<T> mkc(T a, T b) { cx<T> r; r.x = a; r.y = b; return r; }
 template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mkc<T>(a.x + b.x, a.y + b.y); }
 template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mkc<T>(a.x - b.x, a.y - b.y); }
