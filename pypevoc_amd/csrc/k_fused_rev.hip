@@ -38,8 +38,9 @@ constexpr int GFR = 8;              // frames staged before the per-peak pass
 #endif
 
 typedef unsigned short u16;
-// a result's store: non-temporal (written once, read by nobody in the launch: +0.6 % at nfft 2048 for leaving the caches to the samples
-// and the hand-over; -DPVX_RESULTS_TEMPORAL=1: the plain store)
+// a kept peak's results: non-temporal stores (written once, read by nobody in the launch: +1.3 % at nfft 2048 / npks 8 for leaving the caches
+// to the samples and the hand-over; -DPVX_RESULTS_TEMPORAL=1: plain stores).  The zero padding of a row stays with plain stores: scattered
+// 8-byte non-temporal writes cost nfft 1024 at npks 20 (one peak, nineteen zeros per row) 12 %.
 #ifdef PVX_RESULTS_TEMPORAL
 #define PVX_RST(ptr, idx, val) ((ptr)[idx] = (val))
 #else
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                     const int64_t orow2 = (int64_t)Lorow[g2];
                     gdouble* of2 = (gdouble*)q->f + orow2 * K; gdouble* om2 = (gdouble*)q->mag + orow2 * K; gdouble* op2 = (gdouble*)q->ph + orow2 * K;
                     gdouble* orp2 = (gdouble*)q->realph + orow2 * K; gdouble* ob2 = (gdouble*)q->binno + orow2 * K;
-                    for (int j = nout2 + c2; j < K; j += 8) { PVX_RST(ob2, j, 0.0); PVX_RST(of2, j, 0.0); PVX_RST(om2, j, 0.0); PVX_RST(op2, j, 0.0); PVX_RST(orp2, j, 0.0); }
+                    for (int j = nout2 + c2; j < K; j += 8) { ob2[j] = 0.0; of2[j] = 0.0; om2[j] = 0.0; op2[j] = 0.0; orp2[j] = 0.0; }
                     if (c2 == 0) {
                         const int64_t fr = Lfrm[g2];
                         if (q->totalmag) ((gdouble*)q->totalmag)[orow2] = sqrt(Ltot[g2]);                                  // PV.py:210
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         }
         if (cnt >= 0) {
             for (int j = nout + e0; j < K; j += LPF) {                // zero padding, PV.py:226-239
-                PVX_RST(ob, j, 0.0); PVX_RST(of, j, 0.0); PVX_RST(om, j, 0.0); PVX_RST(op, j, 0.0); PVX_RST(orp, j, 0.0);
+                ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
             }
             if (e0 == 0) {
                 const int64_t fr = Lfrm[g];

@@ -42,8 +42,9 @@ namespace {
 constexpr int GFT = 8;              // frames staged before the per-peak pass
 
 typedef unsigned short u16;
-// a result's store: non-temporal (written once, read by nobody in the launch: +0.6 % at nfft 2048 for leaving the caches to the samples
-// and the hand-over; -DPVX_RESULTS_TEMPORAL=1: the plain store)
+// a kept peak's results: non-temporal stores (written once, read by nobody in the launch: +1.3 % at nfft 2048 / npks 8 for leaving the caches
+// to the samples and the hand-over; -DPVX_RESULTS_TEMPORAL=1: plain stores).  The zero padding of a row stays with plain stores: scattered
+// 8-byte non-temporal writes cost nfft 1024 at npks 20 (one peak, nineteen zeros per row) 12 %.
 #ifdef PVX_RESULTS_TEMPORAL
 #define PVX_RST(ptr, idx, val) ((ptr)[idx] = (val))
 #else
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         if (gvalid) {
             if (wid == S - 1) {
                 for (int j = tot + e0; j < K; j += LPF) {             // zero padding, PV.py:226-239
-                    PVX_RST(ob, j, 0.0); PVX_RST(of, j, 0.0); PVX_RST(om, j, 0.0); PVX_RST(op, j, 0.0); PVX_RST(orp, j, 0.0);
+                    ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
                 }
             }
             if (wid == 0 && e0 == 0) {
