@@ -146,3 +146,17 @@ def test_generated_isa_has_no_asm_to_dpp_hazard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 asm -> DPP hazard candidates" in r.stdout
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """INTEGRATION.md's table of environment switches names every PVX_* variable the native sources read."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for path in glob.glob(os.path.join(root, "pypevoc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "pypevoc_amd", "csrc", "*.h")):
+        read |= set(re.findall(r'getenv\("(PVX_[A-Z0-9_]+)"\)', open(path).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(v for v in read if v not in doc)
+    assert read and not missing, missing
