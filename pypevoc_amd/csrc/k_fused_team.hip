@@ -68,7 +68,7 @@ __device__ __forceinline__ void team_sync() {
 #ifndef PVX_TEAM_PRIO_C
 #define PVX_TEAM_PRIO_C 0
 #endif
-template <int S, int PPL = 1> struct TeamGeo {
+template <int S, int PPL = 1, bool DENSE = false> struct TeamGeo {
     static constexpr int L = 1024;                       // complex points per wave
     static constexpr int M = L * S;                      // bins 0..M-1
     static constexpr int N = 2 * M;                      // nfft
@@ -87,7 +87,7 @@ template <int S, int PPL = 1> struct TeamGeo {
     static constexpr size_t OFF_KEYS = (OFF_Y + (size_t)YLEN * 4 + 15) & ~(size_t)15;     // u64 [S][CW] (score, tie-break); before the keys are written: the scan's trash slots
     static constexpr size_t OFF_PSUM = OFF_KEYS + (size_t)S * CW * 8;    // double [S]
     static constexpr size_t OFF_MISC = OFF_PSUM + (size_t)S * 8;         // int nw[S] | float pmax[S] | float pmin[S] | int val[S][GFT]
-    static constexpr size_t OFF_WAVE = (OFF_MISC + (size_t)S * 4 * (3 + GFT) + 15) & ~(size_t)15;
+    static constexpr size_t OFF_WAVE = (OFF_MISC + (size_t)S * 4 * (3 + GFT + (DENSE ? 1 : 0)) + 15) & ~(size_t)15;       // (DENSE: + int nst[S])
     // PPL = 2 stages one frame at a time (npks > 64) and flushes it before the next scan: the candidate list and the staged
     // values are never alive together and share their bytes -- what lets two teams of nfft 8192 into a CU's LDS at npks 128
     __host__ __device__ static size_t ci_or_sval(int K) {
@@ -97,18 +97,21 @@ template <int S, int PPL = 1> struct TeamGeo {
     __host__ __device__ static size_t per_wave(int K) {
         const size_t kpad = (size_t)((K + 3) & ~3);
         const size_t gs = (size_t)staged_frames(K, GFT);
-        size_t b = GFT * 8 + GFT * 4 * 2                                 // tot | orow | cnt
-                 + kpad * 4 + gs * kpad * 4;                             // sel | sbin
+        // DENSE (8 < npks <= 24, PPL = 1): 64 slots per wave, a frame's kept peaks behind the previous frame's (k_fused_rev.hip), + off[GFT]
+        const size_t slots = DENSE ? (size_t)64 : gs * kpad;
+        size_t b = GFT * 8 + GFT * 4 * 2 + (DENSE ? GFT * 4 : 0)         // tot | orow | cnt | (off)
+                 + kpad * 4 + slots * 4;                                 // sel | sbin
         if (PPL == 2) b += ci_or_sval(K);
-        else b += (size_t)CAPW * 2 + gs * kpad * 5 * 4;                  // ci (u16) | sval
+        else b += (size_t)CAPW * 2 + slots * 5 * 4;                      // ci (u16) | sval
         return (b + 15) & ~(size_t)15;
     }
     __host__ __device__ static size_t total(int K) { return OFF_WAVE + per_wave(K) * S; }
 };
 
-template <int S, typename InT, bool AL2, int H, int PPL = 1>
+template <int S, typename InT, bool AL2, int H, int PPL = 1, bool DENSE = false>
 __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
-    using TG = TeamGeo<S, PPL>;
+    static_assert(!DENSE || PPL == 1, "dense staging is for one candidate per lane");
+    using TG = TeamGeo<S, PPL, DENSE>;
     constexpr int CW = TG::CW;
     constexpr int R = 16, L = TG::L, M = TG::M, T = TG::T, REG = TG::REG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     float* const Lpmax = (float*)(Lnw + S);
     float* const Lpmin = Lpmax + S;
     int* const Lval = (int*)(Lpmin + S);
+    int* const Lnst = Lval + S * GFT;                               // (DENSE) slots every wave has staged since the last per-peak pass
     // per-wave region (see k_fused_rev.hip for the opaque offset)
     unsigned wboff = (unsigned)(TG::OFF_WAVE + TG::per_wave(K) * wid);
     asm volatile("" : "+s"(wboff));
@@ -136,11 +140,12 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     double* const Ltot = (double*)wb;
     int* const Lorow = (int*)(Ltot + GFT);                          // output row (the launcher checks that rows fit 32 bits)
     int* const Lcnt = Lorow + GFT;
-    u16* const Lci = (u16*)(Lcnt + GFT);
+    int* const Lsoff = Lcnt + GFT;                                  // (DENSE) a staged frame's first slot
+    u16* const Lci = (u16*)(Lsoff + (DENSE ? GFT : 0));
     // PPL = 1: ci | sel | sbin | sval.  PPL = 2: (ci or sval) | sel | sbin  (see per_wave)
     int* const Lsel = (PPL == 2) ? (int*)((unsigned char*)Lci + TG::ci_or_sval(K)) : (int*)(Lci + TG::CAPW);
     int* const Lsbin = Lsel + kpad;
-    float* const Lsval = (PPL == 2) ? (float*)Lci : (float*)(Lsbin + gs * kpad);
+    float* const Lsval = (PPL == 2) ? (float*)Lci : (float*)(Lsbin + (DENSE ? 64 : gs * kpad));
     const int trash0 = (int)(((const unsigned char*)(Lkeys + wid * CW) - (const unsigned char*)Lci) / 2);    // in u16 slots from Lci
     unsigned xoff = (unsigned)(TG::OFF_X + (size_t)REG * 8 * wid);
     asm volatile("" : "+s"(xoff));
@@ -282,6 +287,70 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
         asm volatile("" : "+s"(q));                                  // loads through q stay here
         PeakConst pc;
         pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = TG::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
+        if constexpr (DENSE) {
+            // ---- this wave's staged peaks sit back to back in its 64 slots (k_fused_rev.hip's dense pass); the waves of the team exchange
+            // per FRAME how many each emitted and write theirs behind those of the waves below
+            static_assert(GFT == 8, "two 16-byte reads per table");
+            const int4 oa = *(const int4*)Lsoff, ob4 = *((const int4*)Lsoff + 1), ca = *(const int4*)Lcnt, cb4 = *((const int4*)Lcnt + 1);
+            const int offs[8] = {oa.x, oa.y, oa.z, oa.w, ob4.x, ob4.y, ob4.z, ob4.w}, cnts[8] = {ca.x, ca.y, ca.z, ca.w, cb4.x, cb4.y, cb4.z, cb4.w};
+            int top = 0, cnt = 0, g = 0, start = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { if (j == ng - 1) top = offs[j] + cnts[j]; }
+            cnt = cnts[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) { if (j < ng && offs[j] <= lnf) { g = j; start = offs[j]; cnt = cnts[j]; } }
+            bool valid = lnf < top;
+            int nbin = 0;
+            PeakOut o;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            if (valid) {
+                nbin = Lsbin[lnf];
+                const float* sv = Lsval + (size_t)lnf * 5;
+                o = peak_math<float, true>(nbin, sv[0], sv[1], sv[2], sv[3], sv[4], pc);
+                valid = o.valid;
+            }
+            const unsigned long long ball = __ballot(valid);
+            const unsigned long long gm = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << start;
+            // eight lanes per staged frame: frame g2, column offset c2
+            const int g2 = lnf >> 3, c2 = lnf & 7;
+            int o2 = 0, n2 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { if (j == g2) { o2 = offs[j]; n2 = cnts[j]; } }
+            const unsigned long long gm2 = (n2 >= 64 ? ~0ull : ((1ull << n2) - 1ull)) << o2;
+            if (c2 == 0) Lval[wid * GFT + g2] = (g2 < ng) ? __popcll(ball & gm2) : 0;
+            team_sync();                                             // the waves' emitted counts, frame by frame
+            if (valid) {
+                int off = 0;
+#pragma unroll
+                for (int w = 0; w < S; w++) off += (w < wid) ? Lval[w * GFT + g] : 0;
+                const int64_t orow = (int64_t)Lorow[g];
+                const int oi = off + __popcll(ball & gm & ((1ull << lnf) - 1ull));
+                PVX_RST(((gdouble*)q->binno + orow * K), oi, (double)nbin);
+                PVX_RST(((gdouble*)q->f + orow * K), oi, o.freq);
+                PVX_RST(((gdouble*)q->mag + orow * K), oi, o.mag);
+                PVX_RST(((gdouble*)q->ph + orow * K), oi, o.thisph);
+                PVX_RST(((gdouble*)q->realph + orow * K), oi, o.thisph + kPi * o.dfb / pc.fstep);      // PV.py:207
+            }
+            if (g2 < ng && (wid == S - 1 || (wid == 0 && c2 == 0))) {
+                const int64_t orow2 = (int64_t)Lorow[g2];
+                if (wid == S - 1) {
+                    int tot2 = 0;
+#pragma unroll
+                    for (int w = 0; w < S; w++) tot2 += Lval[w * GFT + g2];
+                    gdouble* of2 = (gdouble*)q->f + orow2 * K; gdouble* om2 = (gdouble*)q->mag + orow2 * K; gdouble* op2 = (gdouble*)q->ph + orow2 * K;
+                    gdouble* orp2 = (gdouble*)q->realph + orow2 * K; gdouble* ob2 = (gdouble*)q->binno + orow2 * K;
+                    for (int j = tot2 + c2; j < K; j += 8) { ob2[j] = 0.0; of2[j] = 0.0; om2[j] = 0.0; op2[j] = 0.0; orp2[j] = 0.0; }     // zero padding, PV.py:226-239
+                }
+                if (wid == 0 && c2 == 0) {
+                    const int64_t fr = orow2 % (int64_t)Fi;                                               // frame within its signal
+                    if (q->totalmag) ((gdouble*)q->totalmag)[orow2] = sqrt(Ltot[g2]);                                  // PV.py:210
+                    if (q->t) ((gdouble*)q->t)[orow2] = ((double)(fr * (int64_t)pc.hop) + TG::N / 2.0) / q->sr;        // PV.py:247
+                }
+            }
+            if (lnf == 0) Lnst[wid] = 0;
+            wave_sync();
+            return;
+        }
         const int g = gl;
         const bool gvalid = g < ng;
         const int cnt = gvalid ? Lcnt[g] : -1;
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     // ---- (signal b, row-in-signal q) of the team's first row g = r1 - 1; rows go down by one
     int g = r1 - 1, gb = g / rows1, gq = g - gb * rows1;            // the only division
     { const InT* s0 = row_src(g, gb, gq); prefetch_part(s0, 0); prefetch_part(s0, 1); prefetch_part(s0, 2); prefetch_part(s0, 3); }
-    int ng = 0;
+    int ng = 0, nst = 0;                                            // (nst, DENSE: slots this wave has staged since the last per-peak pass)
     bool pend = false, pend_prev0 = false;                          // the frame staged last still waits for its previous spectrum
     int pend_nk = 0, own[PPL];                                      // the lane's staged peaks: slot << 16 | bin, -1: none (one register each across the transform)
 #pragma unroll
@@ -396,12 +465,19 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 }
             } else
             for (int e = fresh_lane(); e < pend_nk; e += 64) {      // (rare: the first frame of a streamed call)
-                const int sl = (ng - 1) * kpad + e;
+                const int sl = (DENSE ? nst - pend_nk : (ng - 1) * kpad) + e;
                 const int nbin = Lsbin[sl];
                 Lsval[(size_t)sl * 5 + 2] = (float)p.prev0[2 * nbin];
                 Lsval[(size_t)sl * 5 + 3] = (float)p.prev0[2 * nbin + 1];
             }
             pend = false;
+            if constexpr (DENSE) {
+                // (team-uniform: every wave reads all the waves' slot counts, written before the barriers of this row's transform)
+                int need = 0;
+#pragma unroll
+                for (int w = 0; w < S; w++) { const int v_ = Lnst[w]; need = v_ > need ? v_ : need; }
+                if (ng == GFT || need + K > 64) { flush(ng); ng = 0; nst = 0; }
+            } else
             if (ng == gs) { flush(ng); ng = 0; }                    // team-uniform
         }
         const bool real = !zero_row && g >= r0;                     // team-uniform
@@ -519,7 +595,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                     const bool keep = take[h] && (p.rad < 0 || bad[h] == 0);
                     const unsigned long long bal = __ballot(keep);
                     if (keep) {
-                        const int sl = ng * kpad + nk + lane_prefix(bal);       // entries l before entries l + 64: ascending bins
+                        const int sl = (DENSE ? nst : ng * kpad) + nk + lane_prefix(bal);       // entries l before entries l + 64: ascending bins
                         // PV.py:197-199: 3-bin energy, bin 0 excluded (1 <= pb <= M-2)
                         float s3;
                         if constexpr (PPL == 1) {
@@ -555,7 +631,7 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                     for (int h = 0; h < PPL; h++) {
                         const unsigned long long bal = __ballot(keep[h]);
                         if (keep[h]) {
-                            const int sl = ng * kpad + nk + lane_prefix(bal);
+                            const int sl = (DENSE ? nst : ng * kpad) + nk + lane_prefix(bal);
                             const float2 cc = X[xa4(sb2[h])];
                             const float2 cm = X[xa4(sb2[h] - 1)], cp = X[xa4(sb2[h] + 1)];
                             const float em = (sb2[h] > 1) ? __builtin_fmaf(cm.x, cm.x, cm.y * cm.y) : 0.f;
@@ -570,7 +646,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
                 }
                 team_sync();
             }
-            if (lane == 0) { Lcnt[ng] = nk; Lorow[ng] = (int)orow; Ltot[ng] = tot; }
+            if (lane == 0) { Lcnt[ng] = nk; Lorow[ng] = (int)orow; Ltot[ng] = tot; if constexpr (DENSE) { Lsoff[ng] = nst; Lnst[wid] = nst + nk; } }
+            if constexpr (DENSE) nst += nk;
             ng++;
             pend = true; pend_nk = nk; pend_prev0 = (p.prev0 != nullptr) && (orow == 0);
         }
@@ -579,8 +656,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
     if (ng > 0) flush(ng);
 }
 
-template <int S, int PPL> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
-    using TG = TeamGeo<S, PPL>;
+template <int S, int PPL, bool DENSE = false> int launch_team(const FusedParams& p, int x_dtype, hipStream_t s) {
+    using TG = TeamGeo<S, PPL, DENSE>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -594,10 +671,10 @@ template <int S, int PPL> int launch_team(const FusedParams& p, int x_dtype, hip
     const bool al2 = (x_dtype == PVX_F32) && (p.hop % 2 == 0) && (p.sig_stride % 2 == 0) && (((uintptr_t)p.x) % 8 == 0);
     const int H = (p.hop == 32 * R * S) ? R / 4 : (p.hop == 64 * R * S) ? R / 2 : 0;
     const void* fn = nullptr;
-#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4, PPL> : H ? (const void*)k_fused_team<S, INT, AL, R / 2, PPL> : (const void*)k_fused_team<S, INT, AL, 0, PPL>)
+#define PVX_TEAM_PICK(INT, AL) (H == R / 4 ? (const void*)k_fused_team<S, INT, AL, R / 4, PPL, DENSE> : H ? (const void*)k_fused_team<S, INT, AL, R / 2, PPL, DENSE> : (const void*)k_fused_team<S, INT, AL, 0, PPL, DENSE>)
     switch (x_dtype) {
         // (two candidates per lane: without the 8-byte sample loads' instantiations -- a row's new samples are a quarter of its loads)
-        case PVX_F32: if constexpr (PPL == 1) { fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); } else { fn = PVX_TEAM_PICK(float, false); } break;
+        case PVX_F32: if constexpr (PPL == 1 && !DENSE) { fn = al2 ? PVX_TEAM_PICK(float, true) : PVX_TEAM_PICK(float, false); } else { fn = PVX_TEAM_PICK(float, false); } break;
         case PVX_I16: fn = PVX_TEAM_PICK(int16_t, false); break;
         default: pvx_set_error("the fused kernels take float32 or int16 samples (x_dtype %d: float64 is narrowed before the launch)", x_dtype); return PVX_ERR_INVALID;
     }
@@ -646,9 +723,11 @@ int pvx_fused_team_supported(int nfft, int precision, int K) {
 
 int pvx_launch_fused_team(const FusedParams& p, int nfft, int x_dtype, hipStream_t s) {
     if (p.total_rows <= 0) return PVX_OK;
+    const bool dense = p.K > 8 && p.K <= 24 && getenv("PVX_TEAM_NO_DENSE") == nullptr;
     switch (nfft) {
-        case 4096: return p.K > 64 ? launch_team<2, 2>(p, x_dtype, s) : launch_team<2, 1>(p, x_dtype, s);
-        case 8192: return p.K > 64 ? launch_team<4, 2>(p, x_dtype, s) : launch_team<4, 1>(p, x_dtype, s);
+        // (8 < npks <= 24: the dense staging of k_fused_rev.hip for the teams; PVX_TEAM_NO_DENSE=1: the strided one -- A/B, tests)
+        case 4096: return p.K > 64 ? launch_team<2, 2>(p, x_dtype, s) : (dense ? launch_team<2, 1, true>(p, x_dtype, s) : launch_team<2, 1>(p, x_dtype, s));
+        case 8192: return p.K > 64 ? launch_team<4, 2>(p, x_dtype, s) : (dense ? launch_team<4, 1, true>(p, x_dtype, s) : launch_team<4, 1>(p, x_dtype, s));
         default: pvx_set_error("the team kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }

@@ -709,6 +709,53 @@ def test_rev_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monke
     same(a, b, "int16")
 
 
+@pytest.mark.parametrize("nfft", [4096, 8192])
+def test_team_kernel_dense_staging_is_bit_identical_to_strided(amd, oracle, monkeypatch, nfft):
+    """k_fused_team at 8 < npks <= 24: every wave stages its kept peaks densely and the team runs the per-peak pass when any wave's next
+    frame might not fit (PVX_TEAM_NO_DENSE=1: the strided staging).  Bit for bit the same -- peaks in one wave's segment only, in every
+    segment, dense frames, silence, several signals per call, other grids -- and against the oracle."""
+    rng = np.random.default_rng(907)
+    sr = 44100.0
+    n = 40000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    high = 0.2 * np.sin(2 * np.pi * 0.23 * sr * t) + 0.1 * np.sin(2 * np.pi * 0.249 * sr * t) + 0.02 * rng.standard_normal(n)
+    rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 61)) + 1e-4 * rng.standard_normal(n)
+
+    def pair(make):
+        a = make()
+        monkeypatch.setenv("PVX_TEAM_NO_DENSE", "1")
+        b = make()
+        monkeypatch.delenv("PVX_TEAM_NO_DENSE")
+        return a, b
+
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("high", high), ("rich", rich)):
+        x = x.astype(np.float32)
+        for K, thr, hop, nb in ((20, 0.005, nfft // 4, None), (9, 0.005, nfft // 2, "3"), (24, 0.0005, nfft // 4, None), (12, 0.3, 333 * nfft // 2048, None),
+                                (17, 0.0, nfft // 4, "1000"), (23, 0.005, nfft - 1, "1")):
+            if nb:
+                monkeypatch.setenv("PVX_FUSED_BLOCKS", nb)
+            a, b = pair(lambda: run_pv(amd, x, sr, nfft, hop, K, thr, precision=32))
+            if nb:
+                monkeypatch.delenv("PVX_FUSED_BLOCKS")
+            assert _lib_mode(a) == 5
+            for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+                assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (name, K, thr, hop, nb, k)
+        o = oracle.analyze(x.astype(np.float64), sr, nfft, nfft // 4, 20)
+        c = compare_analysis(pv_result(run_pv(amd, x, sr, nfft, nfft // 4, 20, precision=32)), o, nfft, nfft // 4, sr)
+        if name == "gaps":
+            assert c["bad_peaks"] <= max(40, 0.06 * c["ref_peaks"]), c
+        else:
+            assert_f32(c, absolute=False)
+    for ns in (nfft + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 20):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[n // 7 - 1000:n // 7 - 1000 + ns], rich[:ns]]).astype(np.float32)
+        a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=32).run_pv())
+        for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, k)
+
+
 @pytest.mark.parametrize("precision", [64, 32])
 @pytest.mark.parametrize("nfft", [2048, 1024, 512])
 def test_general_kernel_dense_peak_pass_is_bit_identical(amd, oracle, monkeypatch, nfft, precision):
