@@ -43,6 +43,12 @@ typedef enum {
 /* sample types accepted for the input signal x (PV.py:84 copies whatever the caller passed) */
 typedef enum { PVX_F32 = 0, PVX_F64 = 1, PVX_I16 = 2 } pvx_dtype;
 
+/* Every function declared below is an exported entry point of libpvx_hip.so, and nothing else is: the library is built with
+ * -fvisibility=hidden, these declarations carry default visibility (tests/test_abi_cpu.py checks both directions). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 /* ---- library ------------------------------------------------------------------------- */
 
 /* Select and initialise the HIP device (idempotent per device).  device < 0: current device. */
@@ -375,6 +381,10 @@ int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, con
 int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f,
                         double* d_mag, double* d_ph, double* d_realph, double* d_binno,
                         double* d_totalmag, void* stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -23,9 +23,9 @@ def _funcwind_op(func):
     max / min count as their numpy namesakes) or a TypeError: other callables would have to run in Python per frame."""
     if isinstance(func, str):
         name = func
-    elif func in (sum, max, min):
+    elif any(func is b for b in (sum, max, min)):                    # (identity: `in` would compare an array-like elementwise)
         name = func.__name__
-    elif getattr(func, "__module__", "").split(".")[0] == "numpy" and getattr(np, getattr(func, "__name__", ""), None) is func:
+    elif (getattr(func, "__module__", None) or "").split(".")[0] == "numpy" and getattr(np, getattr(func, "__name__", ""), None) is func:
         name = func.__name__
     else:
         name = None

@@ -170,8 +170,9 @@ def _bind(path):
     have = lib.pvx_build_fingerprint().decode()
     if want is not None and have != want and not os.environ.get("PVX_ALLOW_STALE_LIB"):
         raise ImportError(
-            "pypevoc_amd: %s was built from other sources (fingerprint %s, pypevoc_amd/csrc is %s) -- rebuild it with "
-            "`make -C pypevoc_amd/csrc` (PVX_ALLOW_STALE_LIB=1 loads it anyway)." % (path, have, want))
+            "pypevoc_amd: %s was built from other sources, or with other compiler flags / another ARCH than the Makefile's "
+            "defaults (fingerprint %s; pypevoc_amd/csrc with the default flags is %s) -- rebuild it with "
+            "`make -C pypevoc_amd/csrc`, or load it as it is with PVX_ALLOW_STALE_LIB=1." % (path, have, want))
     return lib
 
 

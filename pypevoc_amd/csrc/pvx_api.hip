@@ -166,6 +166,11 @@ struct pvx_plan {
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
     bool use_stft = false;       // float64, nfft 512..2048: k_stft writes the spectrum rows (no frame buffer, no rocFFT)
     bool use_stft_pv = false;    // ... and finds the peaks in the same launch (k_stft_pv.hip)
+    bool use_pv_rev = false;     // ... without writing a spectrum row: rows walked downwards, the row at hand on chip (k_pv_rev.hip; npks <= 64)
+    double* d_lastspec = nullptr;   // k_pv_rev: [N2][2] the spectrum of the one row a call asks for (chunk carry, last_spec)
+    bool last_from_rev = false;  // the last analyze_rows() left its requested spectrum row in d_lastspec
+    void* d_pvstage = nullptr;   // k_pv_rev at nfft 2048: the kept peaks' values between the frames (PvRevParams::stage)
+    size_t pvstage_cap = 0;
     int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
     bool rocfft_small = false;   // ... and its output then goes to d_rspec, not to the analysis' d_spec
     void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
@@ -254,6 +259,8 @@ static void plan_free(pvx_plan* p) {
     if (p->d_hx) (void)hipFree(p->d_hx);
     if (p->d_hprev) (void)hipFree(p->d_hprev);
     if (p->d_carry) (void)hipFree(p->d_carry);
+    if (p->d_lastspec) (void)hipFree(p->d_lastspec);
+    if (p->d_pvstage) (void)hipFree(p->d_pvstage);
     for (int i = 0; i < 2; i++) {
         if (p->d_in[i]) (void)hipFree(p->d_in[i]);
         if (p->d_out[i]) (void)hipFree(p->d_out[i]);
@@ -435,6 +442,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (hipMemcpy(p->d_twiddle64, src, tw.size() * rs, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(stft twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         p->use_stft = true;
         p->use_stft_pv = pvx_stft_pv_supported(nfft, precision, npks) != 0 && !getenv("PVX_NO_STFT_PV");
+        p->use_pv_rev = p->use_stft_pv && pvx_pv_rev_supported(nfft, precision, npks) != 0 && !getenv("PVX_NO_PV_REV");
         if (!getenv("PVX_MAX_ROWS")) {
             int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 2 * rs));
             if (big > 262144) big = 262144;
@@ -673,6 +681,36 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
             rc = pvx_launch_fused_mw(fp, p->nfft, x_dtype, s);
         if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
+    }
+    p->last_from_rev = false;
+    if (p->use_stft && p->use_pv_rev && pvx_pv_rev_takes(p->nfft, x_dtype, p->hop) && total_rows < 0x7fffff00LL) {
+        // float64, nfft 512 .. 2048, npks <= 64: ONE launch over all rows, no spectrum workspace (k_pv_rev.hip)
+        PvRevParams rp;
+        rp.x = d_x; rp.sig_stride = sig_stride; rp.F = F; rp.total_rows = total_rows;
+        rp.hop = p->hop; rp.K = p->npks; rp.rad = 5;                                     // PV.py:177
+        rp.thr = p->pkthresh; rp.sr = p->sr; rp.fstep = p->fstep; rp.dt = p->dt;
+        rp.wfbin = p->d_wfbin; rp.prev0 = d_prev0;
+        rp.f = d_f; rp.mag = d_mag; rp.ph = d_ph; rp.realph = d_realph; rp.binno = d_binno;
+        rp.t = d_t; rp.totalmag = d_totalmag; rp.win = p->d_win; rp.twiddle = p->d_twiddle64;
+        rp.spec_out = nullptr; rp.spec_row = -1;
+        if (spec_row >= 0) {
+            if (!p->d_lastspec) PVX_HIP_CHECK(hipMalloc((void**)&p->d_lastspec, sizeof(double) * 2 * (size_t)(p->N2 > 0 ? p->N2 : 1)));
+            rp.spec_out = p->d_lastspec; rp.spec_row = spec_row;
+        }
+        rp.blocks_override = 0;
+        if (const char* e = getenv("PVX_PV_REV_BLOCKS")) { const long long v = atoll(e); if (v >= 1) rp.blocks_override = v; }   // tests: other grids
+        rp.win_symmetric = p->win_symmetric ? 1 : 0;
+        rp.stage = nullptr; rp.stage_bytes = 0;
+        const size_t need = pvx_pv_rev_stage_bytes(p->nfft);
+        if (need > 0) {
+            if ((rc = grow_dev(&p->d_pvstage, &p->pvstage_cap, need)) != PVX_OK) return rc;
+            rp.stage = p->d_pvstage; rp.stage_bytes = p->pvstage_cap;
+        }
+        if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
+        if ((rc = pvx_launch_pv_rev(rp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
+        if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
+        p->last_from_rev = spec_row >= 0;
+        return plan_progress(p, s, total_rows, total_rows, nsig);
     }
     if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
     else {
@@ -951,6 +989,7 @@ static const size_t kSmallAnalyze = kStageMin;
 static int carry_spectrum(pvx_plan* p, int64_t rows_in_call, hipStream_t s) {
     if (!p->d_prev) PVX_HIP_CHECK(hipMalloc((void**)&p->d_prev, sizeof(double) * 2 * (size_t)(p->N2 > 0 ? p->N2 : 1)));
     if (p->fft_mode != 0) return pvx_launch_spec_to_prev(p->d_prev, p->d_specrow, 2 * p->N2, 1, s);
+    if (p->last_from_rev) return pvx_launch_spec_to_prev(p->d_prev, p->d_lastspec, 2 * p->N2, 0, s);
     const int64_t lastR0 = ((rows_in_call - 1) / p->max_rows) * p->max_rows;
     const int64_t wsrow = (rows_in_call - 1) - lastR0 + 1;
     const size_t rs = real_size(p->precision);
@@ -1168,6 +1207,7 @@ static int64_t analyze_host(pvx_plan* p, const void* x, int x_dtype, int64_t nsa
     const size_t rs = real_size(p->fft_mode != 0 ? 32 : p->precision);
     const void* d_last = nullptr;
     if (last_spec && p->fft_mode != 0) d_last = p->d_specrow;
+    else if (last_spec && p->last_from_rev) d_last = p->d_lastspec;
     else if (last_spec) {
         const int64_t lastR0 = ((last_rows - 1) / p->max_rows) * p->max_rows;
         const int64_t wsrow = (last_rows - 1) - lastR0 + 1;

@@ -141,6 +141,28 @@ int pvx_stft_pv_supported(int nfft, int precision, int K);
 int pvx_stft_pv_takes(int nfft, int precision, int x_dtype, int hop);
 int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec, int64_t ldo, const void* twiddle, int x_dtype,
                        int precision, hipStream_t s);
+// k_pv_rev.hip: the float64 analysis in one launch with the spectrum rows kept on chip (rows walked downwards; nfft 512 .. 2048, npks <= 64)
+struct PvRevParams {
+    const void* x;        // input samples
+    int64_t sig_stride, F, total_rows;
+    int hop, K, rad;
+    double thr, sr, fstep, dt;
+    const double* wfbin;
+    const double* prev0;
+    double *f, *mag, *ph, *realph, *binno, *t, *totalmag;
+    const void* win;      // double[nfft] window / wfact
+    const void* twiddle;  // complex double [nfft] W_nfft^j
+    double* spec_out;     // optional: half spectrum (nfft/2 complex float64) of global row spec_row
+    int64_t spec_row;
+    int64_t blocks_override;
+    int win_symmetric;
+    void* stage;          // nfft 2048: double [workgroups x waves][64][5], the kept peaks' values between the frames (pvx_pv_rev_stage_bytes)
+    size_t stage_bytes;
+};
+int pvx_pv_rev_supported(int nfft, int precision, int K);
+int pvx_pv_rev_takes(int nfft, int x_dtype, int hop);
+size_t pvx_pv_rev_stage_bytes(int nfft);
+int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
 

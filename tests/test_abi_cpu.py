@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libpvx_hip.so lacks %s declared in include/pvx.h" % n
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == names
+    # the other direction: the library exports NOTHING but the declared functions (-fvisibility=hidden, default visibility on
+    # the header's declarations, csrc/pvx.map for the weak template instantiations of the standard headers) -- also the
+    # witness build of the bit-identity tests
+    import os
+    import subprocess
+    for path in (_lib.LIB_PATH, os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpvx_witness.so")):
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        assert exported == names, (path, sorted(set(exported) ^ set(names)))
 
 
 def test_nframes_and_synth_len_host_logic():

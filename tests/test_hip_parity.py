@@ -771,6 +771,7 @@ def test_general_kernel_dense_peak_pass_is_bit_identical(amd, oracle, monkeypatc
     gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
     rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 31)) + 1e-4 * rng.standard_normal(n)
     monkeypatch.setenv("PVX_FFT_MODE", "0")
+    monkeypatch.setenv("PVX_NO_PV_REV", "1")                        # (float64 at npks <= 64 runs k_pv_rev by default: this test is about k_stft_pv)
 
     def pair(make):
         a = make()
@@ -794,6 +795,81 @@ def test_general_kernel_dense_peak_pass_is_bit_identical(amd, oracle, monkeypatc
     a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=precision).run_pv())
     for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
         assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), k
+
+
+@pytest.mark.parametrize("nfft", [2048, 1024, 512])
+def test_descending_float64_kernel_is_bit_identical_to_the_row_storing_one(amd, oracle, monkeypatch, nfft):
+    """k_pv_rev (float64, nfft 512 .. 2048, npks <= 64: rows walked downwards, the spectrum row on chip, no workspace) against
+    k_stft_pv (PVX_NO_PV_REV=1: every spectrum row through the workspace), whose arithmetic it restates: every output bit for bit --
+    signals (dense candidates, exact silence, threshold 0), npks 1 .. 64, hops with and without the sliding window, float64 /
+    float32 / int16 samples, grids from one wave to one row per wave, an asymmetric window (nfft 2048: the seven-wave form),
+    batches, host input in chunks (the carried spectrum) -- and strictly against the oracle."""
+    rng = np.random.default_rng(611)
+    sr = 44100.0
+    n = 50000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 31)) + 1e-4 * rng.standard_normal(n)
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+    keys = ("f", "mag", "ph", "realph", "binno", "t", "totalmag")
+
+    def pair(make):
+        a = make()
+        monkeypatch.setenv("PVX_NO_PV_REV", "1")
+        b = make()
+        monkeypatch.delenv("PVX_NO_PV_REV")
+        return a, b
+
+    cases = ((8, 0.005, nfft // 4, None), (20, 0.005, nfft // 2, "3"), (64, 0.0005, nfft // 4, None), (12, 0.3, 333 * nfft // 2048, None),
+             (1, 0.005, nfft // 4, "1"), (33, 0.0, nfft // 4, "100000"), (5, 0.005, nfft - 1, None))
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("rich", rich)):
+        for K, thr, hop, nb in cases:
+            for xin in (x, x.astype(np.float32), np.round(x * 20000).astype(np.int16)):
+                if xin.dtype != np.float64 and name not in ("harm", "gaps"):
+                    continue
+                if nfft == 2048 and xin.dtype == np.float64 and hop not in (nfft // 4, nfft // 2):
+                    continue                                         # (float64 samples at nfft 2048: the one-launch kernels take the sliding-window hops)
+                if nb:
+                    monkeypatch.setenv("PVX_PV_REV_BLOCKS", nb)
+                a, b = pair(lambda: run_pv(amd, xin, sr, nfft, hop, K, thr, precision=64))
+                if nb:
+                    monkeypatch.delenv("PVX_PV_REV_BLOCKS")
+                assert _lib_mode(a) == 0
+                for k in keys:
+                    assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (name, K, thr, hop, nb, xin.dtype, k)
+                assert np.array_equal(a.oldfft, b.oldfft), (name, K, hop, xin.dtype)
+        o = oracle.analyze(x, sr, nfft, nfft // 4, 20)
+        assert_f64(compare_analysis(pv_result(run_pv(amd, x, sr, nfft, nfft // 4, 20, precision=64)), o, nfft, nfft // 4, sr))
+    # an asymmetric window (at nfft 2048 the half-window form does not apply)
+    wa = np.hanning(nfft).copy(); wa[3] *= 1.01
+    for xin in (harm, harm.astype(np.float32)):
+        a, b = pair(lambda: run_pv(amd, xin, sr, nfft, nfft // 4, 8, precision=64, wind=lambda m: wa))
+        for k in keys:
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), ("asym", xin.dtype, k)
+    o = oracle.analyze(harm, sr, nfft, nfft // 4, 8, win=wa)
+    assert_f64(compare_analysis(pv_result(run_pv(amd, harm, sr, nfft, nfft // 4, 8, precision=64, wind=lambda m: wa)), o, nfft, nfft // 4, sr))
+    # batches: signals of a few rows each, so that waves cross signal boundaries (zero rows inside a wave's range)
+    for ns in (nfft + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 20):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[n // 7 - 1000:n // 7 - 1000 + ns], rich[:ns]])
+        for nb in (None, "1", "2"):
+            if nb:
+                monkeypatch.setenv("PVX_PV_REV_BLOCKS", nb)
+            a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=64).run_pv())
+            if nb:
+                monkeypatch.delenv("PVX_PV_REV_BLOCKS")
+            for k in ("f", "mag", "ph", "realph", "binno", "totalmag"):
+                assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, nb, k)
+    # host input in chunks of a few frames: the last spectrum of a chunk is the next one's previous spectrum
+    ref = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+    for fpc in (7, 40):
+        monkeypatch.setenv("PVX_MAX_DEVICE_BYTES", str(nfft * 8 + fpc * ((nfft // 4) * 8 + (5 * 8 + 2) * 8) + 8))
+        q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+        monkeypatch.delenv("PVX_MAX_DEVICE_BYTES")
+        for k in keys:
+            assert np.array_equal(np.asarray(getattr(q, k)), np.asarray(getattr(ref, k))), ("chunks", fpc, k)
+        assert np.array_equal(q.oldfft, ref.oldfft)
 
 
 def _lib_mode(p):
