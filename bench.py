@@ -265,6 +265,7 @@ def compact_line(full, detail_path):
         out["f64_value"] = g(full, "f64", "value")
         out["f64_ok"] = g(full, "f64", "self_check", "ok")
         out["f64_frac"] = g(full, "f64", "roofline", "frac")
+        out["f64_traffic_over_algorithmic"] = g(full, "f64", "roofline", "traffic_over_algorithmic")
     if full.get("workloads"):
         out["noise_value"] = g(full, "workloads", "white_noise", "value")
         out["violin_value"] = g(full, "workloads", "violin_g7_tiled", "value")
@@ -293,7 +294,7 @@ def compact_line(full, detail_path):
     s = json.dumps(out, separators=(",", ":"))
     if len(s) > COMPACT_MAX:                       # never again a line the driver cannot parse: drop the optional scalars first
         for k in ("per_rank_ms_per_step", "host_batch_value", "violin_value", "nfft4096_value", "nfft8192_value", "chain_tracker_ms",
-                  "chain_resynthesis_ms", "c5_2048_512_value", "f64_frac", "value_is"):
+                  "chain_resynthesis_ms", "c5_2048_512_value", "f64_traffic_over_algorithmic", "f64_frac", "value_is"):
             if len(s) <= COMPACT_MAX:
                 break
             if k == "per_rank_ms_per_step" and out["n_gpus"] > 1:
@@ -739,11 +740,15 @@ def main():
             _lib.check(lib.pvx_plan_set_timing(p64, 0), "pvx_plan_set_timing")
             ab64 = alg_bytes(s=8, c=16)
             stft = n64[0] > 0 and n64[1] == 0                      # k_stft.hip wrote the spectra: no frame buffer, no rocFFT
+            kern64 = (lib.pvx_plan_last_kernels(p64) or b"").decode()
+            rev64 = "analysis=k_pv_rev" in kern64                  # rows walked downwards, no spectrum row in HBM (k_pv_rev.hip)
             # input samples are float32 in HBM.  k_stft: hop*4 in, (nfft/2)*16 out; framing kernel: hop*4 in, nfft*8 out
-            # k_stft_pv (one launch): hop*4 in, the spectrum row (nfft/2)*16 and the result row out
+            # the one-launch kernels are priced at the FUSED bytes -- hop*4 in, the result row out (SURVEY 8(d)'s lower bound: 2 384 B
+            # per frame here) --, whether they keep the row on chip (k_pv_rev) or stream it through a workspace (k_stft_pv: its
+            # 16 KB per frame then show as traffic_over_algorithmic, not as "algorithmic" bytes)
             ab64k = [HOP * 4 + (NFFT // 2) * 16 if stft else HOP * 4 + NFFT * 8, ab64["fft"], (NFFT // 2) * 16 + NPKS * 40 + 16,
-                     HOP * 4 + (NFFT // 2) * 16 + NPKS * 40 + 16]
-            n64names = ["k_stft" if stft else "k_frames", "rocfft_r2c", "k_phase_peaks", "k_stft_pv"]
+                     HOP * 4 + NPKS * 40 + 16]
+            n64names = ["k_stft" if stft else "k_frames", "rocfft_r2c", "k_phase_peaks", "k_pv_rev" if rev64 else "k_stft_pv"]
             k64 = []
             for i in range(4):
                 if n64[i]:
@@ -753,14 +758,15 @@ def main():
                                     alg_bytes_per_frame=ab64k[i], achieved_GBps=round(ab64k[i] * fpl / dur / 1e9, 1),
                                     frac=round(ab64k[i] * fpl / dur / HBM_PEAK, 4)))
             stage64 = sum(ab64k[i] for i in range(4) if n64[i])    # what the kernels of this path have to move per frame
-            tr64, tr64_prov = committed_traffic("k_stft_pv_f64")
+            tr64, tr64_prov = committed_traffic("k_pv_rev_f64" if rev64 else "k_stft_pv_f64")
             f64 = dict(value=round(F64 / ms64 * 1e3, 1), unit="frames/s", ms_per_step=round(ms64, 4), steps=args.steps, dtype="f64",
-                       fft_mode=int(lib.pvx_plan_get_fft_mode(p64)),
+                       fft_mode=int(lib.pvx_plan_get_fft_mode(p64)), kernels=kern64,
                        contract_bytes_per_frame=ab64["contract"] - HOP * 4,
                        self_check=(check_block(host_block(out64, F64), o, F64, K, NFFT, HOP, 64, "f64") if checks else None),
                        roofline=dict(bound="hbm", stage_alg_bytes_per_frame=stage64, traffic=tr64, traffic_provenance=tr64_prov,
                                      achieved=round(stage64 * F64 / (ms64 * 1e-3) / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                                     frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4), kernels=k64))
+                                     frac=round(stage64 * F64 / (ms64 * 1e-3) / HBM_PEAK, 4),
+                                     traffic_over_algorithmic=(round(tr64 / float(stage64 * F64), 3) if tr64 else None), kernels=k64))
             Fn64, msn64, outn64 = quick(p64, xn, 5)
             f64["white_noise"] = dict(value=round(Fn64 / msn64 * 1e3, 1), unit="frames/s", ms_per_step=round(msn64, 4),
                                       self_check=(check_block(host_block(outn64, Fn64), on, Fn64, K, NFFT, HOP, 64, "f64 white noise", well_conditioned=False) if checks else None))

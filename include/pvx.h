@@ -97,8 +97,8 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   4  mode 1's arithmetic again (bit-identical results) with every wave on its own: a wave walks a contiguous range
  *      of rows DOWNWARDS over one spectrum buffer, the previous spectrum a frame's peaks need arrives one row later;
  *      sliding sample window at hop = nfft/4, nfft/2 (precision = 32, nfft in {512, 1024, 2048})
- * Mode 0 itself runs as one launch (window + FFT + peaks, k_stft_pv) for nfft in {512, 1024, 2048}, as fused STFT +
- * phase/peak kernel for nfft 4096 / 8192, and through rocFFT otherwise.
+ * Mode 0 itself runs as one launch for nfft in {512, 1024, 2048} (window + FFT + peaks: k_pv_rev at float64 with npks <= 64,
+ * no spectrum workspace; k_stft_pv otherwise), as fused STFT + phase/peak kernel for nfft 4096 / 8192, and through rocFFT otherwise.
  * A new plan uses 4 where it is supported, else 3, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
@@ -107,6 +107,11 @@ int pvx_plan_get_fft_mode(const pvx_plan* plan);
  * that takes a plan fails with PVX_ERR_INVALID when the calling thread is bound to another device (pvx_init(d), or a
  * pvx_batch worker's device) instead of running kernels on buffers of the wrong device. */
 int pvx_plan_device(const pvx_plan* plan);
+/* Which kernels the plan's last calls ran, as "analysis=<kernel>;tracker=<kernel>;synth=<kernel>" (a part is missing until its
+ * call has run): k_fused_rev | k_fused_team | k_fused_mw | k_pv_rev | k_stft_pv | k_stft+k_phase_peaks | k_frames+rocfft+k_phase_peaks
+ * for the analysis, k_synth_bodies<f64> | k_synth_bodies<f32> for the resynthesis.  For tests and benchmarks that must
+ * know what they measured; the string lives in the plan and is valid until its next call. */
+const char* pvx_plan_last_kernels(const pvx_plan* plan);
 /*
  * Progress reporting: replaces Progress.update (pypevoc/ProgressDisplay.py:82-88), which the
  * reference calls once per frame (PV.py:250-254, 528).  The HOST entry points pvx_analyze and

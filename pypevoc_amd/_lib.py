@@ -39,6 +39,7 @@ SIGNATURES = {
     "pvx_plan_set_fft_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pvx_plan_get_fft_mode": (ctypes.c_int, [ctypes.c_void_p]),
     "pvx_plan_device": (ctypes.c_int, [ctypes.c_void_p]),
+    "pvx_plan_last_kernels": (ctypes.c_char_p, [ctypes.c_void_p]),
     "pvx_plan_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pvx_plan_get_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int64_p]),
     "pvx_analyze_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,

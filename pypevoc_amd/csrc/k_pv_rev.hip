@@ -119,8 +119,9 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
     auto XA = [](int k) -> int { if constexpr (X4) return xa4(k); else return zpadT<R, T>(k); };     // slot of bin k in dz
 
     // ---- rows of this wave: [r0, r1) walked downwards, then row r0 - 1 (spectrum only: the previous one of its last frame)
-    const int64_t Wn = (int64_t)gridDim.x * NW, wv = (int64_t)blockIdx.x * NW + wid;
-    const int r0 = (int)(p.total_rows * wv / Wn), r1 = (int)(p.total_rows * (wv + 1) / Wn);
+    // (the launch covers global rows [row_begin, row_end): all of them, or one piece of a call that reports its progress)
+    const int64_t Wn = (int64_t)gridDim.x * NW, wv = (int64_t)blockIdx.x * NW + wid, nrows = p.row_end - p.row_begin;
+    const int r0 = (int)(p.row_begin + nrows * wv / Wn), r1 = (int)(p.row_begin + nrows * (wv + 1) / Wn);
     const bool idle_wave = r0 >= r1;
     const int glast = r0 - 1;
     const int Fi = (int)p.F, rows1 = Fi + 1;
@@ -570,7 +571,7 @@ template <int R, bool SYM, int NW> int launch_rv(const PvRevParams& p, int x_dty
     if (lds > 64 * 1024) PVX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t nblocks = ncu;                                             // one workgroup per CU: its waves share the tables
     if (p.blocks_override > 0) nblocks = p.blocks_override;
-    const int64_t maxb = (p.total_rows + NW - 1) / NW;                // never more waves than rows
+    const int64_t maxb = (p.row_end - p.row_begin + NW - 1) / NW;     // never more waves than rows
     if (nblocks > maxb) nblocks = maxb > 0 ? maxb : 1;
     if (!G::LV && (p.stage == nullptr || p.stage_bytes < (size_t)nblocks * NW * kSlots * 5 * 8)) {
         pvx_set_error("k_pv_rev: the staging block holds %zu bytes, %zu needed", p.stage_bytes, (size_t)nblocks * NW * kSlots * 5 * 8);
@@ -608,7 +609,8 @@ size_t pvx_pv_rev_stage_bytes(int nfft) {
 }
 
 int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s) {
-    if (p.total_rows <= 0) return PVX_OK;
+    if (p.total_rows <= 0 || p.row_end <= p.row_begin) return PVX_OK;
+    if (p.row_begin < 0 || p.row_end > p.total_rows) { pvx_set_error("k_pv_rev: rows [%lld, %lld) of %lld", (long long)p.row_begin, (long long)p.row_end, (long long)p.total_rows); return PVX_ERR_INVALID; }
     if (p.K > kSlots) { pvx_set_error("k_pv_rev stages at most %d peaks per frame (npks = %d)", kSlots, p.K); return PVX_ERR_UNSUPPORTED; }
     switch (nfft) {
         case 512: return launch_rv<4, false, 12>(p, x_dtype, s);

@@ -80,6 +80,26 @@ __device__ __forceinline__ void fsincos(double x, double& s, double& c) {
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
 }
+// The float32 form for the precision-32 sample loop (k_synth_bodies<R, float>): the argument and its reduction in float64 as above --
+// phases reach 1e4 rad, a float32 argument would carry 1e-3 rad of error --, the polynomials on |r| <= pi/4 in float32 (fdlibm's
+// k_sinf / k_cosf coefficients: absolute error < 1e-7).  Eight float64 and sixteen float32 instructions instead of thirty-five float64.
+__device__ __forceinline__ void fsincos_f(double x, float& s, float& c) {
+    const double n = rint(x * 6.36619772367581382433e-01);                 // 2/pi
+    double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+    r = fabs(r) <= 1.0 ? r : 0.0;
+    const float rf = (float)r, z = rf * rf;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(rf * z, ps, rf);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = (int)__builtin_fma(-4.0, rint(n * 0.25), n);              // n mod 4 in {-2 .. 2}
+    const float a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
 // a / b for a launch-wide b with rb = 1 / b correctly rounded (computed on the host): the quotient estimate, its exact
 // residual and one correction -- the correctly rounded quotient (Markstein), i.e. what the reference's division gives, in
 // three instructions instead of the ~35 of the general routine (no scaling or special cases needed: b is a hop, a sample
@@ -565,7 +585,7 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
 }
 
 // seeds of a body at sample s on the pieces (fa, ma): z = exp(i phase(s)), w = exp(i (phase(s+1) - phase(s))), amplitude
-#define PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)                                                                        \
+#define PVX_BODY_PHASE(c, s, ds, ts, fa)                                                                            \
     double ph_, dl_;                                                                                                \
     if (fa) {                                                                                                       \
         const double fa0_ = (c)->fa0, fsa_ = (c)->fsa;                                                              \
@@ -581,7 +601,9 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
         const double step_ = (c)->step;                                                                             \
         ph_ += __builtin_fma(step_, ds, (c)->ph0);                                                                  \
         dl_ += step_;                                                                                               \
-    }                                                                                                               \
+    }
+#define PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)                                                                        \
+    PVX_BODY_PHASE(c, s, ds, ts, fa)                                                                                \
     double zr, zi, wr, wi;                                                                                          \
     fsincos(ph_, zi, zr);                                                                                           \
     fsincos(dl_, wi, wr);                                                                                           \
@@ -600,8 +622,16 @@ constexpr int kTile = 40;                        // least records per wave and L
 #endif
 constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_synth_bodies: its waves never meet, and one-wave workgroups
                                                  // start as soon as ANY wave slot is free (four-wave ones wait for four: 124 against 129 us)
-template <int R>
-__global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_SYNTH_WAVES(R), PVX_SYNTH_WAVES(R)))) void k_synth_bodies(SampK q) {
+// S = double: the reference's arithmetic (every waveform fixture within 1e-10).  S = float (plans at precision 32, PVX_SYNTH_F32): the seeds
+// of a run from the float64 closed form as before -- the phase reaches 1e4 rad --, then the rotation recurrence, the amplitude
+// ramp and the R sums in float32: the recurrence's rounding grows like R^2 / 2 x 6e-8 = 3e-5 rad over a run of 32, inside the
+// stated precision-32 tolerance of 1e-4 max|w|, at half the vector-ALU cycles of the float64 loop and half the
+// registers for the sums (four waves per SIMD instead of three).
+#ifndef PVX_SYNTH_WAVES_F32
+#define PVX_SYNTH_WAVES_F32(R) ((R) <= 8 ? 6 : ((R) <= 16 ? 5 : 4))
+#endif
+template <int R, typename S = double>
+__global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((sizeof(S) == 4 ? PVX_SYNTH_WAVES_F32(R) : PVX_SYNTH_WAVES(R)), (sizeof(S) == 4 ? PVX_SYNTH_WAVES_F32(R) : PVX_SYNTH_WAVES(R))))) void k_synth_bodies(SampK q) {
     // everything is per wave (a wave's 64 runs are consecutive, so are the records of their segments): no workgroup barrier
     // (q.tile records per wave, at least kTile: all the records a wave's 64 runs can need -- a few segments' K slots -- so that
     // its lanes walk their segments' bodies together; with a tile shorter than that, the lanes of different segments take
@@ -626,7 +656,7 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
     else { s = q.c2 + (run - q.n0 - q.n1) * R; len = h - s; }
     if (len > R) len = R;
     const double ds = (double)s, ts = 0.5 * ds * (double)(s - 1);
-    double a[R];
+    S a[R];
     // where this thread's run goes, for the lanes that move it between memory and the wave's staging rows (four lanes per
     // run, 8 doubles at a time: an instruction then touches the 64 contiguous bytes of 16 runs)
     const bool flagged = live && q.segflag[seg] == q.gen;      // k_synth_extras has left this segment's attacks / releases in w
@@ -659,13 +689,13 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const double2 v = *(const double2*)(lds + lane * kLaneB + 16 * j);
-                a[8 * c8 + 2 * j] = v.x; a[8 * c8 + 2 * j + 1] = v.y;
+                a[8 * c8 + 2 * j] = (S)v.x; a[8 * c8 + 2 * j + 1] = (S)v.y;
             }
             __builtin_amdgcn_wave_barrier();
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < R; k++) a[k] = 0.0;
+        for (int k = 0; k < R; k++) a[k] = (S)0;
     }
     const bool mine = live && seg >= q.fb0 && seg < q.fb1;
     const int m0 = (seg - q.fx0) * K, m1 = m0 + K;                          // (a slice holds at most 2^20 + 2 EF K nodes)
@@ -698,6 +728,26 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
                     const BodyRec* c = (const BodyRec*)lds + (li - tile);
                     // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
                     const bool fa = s < c->fmb, ma = s < c->mmb;
+                    if constexpr (sizeof(S) == 4) {
+                        PVX_BODY_PHASE(c, s, ds, ts, fa)
+                        float zr, zi, wr, wi;
+                        fsincos_f(ph_, zi, zr);
+                        fsincos_f(dl_, wi, wr);
+                        const float dr = (float)(fa ? c->dar : c->dbr), di = (float)(fa ? c->dai : c->dbi);
+                        const float dms = (float)(ma ? c->msa : c->msb);
+                        float ms = (float)__builtin_fma(ma ? c->msa : c->msb, ds, ma ? c->ma0 : c->mb0);
+#pragma unroll
+                        for (int k = 0; k < R; k++) {
+                            a[k] = __builtin_fmaf(ms, zr, a[k]);                 // PVAnalysis.py:734-736
+                            const float t_ = __builtin_fmaf(zr, wr, -(zi * wi));
+                            zi = __builtin_fmaf(zr, wi, zi * wr);
+                            zr = t_;
+                            const float u_ = __builtin_fmaf(wr, dr, __builtin_fmaf(-wi, di, wr));
+                            wi = __builtin_fmaf(wr, di, __builtin_fmaf(wi, dr, wi));
+                            wr = u_;
+                            ms += dms;
+                        }
+                    } else {
                     PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
 #pragma unroll
                     for (int k = 0; k < R; k++) {
@@ -705,6 +755,7 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
                         PVX_CMUL(zr, zi, wr, wi);
                         PVX_CROT(wr, wi, dr, di);
                         ms += dms;
+                    }
                     }
                 });
             }
@@ -719,7 +770,7 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu(PVX_S
 #pragma unroll
     for (int c8 = 0; c8 < R / 8; c8++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) *(double2*)(lds + lane * kLaneB + 16 * j) = make_double2(a[8 * c8 + 2 * j], a[8 * c8 + 2 * j + 1]);
+        for (int j = 0; j < 4; j++) *(double2*)(lds + lane * kLaneB + 16 * j) = make_double2((double)a[8 * c8 + 2 * j], (double)a[8 * c8 + 2 * j + 1]);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -1093,9 +1144,15 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
             k.tile = (int)need;
         }
         const size_t blds = (size_t)k.tile * sizeof(BodyRec) * (kBodiesTB / 64);
+        if (p.f32_samples) {
+            if (R == 8) hipLaunchKernelGGL((k_synth_bodies<8, float>), grid, dim3(kBodiesTB), blds, s, k);
+            else if (R == 16) hipLaunchKernelGGL((k_synth_bodies<16, float>), grid, dim3(kBodiesTB), blds, s, k);
+            else hipLaunchKernelGGL((k_synth_bodies<32, float>), grid, dim3(kBodiesTB), blds, s, k);
+        } else {
         if (R == 8) hipLaunchKernelGGL(k_synth_bodies<8>, grid, dim3(kBodiesTB), blds, s, k);
         else if (R == 16) hipLaunchKernelGGL(k_synth_bodies<16>, grid, dim3(kBodiesTB), blds, s, k);
         else hipLaunchKernelGGL(k_synth_bodies<32>, grid, dim3(kBodiesTB), blds, s, k);
+        }
     }
     PVX_HIP_CHECK(hipGetLastError());
     return PVX_OK;

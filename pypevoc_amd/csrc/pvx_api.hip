@@ -147,6 +147,10 @@ struct pvx_plan {
     double sr = 0, pkthresh = 0, wfact = 0, fstep = 0, dt = 0;
     int nfft = 0, hop = 0, npks = 0, N2 = 0, precision = 32, fft_mode = 0;
     int64_t max_rows = 0;     // rows per launch (without the halo row)
+    bool rows_from_env = false;   // ... as PVX_MAX_ROWS set them
+    const char* last_analysis = nullptr;   // kernels of the last calls (pvx_plan_last_kernels)
+    const char* last_synth = nullptr;
+    std::string last_kernels;
     int64_t ldi = 0, ldo = 0; // workspace row pitches (elements / complex elements)
     std::vector<double> win;  // caller's window
     bool win_symmetric = false;  // win[n] == win[nfft-1-n] for every n
@@ -234,6 +238,14 @@ struct pvx_plan {
 };
 static int plan_device(const pvx_plan* p) { return p->device; }
 extern "C" int pvx_plan_device(const pvx_plan* plan) { return plan ? plan->device : PVX_ERR_INVALID; }
+extern "C" const char* pvx_plan_last_kernels(const pvx_plan* plan) {
+    if (!plan) return "";
+    pvx_plan* p = const_cast<pvx_plan*>(plan);
+    p->last_kernels.clear();
+    if (p->last_analysis) { p->last_kernels += "analysis="; p->last_kernels += p->last_analysis; }
+    if (p->last_synth) { if (!p->last_kernels.empty()) p->last_kernels += ";"; p->last_kernels += "synth="; p->last_kernels += p->last_synth; }
+    return p->last_kernels.c_str();
+}
 
 static size_t real_size(int precision) { return precision == 32 ? 4 : 8; }
 
@@ -382,7 +394,7 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
     if (cap_rows > 65536) cap_rows = 65536;
     if (const char* e = getenv("PVX_MAX_ROWS")) {
         const long long v = atoll(e);
-        if (v >= 2) cap_rows = (int64_t)v;
+        if (v >= 2) { cap_rows = (int64_t)v; p->rows_from_env = true; }
     }
     if (const char* e = getenv("PVX_FPW")) {
         const int v = atoi(e);
@@ -677,8 +689,11 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
            : (p->fft_mode == 5) ? pvx_launch_fused_team(fp, p->nfft, x_dtype, s) : pvx_launch_fused_rev(fp, p->nfft, x_dtype, s);
         // (what the plan could not know when it chose the team kernel -- a salience radius beyond its fetch, a row count
         // beyond 32 bits -- goes to the kernel of several waves per frame instead of failing the call)
-        if (rc == PVX_ERR_UNSUPPORTED && p->fft_mode == 5 && pvx_fused_mw_supported(p->nfft, p->precision, p->npks))
+        p->last_analysis = p->fft_mode == 1 ? "k_fused" : p->fft_mode == 2 ? "k_fused_mw" : p->fft_mode == 3 ? "k_fused_ring" : p->fft_mode == 5 ? "k_fused_team" : "k_fused_rev";
+        if (rc == PVX_ERR_UNSUPPORTED && p->fft_mode == 5 && pvx_fused_mw_supported(p->nfft, p->precision, p->npks)) {
             rc = pvx_launch_fused_mw(fp, p->nfft, x_dtype, s);
+            p->last_analysis = "k_fused_mw";
+        }
         if (rc != PVX_OK) return rc;
         return plan_event(p, s, -1);
     }
@@ -706,11 +721,18 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
             if ((rc = grow_dev(&p->d_pvstage, &p->pvstage_cap, need)) != PVX_OK) return rc;
             rp.stage = p->d_pvstage; rp.stage_bytes = p->pvstage_cap;
         }
-        if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
-        if ((rc = pvx_launch_pv_rev(rp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
-        if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
+        // one launch -- unless the caller set PVX_MAX_ROWS: then pieces of that many rows, each reported (tests, progress displays)
+        const int64_t piece = p->rows_from_env ? p->max_rows : total_rows;
+        for (int64_t R0 = 0; R0 < total_rows; R0 += piece) {
+            rp.row_begin = R0; rp.row_end = (total_rows - R0 < piece) ? total_rows : R0 + piece;
+            if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
+            if ((rc = pvx_launch_pv_rev(rp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
+            if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
+            if ((rc = plan_progress(p, s, rp.row_end, total_rows, nsig)) != PVX_OK) return rc;
+        }
         p->last_from_rev = spec_row >= 0;
-        return plan_progress(p, s, total_rows, total_rows, nsig);
+        p->last_analysis = "k_pv_rev";
+        return PVX_OK;
     }
     if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
     else {
@@ -743,6 +765,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
             if ((rc = pvx_launch_stft_pv(fp, pp, p->d_spec, p->ldo, p->d_twiddle64, x_dtype, p->precision, s)) != PVX_OK) return rc;
             if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
             if ((rc = plan_progress(p, s, R0 + nrows, total_rows, nsig)) != PVX_OK) return rc;
+            p->last_analysis = "k_stft_pv";
             continue;
         }
         if ((rc = plan_event(p, s, 0)) != PVX_OK) return rc;
@@ -758,6 +781,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         }
         if ((rc = plan_event(p, s, 2)) != PVX_OK) return rc;
         if ((rc = pvx_launch_phase_peaks(pp, p->precision, s)) != PVX_OK) return rc;
+        p->last_analysis = p->use_stft ? "k_stft+k_phase_peaks" : "k_frames+rocfft+k_phase_peaks";
         if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
         if ((rc = plan_progress(p, s, R0 + nrows, total_rows, nsig)) != PVX_OK) return rc;
     }

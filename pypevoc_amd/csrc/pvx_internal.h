@@ -145,6 +145,7 @@ int pvx_launch_stft_pv(const FrameParams& fp, const PeaksParams& pp, void* spec,
 struct PvRevParams {
     const void* x;        // input samples
     int64_t sig_stride, F, total_rows;
+    int64_t row_begin, row_end;   // the global rows this launch analyses (all: 0, total_rows)
     int hop, K, rad;
     double thr, sr, fstep, dt;
     const double* wfbin;
@@ -215,6 +216,7 @@ struct SynthParams {
     double* w;
     int64_t wlen;
     int no_phcor;         // PVX_SYNTH_NO_PHCOR: fstep=None partials (PV.py:710-713)
+    int f32_samples = 0;  // PVX_SYNTH_F32 (plans at precision 32): the bodies' sample loop in float32 (k_synth_bodies<R, float>)
     int64_t seg0 = 0;     // first output segment (hop) of this launch ...
     int64_t seg_count = 0;   // ... and how many (0: all from seg0 on)
     // device workspace of pvx_synth_ws_bytes() bytes (nullptr: a grow-only buffer per stream, owned by the library);

@@ -870,6 +870,13 @@ def test_descending_float64_kernel_is_bit_identical_to_the_row_storing_one(amd, 
         for k in keys:
             assert np.array_equal(np.asarray(getattr(q, k)), np.asarray(getattr(ref, k))), ("chunks", fpc, k)
         assert np.array_equal(q.oldfft, ref.oldfft)
+    # ... and one call as launches of PVX_MAX_ROWS rows each (what a progress display asks for)
+    monkeypatch.setenv("PVX_MAX_ROWS", "37")
+    q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+    monkeypatch.delenv("PVX_MAX_ROWS")
+    for k in keys:
+        assert np.array_equal(np.asarray(getattr(q, k)), np.asarray(getattr(ref, k))), ("pieces", k)
+    assert np.array_equal(q.oldfft, ref.oldfft)
 
 
 def _lib_mode(p):
