@@ -850,9 +850,13 @@ def main():
                     wlen = int(lib.pvx_synth_len(maxend, NFFT, HOP, HOP, 1.0))
                     w_d = torch.empty(wlen, dtype=torch.float64, device=dev)
 
+                    # what SinSum.synth of this analysis runs: the float32 sample loop for a precision-32 plan (k_synth_bodies<R, float>,
+                    # stated tolerance 1e-4 max|w|), the float64 one at precision 64 (1e-9 here, 1e-10 on the fixtures)
+                    sflags = _lib.PVX_SYNTH_F32 if args.precision == 32 else 0
+
                     def synth_once():
-                        _lib.check(lib.pvx_synth_dev(d_f, d_mag, d_rp, pid_d.data_ptr(), F, K, pst_d.data_ptr(), pln_d.data_ptr(), P, float(sr), NFFT, HOP, HOP,
-                                                     1.0, 3, w_d.data_ptr(), wlen, sp), "pvx_synth_dev")
+                        _lib.check(lib.pvx_synth_dev_flags(d_f, d_mag, d_rp, pid_d.data_ptr(), F, K, pst_d.data_ptr(), pln_d.data_ptr(), P, float(sr), NFFT, HOP, HOP,
+                                                           1.0, 3, w_d.data_ptr(), wlen, sp, sflags), "pvx_synth_dev_flags")
 
                     synth_once()
                     e0 = torch.cuda.Event(enable_timing=True)
@@ -865,7 +869,8 @@ def main():
                     ms_syn = e0.elapsed_time(e1) / 5
                     chain["resynthesis"] = dict(value=round(F / ms_syn * 1e3, 1), unit="frames/s", ms=round(ms_syn, 4), samples_out=wlen,
                                                 samples_per_s=round(wlen / ms_syn * 1e3, 1), output_GBps=round(wlen * 8 / ms_syn / 1e6, 1),
-                                                what="pvx_synth_dev (k_synth.hip: alloc, scatter, params, extras, bodies), waveform left in HBM; HIP events over 5 launches")
+                                                sample_loop="f32" if sflags else "f64",
+                                                what="pvx_synth_dev_flags (k_synth.hip: params, extras, bodies), waveform left in HBM; HIP events over 5 launches")
                     # the whole path device to device: one analysis step, the tracker and the resynthesis back to back on the
                     # resident signal (wall clock around the three calls; the tracker's call returns the partial count)
                     rpl = rp2[last]
@@ -908,8 +913,9 @@ def main():
                         ncmp = (FC - 8) * HOP
                         hw = w_d[:ncmp].cpu().numpy()
                         err = float(np.abs(hw - ow[:ncmp]).max())
-                        okw = err <= 1e-9 * max(1.0, float(np.abs(ow[:ncmp]).max()))
-                        chain["resynthesis"]["check"] = dict(ok=bool(okw), max_abs_err=err, samples_compared=int(ncmp),
+                        wtol = 1e-4 * float(np.abs(ow[:ncmp]).max()) if sflags else 1e-9 * max(1.0, float(np.abs(ow[:ncmp]).max()))
+                        okw = err <= wtol
+                        chain["resynthesis"]["check"] = dict(ok=bool(okw), max_abs_err=err, tolerance=wtol, samples_compared=int(ncmp),
                                                              against="oracle/pvoracle.c resynthesis of the first %d frames of the same arrays" % FC)
                         if not (same_tab and okw):
                             sys.stderr.write("bench.py: the tracker / resynthesis of the headline results differ from the oracle: %s\n" % json.dumps(chain))

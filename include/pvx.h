@@ -299,6 +299,10 @@ int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph
  * only carry the overlap (hop_analysis / nfft).
  */
 #define PVX_SYNTH_NO_PHCOR 1
+/* PVX_SYNTH_F32: the sample loop of the partials' bodies in float32 (what pvx_synth_resident does for a plan at precision 32):
+ * the seeds of every run of 32 samples still come from the float64 closed form; waveform within 1e-4 max|w| of the float64 one
+ * (measured: see DESIGN.md), at about half the time. */
+#define PVX_SYNTH_F32 2
 int pvx_synth_flags(const double* f, const double* mag, const double* realph, const int32_t* partial_id,
                     int64_t F, int K, const int32_t* part_start, const int32_t* part_len, int64_t P,
                     double sr, int nfft, int hop_analysis, int hop_synth, double edge, int minframes,

@@ -538,6 +538,7 @@ class PV(object):
         call add_frame without it), so tracks are always built with the 0.5-semitone default.
         '''
         ss = SinSum(self.sr, nfft=self.nfft, hop=self.hop)
+        ss._precision = int(self.precision)                      # (32: SinSum.synth's sample loop in float32, like the analysis)
         if self.nframes > 0:
             if self._on_device():
                 ss._from_resident(self)                          # tracker on the arrays in HBM, table stays there
@@ -829,6 +830,7 @@ class SinSum(object):
         self._tab = None
         self._materialised = True
         self._rpv = None            # the PV whose resident results (and resident partial table) this object reads
+        self._precision = 64        # 32 for the SinSum of a precision-32 analysis: the resynthesis' sample loop in float32 (tolerance 1e-4 max|w|)
         self._rP = 0
         self._rmaxend = -1
 
@@ -840,6 +842,7 @@ class SinSum(object):
         P = _lib.load().pvx_track_resident(pv._plan.handle, float(maxpitchjmp), ctypes.byref(me))
         _lib.check(P, "pvx_track_resident")
         self._rpv, self._rP, self._rmaxend = pv, int(P), int(me.value)
+        self._precision = int(getattr(pv, "precision", 64))
         self._tab = None
         self._materialised = False
         pv._dependents.append(weakref.ref(self))
@@ -1070,15 +1073,17 @@ class SinSum(object):
                        "pvx_synth_resident")
             return w
         self._detach_resident()
+        # (the SinSum of a precision-32 analysis resynthesises like its resident form does: float32 sample loop)
+        flags = _lib.PVX_SYNTH_F32 if (self._precision == 32 and not os.environ.get("PVX_SYNTH_F64")) else 0
         if self._tab is not None and not self._tab_dirty:
             tab = self._tab
             if len(tab['st']) == 0:
                 raise ValueError("max() arg is an empty sequence")
             return _device_synth(tab['f'], tab['mag'], tab['realph'], tab['pid'], tab['st'], tab['ln'],
-                                 sr, self.nfft, int(self.hop), hop, edge, minframes)
+                                 sr, self.nfft, int(self.hop), hop, edge, minframes, flags)
         self._materialise()
         f, mag, rp, pid, st, ln = self._pack_partials()
-        return _device_synth(f, mag, rp, pid, st, ln, sr, self.nfft, int(self.hop), hop, edge, minframes)
+        return _device_synth(f, mag, rp, pid, st, ln, sr, self.nfft, int(self.hop), hop, edge, minframes, flags)
 
     def get_avfreq(self):
         return np.array([np.mean(xx.f) for xx in self.partial])

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVX_LIB") or os.path.join(_HERE, "libpvx_hip.so")   # PVX_LIB: A/B builds of the same library
 
 PVX_SYNTH_NO_PHCOR = 1
+PVX_SYNTH_F32 = 2
 PVX_ERR_SIZE = -6            # include/pvx.h
 PVX_F32, PVX_F64, PVX_I16 = 0, 1, 2
 

@@ -731,11 +731,18 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
                     if constexpr (sizeof(S) == 4) {
                         PVX_BODY_PHASE(c, s, ds, ts, fa)
                         float zr, zi, wr, wi;
+#ifdef PVX_AB_SYNTH_NOSEED      // tools/ab: timing-only builds (wrong waveform)
+                        zr = (float)ph_; zi = 0.f; wr = (float)dl_; wi = 0.f;
+#else
                         fsincos_f(ph_, zi, zr);
                         fsincos_f(dl_, wi, wr);
+#endif
                         const float dr = (float)(fa ? c->dar : c->dbr), di = (float)(fa ? c->dai : c->dbi);
                         const float dms = (float)(ma ? c->msa : c->msb);
                         float ms = (float)__builtin_fma(ma ? c->msa : c->msb, ds, ma ? c->ma0 : c->mb0);
+#ifdef PVX_AB_SYNTH_NOLOOP
+                        a[0] += ms * zr + wr * dr + wi * di + dms;
+#else
 #pragma unroll
                         for (int k = 0; k < R; k++) {
                             a[k] = __builtin_fmaf(ms, zr, a[k]);                 // PVAnalysis.py:734-736
@@ -747,6 +754,7 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
                             wr = u_;
                             ms += dms;
                         }
+#endif
                     } else {
                     PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
 #pragma unroll
@@ -777,7 +785,11 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
             const double2 v = *(const double2*)(lds + (16 * i + (lane >> 2)) * kLaneB + 16 * (lane & 3));
             const int k = 8 * c8 + 2 * (lane & 3);
             const long long o = oo[i] + k;
+#ifdef PVX_AB_SYNTH_NOSTORE      // tools/ab: timing-only build without the waveform stores
+            const bool v0 = k < ll[i] && o < q.wlen && q.wlen < 0, v1 = k + 1 < ll[i] && o + 1 < q.wlen && q.wlen < 0;
+#else
             const bool v0 = k < ll[i] && o < q.wlen, v1 = k + 1 < ll[i] && o + 1 < q.wlen;
+#endif
             if (v0 && v1 && (o & 1) == 0) *(double2*)(q.w + o) = v;
             else {
                 if (v0) q.w[o] = v.x;

@@ -1627,7 +1627,10 @@ extern "C" int64_t pvx_synth_len(int64_t max_end_frame, int nfft, int hop_analys
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
                        double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
-                       void* ws, size_t ws_bytes, unsigned* ws_gen);
+                       void* ws, size_t ws_bytes, unsigned* ws_gen, int f32_samples);
+// plans at precision 32 resynthesise with the float32 sample loop (k_synth_bodies<R, float>: the stated waveform tolerance there is
+// 1e-4 max|w|); PVX_SYNTH_F64=1: the float64 loop whatever the plan's precision (tests, A/B)
+static int plan_synth_f32(const pvx_plan* p);
 
 // ---- the chain on resident results: toSinSum -> synth, descriptors -------------------------------
 extern "C" int64_t pvx_track_resident(pvx_plan* p, double maxpitchjmp, int64_t* max_end_frame) {
@@ -1699,7 +1702,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         // it (posted writes over PCIe, spread over the kernel's run time as workgroups finish) -- no copy operation
         // behind the kernel at all
         rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                         p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen);
+                         p->hop, hop_synth, edge, minframes, w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen, plan_synth_f32(p));
         if (rc != PVX_OK) return rc;
         tr.mark("kernel issued");
         PVX_HIP_CHECK(hipStreamSynchronize(p->s_host));
@@ -1719,7 +1722,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
             if (s0 >= nseg) break;
             const int64_t cnt = nseg - s0 < per ? nseg - s0 : per;
             rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft, p->hop, hop_synth,
-                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0, p->d_sws, p->sws_cap, &p->sws_gen);
+                             edge, minframes, p->d_w, wlen, p->s_host, s0, cnt, i == 0, p->d_sws, p->sws_cap, &p->sws_gen, plan_synth_f32(p));
             if (rc != PVX_OK) return rc;
             PVX_HIP_CHECK(hipEventRecord(p->ev_ring[i], p->s_host));
             PVX_HIP_CHECK(hipStreamWaitEvent(p->s_copy, p->ev_ring[i], 0));
@@ -1733,7 +1736,7 @@ extern "C" int pvx_synth_resident(pvx_plan* p, double sr, int hop_synth, double 
         return PVX_OK;
     }
     rc = synth_slice(all.f, all.mag, all.realph, p->d_pid, p->res_F, p->npks, p->d_pst, p->d_pln, p->res_P, sr, p->nfft,
-                     p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen);
+                     p->hop, hop_synth, edge, minframes, p->d_w, wlen, p->s_host, 0, 0, true, p->d_sws, p->sws_cap, &p->sws_gen, plan_synth_f32(p));
     if (rc != PVX_OK) return rc;
     if (pinned) {
         // the caller's array is page-locked: the DMA lands in it, nothing to stage or copy
@@ -2191,6 +2194,7 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
     sp.part_start = d_part_start; sp.part_len = d_part_len; sp.F = F; sp.P = P; sp.K = K;
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
     sp.w = d_w; sp.wlen = wlen; sp.no_phcor = (flags & PVX_SYNTH_NO_PHCOR) ? 1 : 0;
+    sp.f32_samples = (flags & PVX_SYNTH_F32) ? 1 : 0;
     return pvx_launch_synth(sp, (hipStream_t)stream);
 }
 
@@ -2198,8 +2202,9 @@ extern "C" int pvx_synth_dev_flags(const double* d_f, const double* d_mag, const
 static int synth_slice(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id, int64_t F, int K,
                        const int32_t* d_part_start, const int32_t* d_part_len, int64_t P, double sr, int nfft, int hop_analysis, int hop_synth,
                        double edge, int minframes, double* d_w, int64_t wlen, hipStream_t stream, int64_t seg0, int64_t seg_count, bool first,
-                       void* ws, size_t ws_bytes, unsigned* ws_gen) {
+                       void* ws, size_t ws_bytes, unsigned* ws_gen, int f32_samples) {
     SynthParams sp;
+    sp.f32_samples = f32_samples;
     sp.skip_prepare = first ? 0 : 1;          // the partial-major copy of the analysis arrays is made with the first slice
     sp.ws = ws; sp.ws_bytes = ws_bytes; sp.ws_gen = ws_gen;
     sp.f = d_f; sp.mag = d_mag; sp.realph = d_realph; sp.partial_id = d_partial_id;
@@ -2207,6 +2212,12 @@ static int synth_slice(const double* d_f, const double* d_mag, const double* d_r
     sp.sr = sr; sp.edge = edge; sp.nfft = nfft; sp.hop_a = hop_analysis; sp.hop_s = hop_synth; sp.minframes = minframes;
     sp.w = d_w; sp.wlen = wlen; sp.no_phcor = 0; sp.seg0 = seg0; sp.seg_count = seg_count;
     return pvx_launch_synth(sp, stream);
+}
+
+static int plan_synth_f32(const pvx_plan* p) {
+    const int f32 = (p->precision == 32 && getenv("PVX_SYNTH_F64") == nullptr) ? 1 : 0;
+    const_cast<pvx_plan*>(p)->last_synth = f32 ? "k_synth_bodies<f32>" : "k_synth_bodies<f64>";
+    return f32;
 }
 
 extern "C" int pvx_synth_dev(const double* d_f, const double* d_mag, const double* d_realph, const int32_t* d_partial_id,

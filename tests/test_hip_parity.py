@@ -257,30 +257,76 @@ def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
     ref = g["w_hop%d" % h].astype(np.float64)
     p = run_golden(amd, g, 32)
     ss = p.toSinSum()
-    ws = {}
-    for run in ("8", "16", "32"):
-        monkeypatch.setenv("PVX_SYNTH_RUN", run)
-        ws[run] = ss.synth(g["sr"], h)
-        assert np.abs(ws[run] - ref).max() <= 1e-4 * np.abs(ref).max()
-        # the same additions in the same order whatever the slices (each slice recomputes the records it needs)
-        monkeypatch.setenv("PVX_SYNTH_SLICE", "7")
-        assert np.array_equal(ss.synth(g["sr"], h), ws[run])
-        monkeypatch.delenv("PVX_SYNTH_SLICE")
-        # ... and float64 round-off apart when every body takes the general path
-        monkeypatch.setenv("PVX_SYNTH_NO_CUTS", "1")
-        wx = ss.synth(g["sr"], h)
-        monkeypatch.delenv("PVX_SYNTH_NO_CUTS")
-        assert np.abs(wx - ws[run]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
-    monkeypatch.delenv("PVX_SYNTH_RUN")
-    assert np.abs(ws["16"] - ws["32"]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # a precision-32 plan resynthesises with the float32 sample loop (k_synth_bodies<R, float>); PVX_SYNTH_F64=1: the float64 one.
+    # The launch shapes give the same additions in the same order: float64 round-off apart in float64, float32 round-off in float32.
+    for loop, rel in (("f64", 1e-12), ("f32", 2e-5)):
+        if loop == "f64":
+            monkeypatch.setenv("PVX_SYNTH_F64", "1")
+        ws = {}
+        for run in ("8", "16", "32"):
+            monkeypatch.setenv("PVX_SYNTH_RUN", run)
+            ws[run] = ss.synth(g["sr"], h)
+            assert np.abs(ws[run] - ref).max() <= 1e-4 * np.abs(ref).max()
+            # the same additions in the same order whatever the slices (each slice recomputes the records it needs)
+            monkeypatch.setenv("PVX_SYNTH_SLICE", "7")
+            assert np.array_equal(ss.synth(g["sr"], h), ws[run])
+            monkeypatch.delenv("PVX_SYNTH_SLICE")
+            # ... and round-off apart when every body takes the general path
+            monkeypatch.setenv("PVX_SYNTH_NO_CUTS", "1")
+            wx = ss.synth(g["sr"], h)
+            monkeypatch.delenv("PVX_SYNTH_NO_CUTS")
+            assert np.abs(wx - ws[run]).max() <= rel * max(1.0, np.abs(ref).max()), (loop, run)
+        monkeypatch.delenv("PVX_SYNTH_RUN")
+        assert np.abs(ws["16"] - ws["32"]).max() <= rel * max(1.0, np.abs(ref).max()), loop
+        if loop == "f64":
+            w64 = ws["32"].copy()
+            monkeypatch.delenv("PVX_SYNTH_F64")
+        else:
+            assert 0 < np.abs(ws["32"] - w64).max() <= 2e-5 * np.abs(ref).max()      # the two loops differ, by float32 round-off
     keep = ws["32"].copy()
     w3 = ss.synth(g["sr"], h)                      # a third buffer of the same size while two are alive
     assert ws["32"].flags.writeable and np.array_equal(ws["32"], keep)
     w3 += 1.0
     assert np.array_equal(ws["32"], keep)
     del ws, w3
-    w4 = ss.synth(g["sr"], h)                      # reuses a returned buffer
-    assert np.abs(w4 - keep).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    w4 = ss.synth(g["sr"], h)                      # reuses a returned buffer (default run length, float32 loop: round-off apart)
+    assert np.abs(w4 - keep).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_resynthesis_sample_loop_follows_the_plan_precision(amd, monkeypatch):
+    """SinSum.synth of a precision-32 analysis runs k_synth_bodies<R, float> (float64 seeds per run, the rotation recurrence, the
+    amplitude ramp and the sums in float32: waveform within the stated 1e-4 max|w| of the reference's), of a precision-64 analysis
+    k_synth_bodies<R, double> (<= 1e-10); pvx_plan_last_kernels says which ran.  The host chain of a SinSum (results edited on the
+    host) follows its analysis' precision too; PVX_SYNTH_F64=1 forces the float64 loop."""
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+    for name in ("G4_harm8_vibrato", "G7_perlman"):
+        g = load_golden(name)
+        h = int(g["hop"])
+        ref = g["w_hop%d" % h].astype(np.float64)
+        out = {}
+        for prec in (32, 64):
+            p = run_golden(amd, g, prec)
+            ss = p.toSinSum()
+            out[prec] = np.array(ss.synth(g["sr"], h))
+            kern = lib.pvx_plan_last_kernels(p._plan.handle).decode()
+            assert ("synth=k_synth_bodies<f32>" if prec == 32 else "synth=k_synth_bodies<f64>") in kern, (prec, kern)
+            assert ("analysis=k_fused" if prec == 32 else "analysis=k_") in kern, kern
+            tol = 1e-4 * np.abs(ref).max() if prec == 32 else (1e-10 if g["w_hop%d" % h].dtype == np.float64 else 2e-7) * max(1.0, np.abs(ref).max())
+            assert np.abs(out[prec] - ref).max() <= tol, (name, prec, float(np.abs(out[prec] - ref).max()))
+            if prec == 32:
+                monkeypatch.setenv("PVX_SYNTH_F64", "1")
+                w_forced = np.array(ss.synth(g["sr"], h))
+                monkeypatch.delenv("PVX_SYNTH_F64")
+                assert "synth=k_synth_bodies<f64>" in lib.pvx_plan_last_kernels(p._plan.handle).decode()
+                d = np.abs(w_forced - out[32]).max()
+                assert 0 < d <= 2e-5 * np.abs(ref).max(), d                  # float32 round-off of the sample loop, nothing else
+                # the host chain (an edited result takes the object off the resident path): the same loop as the resident one
+                p.mag = np.array(p.mag)
+                sh = p.toSinSum()
+                assert sh._precision == 32
+                wh = np.array(sh.synth(g["sr"], h))
+                assert np.abs(wh - out[32]).max() <= 1e-6 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("name", ["G4_harm8_vibrato", "G6_silence_gaps", "G12_hop_eighth", "G2_readme_defaulthop"])
