@@ -288,7 +288,7 @@ def compact_line(full, detail_path):
     if "extras_ok" in full:
         out["extras_ok"] = full["extras_ok"]
     if full.get("gather"):
-        out["gather"] = {k: full["gather"].get(k) for k in ("collective", "rccl_world", "wire_bytes_per_rank", "result_bytes_per_rank", "exposed_ms_per_step",
+        out["gather"] = {k: full["gather"].get(k) for k in ("collective", "rccl_world", "wire_bytes_per_rank", "result_bytes_per_rank", "exposed_ms_per_step", "host_issue_ms_per_step",
                                                             "valid_peaks_gathered", "checked_signals", "check_ok") if k in full["gather"]}
     out["detail"] = detail_path
     s = json.dumps(out, separators=(",", ":"))
@@ -327,6 +327,7 @@ def main():
                     help="where the full record goes (config5 points, workloads, other_nfft, issue view, every oracle check); stdout carries one compact line")
     ap.add_argument("--seconds", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--shard-signals", type=int, default=0, help=argparse.SUPPRESS)    # tests: fewer signals per GPU than the workload's
+    ap.add_argument("--comm-cus", type=int, default=0, help="gathered runs: compute units left without an analysis workgroup, for the collective's kernels (0: none)")
     ap.add_argument("--unpack-in-step", action="store_true", help="rank 0 unpacks every gathered block inside the step (default: the blocks stay in wire format)")
     ap.add_argument("--check-gathered", type=int, default=0,
                     help="with a gather (N > 1, or PVX_BENCH_FORCE_GATHER=1): compare the gathered + unpacked results of rank 0's first "
@@ -389,6 +390,16 @@ def main():
             _lib.check(lib.pvx_plan_set_fft_mode(pl, mode), "pvx_plan_set_fft_mode")
         return pl
 
+    # --comm-cus N (default 0): a gathered run may leave N compute units without an analysis workgroup -- k_fused_rev puts ONE workgroup of
+    # twelve waves on every CU for the whole launch (504 of a SIMD's 512 vector registers), so a collective's kernels find no CU before
+    # the analysis has finished.  Measured with the collective forced at world size 1 it does not pay (0.1199 ms per step with none,
+    # 0.1241 with eight, 0.1319 with 32: profiles/r06_ab_steps.txt) -- what a gathered step waited for was the stream-level wait on the
+    # slot's previous gather, see PipelinedGather.host_retire --; kept for an N > 1 run to try.
+    gathered = world > 1 or os.environ.get("PVX_BENCH_FORCE_GATHER") == "1"
+    if gathered and args.comm_cus > 0 and "PVX_FUSED_BLOCKS" not in os.environ:
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if ncu > 2 * args.comm_cus:
+            os.environ["PVX_FUSED_BLOCKS"] = str(ncu - args.comm_cus)
     plan = make_plan(args.precision, args.fft_mode)
     # compute runs on an explicit stream, never on the legacy default stream: launches there synchronise
     # implicitly with other streams
@@ -405,7 +416,6 @@ def main():
     # packed to the 18 B/slot wire format (include/pvx.h), gathered asynchronously (RCCL, its own
     # stream, double-buffered so that the gather of step i overlaps the kernels of step i+1) and
     # unpacked on rank 0 into the full [world, ...] result, bit-identical to what each rank computed.
-    gathered = world > 1 or os.environ.get("PVX_BENCH_FORCE_GATHER") == "1"
     if gathered and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -425,10 +435,16 @@ def main():
     # The gathered blocks stay in the wire format on rank 0 (bit-exact, decoded when somebody reads them -- here after
     # the timed region, for the checks): unpacking world blocks per step on rank 0 would load the one rank every other
     # rank waits for with world x the work of a step's pack.  --unpack-in-step restores the unpack inside the step.
-    pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume if args.unpack_in_step else None, force=gathered)
-    pack_stream = torch.cuda.Stream(device=dev) if gathered else None
-    packed = [None, None]                                          # events: res2[j] has been packed
+    # (four slots, retired by the host: the compute stream never waits for a collective -- see PipelinedGather.host_retire)
+    pipe = PipelinedGather(wire.nbytes, torch.uint8, dev, dst=0, consume=consume if args.unpack_in_step else None, force=gathered,
+                           depth=2 if args.unpack_in_step else 4, host_retire=not args.unpack_in_step)
     counter = [0]
+    if gathered:
+        # (the frame times of the two result blocks, once: the wire format does not carry them)
+        for j in range(2):
+            _lib.check(lib.pvx_analyze_dev(plan, x.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, rp2[j][0], rp2[j][1], rp2[j][2], rp2[j][3], rp2[j][4],
+                                           tp2[j], rp2[j][5], None, ctypes.c_void_p(stream.cuda_stream)), "pvx_analyze_dev")
+        torch.cuda.synchronize(dev)
 
     def step(single=False):
         i = counter[0]
@@ -436,34 +452,36 @@ def main():
         j = i % 2
         single = single or args.streams == 1
         cs = cstreams[0] if single else cstreams[j]
-        if packed[j] is not None:
-            cs.wait_event(packed[j])              # the pack of step i-2 has read this block
+        if gathered:
+            # the analysis writes the step's rows straight into the wire block the gather sends (pvx_analyze_dev_wire: k_fused_rev
+            # stores 18 B per slot itself; a packing kernel behind it could not run beside the next step's analysis -- twelve waves
+            # of 168 registers leave a CU none for another kernel -- and cost a gathered step 23 us of 125)
+            with torch.cuda.stream(cs):
+                buf = pipe.buffer(i)              # its previous gather has completed (and been unpacked): cs waits for it
+                r = lib.pvx_analyze_dev_wire(plans[0] if single else plans[j], x.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp,
+                                             buf.data_ptr(), ctypes.c_void_p(cs.cuda_stream))
+                _lib.check(r, "pvx_analyze_dev_wire")
+                if not os.environ.get("PVX_BENCH_NO_SUBMIT"):     # (A/B: the step without its collective)
+                    pipe.submit(i)                # asynchronous gather to rank 0 (RCCL's stream waits for cs here)
+            return j
         rp = rp2[j]
         r = lib.pvx_analyze_dev(plans[0] if single else plans[j], x.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp,
                                 rp[0], rp[1], rp[2], rp[3], rp[4], tp2[j], rp[5], None, ctypes.c_void_p(cs.cuda_stream))
         _lib.check(r, "pvx_analyze_dev")
-        if gathered:
-            done = torch.cuda.Event()
-            done.record(cs)
-            with torch.cuda.stream(pack_stream):
-                pack_stream.wait_event(done)
-                buf = pipe.buffer(i)              # its previous gather has completed and been unpacked
-                wire.pack(res2[j].data_ptr(), buf.data_ptr(), ctypes.c_void_p(pack_stream.cuda_stream))
-                ev = torch.cuda.Event()
-                ev.record(pack_stream)
-                packed[j] = ev
-                pipe.submit(i)                    # asynchronous gather to rank 0
         return j
 
+    def local_block(step_no, j):
+        """gathered runs: this rank's rows of step `step_no` in the reference's layout, decoded from the wire block it sent (after a fence)"""
+        wire.unpack(pipe.bufs[step_no % pipe.depth].data_ptr(), res2[j].data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize(dev)
+
     def fence():
-        if gathered:
-            with torch.cuda.stream(pack_stream):
-                pipe.drain()                      # every outstanding gather has been waited for and unpacked
-        else:
-            pipe.drain()
+        pipe.drain()                              # every outstanding gather has been waited for (and unpacked)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    enq = [0.0]
 
     def timed(nsteps):
         """Exactly nsteps steps between two fences; returns (wall seconds, HIP-event ms, result block index of the last step)."""
@@ -477,6 +495,7 @@ def main():
         last = 0
         for _ in range(nsteps):
             last = step()
+        enq[0] = time.perf_counter() - t0         # the host's part: launches (and collectives) issued, nothing waited for
         if args.streams == 2:
             cstreams[0].wait_stream(cstreams[1])
         e1.record(cstreams[0])
@@ -513,6 +532,12 @@ def main():
     fence()
     # ---- timed region: exactly K steps
     elapsed_local, ev_ms, last = timed(args.steps)
+    host_issue_ms = enq[0] / args.steps * 1e3
+    if os.environ.get("PVX_BENCH_NO_SUBMIT"):                     # (A/B only: no collective was posted, nothing below applies)
+        print(json.dumps(dict(ab="gathered step without its collective", ms_per_step=round(elapsed_local / args.steps * 1e3, 4), host_issue_ms_per_step=round(host_issue_ms, 4))))
+        return 0
+    if gathered:
+        local_block(counter[0] - 1, last)         # what was timed is what is checked: the last timed step's rows, from the block it sent
     res = res2[last]
     # ---- the same K steps once more with libpvx_hip's stage events on the launch stream: per-kernel
     # launch durations for the roofline line (kept out of the timed region: the extra event records
@@ -521,6 +546,8 @@ def main():
     for _ in range(args.steps):
         last2 = step(single=True)                 # one stream, one plan: launches do not overlap here
     fence()
+    if gathered:
+        local_block(counter[0] - 1, last2)
     ms = (ctypes.c_double * 4)()
     nl = (ctypes.c_int64 * 4)()
     _lib.check(lib.pvx_plan_get_timing(plan, ms, nl), "pvx_plan_get_timing")
@@ -1047,7 +1074,9 @@ def main():
         if gather_info:
             gather_info["ms_per_step_kernels_only"] = stage["step_ms_hip_events"]
             gather_info["exposed_ms_per_step"] = round(max(0.0, elapsed / args.steps * 1e3 - stage["step_ms_hip_events"]), 4)
-            gather_info["note"] = "exposed = wall time per step minus the analysis kernels' time on the compute stream (launch gaps included)"
+            gather_info["host_issue_ms_per_step"] = round(host_issue_ms, 4)
+            gather_info["note"] = ("exposed = wall time per step minus the analysis kernels' time on the compute stream (launch gaps included); "
+                                   "host_issue = the host's time to issue a step (analysis launch + the collective's enqueue): a step cannot be shorter")
             line["gather"] = gather_info
         try:
             ctypes.CDLL(None).fflush(None)        # RCCL's version banner (C stdio) goes out before the JSON line

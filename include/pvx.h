@@ -387,6 +387,12 @@ int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows);
 int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
                       const double* d_ph, const double* d_binno, const double* d_totalmag,
                       void* d_wire, void* stream);
+/* run_pv of nsig device-resident signals straight into a wire block of pvx_wire_bytes(plan, nsig * F) bytes: what a rank of a
+ * multi-GPU job hands to the gather (bench.py).  The fused float32 kernel of nfft 512 / 1024 / 2048 writes the block itself -- 18
+ * bytes per slot instead of 40, and no packing pass behind the analysis --; any other plan analyses into a plan-owned block and packs
+ * it.  pvx_unpack_rows_dev of the block gives the arrays pvx_analyze_dev would have written, bit for bit.  Returns F. */
+int64_t pvx_analyze_dev_wire(pvx_plan* plan, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                             void* d_wire, void* stream);
 int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f,
                         double* d_mag, double* d_ph, double* d_realph, double* d_binno,
                         double* d_totalmag, void* stream);

@@ -113,6 +113,8 @@ SIGNATURES = {
     "pvx_analyze_batch": (ctypes.c_int64, [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, c_int32_p, ctypes.c_int]),
     "pvx_pack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 7),
+    "pvx_analyze_dev_wire": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_unpack_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8),
 }
 

@@ -287,7 +287,7 @@ class PipelinedGather(object):
     There is no other communication on this path.
     """
 
-    def __init__(self, numel, dtype, device, group=None, dst=0, depth=2, consume=None, force=False):
+    def __init__(self, numel, dtype, device, group=None, dst=0, depth=2, consume=None, force=False, host_retire=False):
         import torch
         import torch.distributed as dist
         self._torch = torch
@@ -296,6 +296,11 @@ class PipelinedGather(object):
         self.dst = dst
         self.depth = depth
         self.consume = consume
+        # host_retire: a slot is handed out again once the HOST has seen its gather complete (polling the work object) instead of
+        # making the caller's stream wait for it.  A stream-level wait is a barrier packet in the compute stream's queue on every step:
+        # measured on MI355X it costs a step of 0.10 ms about 0.015 ms whether or not the gather had long finished.  With a few slots
+        # of depth the gather of step i - depth is always done by the time the host issues step i, so the poll never spins.
+        self.host_retire = bool(host_retire) and consume is None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # world 1: nothing to gather, unless `force` asks for the collective anyway (single-GPU test
@@ -327,6 +332,15 @@ class PipelinedGather(object):
                 ev.record(self.side)
             self.done[j] = ev
             torch.cuda.current_stream().wait_event(ev)     # before the slot's buffers are written again
+        elif self.host_retire and self.cuda:
+            import time
+            t_end = time.perf_counter() + 30.0
+            while not w.is_completed():
+                if time.perf_counter() > t_end:            # (never seen; a stuck collective must not hang the caller silently)
+                    w.wait()
+                    torch.cuda.current_stream().synchronize()
+                    break
+                time.sleep(0)
         else:
             w.wait()
             if self.consume is not None and self.lists is not None:

@@ -48,6 +48,28 @@ typedef unsigned short u16;
 #endif
 constexpr int kDense = 64;               // slots of the dense staging: one per lane of the per-peak pass
 
+// FusedParams::wire: the result rows leave in the wire format of the multi-GPU gather (k_wire.hip: f float64 | mag float32 | ph float32 |
+// binno uint16 | totalmag float64, no realph -- the receiver rebuilds it with the expression above) instead of the reference's five
+// float64 arrays: p.f / p.mag / p.ph / p.binno / p.totalmag then point at the sections of the wire block.  A rank that only feeds the
+// gather writes 18 bytes per slot instead of 40 and needs no packing pass behind the analysis (which cannot run beside it: twelve
+// waves of 168 registers leave a CU no register for another kernel's wave -- the pass cost a gathered step 23 us of 125).
+typedef const __attribute__((address_space(4))) FusedParams* wire_kargs_t;
+__device__ __forceinline__ void emit_wire(wire_kargs_t q, int64_t i, int nbin, const PeakOut& o) {
+    typedef __attribute__((address_space(1))) double gd;
+    typedef __attribute__((address_space(1))) float gf;
+    typedef __attribute__((address_space(1))) unsigned short gu;
+    ((gd*)q->f)[i] = o.freq;
+    ((gf*)q->mag)[i] = (float)o.mag;                                 // (exact: float32 values widened at precision 32)
+    ((gf*)q->ph)[i] = (float)o.thisph;
+    ((gu*)q->binno)[i] = (unsigned short)nbin;
+}
+__device__ __forceinline__ void pad_wire(wire_kargs_t q, int64_t i) {
+    typedef __attribute__((address_space(1))) double gd;
+    typedef __attribute__((address_space(1))) float gf;
+    typedef __attribute__((address_space(1))) unsigned short gu;
+    ((gd*)q->f)[i] = 0.0; ((gf*)q->mag)[i] = 0.f; ((gf*)q->ph)[i] = 0.f; ((gu*)q->binno)[i] = 0;
+}
+
 template <int R> struct RevGeo {
     using G = Geo<R>;
     static constexpr bool X4 = (R == 16);                            // nfft 2048: four 256-point transforms per wave (pvx_fft4.h)
@@ -402,13 +424,17 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             // the lanes of this frame: [start - base, start - base + cnt)
             const unsigned long long gm = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << (start - base);
             const unsigned long long ball = __ballot(valid);
+            const bool wire = q->wire != 0;                           // the rows leave in the gather's wire format (see emit_wire)
             if (valid) {
                 const int oi = __popcll(ball & gm & ((1ull << lnf) - 1ull));
+                if (wire) emit_wire(q, orow * K + oi, nbin, o);
+                else {
                 PVX_RST(ob, oi, (double)nbin);
                 PVX_RST(of, oi, o.freq);
                 PVX_RST(om, oi, o.mag);
                 PVX_RST(op, oi, o.thisph);
                 PVX_RST(orp, oi, o.thisph + kPi * o.dfb / pc.fstep);          // PV.py:207
+                }
             }
             {
                 // zero padding (PV.py:226-239) and the frames' scalars: eight lanes per staged frame, lane c of a frame takes the
@@ -423,6 +449,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
                     const int64_t orow2 = (int64_t)Lorow[g2];
                     gdouble* of2 = (gdouble*)q->f + orow2 * K; gdouble* om2 = (gdouble*)q->mag + orow2 * K; gdouble* op2 = (gdouble*)q->ph + orow2 * K;
                     gdouble* orp2 = (gdouble*)q->realph + orow2 * K; gdouble* ob2 = (gdouble*)q->binno + orow2 * K;
+                    if (wire) { for (int j = nout2 + c2; j < K; j += 8) pad_wire(q, orow2 * K + j); }
+                    else
                     for (int j = nout2 + c2; j < K; j += 8) { ob2[j] = 0.0; of2[j] = 0.0; om2[j] = 0.0; op2[j] = 0.0; orp2[j] = 0.0; }
                     if (c2 == 0) {
                         const int64_t fr = Lfrm[g2];
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
         const unsigned long long gmask = (LPF == 64 ? ~0ull : ((1ull << LPF) - 1ull)) << (gl * LPF);
         kargs_t q = kargs;
         asm volatile("" : "+s"(q));                                  // loads through q stay here
+        const bool wire = q->wire != 0;
         PeakConst pc;
         pc.fstep = q->fstep; pc.dt = q->dt; pc.nfft = G::N; pc.hop = q->hop; pc.wfbin = q->wfbin;
         const int g = gbeg + gl;
@@ -468,15 +497,20 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             const unsigned long long bal = __ballot(valid) & gmask;
             if (valid) {
                 const int oi = nout + __popcll(bal & ((1ull << lnf) - 1ull));
+                if (wire) emit_wire(q, orow * K + oi, nbin, o);
+                else {
                 PVX_RST(ob, oi, (double)nbin);
                 PVX_RST(of, oi, o.freq);
                 PVX_RST(om, oi, o.mag);
                 PVX_RST(op, oi, o.thisph);
                 PVX_RST(orp, oi, o.thisph + kPi * o.dfb / pc.fstep);          // PV.py:207
+                }
             }
             nout += __popcll(bal);
         }
         if (cnt >= 0) {
+            if (wire) { for (int j = nout + e0; j < K; j += LPF) pad_wire(q, orow * K + j); }
+            else
             for (int j = nout + e0; j < K; j += LPF) {                // zero padding, PV.py:226-239
                 ob[j] = 0.0; of[j] = 0.0; om[j] = 0.0; op[j] = 0.0; orp[j] = 0.0;
             }

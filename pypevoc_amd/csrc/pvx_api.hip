@@ -175,6 +175,8 @@ struct pvx_plan {
     bool last_from_rev = false;  // the last analyze_rows() left its requested spectrum row in d_lastspec
     void* d_pvstage = nullptr;   // k_pv_rev at nfft 2048: the kept peaks' values between the frames (PvRevParams::stage)
     size_t pvstage_cap = 0;
+    double* d_wiretmp = nullptr; // pvx_analyze_dev_wire on plans whose kernels do not write the wire format themselves: the result block that is then packed
+    size_t wiretmp_cap = 0;
     int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
     bool rocfft_small = false;   // ... and its output then goes to d_rspec, not to the analysis' d_spec
     void* d_rspec = nullptr;     // rocFFT output when the main spectrum workspace belongs to k_stft
@@ -273,6 +275,7 @@ static void plan_free(pvx_plan* p) {
     if (p->d_carry) (void)hipFree(p->d_carry);
     if (p->d_lastspec) (void)hipFree(p->d_lastspec);
     if (p->d_pvstage) (void)hipFree(p->d_pvstage);
+    if (p->d_wiretmp) (void)hipFree(p->d_wiretmp);
     for (int i = 0; i < 2; i++) {
         if (p->d_in[i]) (void)hipFree(p->d_in[i]);
         if (p->d_out[i]) (void)hipFree(p->d_out[i]);
@@ -647,9 +650,12 @@ template <typename T> static int grow_dev(T** p, size_t* cap, size_t need);
 static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                         int64_t F, double* d_f, double* d_mag, double* d_ph, double* d_realph, double* d_binno,
                         double* d_t, double* d_totalmag, const double* d_prev0, hipStream_t s,
-                        int64_t spec_row = -1) {
+                        int64_t spec_row = -1, bool wire_out = false) {
     const int64_t total_rows = nsig * (F + 1);
     int rc;
+    // wire_out: d_f / d_mag / d_ph / d_binno / d_totalmag are the sections of a wire block (pvx_analyze_dev_wire): only the kernels
+    // that write it themselves take such a call
+    if (wire_out && !(p->fft_mode == 4 && p->precision == 32)) return PVX_ERR_UNSUPPORTED;
     if (p->fft_mode >= 1 && p->fft_mode <= 5) {
         // one launch: window + FFT + peaks, no intermediate arrays (k_fused.hip / k_fused_mw.hip)
         if (x_dtype == PVX_F64) {
@@ -671,6 +677,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.spec_out = spec_row >= 0 ? (p->spec_host ? p->spec_host : p->d_specrow) : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
         fp.stash = nullptr; fp.stash_bytes = 0;
+        fp.wire = wire_out ? 1 : 0;
         if (p->fft_mode == 4) {
             // k_fused_rev: the block where its waves hand a spectrum to the wave below them (sized once, for a full grid)
             if (!p->d_stash) {
@@ -2155,6 +2162,41 @@ extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const doubl
     wp.rows = rows; wp.K = plan->npks; wp.precision = plan->precision; wp.fstep = plan->fstep; wp.wire = d_wire;
     wp.f = d_f; wp.mag = d_mag; wp.ph = d_ph; wp.binno = d_binno; wp.totalmag = d_totalmag;
     return pvx_launch_wire(wp, true, (hipStream_t)stream);
+}
+
+// run_pv straight into the wire format: what a rank of a multi-GPU job hands to the gather.  k_fused_rev (precision 32, nfft 512 ..
+// 2048) writes the block itself; every other plan analyses into a plan-owned result block and packs it.
+extern "C" int64_t pvx_analyze_dev_wire(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
+                                        void* d_wire, void* stream) {
+    int rc = pvx_require_plan_device(p);
+    if (rc != PVX_OK) return rc;
+    rc = check_analyze_args(p, d_x, x_dtype, nsamp, nsig, sig_stride, nullptr);
+    if (rc != PVX_OK) return rc;
+    const int64_t F = pvx_nframes(nsamp, p->nfft, p->hop);
+    if (F == 0) return 0;
+    if (!d_wire) { pvx_set_error("null wire block"); return PVX_ERR_INVALID; }
+    if (pvx_wire_bytes(p, nsig * F) < 0) return PVX_ERR_INVALID;
+    const int64_t rows = nsig * F;
+    const size_t n = (size_t)rows * (size_t)p->npks, ts = p->precision == 64 ? 8 : 4;
+    auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    unsigned char* w = (unsigned char*)d_wire;
+    if (p->fft_mode == 4 && p->precision == 32 && getenv("PVX_NO_WIRE_OUT") == nullptr) {
+        // the sections of the block (k_wire.hip) as the kernel's output arrays
+        double* wf = (double*)w;
+        double* wm = (double*)(w + al8(n * 8));
+        double* wp = (double*)(w + al8(n * 8) + al8(n * ts));
+        double* wb = (double*)(w + al8(n * 8) + 2 * al8(n * ts));
+        double* wt = (double*)(w + al8(n * 8) + 2 * al8(n * ts) + al8(n * 2));
+        rc = analyze_rows(p, d_x, x_dtype, nsamp, nsig, sig_stride, F, wf, wm, wp, nullptr, wb, nullptr, wt, nullptr, (hipStream_t)stream, -1, true);
+        return rc == PVX_OK ? F : rc;
+    }
+    const size_t per_frame_out = (size_t)(5 * p->npks + 2) * sizeof(double);
+    if ((rc = grow_dev(&p->d_wiretmp, &p->wiretmp_cap, (size_t)rows * per_frame_out)) != PVX_OK) return rc;
+    const HostOut o = block_ptrs(p->d_wiretmp, rows, p->npks);
+    rc = analyze_rows(p, d_x, x_dtype, nsamp, nsig, sig_stride, F, o.f, o.mag, o.ph, o.realph, o.binno, nullptr, o.totalmag, nullptr, (hipStream_t)stream);
+    if (rc != PVX_OK) return rc;
+    rc = pvx_pack_rows_dev(p, rows, o.f, o.mag, o.ph, o.binno, o.totalmag, d_wire, stream);
+    return rc == PVX_OK ? F : rc;
 }
 
 extern "C" int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const void* d_wire, double* d_f, double* d_mag,

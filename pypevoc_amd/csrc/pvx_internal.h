@@ -112,6 +112,8 @@ struct FusedParams {      // k_fused.hip: window + FFT + untangle + peaks in one
     // the row below its range itself.  pvx_fused_rev_stash_bytes: what the launch of these parameters would use.
     void* stash;
     size_t stash_bytes;
+    // k_fused_rev.hip: 1 = f / mag / ph / binno / totalmag point at the sections of a wire block (k_wire.hip; realph and t unused)
+    int wire = 0;
 };
 size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft);
 int pvx_fused_supported(int nfft, int precision, int K);

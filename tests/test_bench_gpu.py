@@ -68,7 +68,9 @@ def test_bench_extras_are_all_checked_against_the_oracle():
     assert all(w["self_check"]["ok"] for w in j["other_nfft"].values())
     c = j["chain"]
     assert c["tracker"]["check"]["ok"] and c["tracker"]["partials"] > 0 and c["tracker"]["value"] > 0
-    assert c["resynthesis"]["check"]["ok"] and c["resynthesis"]["check"]["max_abs_err"] <= 1e-9 and c["resynthesis"]["value"] > 0
+    # (the headline is precision 32: its resynthesis runs the float32 sample loop, stated tolerance 1e-4 max|w|; measured ~1e-5)
+    assert c["resynthesis"]["sample_loop"] == "f32" and c["resynthesis"]["check"]["ok"] and c["resynthesis"]["value"] > 0
+    assert c["resynthesis"]["check"]["max_abs_err"] <= c["resynthesis"]["check"]["tolerance"] <= 1e-4
     assert c["total"]["ms"] >= c["tracker"]["ms"] + c["resynthesis"]["ms"] and c["total_ms"] == c["total"]["ms"]
     # BASELINE config 5 (here on a 20-s signal): all ten (nfft, hop) points, each timed, priced against the contract
     # target and checked against the oracle

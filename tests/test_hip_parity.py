@@ -1602,6 +1602,68 @@ def test_result_wire_round_trip_is_bit_exact(amd, precision, nfft, mode, monkeyp
     assert np.array_equal(out.view(np.int64), src.view(np.int64))
 
 
+@pytest.mark.parametrize("nfft,precision,K", [(2048, 32, 8), (2048, 32, 20), (1024, 32, 8), (512, 32, 3), (4096, 32, 8), (2048, 64, 8)])
+def test_analysis_straight_into_the_wire_block(amd, monkeypatch, nfft, precision, K):
+    """pvx_analyze_dev_wire: the rows a rank hands to the gather, written by the analysis kernel itself (k_fused_rev at precision 32,
+    nfft 512 .. 2048: 18 bytes per slot, no packing pass) -- byte for byte the block pvx_pack_rows_dev makes of pvx_analyze_dev's
+    arrays, for a batch of signals with silent stretches (zero rows, x/0 frames); plans of other kernels analyse and pack inside
+    the call (nfft 4096, precision 64); PVX_NO_WIRE_OUT=1 forces that everywhere."""
+    import ctypes
+    import torch
+    from pypevoc_amd import _lib
+    from pypevoc_amd.batch import ResultWire
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    sr, hop = 44100.0, nfft // 4
+    nsamp, nsig = nfft + hop * 150 + 9, 3
+    t = np.arange(nsamp) / sr
+    xb = np.stack([0.2 * np.sin(2 * np.pi * 440 * (b + 1) * t) + 0.01 * rng.standard_normal(nsamp) for b in range(nsig)]).astype(np.float32)
+    xb[1, hop * 40: hop * 40 + 3 * nfft] = 0.0
+    dev = torch.device("cuda", 0)
+    dx = torch.from_numpy(xb).to(dev)
+    plan = ctypes.c_void_p()
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan), sr, nfft, hop, K, 0.005, _lib.dptr(np.hanning(nfft)), precision, 0), "pvx_plan_create")
+    try:
+        F = int(lib.pvx_nframes(nsamp, nfft, hop))
+        rows = nsig * F
+        wire = ResultWire(plan, rows, K)
+        res = torch.zeros(wire.result_numel() + rows, dtype=torch.float64, device=dev)
+        rp = wire.result_ptrs(res.data_ptr())
+        _lib.check(lib.pvx_analyze_dev(plan, dx.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, rp[0], rp[1], rp[2], rp[3], rp[4],
+                                       res.data_ptr() + wire.result_numel() * 8, rp[5], None, None), "pvx_analyze_dev")
+        w_pack = torch.zeros(wire.nbytes, dtype=torch.uint8, device=dev)
+        wire.pack(res.data_ptr(), w_pack.data_ptr())
+        blocks = {}
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("PVX_NO_WIRE_OUT", env)
+            w = torch.full((wire.nbytes,), 0xAB, dtype=torch.uint8, device=dev)
+            r = lib.pvx_analyze_dev_wire(plan, dx.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, w.data_ptr(), None)
+            if env:
+                monkeypatch.delenv("PVX_NO_WIRE_OUT")
+            assert r == F, (r, lib.pvx_last_error())
+            torch.cuda.synchronize()
+            blocks[env] = w.cpu().numpy()
+        ref = w_pack.cpu().numpy()
+        # (the alignment gaps between the sections -- fewer than 8 bytes each -- are nobody's: compare the sections' bytes)
+        n = rows * K
+        ts = 4 if precision == 32 else 8
+        al8 = lambda v: (v + 7) & ~7
+        secs = [(0, n * 8), (al8(n * 8), n * ts), (al8(n * 8) + al8(n * ts), n * ts), (al8(n * 8) + 2 * al8(n * ts), n * 2),
+                (al8(n * 8) + 2 * al8(n * ts) + al8(n * 2), rows * 8)]
+        for env, b in blocks.items():
+            for o, ln in secs:
+                assert np.array_equal(b[o:o + ln], ref[o:o + ln]), (env, o)
+        # ... and the round trip gives pvx_analyze_dev's arrays back, realph included
+        out = torch.full((wire.result_numel(),), np.nan, dtype=torch.float64, device=dev)
+        wire.unpack(torch.from_numpy(blocks[None]).to(dev).data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.int64), res[: wire.result_numel()].cpu().numpy().view(np.int64))
+        assert (res[: n] > 0).sum().item() > rows
+    finally:
+        lib.pvx_plan_destroy(plan)
+
+
 # ------------------------------------------------------------------ PVHarmonic (SURVEY 8f, N3)
 HARMONIC = golden_names(prefix="H", exclude=())
 
