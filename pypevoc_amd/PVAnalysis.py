@@ -107,7 +107,7 @@ class _Plan(object):
         # `_lib.init(1)` a PV of the same parameters gets a plan of device 1, not the pooled one of device 0
         key = (_lib.init(), float(sr), int(nfft), int(hop), int(npks), float(pkthresh), int(precision), win.tobytes(), bucket,
                os.environ.get("PVX_FFT_MODE"), os.environ.get("PVX_MAX_ROWS"), os.environ.get("PVX_FUSED_BLOCKS"), os.environ.get("PVX_FPW"),
-               os.environ.get("PVX_NO_STFT"), os.environ.get("PVX_NO_STFT_PV"), os.environ.get("PVX_NO_PV_REV"))
+               os.environ.get("PVX_NO_STFT"), os.environ.get("PVX_NO_STFT_PV"), os.environ.get("PVX_NO_PV_REV"), os.environ.get("PVX_PV_TEAM"))
         plans = cls._pool.setdefault(key, [])
         free = [pl for pl in plans if pl.owner is None or pl.owner() is None]
         if free:

@@ -315,8 +315,8 @@ __global__ __launch_bounds__(64 * S, 2) void k_fused_team(FusedParams p) {
             const int g2 = lnf >> 3, c2 = lnf & 7;
             int o2 = 0, n2 = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { if (j == g2) { o2 = offs[j]; n2 = cnts[j]; } }
-            const unsigned long long gm2 = (n2 >= 64 ? ~0ull : ((1ull << n2) - 1ull)) << o2;
+            for (int j = 0; j < 8; j++) { if (j == g2 && j < ng) { o2 = offs[j]; n2 = cnts[j]; } }      // (frames from ng on: slots nobody wrote this batch -- a shift by their "offset" is undefined)
+            const unsigned long long gm2 = (n2 >= 64 ? ~0ull : ((1ull << n2) - 1ull)) << (o2 & 63);
             if (c2 == 0) Lval[wid * GFT + g2] = (g2 < ng) ? __popcll(ball & gm2) : 0;
             team_sync();                                             // the waves' emitted counts, frame by frame
             if (valid) {

@@ -5,6 +5,9 @@
 // witnesses for the bit-identity tests (modes 1 = 3 = 4 at nfft 1024 / 512, 1 = 3 at 2048) and are built into
 // tests/libpvx_witness.so only (`make -C pypevoc_amd/csrc witness`): libpvx_hip.so, the product, carries fft modes 0, 2, 4
 // and 5.  Here their entry points say so.
+// k_pv_team.hip (float64 at nfft 4096 / 8192 as ONE launch: a team of waves per frame, rows walked downwards, the row on chip) is a
+// witness of another kind: built, bit-identical to the two-kernel path -- and slower than it (profiles/r06_ab_steps.txt), so the
+// product keeps k_stft_split + k_phase_peaks there and the kernel lives in the witness library with its test.
 #include "pvx_internal.h"
 
 int pvx_fused_supported(int, int, int) { return 0; }
@@ -16,3 +19,10 @@ static int not_here(int mode) {
 }
 int pvx_launch_fused(const FusedParams&, int, int, hipStream_t) { return not_here(1); }
 int pvx_launch_fused_ring(const FusedParams&, int, int, hipStream_t) { return not_here(3); }
+
+int pvx_pv_team_supported(int, int, int, int) { return 0; }
+size_t pvx_pv_team_stage_bytes(int) { return 0; }
+int pvx_launch_pv_team(const PvRevParams&, int, int, hipStream_t) {
+    pvx_set_error("k_pv_team is a witness kernel: it is built into tests/libpvx_witness.so (make -C pypevoc_amd/csrc witness), not into libpvx_hip.so");
+    return PVX_ERR_UNSUPPORTED;
+}

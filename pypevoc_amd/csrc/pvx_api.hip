@@ -170,6 +170,7 @@ struct pvx_plan {
     bool rocfft_ready = false;   // frames/spectrum workspace + rocFFT plan are created on first use
     bool use_stft = false;       // float64, nfft 512..2048: k_stft writes the spectrum rows (no frame buffer, no rocFFT)
     bool use_stft_pv = false;    // ... and finds the peaks in the same launch (k_stft_pv.hip)
+    bool use_pv_team = false;    // float64 at nfft 4096 / 8192, npks <= 64, hop nfft/4 or nfft/2: the same with a team of waves per frame (k_pv_team.hip)
     bool use_pv_rev = false;     // ... without writing a spectrum row: rows walked downwards, the row at hand on chip (k_pv_rev.hip; npks <= 64)
     double* d_lastspec = nullptr;   // k_pv_rev: [N2][2] the spectrum of the one row a call asks for (chunk carry, last_spec)
     bool last_from_rev = false;  // the last analyze_rows() left its requested spectrum row in d_lastspec
@@ -458,6 +459,9 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         p->use_stft = true;
         p->use_stft_pv = pvx_stft_pv_supported(nfft, precision, npks) != 0 && !getenv("PVX_NO_STFT_PV");
         p->use_pv_rev = p->use_stft_pv && pvx_pv_rev_supported(nfft, precision, npks) != 0 && !getenv("PVX_NO_PV_REV");
+        // (k_pv_team is a witness kernel -- tests/libpvx_witness.so, asked for with PVX_PV_TEAM=1: correct, one launch, and slower than
+        // the two kernels it would replace, profiles/r06_ab_steps.txt; in the product library pvx_pv_team_supported() says no)
+        p->use_pv_team = precision == 64 && (nfft == 4096 || nfft == 8192) && npks <= 64 && getenv("PVX_PV_TEAM") != nullptr;
         if (!getenv("PVX_MAX_ROWS")) {
             int64_t big = (int64_t)(((size_t)1 << 30) / ((size_t)p->ldo * 2 * rs));
             if (big > 262144) big = 262144;
@@ -705,8 +709,11 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         return plan_event(p, s, -1);
     }
     p->last_from_rev = false;
-    if (p->use_stft && p->use_pv_rev && pvx_pv_rev_takes(p->nfft, x_dtype, p->hop) && total_rows < 0x7fffff00LL) {
-        // float64, nfft 512 .. 2048, npks <= 64: ONE launch over all rows, no spectrum workspace (k_pv_rev.hip)
+    const bool take_rev = p->use_stft && p->use_pv_rev && pvx_pv_rev_takes(p->nfft, x_dtype, p->hop) && total_rows < 0x7fffff00LL;
+    const bool take_team = p->use_stft && p->use_pv_team && pvx_pv_team_supported(p->nfft, p->precision, p->npks, p->hop) != 0 && total_rows < 0x7fffff00LL;
+    if (take_rev || take_team) {
+        // float64, npks <= 64: ONE launch over all rows, no spectrum workspace -- nfft 512 .. 2048: a wave per frame (k_pv_rev.hip);
+        // nfft 4096 / 8192 at the sliding-window hops: a team of waves per frame (k_pv_team.hip)
         PvRevParams rp;
         rp.x = d_x; rp.sig_stride = sig_stride; rp.F = F; rp.total_rows = total_rows;
         rp.hop = p->hop; rp.K = p->npks; rp.rad = 5;                                     // PV.py:177
@@ -723,7 +730,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         if (const char* e = getenv("PVX_PV_REV_BLOCKS")) { const long long v = atoll(e); if (v >= 1) rp.blocks_override = v; }   // tests: other grids
         rp.win_symmetric = p->win_symmetric ? 1 : 0;
         rp.stage = nullptr; rp.stage_bytes = 0;
-        const size_t need = pvx_pv_rev_stage_bytes(p->nfft);
+        const size_t need = take_team ? pvx_pv_team_stage_bytes(p->nfft) : pvx_pv_rev_stage_bytes(p->nfft);
         if (need > 0) {
             if ((rc = grow_dev(&p->d_pvstage, &p->pvstage_cap, need)) != PVX_OK) return rc;
             rp.stage = p->d_pvstage; rp.stage_bytes = p->pvstage_cap;
@@ -733,12 +740,12 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         for (int64_t R0 = 0; R0 < total_rows; R0 += piece) {
             rp.row_begin = R0; rp.row_end = (total_rows - R0 < piece) ? total_rows : R0 + piece;
             if ((rc = plan_event(p, s, 3)) != PVX_OK) return rc;
-            if ((rc = pvx_launch_pv_rev(rp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
+            if ((rc = take_team ? pvx_launch_pv_team(rp, p->nfft, x_dtype, s) : pvx_launch_pv_rev(rp, p->nfft, x_dtype, s)) != PVX_OK) return rc;
             if ((rc = plan_event(p, s, -1)) != PVX_OK) return rc;
             if ((rc = plan_progress(p, s, rp.row_end, total_rows, nsig)) != PVX_OK) return rc;
         }
         p->last_from_rev = spec_row >= 0;
-        p->last_analysis = "k_pv_rev";
+        p->last_analysis = take_team ? "k_pv_team" : "k_pv_rev";
         return PVX_OK;
     }
     if (p->use_stft) { if ((rc = ensure_spec_ws(p)) != PVX_OK) return rc; }
@@ -1621,7 +1628,9 @@ extern "C" int64_t pvx_track_dev(const double* d_f, const double* d_mag, int64_t
     if (!pin3 && hipHostMalloc((void**)&pin3, 64, hipHostMallocPortable) != hipSuccess) { pin3 = nullptr; (void)hipGetLastError(); }
     int dev = 0;
     PVX_HIP_CHECK(hipGetDevice(&dev));
-    DevWs& w = wsd[dev];
+    DevWs* wp = nullptr;
+    try { wp = &wsd[dev]; } catch (...) { pvx_set_error("out of memory for the tracker's per-device workspace record"); return PVX_ERR_ALLOC; }   // (no C++ exception leaves the C ABI)
+    DevWs& w = *wp;
     if ((rc = grow_dev(&w.ws, &w.cap, track_ws_bytes(F, K))) != PVX_OK) return rc;
     return track_on(d_f, d_mag, F, K, maxpitchjmp, d_partial_id, d_part_start, d_part_len, cap, w.ws, (hipStream_t)stream, nullptr, pin3);
 }

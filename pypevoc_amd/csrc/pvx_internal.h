@@ -166,6 +166,10 @@ int pvx_pv_rev_supported(int nfft, int precision, int K);
 int pvx_pv_rev_takes(int nfft, int x_dtype, int hop);
 size_t pvx_pv_rev_stage_bytes(int nfft);
 int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s);
+// k_pv_team.hip: the same at nfft 4096 / 8192 with a team of waves per frame (hop nfft/4 or nfft/2, npks <= 64)
+int pvx_pv_team_supported(int nfft, int precision, int K, int hop);
+size_t pvx_pv_team_stage_bytes(int nfft);
+int pvx_launch_pv_team(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s);
 int pvx_launch_peak_rows(const PeakRowsParams& p, hipStream_t s);
 size_t pvx_phase_peaks_lds_bytes(int N2, int K, int precision, int waves);
 

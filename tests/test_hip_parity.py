@@ -925,6 +925,119 @@ def test_descending_float64_kernel_is_bit_identical_to_the_row_storing_one(amd, 
     assert np.array_equal(q.oldfft, ref.oldfft)
 
 
+@pytest.mark.parametrize("norev", [None, "1"])
+def test_half_window_form_is_bit_identical_to_the_whole_window(amd, monkeypatch, norev):
+    """float64 at nfft 2048 with a symmetric window keeps half of it in LDS and reads the upper half's pairs backwards (an eighth
+    wave per CU: k_pv_rev<16, ..., SYM> and k_stft_pv<16, ..., SYM>); PVX_STFT_PV_NOSYM=1 keeps the whole window (seven waves).  The
+    same products in the same order: every output bit for bit, for both sliding hops, float64 / float32 / int16 samples, npks 8 and
+    20 -- on both one-launch kernels (PVX_NO_PV_REV=1: the row-storing one)."""
+    rng = np.random.default_rng(83)
+    sr, nfft = 44100.0, 2048
+    n = 40000
+    t = np.arange(n) / sr
+    x = sum(0.3 / h * np.sin(2 * np.pi * 233 * h * t) for h in range(1, 12)) + 0.01 * rng.standard_normal(n)
+    x[9000:9000 + 2 * nfft] = 0.0
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+    if norev:
+        monkeypatch.setenv("PVX_NO_PV_REV", norev)
+    from pypevoc_amd import _lib
+    for hop in (512, 1024):
+        for K in (8, 20):
+            for xin in (x, x.astype(np.float32), np.round(x * 20000).astype(np.int16)):
+                a = run_pv(amd, xin, sr, nfft, hop, K, precision=64)
+                kern = _lib.load().pvx_plan_last_kernels(a._plan.handle).decode()
+                assert ("analysis=k_stft_pv" if norev else "analysis=k_pv_rev") in kern, kern
+                monkeypatch.setenv("PVX_STFT_PV_NOSYM", "1")
+                b = run_pv(amd, xin, sr, nfft, hop, K, precision=64)
+                monkeypatch.delenv("PVX_STFT_PV_NOSYM")
+                for k in ("f", "mag", "ph", "realph", "binno", "t", "totalmag"):
+                    assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (hop, K, xin.dtype, k)
+                assert (np.asarray(a.f) > 0).sum() > a.nframes
+
+
+@pytest.mark.parametrize("nfft", [4096, 8192])
+def test_float64_team_kernel_is_bit_identical_to_the_two_kernel_path(amd, oracle, monkeypatch, witness, nfft):
+    """k_pv_team (a witness kernel, tests/libpvx_witness.so with PVX_PV_TEAM=1: float64, nfft 4096 / 8192, hop nfft/4 or nfft/2, npks <= 64
+    -- a team of waves per frame, rows walked downwards, the row on chip, one launch; measured slower than the product's two kernels,
+    profiles/r06_ab_steps.txt) against k_stft_split + k_phase_peaks (every row through the workspace): the five result
+    arrays and t bit for bit, totalmag to float64 round-off (the two paths sum a row's energy in different orders) -- signals (dense
+    candidates, exact silence, threshold 0), npks 1 .. 64, both hops, float64 / float32 / int16 samples, grids from one team to one
+    row per team, batches, host input in chunks -- and strictly against the oracle."""
+    rng = np.random.default_rng(612)
+    sr = 44100.0
+    n = 60000 * nfft // 2048
+    t = np.arange(n) / sr
+    noise = 0.1 * rng.standard_normal(n)
+    harm = sum(0.3 / h * np.sin(2 * np.pi * 220 * h * t) for h in range(1, 9)) + 1e-3 * rng.standard_normal(n)
+    gaps = harm.copy(); gaps[n // 7:n // 7 + 3 * nfft] = 0.0; gaps[n // 2:n // 2 + nfft + 100] = 0.0
+    rich = sum(0.2 / h * np.sin(2 * np.pi * 110 * h * t) for h in range(1, 61)) + 1e-4 * rng.standard_normal(n)
+    monkeypatch.setenv("PVX_FFT_MODE", "0")
+    from pypevoc_amd import _lib
+    lib = _lib.load()
+
+    def pair(make):
+        monkeypatch.setenv("PVX_PV_TEAM", "1")
+        a = make()
+        monkeypatch.delenv("PVX_PV_TEAM")
+        b = make()
+        return a, b
+
+    def same(a, b, what):
+        for k in ("f", "mag", "ph", "realph", "binno", "t"):
+            assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), what + (k,)
+        ta, tb = np.asarray(a.totalmag), np.asarray(b.totalmag)
+        assert np.all(np.abs(ta - tb) <= 1e-14 * np.maximum(np.abs(tb), 1e-300)), what
+
+    cases = ((8, 0.005, nfft // 4, None), (20, 0.005, nfft // 2, "3"), (64, 0.0005, nfft // 4, None), (1, 0.005, nfft // 4, "1"),
+             (33, 0.0, nfft // 4, "100000"), (12, 0.3, nfft // 2, None))
+    for name, x in (("noise", noise), ("harm", harm), ("gaps", gaps), ("rich", rich)):
+        for K, thr, hop, nb in cases:
+            for xin in (x, x.astype(np.float32), np.round(x * 20000).astype(np.int16)):
+                if xin.dtype != np.float64 and name not in ("harm", "gaps"):
+                    continue
+                if nb:
+                    monkeypatch.setenv("PVX_PV_REV_BLOCKS", nb)
+                a, b = pair(lambda: run_pv(amd, xin, sr, nfft, hop, K, thr, precision=64))
+                if nb:
+                    monkeypatch.delenv("PVX_PV_REV_BLOCKS")
+                same(a, b, (name, K, thr, hop, nb, str(xin.dtype)))
+                assert np.array_equal(a.oldfft, b.oldfft), (name, K, hop, xin.dtype)
+        monkeypatch.setenv("PVX_PV_TEAM", "1")
+        p = run_pv(amd, x, sr, nfft, nfft // 4, 20, precision=64)
+        assert "analysis=k_pv_team" in lib.pvx_plan_last_kernels(p._plan.handle).decode()
+        o = oracle.analyze(x, sr, nfft, nfft // 4, 20)
+        assert_f64(compare_analysis(pv_result(p), o, nfft, nfft // 4, sr))
+        # a hop that does not slide the window keeps the two-kernel path
+        q = run_pv(amd, harm, sr, nfft, 700, 8, precision=64)
+        assert "k_pv_team" not in lib.pvx_plan_last_kernels(q._plan.handle).decode()
+        monkeypatch.delenv("PVX_PV_TEAM")
+    # batches: signals of a few rows each (zero rows inside a team's range)
+    for ns in (nfft + 1, nfft + (nfft // 4) * 9 + 5, nfft + (nfft // 4) * 20):
+        xb = np.stack([noise[:ns], harm[:ns], gaps[n // 7 - 1000:n // 7 - 1000 + ns], rich[:ns]])
+        for nb in (None, "1", "2"):
+            if nb:
+                monkeypatch.setenv("PVX_PV_REV_BLOCKS", nb)
+            a, b = pair(lambda: amd.PVBatch(xb, sr, nfft=nfft, hop=nfft // 4, npks=20, precision=64).run_pv())
+            if nb:
+                monkeypatch.delenv("PVX_PV_REV_BLOCKS")
+            for k in ("f", "mag", "ph", "realph", "binno"):
+                assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), (ns, nb, k)
+    # host input in chunks of a few frames (the carried spectrum), and one call as launches of PVX_MAX_ROWS rows
+    ref = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+    monkeypatch.setenv("PVX_PV_TEAM", "1")
+    for fpc in (7, 40):
+        monkeypatch.setenv("PVX_MAX_DEVICE_BYTES", str(nfft * 8 + fpc * ((nfft // 4) * 8 + (5 * 8 + 2) * 8) + 8))
+        q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+        monkeypatch.delenv("PVX_MAX_DEVICE_BYTES")
+        same(q, ref, ("chunks", fpc))
+        assert np.array_equal(q.oldfft, ref.oldfft)
+    monkeypatch.setenv("PVX_MAX_ROWS", "37")
+    q = run_pv(amd, gaps, sr, nfft, nfft // 4, 8, precision=64)
+    monkeypatch.delenv("PVX_MAX_ROWS")
+    same(q, ref, ("pieces",))
+    monkeypatch.delenv("PVX_PV_TEAM")
+
+
 def _lib_mode(p):
     from pypevoc_amd import _lib
     return _lib.load().pvx_plan_get_fft_mode(p._plan.handle)
