@@ -56,19 +56,31 @@ constexpr int kSlots = 64;            // staging slots: one per lane of the per-
 #ifndef PVX_PVR_PRIO_MINR
 #define PVX_PVR_PRIO_MINR 8
 #endif
+// tools/ab knobs: waves per CU at nfft 1024 (12 = three per SIMD: the staged values then live in the global block and the wave has 168
+// registers; 8 = two per SIMD, values in LDS) for float32 / int16 and for float64 samples, bins per piece of the candidate scan
+#ifndef PVX_PVR_NW1024
+#define PVX_PVR_NW1024 12
+#endif
+#ifndef PVX_PVR_PIECE
+#define PVX_PVR_PIECE 512
+#endif
 
 // LDS: the block's tables as k_stft_pv lays them out (PvGeo there), then per wave the transform buffer and the staging
-template <int R, bool SYM> struct RvGeo : StftGeo<R, double> {
+template <int R, bool SYM, bool LVP = true> struct RvGeo : StftGeo<R, double> {
     using T = double;
     using B = StftGeo<R, double>;
     static constexpr bool X4 = (R == 16);
     static_assert(!SYM || X4, "the half window exists for the four-quarter layout");
-    static constexpr bool LV = !X4;                                  // the staged values live in LDS (else: global staging block)
+    static constexpr bool LV = !X4 && LVP;                           // the staged values live in LDS (else: global staging block)
     static constexpr int TW8N = X4 ? 512 : ((B::HALF / 2 + 1 + 7) & ~7);
     static constexpr size_t OFF_T1 = SYM ? (size_t)(B::N / 2) * sizeof(T) : B::OFF_T1;
     static constexpr size_t OFF_T2 = X4 ? OFF_T1 + (size_t)256 * 2 * sizeof(T) : B::OFF_T2;
     static constexpr size_t OFF_TW3 = X4 ? OFF_T2 : B::OFF_TW3;
-    static constexpr size_t OFF_BUF = OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);
+    // (the twelve-wave form of nfft 1024: the lanes' cross-lane twiddles cw [LOGP][64] wait in LDS instead of in registers across the loop
+    // -- as loop invariants of a 168-register kernel they were spilled to scratch and reloaded from there in every frame)
+    static constexpr bool CWL = !X4 && !LVP;
+    static constexpr size_t OFF_CW = OFF_TW3 + (size_t)TW8N * 2 * sizeof(T);
+    static constexpr size_t OFF_BUF = OFF_CW + (CWL ? (size_t)(B::LOGP > 0 ? B::LOGP : 1) * 64 * 2 * sizeof(T) : 0);
     // per wave: dz [BUFC] cx | orow [GFV] i64 | tot [GFV] f64 | cnt, off, frm [GFV] int | bin [kSlots] int | (LV) val [kSlots][5] f64
     static constexpr size_t W_OROW = (size_t)B::BUFC * 2 * sizeof(T);
     static constexpr size_t W_TOT = W_OROW + GFV * 8;
@@ -89,7 +101,9 @@ typedef __attribute__((address_space(1))) double gdouble;
 template <int R, typename InT, int H, bool SYM, int NW>
 __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
     using T = double;
-    using G = RvGeo<R, SYM>;
+    // nfft 1024 with twelve waves per CU (three per SIMD: 168 registers) keeps the staged values in the global block like nfft 2048 --
+    // twelve waves' staging does not fit the LDS beside their buffers -- and scans in pieces of 256 bins (fewer values in flight)
+    using G = RvGeo<R, SYM, !(R == 8 && NW > 8)>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH, CAP = G::CAP;
     constexpr bool X4 = G::X4, LV = G::LV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -169,6 +183,13 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
             for (int i = threadIdx.x; i < R * 64; i += 64 * NW) t1L[i] = tab[(2 * (i & 63) * (i >> 6)) & NMASK];
             for (int i = threadIdx.x; i < 64; i += 64 * NW) t2L[i] = tab[((G::N / 64) * (i % P) * (i / P)) & NMASK];   // [t2][l1]
             for (int i = threadIdx.x; i <= G::HALF / 2; i += 64 * NW) tw3[i] = tab[i];
+            if constexpr (G::CWL) {
+                cx<T>* const cwT = (cx<T>*)(smem + G::OFF_CW);
+                for (int i = threadIdx.x; i < G::LOGP * 64; i += 64 * NW) {
+                    const int st = i >> 6, l1 = (i & 63) % P, h = P >> (st + 1);
+                    cwT[i] = (l1 & h) ? tab[((G::N / (2 * h)) * (l1 % h)) & NMASK] : mkc<T>((T)1, (T)0);
+                }
+            }
         }
     }
     __syncthreads();
@@ -177,7 +198,8 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
     const int Q = lane / P, L1 = lane % P;
     T csg[G::LOGP > 0 ? G::LOGP : 1];
     cx<T> cw[G::LOGP > 0 ? G::LOGP : 1];
-    {
+    cx<T>* const cwL = (cx<T>*)(smem + G::OFF_CW);                    // (CWL) [LOGP][64]
+    if constexpr (!G::CWL) {
         const cx<T>* tab = (const cx<T>*)p.twiddle;
         constexpr int NMASK = G::N - 1;
 #pragma unroll
@@ -366,6 +388,13 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
                 prefetch_part(nfull, 3);
                 cx<T> tq2[R];
                 lds_gather<1, R, T>(tq2, t2L + L1, P);
+                if constexpr (G::CWL) {
+#pragma unroll
+                    for (int st = 0; st < G::LOGP; st++) {
+                        cw[st] = cwL[st * 64 + lane];
+                        csg[st] = (L1 & (P >> (st + 1))) ? (T)-1 : (T)1;
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < R; t++) {
                     // twiddle W_64^(l1 t2), then stage 3: P-point DFT across the P lanes of a group (decimation in frequency)
@@ -444,7 +473,7 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
             // ---- PeakFinder(famp, npeaks, minrattomax) + filter_by_salience(rad=5)  (PV.py:175-178), on the squared row (k_stft_pv.hip)
             const double minamp = sqrt((double)maxv) * p.thr;        // PF.py:60
             const double th = (minamp != 0.0) ? minamp * minamp - (double)minv : 0.0;
-            constexpr int PIECE = M < 512 ? M : 512;
+            constexpr int PIECE = (R == 8 && NW > 8) ? 256 : (M < PVX_PVR_PIECE ? M : PVX_PVR_PIECE);
             int C = 0;
 #pragma unroll 1
             for (int kb = 0; kb < M; kb += PIECE) C += peak_scan<T, PIECE / 64>(y, kb, PIECE, M, minv, th, cs + C, ci + C, ln);
@@ -531,7 +560,7 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
 }
 
 template <int R, bool SYM, int NW> int launch_rv(const PvRevParams& p, int x_dtype, hipStream_t s) {
-    using G = RvGeo<R, SYM>;
+    using G = RvGeo<R, SYM, !(R == 8 && NW > 8)>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -549,6 +578,14 @@ template <int R, bool SYM, int NW> int launch_rv(const PvRevParams& p, int x_dty
         switch (x_dtype) {
             case PVX_F32: fn = PVX_RV_PICK_H(float); break;
             case PVX_F64: fn = PVX_RV_PICK_H(double); break;
+            case PVX_I16: fn = PVX_RV_PICK_H(int16_t); break;
+            default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
+        }
+    } else if constexpr (R == 8 && NW > 8) {
+        // three waves per SIMD: the sliding-window hops of float32 / int16 samples (the others need more than 168 registers: two per SIMD)
+        if (H == 0 || x_dtype == PVX_F64) return launch_rv<R, false, 8>(p, x_dtype, s);
+        switch (x_dtype) {
+            case PVX_F32: fn = PVX_RV_PICK_H(float); break;
             case PVX_I16: fn = PVX_RV_PICK_H(int16_t); break;
             default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
         }
@@ -598,14 +635,14 @@ int pvx_pv_rev_takes(int nfft, int x_dtype, int hop) {
 }
 // bytes of global staging a launch may need (nfft 2048: the kept peaks' values; 0 elsewhere)
 size_t pvx_pv_rev_stage_bytes(int nfft) {
-    if (nfft != 2048) return 0;
+    if (nfft != 2048 && nfft != 1024) return 0;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     if (ncu < 256) ncu = 256;
-    return (size_t)ncu * 8 * kSlots * 5 * 8;
+    return (size_t)ncu * 12 * kSlots * 5 * 8;
 }
 
 int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s) {
@@ -614,7 +651,9 @@ int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s
     if (p.K > kSlots) { pvx_set_error("k_pv_rev stages at most %d peaks per frame (npks = %d)", kSlots, p.K); return PVX_ERR_UNSUPPORTED; }
     switch (nfft) {
         case 512: return launch_rv<4, false, 12>(p, x_dtype, s);
-        case 1024: return launch_rv<8, false, 8>(p, x_dtype, s);
+        // nfft 1024: twelve waves per CU for float32 / int16 samples at the sliding-window hops (+13 .. 15 % over eight:
+        // profiles/r06_ab_steps.txt); float64 samples (the next row waits in register pairs) and other hops stay at eight
+        case 1024: return launch_rv<8, false, PVX_PVR_NW1024>(p, x_dtype, s);
         case 2048: {
             // a symmetric window keeps its first half in LDS: an eighth wave per CU (k_stft_pv.hip)
             const bool sym = p.win_symmetric != 0 && (p.hop == 512 || p.hop == 1024) && getenv("PVX_STFT_PV_NOSYM") == nullptr;

@@ -18,7 +18,7 @@ if os.path.exists(g7):
     inputs["violin"] = torch.from_numpy(np.tile(xv, 44100 * 600 // len(xv) + 1)[: 44100 * 600]).to(dev)
 K = int(os.environ.get("AB_K", "8"))                   # peaks per frame (AB_K=100: BASELINE config 3's)
 for nfft in nffts:
-    hop = nfft // 4
+    hop = nfft // int(os.environ.get("AB_HOP_DIV", "4"))                 # (AB_HOP_DIV=2: hop = nfft/2, the reference's default)
     for name, x in inputs.items():
         n = x.numel(); F = int(lib.pvx_nframes(n, nfft, hop))
         out = torch.zeros(5 * F * K + 2 * F, dtype=torch.float64, device=dev); b = out.data_ptr()
