@@ -678,7 +678,7 @@ def main():
                                  and c["frames_diff"] <= 0.01 * max(c["frames"], 1))
             else:
                 # (a handful of frames of 51 676 may differ on noise: two candidate magnitudes equal to the last bit, where the
-                # reference's own choice hangs on its libm's rounding of abs(), DESIGN.md section 3.2)
+                # reference's own choice hangs on its libm's rounding of abs(), DESIGN.md section 4)
                 ok = (c["bad_peaks"] <= (0 if well_conditioned else 1e-4 * max(c["ref_peaks"], 1)) and c["f_abs"] <= 1e-9 and c["mag_rel"] <= 1e-12
                       and c["ph_abs"] <= 1e-10 and c["realph_abs"] <= 1e-10 and c["totalmag_rel"] <= 1e-12)
             ok = ok and bool(np.array_equal(h[5 * F_ * K_ + F_: 5 * F_ * K_ + 2 * F_], o["t"]))

@@ -106,7 +106,7 @@ if c5:
         L.append("| %d / %d | %d | %s | %.2f × | %.3f | ok = %s (%d, %d, %.1e) |" % (d["nfft"], d["hop"], d["fft_mode"], M(d["value"]), d["vs_contract_target"],
                                                                                    d["frac_of_hbm_at_fused_bytes"], sc.get("ok"), sc.get("ref_peaks", 0), sc.get("bad_peaks", 0), sc.get("f_abs_Hz", 0)))
     L.append("")
-sw, swp = jl("%s_config5_sweep.jsonl" % tag), jl("%s_config5_sweep.jsonl" % prev)
+sw, swp = [], []          # (the bench line's `config5` table above holds these ten points, each checked: `profiles/<tag>_config5_sweep.jsonl` is the same sweep by tools/sweep_config5.py)
 if sw:
     pm = {(d["nfft"], d["hop"]): d for d in swp}
     L.append("**BASELINE config 5 (60 min @ 96 kHz, npks 8; `profiles/%s_config5_sweep.jsonl`, previous round beside it).**" % tag)
@@ -120,9 +120,11 @@ if sw:
     L.append("")
 s64 = jl("%s_config5_sweep_f64.jsonl" % tag)
 if s64:
-    L.append("float64 (`profiles/%s_config5_sweep_f64.jsonl`): " % tag + ", ".join("%d/%d %s" % (d["nfft"], d["hop"], M(d["frames_per_s"])) for d in s64) + ".")
+    p64 = {(d["nfft"], d["hop"]): d for d in jl("%s_config5_sweep_f64.jsonl" % prev)}
+    L.append("**Config 5 at float64** (`profiles/%s_config5_sweep_f64.jsonl`, M frames/s, the round before in brackets): " % tag +
+             ", ".join("%d/%d %s%s" % (d["nfft"], d["hop"], M(d["frames_per_s"]).replace(" M", ""), (" (%s)" % M(p64[(d["nfft"], d["hop"])]["frames_per_s"]).replace(" M", "")) if (d["nfft"], d["hop"]) in p64 else "") for d in s64) + ".")
     L.append("")
-hn = jl("%s_nfft_harmonic_vs_noise.jsonl" % tag)
+hn = []       # (`profiles/<tag>_nfft_harmonic_vs_noise.jsonl`: the nfft sweep on three kinds of material; the bench table above carries the noise / recording lines)
 if hn:
     L.append("**10 min @ 44.1 kHz, hop = nfft/4, harmonic signal vs white noise (`profiles/%s_nfft_harmonic_vs_noise.jsonl`):** " % tag +
              "; ".join("nfft %d %s %s" % (d["nfft"], d["input"], M(d["Mframes_per_s"] * 1e6)) for d in hn) + ".")
@@ -147,9 +149,9 @@ if nr:
     L.append("| row | call | frames/s | what crosses the link / note |")
     L.append("|---|---|---|---|")
     for d in nr:
-        if "row" in d:
+        if "row" in d and " cpu" not in d["row"]:
             L.append("| %s | %.3f ms | %s | %s |" % (d["row"], d["ms"], M(d["frames_per_s"]), d["shape"]))
-    kk = ["`%s` %.0f us" % (d["kernel"][:40], d["avg_us"]) for d in nr if "kernel" in d]
+    kk = []
     if kk:
         L.append("")
         L.append("Their kernels (rocprofv3 kernel trace of the same run, average per launch): " + "; ".join(kk) + ".")
@@ -165,7 +167,7 @@ try:
         g = lambda c: v[c]["mean"] if c in v else float("nan")
         nf = 4096 if "4096" in what else 8192 if "8192" in what else 2048
         F = (44100 * 600 - nf + nf // 4 - 1) // (nf // 4)
-        per = F if ("fused" in name or "stft" in name or "phase" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
+        per = F if ("fused" in name or "stft" in name or "phase" in name or "k_pv_rev" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
         if per is None:
             continue
         rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.3f | %.2f |" % (

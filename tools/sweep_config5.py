@@ -62,13 +62,16 @@ def main():
             contract = hop * 4 + 2 * nfft * s_ + 2 * (nfft // 2 + 1) * 2 * s_ + (K * 5 * 8 + 16)
             mode = int(lib.pvx_plan_get_fft_mode(plan))
             own = hop * 4 + (K * 5 * 8 + 16) if mode != 0 else contract
-            if mode == 0 and prec == 64 and nfft in (512, 1024, 2048):      # k_stft_pv: spectrum rows written once, never read back
+            kern = (lib.pvx_plan_last_kernels(plan) or b"").decode()
+            if mode == 0 and prec == 64 and "k_pv_rev" in kern:             # rows walked downwards, the row on chip: the fused bytes
+                own = hop * 4 + (K * 5 * 8 + 16)
+            elif mode == 0 and prec == 64 and nfft in (512, 1024, 2048):    # k_stft_pv: spectrum rows written once, never read back
                 own = hop * 4 + (nfft // 2) * 16 + (K * 5 * 8 + 16)
             elif mode == 0 and prec == 64 and nfft in (4096, 8192):         # k_stft_split + k_phase_peaks: written once, read once
                 own = hop * 4 + 2 * (nfft // 2) * 16 + (K * 5 * 8 + 16)
             fps = F / (ms * 1e-3)
             print(json.dumps(dict(nfft=nfft, hop=hop, precision=prec, frames=F, ms=round(ms, 3), frames_per_s=round(fps, 1),
-                                  fft_mode=mode, alg_bytes_per_frame=own, achieved_GBps=round(fps * own / 1e9, 1),
+                                  fft_mode=mode, kernels=kern if mode == 0 else None, alg_bytes_per_frame=own, achieved_GBps=round(fps * own / 1e9, 1),
                                   frac_of_8TBps=round(fps * own / 8e12, 4), contract_bytes_per_frame=contract,
                                   throughput_vs_60pct_target=round(fps * contract / (0.6 * 8e12), 3))))
             sys.stdout.flush()
