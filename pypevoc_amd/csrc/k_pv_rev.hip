@@ -61,6 +61,9 @@ constexpr int kSlots = 64;            // staging slots: one per lane of the per-
 #ifndef PVX_PVR_NW1024
 #define PVX_PVR_NW1024 12
 #endif
+#ifndef PVX_PVR_NW512
+#define PVX_PVR_NW512 16              // (four waves per SIMD at 128 registers, 20 of them in scratch: +5 .. 8 % over twelve, profiles/r06_ab_steps.txt)
+#endif
 #ifndef PVX_PVR_PIECE
 #define PVX_PVR_PIECE 512
 #endif
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
     using T = double;
     // nfft 1024 with twelve waves per CU (three per SIMD: 168 registers) keeps the staged values in the global block like nfft 2048 --
     // twelve waves' staging does not fit the LDS beside their buffers -- and scans in pieces of 256 bins (fewer values in flight)
-    using G = RvGeo<R, SYM, !(R == 8 && NW > 8)>;
+    using G = RvGeo<R, SYM, !((R == 8 && NW > 8) || (R == 4 && NW > 12))>;
     constexpr int M = G::M, P = G::P, PITCH = G::PITCH, CAP = G::CAP;
     constexpr bool X4 = G::X4, LV = G::LV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(64 * NW) void k_pv_rev(PvRevParams p) {
 }
 
 template <int R, bool SYM, int NW> int launch_rv(const PvRevParams& p, int x_dtype, hipStream_t s) {
-    using G = RvGeo<R, SYM, !(R == 8 && NW > 8)>;
+    using G = RvGeo<R, SYM, !((R == 8 && NW > 8) || (R == 4 && NW > 12))>;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -582,10 +585,11 @@ template <int R, bool SYM, int NW> int launch_rv(const PvRevParams& p, int x_dty
             default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
         }
     } else if constexpr (R == 8 && NW > 8) {
-        // three waves per SIMD: the sliding-window hops of float32 / int16 samples (the others need more than 168 registers: two per SIMD)
-        if (H == 0 || x_dtype == PVX_F64) return launch_rv<R, false, 8>(p, x_dtype, s);
+        // three waves per SIMD at the sliding-window hops (any other hop holds a whole next row in flight: two per SIMD)
+        if (H == 0) return launch_rv<R, false, 8>(p, x_dtype, s);
         switch (x_dtype) {
             case PVX_F32: fn = PVX_RV_PICK_H(float); break;
+            case PVX_F64: fn = PVX_RV_PICK_H(double); break;       // (22 registers in scratch -- the next row's sample pairs -- and still +12 .. 20 % over eight waves)
             case PVX_I16: fn = PVX_RV_PICK_H(int16_t); break;
             default: pvx_set_error("bad x_dtype %d", x_dtype); return PVX_ERR_INVALID;
         }
@@ -635,14 +639,14 @@ int pvx_pv_rev_takes(int nfft, int x_dtype, int hop) {
 }
 // bytes of global staging a launch may need (nfft 2048: the kept peaks' values; 0 elsewhere)
 size_t pvx_pv_rev_stage_bytes(int nfft) {
-    if (nfft != 2048 && nfft != 1024) return 0;
+    if (nfft != 2048 && nfft != 1024 && !(nfft == 512 && PVX_PVR_NW512 > 12)) return 0;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
     if (ncu < 256) ncu = 256;
-    return (size_t)ncu * 12 * kSlots * 5 * 8;
+    return (size_t)ncu * 16 * kSlots * 5 * 8;
 }
 
 int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s) {
@@ -650,9 +654,8 @@ int pvx_launch_pv_rev(const PvRevParams& p, int nfft, int x_dtype, hipStream_t s
     if (p.row_begin < 0 || p.row_end > p.total_rows) { pvx_set_error("k_pv_rev: rows [%lld, %lld) of %lld", (long long)p.row_begin, (long long)p.row_end, (long long)p.total_rows); return PVX_ERR_INVALID; }
     if (p.K > kSlots) { pvx_set_error("k_pv_rev stages at most %d peaks per frame (npks = %d)", kSlots, p.K); return PVX_ERR_UNSUPPORTED; }
     switch (nfft) {
-        case 512: return launch_rv<4, false, 12>(p, x_dtype, s);
-        // nfft 1024: twelve waves per CU for float32 / int16 samples at the sliding-window hops (+13 .. 15 % over eight:
-        // profiles/r06_ab_steps.txt); float64 samples (the next row waits in register pairs) and other hops stay at eight
+        case 512: return launch_rv<4, false, PVX_PVR_NW512>(p, x_dtype, s);
+        // nfft 1024: twelve waves per CU at the sliding-window hops (+12 .. 20 % over eight: profiles/r06_ab_steps.txt); other hops stay at eight
         case 1024: return launch_rv<8, false, PVX_PVR_NW1024>(p, x_dtype, s);
         case 2048: {
             // a symmetric window keeps its first half in LDS: an eighth wave per CU (k_stft_pv.hip)
