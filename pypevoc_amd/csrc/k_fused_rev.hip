@@ -878,11 +878,19 @@ template <int R, int NW, bool DENSE = false> int launch_rev(const FusedParams& p
 
 }  // namespace
 
+#ifndef PVX_REV_NW1024
+#define PVX_REV_NW1024 12
+#endif
+// nfft 512: SIXTEEN waves per CU (four per SIMD; 127 registers, nothing in scratch): +9 .. 13 % over twelve (profiles/r06_ab_steps.txt); nfft 1024
+// at sixteen needs 11 registers in scratch and runs the same as twelve
+#ifndef PVX_REV_NW512
+#define PVX_REV_NW512 16
+#endif
 int pvx_fused_rev_supported(int nfft, int precision, int K) {
     if (precision != 32) return 0;
     switch (nfft) {
         case 2048: return RevGeo<16>::total(K, 8) <= 160 * 1024;
-        case 1024: return RevGeo<8>::total(K, 12) <= 160 * 1024;
+        case 1024: return RevGeo<8>::total(K, PVX_REV_NW1024) <= 160 * 1024;
         case 512: return RevGeo<4>::total(K, 12) <= 160 * 1024;
         default: return 0;
     }
@@ -895,9 +903,6 @@ size_t pvx_fused_rev_stash_bytes(const FusedParams& p, int nfft) {
     if (launch_fused_rev(p, nfft, PVX_F32, nullptr, &need) != PVX_OK) return 0;
     return need;
 }
-#ifndef PVX_REV_NW1024
-#define PVX_REV_NW1024 12
-#endif
 static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStream_t s, size_t* stash_need) {
     if (stash_need) *stash_need = 0;
     if (p.total_rows <= 0) return PVX_OK;
@@ -908,7 +913,7 @@ static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStre
         switch (nfft) {
             case 2048: if (getenv("PVX_REV_NW8") == nullptr) return launch_rev<16, 12, true>(p, x_dtype, s, stash_need); break;
             case 1024: return launch_rev<8, PVX_REV_NW1024, true>(p, x_dtype, s, stash_need);
-            case 512: return launch_rev<4, 12, true>(p, x_dtype, s, stash_need);
+            case 512: return launch_rev<4, PVX_REV_NW512, true>(p, x_dtype, s, stash_need);     // (8 < npks <= 24: sixteen waves' staging always fits)
             default: break;
         }
     }
@@ -916,7 +921,7 @@ static int launch_fused_rev(const FusedParams& p, int nfft, int x_dtype, hipStre
         // three waves per SIMD when the waves' buffers fit (npks up to ~90), else two
         case 2048: return (RevGeo<16>::total(p.K, 12) <= 160 * 1024 && getenv("PVX_REV_NW8") == nullptr) ? launch_rev<16, 12>(p, x_dtype, s, stash_need) : launch_rev<16, 8>(p, x_dtype, s, stash_need);
         case 1024: return launch_rev<8, PVX_REV_NW1024>(p, x_dtype, s, stash_need);
-        case 512: return launch_rev<4, 12>(p, x_dtype, s, stash_need);
+        case 512: return RevGeo<4>::total(p.K, PVX_REV_NW512) <= 160 * 1024 ? launch_rev<4, PVX_REV_NW512>(p, x_dtype, s, stash_need) : launch_rev<4, 12>(p, x_dtype, s, stash_need);
         default: pvx_set_error("the fused kernel does not handle nfft=%d", nfft); return PVX_ERR_UNSUPPORTED;
     }
 }
