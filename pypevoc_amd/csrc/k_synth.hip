@@ -546,7 +546,9 @@ struct SampK {
     int xcs;                             // k_synth_extras: log2 of its chunk of segments
     int tile;                            // k_synth_bodies: records per wave and LDS tile (>= kTile)
     int c1, c2, n0, n1;                  // k_synth_bodies: the cuts of a segment's runs (RunCuts)
-    double vr, vi;                       // k_synth_extras: exp(i pi / edgsam)
+    double vr, vi;                       // k_synth_extras / add_edges: exp(i pi / edgsam)
+    int tail_first;                      // k_synth_bodies: its last tail_first workgroups (the waveform's end: the releases) are dispatched first
+    int edges_inline;                    // k_synth_bodies adds a flagged segment's attacks / releases itself (no k_synth_extras<, false> launch before it)
 };
 
 // Waves per SIMD the register allocation aims at (R sums = 2 R registers + the recurrences' state; the compiler fills
@@ -581,6 +583,70 @@ template <class Fn> __device__ __forceinline__ void for_bits_pre(const unsigned 
             mb &= mb - 1ull;
             fn(li);
         }
+    }
+}
+
+// ---- the attacks and releases that touch the run [s, s + R) of output segment `seg`, added to a[] (float64 arithmetic whatever the
+// sums' type: a partial has two edges, its bodies are many).  Attacks of partials starting at frames seg+1 .. seg+EF (kind 1), then
+// releases of partials whose last frame is seg-EF .. seg-1 (kind 2).  The record of the NEXT edge is fetched before the current one
+// is worked on: on a short waveform a workgroup is one wave with nothing else to hide a load behind.
+template <int R, typename S> __device__ __forceinline__ void add_edges(const SampK& q, int seg, int s, S (&a)[R]) {
+    const int h = q.h, K = q.K;
+    int kind = 0, wd = 0, wend = -1, n0 = 0, n1 = 0;
+    unsigned long long mb = 0ull;
+    auto masked = [&](const unsigned long long* bits, int w) {
+        unsigned long long m = bits[w];
+        if (w == (n0 >> 6)) m &= ~0ull << (n0 & 63);
+        if (w == ((n1 - 1) >> 6) && (n1 & 63)) m &= (1ull << (n1 & 63)) - 1ull;
+        return m;
+    };
+    auto advance = [&]() -> int {                                     // the next edge's node (kind set), or -1
+        for (;;) {
+            if (mb) { const int b = __builtin_ctzll(mb); mb &= mb - 1ull; return (wd << 6) + b; }
+            if (wd < wend) { wd++; mb = masked(kind == 1 ? q.abits : q.rbits, wd); continue; }
+            if (kind >= 2) return -1;
+            kind++;
+            int f0 = kind == 1 ? seg + 1 : seg - q.EF, f1 = kind == 1 ? seg + q.EF + 1 : seg;
+            if (f0 < q.fx0) f0 = q.fx0;
+            if (f1 > q.fx1) f1 = q.fx1;
+            wend = -1; wd = 0;
+            if (f1 <= f0) continue;
+            n0 = (f0 - q.fx0) * K; n1 = (f1 - q.fx0) * K;
+            wd = n0 >> 6; wend = (n1 - 1) >> 6;
+            mb = masked(kind == 1 ? q.abits : q.rbits, wd);
+        }
+    };
+    auto process = [&](const int knd, const EdgeRec& er) {
+        const EdgeRec* e = &er;
+        const long long j0l = (long long)seg * h + s - e->o0;
+        if (j0l + R <= 0 || j0l >= q.edgsam) return;
+        const int j0 = (int)j0l;
+        const double cfr = e->cfr;
+        const double x = (knd == 1) ? e->ph0 - kPi2 * ((double)(q.edgsam - j0) * cfr)
+                                    : e->ph0 + kPi2 * ((double)(j0 + 1) * cfr);
+        double zr, zi, ur, ui;
+        fsincos(x, zi, zr);
+        fsincos(kPi * (double)j0 / (double)q.edgsam, ui, ur);
+        const double ah = e->ah, ahs = (knd == 1) ? -ah : ah;
+        const double ewr = e->wr, ewi = e->wi;
+        const unsigned ulo = (unsigned)(-j0), un = (unsigned)q.edgsam;       // sample k sounds when 0 <= j0 + k < edgsam
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const double v = __builtin_fma(__builtin_fma(ahs, ur, ah), zr, (double)a[k]);
+            a[k] = ((unsigned)k - ulo < un) ? (S)v : a[k];
+            PVX_CMUL(zr, zi, ewr, ewi);
+            PVX_CMUL(ur, ui, q.vr, q.vi);
+        }
+    };
+    int li = advance(), ck = kind;
+    EdgeRec rec;
+    if (li >= 0) rec = (ck == 1 ? q.att : q.rel)[li];
+    while (li >= 0) {
+        const int lj = advance(), nk = kind;
+        EdgeRec nxt;
+        if (lj >= 0) nxt = (nk == 1 ? q.att : q.rel)[lj];
+        process(ck, rec);
+        rec = nxt; li = lj; ck = nk;
     }
 }
 
@@ -642,7 +708,10 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
     static_assert(kTile * sizeof(BodyRec) == 64 * kLaneB, "store staging = the least record tile");
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     unsigned char* lds = lds_dyn + (size_t)(tid >> 6) * q.tile * sizeof(BodyRec);
-    const int64_t gid0 = (int64_t)blockIdx.x * kBodiesTB, gid = gid0 + tid;
+    // (the workgroups of the waveform's end have the releases to add on top of their bodies: dispatched last, they would be the launch's
+    // tail -- 0.073 -> 0.064 ms on a time-stretched resynthesis, hop 700)
+    const unsigned bx = blockIdx.x < (unsigned)q.tail_first ? gridDim.x - 1u - blockIdx.x : blockIdx.x - (unsigned)q.tail_first;
+    const int64_t gid0 = (int64_t)bx * kBodiesTB, gid = gid0 + tid;
     const bool live = gid < q.nthreads;
     const int64_t g = live ? gid : q.nthreads - 1;
     const int64_t segl = g / q.rps;
@@ -663,7 +732,14 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
     s_o[tid] = (int64_t)seg * h + s;
     s_len[tid] = live ? (flagged ? -len : len) : 0;
     __builtin_amdgcn_wave_barrier();
-    if (__ballot(flagged) != 0ull) {
+    if (q.edges_inline) {
+        // the segment's attacks and releases, by this kernel: a launch of their own in front of this one (k_synth_extras<, false>) cost
+        // a dependent launch with almost nothing to do on a tone (0.142 -> 0.131 ms at BASELINE config 2) and a round trip of the flagged
+        // segments through w (white noise, attacks and releases everywhere: 0.149 -> 0.083 ms)
+#pragma unroll
+        for (int k = 0; k < R; k++) a[k] = (S)0;
+        if (flagged) add_edges<R, S>(q, seg, s, a);
+    } else if (__ballot(flagged) != 0ull) {
         long long oo[4];
         int ll[4];
 #pragma unroll
@@ -885,65 +961,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_EXTRAS_
             });
         }
     } else {
-        // attacks of partials starting at frames seg+1 .. seg+EF (kind 1), then releases of partials whose last frame is
-        // seg-EF .. seg-1 (kind 2).  The record of the NEXT edge is fetched before the current one is worked on: on a short
-        // waveform a workgroup is one wave with nothing else to hide a load behind, and every edge would cost a round trip.
-        int kind = 0, wd = 0, wend = -1, n0 = 0, n1 = 0;
-        unsigned long long mb = 0ull;
-        auto masked = [&](const unsigned long long* bits, int w) {
-            unsigned long long m = bits[w];
-            if (w == (n0 >> 6)) m &= ~0ull << (n0 & 63);
-            if (w == ((n1 - 1) >> 6) && (n1 & 63)) m &= (1ull << (n1 & 63)) - 1ull;
-            return m;
-        };
-        auto advance = [&]() -> int {                                 // the next edge's node (kind set), or -1
-            for (;;) {
-                if (mb) { const int b = __builtin_ctzll(mb); mb &= mb - 1ull; return (wd << 6) + b; }
-                if (wd < wend) { wd++; mb = masked(kind == 1 ? q.abits : q.rbits, wd); continue; }
-                if (kind >= 2) return -1;
-                kind++;
-                int f0 = kind == 1 ? seg + 1 : seg - q.EF, f1 = kind == 1 ? seg + q.EF + 1 : seg;
-                if (f0 < q.fx0) f0 = q.fx0;
-                if (f1 > q.fx1) f1 = q.fx1;
-                wend = -1; wd = 0;
-                if (f1 <= f0) continue;
-                n0 = (f0 - q.fx0) * K; n1 = (f1 - q.fx0) * K;
-                wd = n0 >> 6; wend = (n1 - 1) >> 6;
-                mb = masked(kind == 1 ? q.abits : q.rbits, wd);
-            }
-        };
-        auto process = [&](const int kind, const EdgeRec& er) {
-            const EdgeRec* e = &er;
-                const long long j0l = (long long)seg * h + s - e->o0;
-                if (j0l + R <= 0 || j0l >= q.edgsam) return;
-                const int j0 = (int)j0l;
-                const double cfr = e->cfr;
-                const double x = (kind == 1) ? e->ph0 - kPi2 * ((double)(q.edgsam - j0) * cfr)
-                                             : e->ph0 + kPi2 * ((double)(j0 + 1) * cfr);
-                double zr, zi, ur, ui;
-                fsincos(x, zi, zr);
-                fsincos(kPi * (double)j0 / (double)q.edgsam, ui, ur);
-                const double ah = e->ah, ahs = (kind == 1) ? -ah : ah;
-                const double ewr = e->wr, ewi = e->wi;
-                const unsigned ulo = (unsigned)(-j0), un = (unsigned)q.edgsam;       // sample k sounds when 0 <= j0 + k < edgsam
-#pragma unroll
-                for (int k = 0; k < R; k++) {
-                    const double v = __builtin_fma(__builtin_fma(ahs, ur, ah), zr, a[k]);
-                    a[k] = ((unsigned)k - ulo < un) ? v : a[k];
-                    PVX_CMUL(zr, zi, ewr, ewi);
-                    PVX_CMUL(ur, ui, q.vr, q.vi);
-                }
-        };
-        int li = advance(), ck = kind;
-        EdgeRec rec;
-        if (li >= 0) rec = (ck == 1 ? q.att : q.rel)[li];
-        while (li >= 0) {
-            const int lj = advance(), nk = kind;
-            EdgeRec nxt;
-            if (lj >= 0) nxt = (nk == 1 ? q.att : q.rel)[lj];
-            process(ck, rec);
-            rec = nxt; li = lj; ck = nk;
-        }
+        add_edges<R, double>(q, seg, s, a);
     }
 #pragma unroll
     for (int k = 0; k < R; k++)
@@ -1030,6 +1048,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     int R = (nseg_all * ((h + 31) / 32) >= 256 * 64) ? 32 : ((nseg_all * ((h + 15) / 16) >= 256 * 64) ? 16 : 8);
     if (run_env == 8 || run_env == 16 || run_env == 32) R = run_env;
     SampK k;
+    k.edges_inline = 0; k.tail_first = 0;
     bool irregular = false;
     {
         // where the pieces of fsig / msig change inside a segment: np.interp's breakpoints are h (dfr + .5 + j) and h (dfr + j)
@@ -1141,8 +1160,17 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
         kx.xcs = xcs;
         const int64_t nchunks = (q.nseg + (1 << xcs) - 1) >> xcs;
         const int64_t xgrid = nchunks < 768 ? nchunks : 768;
-        if (RX == 8) hipLaunchKernelGGL((k_synth_extras<8, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
-        else hipLaunchKernelGGL((k_synth_extras<16, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        // (without irregular bodies k_synth_bodies adds the attacks and releases itself: one launch less in the dependent chain;
+        // PVX_SYNTH_EDGES_KERNEL=1 keeps the launch of their own, for A/B runs and the tests of that path)
+        k.edges_inline = (!irregular && getenv("PVX_SYNTH_EDGES_KERNEL") == nullptr) ? 1 : 0;
+        {
+            const int64_t tf = k.edges_inline && !getenv("PVX_SYNTH_NO_TAIL_FIRST") ? ((int64_t)(q.EF + 1) * k.rps + kBodiesTB - 1) / kBodiesTB + 1 : 0;
+            k.tail_first = (int)(tf < grid_blocks ? tf : grid_blocks);
+        }
+        if (!k.edges_inline) {
+            if (RX == 8) hipLaunchKernelGGL((k_synth_extras<8, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+            else hipLaunchKernelGGL((k_synth_extras<16, false>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
+        }
         if (irregular) {
             if (RX == 8) hipLaunchKernelGGL((k_synth_extras<8, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);
             else hipLaunchKernelGGL((k_synth_extras<16, true>), dim3((unsigned)xgrid), dim3(256), 0, s, kx);

@@ -247,6 +247,35 @@ def test_synth_parameters_match_reference(amd):
     assert n == 7
 
 
+def test_attacks_and_releases_inside_the_bodies_kernel(amd, monkeypatch):
+    """k_synth_bodies adds a flagged segment's attacks and releases itself (no k_synth_extras<, false> launch in front of it); the
+    launch of their own (PVX_SYNTH_EDGES_KERNEL=1: what irregular cuts still take) gives the same waveform to float64 round-off --
+    its runs start elsewhere, so an edge's recurrence is seeded elsewhere --, both within 1e-10 of the reference's.  The order the
+    workgroups are dispatched in (the waveform's end first) changes nothing.  Fixture S1: partials that start and stop everywhere,
+    edge 0 .. 2, synthesis hops 128 / 256 / 300."""
+    g = load_golden("S1_synth_params")
+    ss = amd.SinSum(g["sr"], nfft=g["nfft"], hop=g["hop"])
+    ss._from_analysis(g["f"], g["mag"], g["ph"], g["realph"])
+    n = 0
+    for k in g:
+        if not k.startswith("w_") or k.startswith("w_hop"):
+            continue
+        h, e100, mf = (int(v) for v in k[2:].split("_"))
+        ref = g[k]
+        w = ss.synth(g["sr"], h, edge=e100 / 100.0, minframes=mf)
+        monkeypatch.setenv("PVX_SYNTH_NO_TAIL_FIRST", "1")
+        assert np.array_equal(ss.synth(g["sr"], h, edge=e100 / 100.0, minframes=mf), w), k
+        monkeypatch.delenv("PVX_SYNTH_NO_TAIL_FIRST")
+        monkeypatch.setenv("PVX_SYNTH_EDGES_KERNEL", "1")
+        wk = ss.synth(g["sr"], h, edge=e100 / 100.0, minframes=mf)
+        monkeypatch.delenv("PVX_SYNTH_EDGES_KERNEL")
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(w - ref).max() <= 1e-10 * scale and np.abs(wk - ref).max() <= 1e-10 * scale, k
+        assert np.abs(w - wk).max() <= 1e-12 * scale, (k, float(np.abs(w - wk).max()))
+        n += 1
+    assert n == 7
+
+
 def test_synth_launch_shapes_and_result_arrays(amd, monkeypatch):
     """The resynthesis kernels' launch shapes -- runs of 16 / 32 samples per thread, the waveform in slices of a few segments,
     the pieces of fsig changing inside runs (no cuts: every body through k_synth_extras' predicated loop) -- and the
