@@ -472,7 +472,7 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
             // a one-ulp error of a quotient q (<= q 2^-52) moves its st by <= 17.312 q 2^-52: where the threshold test or the choice of
             // the nearest partial hangs on less than eps (sixteen times that at q ~ 1; st >= 0.5 sets no link at the default jump),
             // the frame is left to k_track_sequential, which divides (the table is then the reference's whatever the rounding was)
-            if (wo >= 0) {
+            if (wo >= 0 && best < INFINITY) {                       // (best at infinity: every previous peak is taken -- a new partial, nothing hangs on rounding)
                 const double eps = 0x1p-46 * (1.0 + best);
                 bool near = fabs(best - p.maxjmp) <= eps;
                 if (best < p.maxjmp) {
@@ -572,13 +572,12 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
 
 // The scan over the chunks' totals and the roots of the chunks' LAST frames, as k_track_boundaries does for k_track_links:
 // one workgroup; chunkbase[c] = new partials before chunk c.
-__global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// (a workgroup of 1 024 threads; rb: NCH K ints of LDS)
+__device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32_t* rb) {
     if (p.wide != nullptr && *(volatile unsigned*)p.wide_dev == p.gen) return;  // (k_track_links_lane has given up: TrackParams::wide)
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     __shared__ int amb_s, last_s;
-    int32_t* rb = (int32_t*)smem;                                // [NCH][K]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = p.K;
     const int64_t F = p.F;
@@ -615,20 +614,231 @@ __global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
     if (last >= 0) atomicMax(&last_s, last);
     __syncthreads();
     if (tid == 0) { p.chunkbase[NCH] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
-    for (int r = 0; (1 << r) < NCH; r++) {
+    // pointer doubling over the chunks' last frames.  An item is -1 (empty slot), a root that is final (>= 0: a node inside the
+    // item's own chunk, or one that is not on a chunk's last frame), or -2 - j: "whatever item j says" (j: the last-frame node of an
+    // earlier chunk the root so far names) -- the divisions that find j happen once, the rounds are two LDS reads and a write
+    // (eight rounds of three divisions per item were 6 of this kernel's 12 us at BASELINE config 2)
+    for (int w = tid; w < items; w += 1024) {
+        const int v = rb[w];
+        if (v < 0) continue;
+        const int fv = (int)((unsigned)v / (unsigned)K), cv = fv / CLL;   // the frame and chunk v names
+        if (cv >= (int)((unsigned)w / (unsigned)K) || ((fv + 1) & (CLL - 1)) != 0) continue;
+        rb[w] = -2 - (cv * K + (v - fv * K));
+    }
+    __syncthreads();
+    for (int r = 0; r < 40; r++) {                                // (a chain of n hops is done after log2 n + 1 rounds)
         int moved = 0;
         for (int w = tid; w < items; w += 1024) {
-            const int v = rb[w];
-            if (v < 0) continue;                                  // empty slot
-            const int fv = v / K, cv = fv / CLL;                  // the frame and chunk v names
-            if (cv >= w / K) continue;                            // a root inside this item's own chunk: final
-            if (((fv + 1) & (CLL - 1)) != 0) continue;            // a root that is not on a chunk's last frame: final
-            const int nv = rb[cv * K + (v - fv * K)];
-            if (nv != v) { rb[w] = nv; moved = 1; }
+            const int x = rb[w];
+            if (x <= -2) { rb[w] = rb[-2 - x]; moved = 1; }       // (whichever of item j's values this round: both are on the way)
         }
         if (!__syncthreads_or(moved)) break;
     }
-    for (int w = tid; w < items; w += 1024) { const int c = w / K; p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+    for (int w = tid; w < items; w += 1024) { const int c = (int)((unsigned)w / (unsigned)K); p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+}
+
+__global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    boundaries_lane_body(p, (int32_t*)smem);                      // [NCH][K]
+}
+
+// ---- npks <= 8: EIGHT LANES per frame ---------------------------------------------------------------------------
+// k_track_links_lane's tables from eight lanes per frame instead of one: lane l of a group holds slot l of the frame and of the
+// frame before it, the assignment loop's eight steps each cost one quotient per lane and two minima over the group (v_min over
+// three DPP steps: quad_perm, quad_perm, row_half_mirror) instead of eight quotients and sixteen selects in one lane.  A frame per
+// lane left the chip with one wave per SIMD (202 workgroups of 256 frames at BASELINE config 2: a lone wave issues an
+// instruction every 4.5 cycles, a v_cndmask every 19 -- 1 600 of its 5 400 instructions per 64 frames); here a workgroup of 1 024
+// threads takes its chunk of 256 frames in two passes of 128 (four waves per SIMD), the rows are read and the links written
+// lane-contiguous.  The arithmetic -- quotient through the reciprocal, the `near` margins, the exact-tie test -- is
+// k_track_links_lane's, and so are the flags that send a table to k_track_sequential.  The chunk step (creation ranks, roots by
+// pointer doubling in LDS) follows on the frames' results left in LDS.
+constexpr int G8T = 1024;                      // threads per workgroup
+constexpr int G8F = G8T / 8;                   // frames per pass
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
+    __shared__ int R[CLL * KL];
+    __shared__ int Lnn[CLL];                                              // per frame of the chunk: new partials | kAmbBit | kHasBit
+    __shared__ __attribute__((aligned(16))) double Lrow[G8F][3 * KL];     // per frame of a pass: magnitudes' keys now | before; new frequencies by rank
+    __shared__ int wtot[CLL / 64], wamb[CLL / 64], wlast[CLL / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, K = p.K;
+    const int l = tid & 7, g = tid >> 3, sh = lane & ~7;
+    const int64_t fb = (int64_t)blockIdx.x * CLL;
+    constexpr int kOut = 1 << 20;
+    // rows of more than KL slots: as k_track_links_lane (TrackParams::wide)
+    if (K > KL) {
+        bool widefr = false;
+        for (int ps = 0; ps < CLL / G8F; ps++) {
+            const int64_t fr = fb + ps * G8F + g;
+            if (fr < p.F) for (int s2 = KL + l; s2 < K; s2 += 8) widefr = widefr || (p.f[fr * K + s2] > 0.0 && p.mag[fr * K + s2] > 0.0);
+        }
+        if (__syncthreads_or(widefr)) {
+            if (tid == 0) { *p.wide = p.gen; *p.wide_dev = p.gen; }
+            return;
+        }
+    }
+    // (the rows of both passes are asked for before the first pass starts)
+    double cf_[CLL / G8F], cm_[CLL / G8F], pf_[CLL / G8F], pm_[CLL / G8F];
+#pragma unroll
+    for (int ps = 0; ps < CLL / G8F; ps++) {
+        const int64_t fr = fb + ps * G8F + g;
+        cf_[ps] = cm_[ps] = pf_[ps] = pm_[ps] = 0.0;
+        if (fr < p.F && l < K) {
+            cf_[ps] = p.f[fr * K + l]; cm_[ps] = p.mag[fr * K + l];
+            if (fr > 0) { pf_[ps] = p.f[(fr - 1) * K + l]; pm_[ps] = p.mag[(fr - 1) * K + l]; }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < CLL / G8F; ps++) {
+        const int fl = ps * G8F + g;                                      // frame of the chunk
+        const int64_t fr = fb + fl;
+        const bool live = fr < p.F;
+        const double cf = cf_[ps], cm = cm_[ps], pf = pf_[ps], pm = pm_[ps];
+        // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first (see the header)
+        const bool vc = cf > 0.0 && cm > 0.0, vp = pf > 0.0 && pm > 0.0;
+        const double kc = vc ? cm : -1.0, kpv = vp ? pm : -1.0;          // invalid entries rank below every valid one
+        double* row = &Lrow[g][0];
+        row[l] = kc; row[KL + l] = kpv;
+        pvxw::wave_sync();
+        int ra = 0, rb = 0;
+#pragma unroll
+        for (int j = 0; j < KL; j++) {
+            const double cj = row[j], pj = row[KL + j];
+            ra += (cj > kc) | ((cj == kc) & (j > l));
+            rb += (pj > kpv) | ((pj == kpv) & (j > l));
+        }
+        const int rc = vc ? ra : KL, rp = vp ? rb : KL;
+        const int nc = __popc((unsigned)(__ballot(vc) >> sh) & 0xffu);
+        if (vc) row[2 * KL + rc] = cf;                                    // the new peaks' frequencies by rank
+        pvxw::wave_sync();
+        double cfs[KL];
+#pragma unroll
+        for (int c = 0; c < KL; c++) cfs[c] = row[2 * KL + c];           // (entries from nc on: not used)
+        const double pfc = vp ? pf : 1.0;
+        const double rpf = 1.0 / pfc;
+        // (a frequency whose reciprocal or quotients could leave the normal range: let the exact loop build the table)
+        bool amb = vp && !(pfc > 1e-290 && pfc < 1e290);
+        // the assignment loop (PVAnalysis.py:903-957): this lane is previous peak l, and the new peak of rank rc
+        int link = -2, nrk = -1, nnew = 0;
+        bool used = false;
+#pragma unroll
+        for (int c = 0; c < KL; c++) {
+            if (c < nc) {                                                 // (the same for the eight lanes of a frame)
+                const double fcur = cfs[c];
+                // fcur / pf through the previous peak's reciprocal, then dpitch2st: k_track_links_lane's expressions
+                const double q0 = fcur * rpf;
+                const double q = __builtin_fma(__builtin_fma(-q0, pf, fcur), rpf, q0);
+                const bool avail = vp && !used;
+                const double st = avail ? fabs(17.312 * (q - 1.0)) : INFINITY;
+                double best = st;
+                best = min_nn(best, pvxw::dpp_d<0xB1>(best));
+                best = min_nn(best, pvxw::dpp_d<0x4E>(best));
+                best = min_nn(best, pvxw::dpp_d<0x141>(best));
+                // the first minimum in the order of the previous partials (np.argmin over the sorted list, PVAnalysis.py:893, 920)
+                const bool cand = avail && st == best;
+                int wr = cand ? rp : KL;
+                wr = min(wr, dpp_i<0xB1>(wr));
+                wr = min(wr, dpp_i<0x4E>(wr));
+                wr = min(wr, dpp_i<0x141>(wr));
+                const bool win = cand && rp == wr;
+                const unsigned gw = (unsigned)(__ballot(win) >> sh) & 0xffu;
+                const bool some = gw != 0u;                               // an unused previous peak exists (best is finite)
+                const bool hit = some && best < p.maxjmp;                 // PVAnalysis.py:923
+                // where the threshold test or the choice of the nearest partial hangs on less than the quotients' rounding: see
+                // k_track_links_lane
+                const double eps = 0x1p-46 * (1.0 + best);
+                const bool n2 = hit && !win && (st - best <= eps);        // (unavailable ones are at infinity)
+                const bool near = some && (fabs(best - p.maxjmp) <= eps || ((unsigned)(__ballot(n2) >> sh) & 0xffu) != 0u);
+                amb = amb || near;
+                if (hit) {
+                    const unsigned ge = (unsigned)(__ballot(st == best) >> sh) & 0xffu;
+                    if (__popc(ge) > 1) {
+                        // another unused previous partial exactly as near: if it is also exactly as strong as the winner the
+                        // reference would let the partial index decide (see the header)
+                        const double wm = row[KL + (__ffs((int)gw) - 1)];   // (the winner is a valid peak: its key is its magnitude)
+                        const unsigned gs = (unsigned)(__ballot(st == best && pm == wm) >> sh) & 0xffu;
+                        amb = amb || __popc(gs) > 1;
+                    }
+                    used = used || win;
+                    if (rc == c) link = __ffs((int)gw) - 1;
+                } else {
+                    if (rc == c) { link = -1; nrk = nnew; }               // add_empty_partial
+                    nnew++;
+                }
+            }
+        }
+        // ---- the frame's rows of the table's workspace
+        if (live) {
+            if (l < K) {
+                p.link[fr * K + l] = link >= 0 ? link : (link == -2 ? -1 : -(nrk + 2));   // the table's code (pvx_internal.h)
+                if (fr > 0) p.succ[(fr - 1) * K + l] = (unsigned char)used;          // by slot of frame fr-1: continued
+                if (fr == p.F - 1) p.succ[fr * K + l] = 0;
+            }
+            for (int s2 = KL + l; s2 < K; s2 += 8) {                      // (empty slots of a wide row)
+                p.link[fr * K + s2] = -1;
+                if (fr > 0) p.succ[(fr - 1) * K + s2] = 0;
+                if (fr == p.F - 1) p.succ[fr * K + s2] = 0;
+                p.root[fr * K + s2] = -1;
+            }
+        }
+        const bool amb_any = ((unsigned)(__ballot(amb) >> sh) & 0xffu) != 0u;
+        if (l == 0) {
+            const int v = live ? (nnew | (amb_any ? kAmbBit : 0) | (nc > 0 ? kHasBit : 0)) : 0;
+            Lnn[fl] = v;
+            if (live) p.newcount[fr] = v;
+        }
+        // roots: a new partial's root is its own node, a continued peak starts at its predecessor's node (k_track_links_lane)
+        R[fl * KL + l] = (!live || l >= K || link == -2) ? -1 : (link == -1 ? fl * KL + l : (fl == 0 ? kOut + link : (fl - 1) * KL + link));
+    }
+    __syncthreads();
+    // ---- creation ranks inside the chunk, the chunk's totals: thread t < CLL is frame t
+    const int64_t fr2 = fb + tid;
+    const bool live2 = tid < CLL && fr2 < p.F;
+    const int v2 = live2 ? Lnn[tid] : 0;
+    const int mine = v2 & 0xff;
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    const unsigned long long bamb = __ballot((v2 & kAmbBit) != 0), bhas = __ballot((v2 & kHasBit) != 0);
+    if (tid < CLL) {
+        if (lane == 63) wtot[wid] = inc;
+        if (lane == 0) { wamb[wid] = bamb != 0ull; wlast[wid] = bhas ? (int)(fb + wid * 64 + 63 - __builtin_clzll(bhas)) : -1; }
+    }
+    __syncthreads();
+    if (live2) {
+        int64_t before = 0;
+        for (int w = 0; w < wid; w++) before += wtot[w];
+        p.newbase[fr2] = before + inc - mine;
+    }
+    if (tid == 0) {
+        int tot = 0, amb = 0, last = -1;
+        for (int w = 0; w < CLL / 64; w++) { tot += wtot[w]; amb |= wamb[w]; last = wlast[w] > last ? wlast[w] : last; }
+        p.chunktot[blockIdx.x] = tot | (amb ? kAmbBit : 0);
+        p.chunklast[blockIdx.x] = last;
+    }
+    // pointer doubling until every node of the chunk names a root or a node of the frame before the chunk
+    for (int round = 0; round < 8; round++) {
+        int moved = 0;
+#pragma unroll
+        for (int n = tid; n < CLL * KL; n += G8T) {
+            const int r = R[n];
+            if (r >= 0 && r < kOut && r != n) {                           // a node of this chunk that is not me: where does it point?
+                const int rr = R[r];
+                if (rr != r) { R[n] = rr; moved = 1; }
+            }
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+#pragma unroll
+    for (int n = tid; n < CLL * KL; n += G8T) {
+        const int fl = n >> 3, s2 = n & 7;
+        if (fb + fl < p.F && s2 < K) {
+            const int r = R[n];
+            p.root[(fb + fl) * K + s2] = r < 0 ? -1 : (r >= kOut ? (int)((fb - 1) * K + (r - kOut)) : (int)((fb + (r >> 3)) * K + (r & 7)));
+        }
+    }
 }
 
 // The reference's loop as it stands (PVAnalysis.py:871-957), one wave, frames in order, partial indices at
@@ -910,7 +1120,9 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
         if (fits && p.chunkbase && !getenv("PVX_TRACK_CHUNK") && !getenv("PVX_TRACK_GENERIC") && !getenv("PVX_TRACK_LARGE") &&
             !getenv("PVX_TRACK_FPW") && !getenv("PVX_TRACK_WAVES")) {
             p.chunk = CLL;
-            hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
+            // (PVX_TRACK_LANE_FRAME=1: the frame-per-lane kernel, the same tables -- tests and A/B runs)
+            if (getenv("PVX_TRACK_LANE_FRAME")) hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
+            else hipLaunchKernelGGL(k_track_links_g8, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
             if (blds > 48 * 1024)
                 PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
             hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);

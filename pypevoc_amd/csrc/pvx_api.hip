@@ -1596,6 +1596,10 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
         if (!pinned3) PVX_HIP_CHECK(hipMemcpyAsync(pa_, tp.npartials, 24, hipMemcpyDeviceToHost, s));
         PVX_HIP_CHECK(hipStreamSynchronize(s));
     }
+    if (pa[1] != 0 && getenv("PVX_TRACK_FORBID_SEQUENTIAL")) {      // tests: which tables the frame-parallel kernels hand over
+        pvx_set_error("the frame-parallel tracker kernels left this table to k_track_sequential");
+        return PVX_ERR_UNSUPPORTED;
+    }
     if (pa[1] != 0 || getenv("PVX_TRACK_SEQUENTIAL")) {
         // an exact double tie (k_track.hip): the reference's order of the previous partials decides; redo the
         // table with the sequential kernel, which has the partial indices at hand

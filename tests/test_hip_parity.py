@@ -170,6 +170,61 @@ def test_tracker_variants_give_the_reference_table(amd, name, env, monkeypatch):
     assert np.array_equal(pid, s2.partial_table()[0])
 
 
+def test_tracker_short_rows_eight_lanes_per_frame(amd, oracle, monkeypatch):
+    """Rows of npks <= 8 (and wider rows whose peaks all sit in the first eight slots) take k_track_links_g8, eight lanes per
+    frame; k_track_links_lane (a frame per lane, PVX_TRACK_LANE_FRAME=1) builds the same table, and both the oracle's: random
+    tables with births, deaths, gaps, equal magnitudes and empty frames, over several chunks of 256 frames and ragged ends.  A
+    new peak that finds every previous peak taken -- a partial born beside continuing ones, the ordinary case -- is no reason to
+    hand the table to the sequential kernel (PVX_TRACK_FORBID_SEQUENTIAL=1 turns that hand-over into an error)."""
+    rng = np.random.default_rng(23)
+    for K, F in ((1, 300), (3, 257), (7, 600), (8, 1), (8, 255), (8, 256), (8, 1100), (12, 700), (20, 513)):
+        kk = min(K, 8)
+        base = np.sort(rng.uniform(80.0, 6000.0, kk))
+        f = np.zeros((F, K))
+        mag = np.zeros((F, K))
+        f[:, :kk] = base * (1.0 + 0.004 * rng.standard_normal((F, kk)))               # slow tones: most peaks continue
+        mag[:, :kk] = rng.uniform(0.1, 1.0, (F, kk))
+        jump = rng.uniform(size=(F, kk)) < 0.05
+        f[:, :kk][jump] *= rng.uniform(1.1, 1.6, int(jump.sum()))                       # births / deaths
+        mag[:, :kk][rng.uniform(size=(F, kk)) < 0.1] = 0.0                              # gaps
+        if F > 40:
+            mag[30:33] = 0.0                                                            # empty frames
+            mag[35, :kk] = 0.5                                                          # equal magnitudes: the tie order of the ranks
+        tables = []
+        for env in ({}, {"PVX_TRACK_LANE_FRAME": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ss = amd.SinSum(44100.0, nfft=2048, hop=512)
+            ss._from_analysis(f, mag, np.zeros((F, K)), np.zeros((F, K)))
+            tables.append(ss.partial_table())
+            for k in env:
+                monkeypatch.delenv(k)
+        opid, ost, oln = oracle.track(f, mag)
+        for pid, st, ln in tables:
+            assert np.array_equal(pid, opid) and np.array_equal(st, ost) and np.array_equal(ln, oln), (K, F)
+    # births beside continuing partials: frame-parallel all the way
+    F, K = 2000, 8
+    f = np.zeros((F, K))
+    mag = np.zeros((F, K))
+    f[:, :5] = np.array([220.0, 440.0, 660.0, 880.0, 1100.0]) * (1.0 + 1e-4 * rng.standard_normal((F, 5)))
+    mag[:, :5] = np.array([1.0, 0.8, 0.6, 0.5, 0.4])
+    for fr in range(10, F, 7):                                                          # a weaker sixth peak comes and goes
+        f[fr:fr + 3, 5] = 3000.0 + fr
+        mag[fr:fr + 3, 5] = 0.1
+    for env in ({}, {"PVX_TRACK_LANE_FRAME": "1"}):
+        monkeypatch.setenv("PVX_TRACK_FORBID_SEQUENTIAL", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ss = amd.SinSum(44100.0, nfft=2048, hop=512)
+        ss._from_analysis(f, mag, np.zeros((F, K)), np.zeros((F, K)))
+        pid, st, ln = ss.partial_table()
+        for k in list(env) + ["PVX_TRACK_FORBID_SEQUENTIAL"]:
+            monkeypatch.delenv(k)
+        opid, ost, oln = oracle.track(f, mag)
+        assert np.array_equal(pid, opid) and np.array_equal(st, ost) and np.array_equal(ln, oln)
+        assert len(ost) == 5 + len(range(10, F, 7))
+
+
 def test_tracker_wide_rows(amd, oracle):
     """npks beyond the register kernels (K > 256: the LDS link loop) and at their edges (64, 65, 128, 129, 256)."""
     rng = np.random.default_rng(11)
