@@ -574,26 +574,31 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
 // one workgroup; chunkbase[c] = new partials before chunk c.
 // (a workgroup of 1 024 threads; rb: NCH K ints of LDS)
 __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32_t* rb) {
-    if (p.wide != nullptr && *(volatile unsigned*)p.wide_dev == p.gen) return;  // (k_track_links_lane has given up: TrackParams::wide)
+    // (one workgroup alone on the chip: every dependent round trip to memory is 2 us of the launch, so the word that says whether
+    // k_track_links_lane has given up (TrackParams::wide), the chunks' totals and their last rows are all asked for at once)
+    const unsigned widev = p.wide != nullptr ? *(volatile unsigned*)p.wide_dev : 0u;
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     __shared__ int amb_s, last_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = p.K;
     const int64_t F = p.F;
-    const int NCH = (int)((F + CLL - 1) / CLL);
+    const int CL = p.chunk;                                       // frames per chunk: 256, or 128 (k_track_links_g8<128>)
+    const int NCH = (int)((F + CL - 1) / CL);
     const int items = NCH * K;
-    auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) * CLL; return (e < F ? e : F) - 1; };
-    for (int w = tid; w < items; w += 1024) { const int c = w / K; rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
+    auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) * CL; return (e < F ? e : F) - 1; };
+    const int raw0 = tid < NCH ? p.chunktot[tid] : 0, last0 = tid < NCH ? p.chunklast[tid] : -1;
+    for (int w = tid; w < items; w += 1024) { const int c = (int)((unsigned)w / (unsigned)K); rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
+    if (p.wide != nullptr && widev == p.gen) return;              // (the same for every thread)
     if (tid == 0) { carry_s = 0; amb_s = 0; last_s = -1; }
     __syncthreads();
     bool amb = false;
     int last = -1;
     for (int base = 0; base < NCH; base += 1024) {
         const int c = base + tid;
-        const int raw = c < NCH ? p.chunktot[c] : 0;
+        const int raw = base == 0 ? raw0 : (c < NCH ? p.chunktot[c] : 0);
         amb = amb || (raw & kAmbBit);
-        if (c < NCH) { const int l = p.chunklast[c]; last = l > last ? l : last; }
+        if (c < NCH) { const int l = base == 0 ? last0 : p.chunklast[c]; last = l > last ? l : last; }
         const long long v = raw & (kAmbBit - 1);
         long long inc = v;
 #pragma unroll
@@ -621,8 +626,8 @@ __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32
     for (int w = tid; w < items; w += 1024) {
         const int v = rb[w];
         if (v < 0) continue;
-        const int fv = (int)((unsigned)v / (unsigned)K), cv = fv / CLL;   // the frame and chunk v names
-        if (cv >= (int)((unsigned)w / (unsigned)K) || ((fv + 1) & (CLL - 1)) != 0) continue;
+        const int fv = (int)((unsigned)v / (unsigned)K), cv = fv / CL;    // the frame and chunk v names (CL a power of two)
+        if (cv >= (int)((unsigned)w / (unsigned)K) || ((fv + 1) & (CL - 1)) != 0) continue;
         rb[w] = -2 - (cv * K + (v - fv * K));
     }
     __syncthreads();
@@ -648,26 +653,27 @@ __global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
 // three DPP steps: quad_perm, quad_perm, row_half_mirror) instead of eight quotients and sixteen selects in one lane.  A frame per
 // lane left the chip with one wave per SIMD (202 workgroups of 256 frames at BASELINE config 2: a lone wave issues an
 // instruction every 4.5 cycles, a v_cndmask every 19 -- 1 600 of its 5 400 instructions per 64 frames); here a workgroup of 1 024
-// threads takes its chunk of 256 frames in two passes of 128 (four waves per SIMD), the rows are read and the links written
-// lane-contiguous.  The arithmetic -- quotient through the reciprocal, the `near` margins, the exact-tie test -- is
+// threads takes its chunk of CL = 256 frames in two passes of 128 (four waves per SIMD) -- or, while the boundary step's rows of
+// twice as many chunks fit its LDS, a chunk of 128 frames in one --, the rows are read and the links written lane-contiguous.  The arithmetic -- quotient through the reciprocal, the `near` margins, the exact-tie test -- is
 // k_track_links_lane's, and so are the flags that send a table to k_track_sequential.  The chunk step (creation ranks, roots by
 // pointer doubling in LDS) follows on the frames' results left in LDS.
 constexpr int G8T = 1024;                      // threads per workgroup
 constexpr int G8F = G8T / 8;                   // frames per pass
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CL>
 __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
-    __shared__ int R[CLL * KL];
-    __shared__ int Lnn[CLL];                                              // per frame of the chunk: new partials | kAmbBit | kHasBit
+    __shared__ int R[CL * KL];
+    __shared__ int Lnn[CL];                                              // per frame of the chunk: new partials | kAmbBit | kHasBit
     __shared__ __attribute__((aligned(16))) double Lrow[G8F][3 * KL];     // per frame of a pass: magnitudes' keys now | before; new frequencies by rank
-    __shared__ int wtot[CLL / 64], wamb[CLL / 64], wlast[CLL / 64];
+    __shared__ int wtot[CL / 64], wamb[CL / 64], wlast[CL / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, K = p.K;
     const int l = tid & 7, g = tid >> 3, sh = lane & ~7;
-    const int64_t fb = (int64_t)blockIdx.x * CLL;
+    const int64_t fb = (int64_t)blockIdx.x * CL;
     constexpr int kOut = 1 << 20;
     // rows of more than KL slots: as k_track_links_lane (TrackParams::wide)
     if (K > KL) {
         bool widefr = false;
-        for (int ps = 0; ps < CLL / G8F; ps++) {
+        for (int ps = 0; ps < CL / G8F; ps++) {
             const int64_t fr = fb + ps * G8F + g;
             if (fr < p.F) for (int s2 = KL + l; s2 < K; s2 += 8) widefr = widefr || (p.f[fr * K + s2] > 0.0 && p.mag[fr * K + s2] > 0.0);
         }
@@ -677,9 +683,9 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
         }
     }
     // (the rows of both passes are asked for before the first pass starts)
-    double cf_[CLL / G8F], cm_[CLL / G8F], pf_[CLL / G8F], pm_[CLL / G8F];
+    double cf_[CL / G8F], cm_[CL / G8F], pf_[CL / G8F], pm_[CL / G8F];
 #pragma unroll
-    for (int ps = 0; ps < CLL / G8F; ps++) {
+    for (int ps = 0; ps < CL / G8F; ps++) {
         const int64_t fr = fb + ps * G8F + g;
         cf_[ps] = cm_[ps] = pf_[ps] = pm_[ps] = 0.0;
         if (fr < p.F && l < K) {
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
         }
     }
 #pragma unroll
-    for (int ps = 0; ps < CLL / G8F; ps++) {
+    for (int ps = 0; ps < CL / G8F; ps++) {
         const int fl = ps * G8F + g;                                      // frame of the chunk
         const int64_t fr = fb + fl;
         const bool live = fr < p.F;
@@ -790,9 +796,9 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
         R[fl * KL + l] = (!live || l >= K || link == -2) ? -1 : (link == -1 ? fl * KL + l : (fl == 0 ? kOut + link : (fl - 1) * KL + link));
     }
     __syncthreads();
-    // ---- creation ranks inside the chunk, the chunk's totals: thread t < CLL is frame t
+    // ---- creation ranks inside the chunk, the chunk's totals: thread t < CL is frame t
     const int64_t fr2 = fb + tid;
-    const bool live2 = tid < CLL && fr2 < p.F;
+    const bool live2 = tid < CL && fr2 < p.F;
     const int v2 = live2 ? Lnn[tid] : 0;
     const int mine = v2 & 0xff;
     int inc = mine;
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
         if (lane >= o) inc += u;
     }
     const unsigned long long bamb = __ballot((v2 & kAmbBit) != 0), bhas = __ballot((v2 & kHasBit) != 0);
-    if (tid < CLL) {
+    if (tid < CL) {
         if (lane == 63) wtot[wid] = inc;
         if (lane == 0) { wamb[wid] = bamb != 0ull; wlast[wid] = bhas ? (int)(fb + wid * 64 + 63 - __builtin_clzll(bhas)) : -1; }
     }
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
     }
     if (tid == 0) {
         int tot = 0, amb = 0, last = -1;
-        for (int w = 0; w < CLL / 64; w++) { tot += wtot[w]; amb |= wamb[w]; last = wlast[w] > last ? wlast[w] : last; }
+        for (int w = 0; w < CL / 64; w++) { tot += wtot[w]; amb |= wamb[w]; last = wlast[w] > last ? wlast[w] : last; }
         p.chunktot[blockIdx.x] = tot | (amb ? kAmbBit : 0);
         p.chunklast[blockIdx.x] = last;
     }
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
     for (int round = 0; round < 8; round++) {
         int moved = 0;
 #pragma unroll
-        for (int n = tid; n < CLL * KL; n += G8T) {
+        for (int n = tid; n < CL * KL; n += G8T) {
             const int r = R[n];
             if (r >= 0 && r < kOut && r != n) {                           // a node of this chunk that is not me: where does it point?
                 const int rr = R[r];
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
         if (!__syncthreads_or(moved)) break;
     }
 #pragma unroll
-    for (int n = tid; n < CLL * KL; n += G8T) {
+    for (int n = tid; n < CL * KL; n += G8T) {
         const int fl = n >> 3, s2 = n & 7;
         if (fb + fl < p.F && s2 < K) {
             const int r = R[n];
@@ -1113,16 +1119,22 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
         // valid peak beyond slot 7 (a tone under the reference's default npks = 20): the kernel says so in *p.wide if one
         // has, and the caller, who waits for the result words anyway, then calls again without the word (track_on).
         // While the last-frame rows of the chunks fit one workgroup's LDS.
-        const int64_t nchl = (p.F + CLL - 1) / CLL;
+        // (chunks of 128 frames for k_track_links_g8 while the boundary step has the LDS for twice the rows; PVX_TRACK_CHUNK256=1: A/B)
+        const bool g8 = getenv("PVX_TRACK_LANE_FRAME") == nullptr;
+        // (... and while every workgroup still has a CU to itself: 0.043 -> 0.038 ms on 25 836 frames of noise; two workgroups on some CUs: no gain)
+        const bool c128 = g8 && (p.F + 127) / 128 <= 256 && (size_t)((p.F + 127) / 128) * p.K * 4 <= 150 * 1024 && !getenv("PVX_TRACK_CHUNK256");
+        const int CLx = c128 ? 128 : CLL;
+        const int64_t nchl = (p.F + CLx - 1) / CLx;
         const size_t blds = (size_t)nchl * p.K * 4;
         const bool hope = p.K > KL;
         const bool fits = blds <= 150 * 1024 && (!hope || (p.K <= 64 && p.wide != nullptr && p.wide_dev != nullptr && p.gen != 0 && !getenv("PVX_TRACK_NO_LANE")));
         if (fits && p.chunkbase && !getenv("PVX_TRACK_CHUNK") && !getenv("PVX_TRACK_GENERIC") && !getenv("PVX_TRACK_LARGE") &&
             !getenv("PVX_TRACK_FPW") && !getenv("PVX_TRACK_WAVES")) {
-            p.chunk = CLL;
+            p.chunk = CLx;
             // (PVX_TRACK_LANE_FRAME=1: the frame-per-lane kernel, the same tables -- tests and A/B runs)
-            if (getenv("PVX_TRACK_LANE_FRAME")) hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
-            else hipLaunchKernelGGL(k_track_links_g8, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
+            if (!g8) hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
+            else if (c128) hipLaunchKernelGGL(k_track_links_g8<128>, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
+            else hipLaunchKernelGGL(k_track_links_g8<256>, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
             if (blds > 48 * 1024)
                 PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
             hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);

@@ -1547,7 +1547,7 @@ static size_t track_ws_bytes(int64_t F, int K) {
     off = (off + 7) & ~(size_t)7;
     off += ((size_t)F + 1) * 8 + 32 + n;
     off = (off + 7) & ~(size_t)7;
-    const size_t nch = (size_t)(F + 255) / 256;                  // k_track_links_lane: chunkbase int64 [nch + 1], chunktot / chunklast int32 [nch]
+    const size_t nch = (size_t)(F + 127) / 128;                  // k_track_links_g8 / _lane: chunkbase int64 [nch + 1], chunktot / chunklast int32 [nch] (chunks of 128 or 256 frames)
     return off + (nch + 1) * 8 + nch * 8;
 }
 
@@ -1565,7 +1565,7 @@ static int64_t track_on(const double* d_f, const double* d_mag, int64_t F, int K
     tp.link = (int32_t*)(w + off_link); tp.root = (int32_t*)(w + off_root);
     tp.succ = (unsigned char*)(w + off_succ); tp.newcount = (int32_t*)(w + off_cnt); tp.newbase = (int64_t*)(w + off_base);
     {
-        const size_t nch = (size_t)(F + 255) / 256, off_cb = (off_succ + n + 7) & ~(size_t)7;
+        const size_t nch = (size_t)(F + 127) / 128, off_cb = (off_succ + n + 7) & ~(size_t)7;
         tp.chunkbase = (int64_t*)(w + off_cb); tp.chunktot = (int32_t*)(w + off_cb + (nch + 1) * 8); tp.chunklast = tp.chunktot + nch;
     }
     // { partials, exact double tie met, last frame with a point }: three single stores by the kernels.  In page-locked
