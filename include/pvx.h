@@ -90,7 +90,7 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *   0  framing kernel -> rocFFT batched real FFT -> phase/peak kernel (any nfft, both precisions)
  *   1  fused kernel: window, in-register/LDS FFT and peak stage in one wave per frame, no
  *      intermediate arrays in HBM (nfft in {512, 1024, 2048}, precision = 32)
- *   2  fused kernel with several waves per frame (nfft in {2048, 4096, 8192}, precision = 32)
+ *   2  (a witness kernel since round 6) fused kernel with several waves per frame (nfft in {2048, 4096, 8192}, precision = 32)
  *   3  mode 1's arithmetic (bit-identical results) with a workgroup of 8 (nfft 2048) or 12 (nfft 512, 1024)
  *      waves walking as many consecutive frames over a shared ring of spectra in LDS: two / three waves per
  *      SIMD (precision = 32; npks <= 120 at nfft 2048: the staging has to fit the LDS next to the ring)
@@ -99,7 +99,8 @@ int64_t pvx_plan_workspace_bytes(const pvx_plan* plan);
  *      sliding sample window at hop = nfft/4, nfft/2 (precision = 32, nfft in {512, 1024, 2048})
  * Mode 0 itself runs as one launch for nfft in {512, 1024, 2048} (window + FFT + peaks: k_pv_rev at float64 with npks <= 64,
  * no spectrum workspace; k_stft_pv otherwise), as fused STFT + phase/peak kernel for nfft 4096 / 8192, and through rocFFT otherwise.
- * A new plan uses 4 where it is supported, else 3, else 1, else 2, else 0 (environment PVX_FFT_MODE overrides).
+ * A new plan uses 4 where it is supported, else 5, else 0 (environment PVX_FFT_MODE overrides); 1, 2 and 3 are witness kernels of the
+ * tests: the product library answers PVX_ERR_UNSUPPORTED for them (tests/libpvx_witness.so carries them).
  */
 int pvx_plan_set_fft_mode(pvx_plan* plan, int mode);
 int pvx_plan_get_fft_mode(const pvx_plan* plan);
@@ -108,7 +109,7 @@ int pvx_plan_get_fft_mode(const pvx_plan* plan);
  * pvx_batch worker's device) instead of running kernels on buffers of the wrong device. */
 int pvx_plan_device(const pvx_plan* plan);
 /* Which kernels the plan's last calls ran, as "analysis=<kernel>;tracker=<kernel>;synth=<kernel>" (a part is missing until its
- * call has run): k_fused_rev | k_fused_team | k_fused_mw | k_pv_rev | k_stft_pv | k_stft+k_phase_peaks | k_frames+rocfft+k_phase_peaks
+ * call has run): k_fused_rev | k_fused_team | k_pv_rev | k_stft_pv | k_stft+k_phase_peaks | k_frames+rocfft+k_phase_peaks
  * for the analysis, k_synth_bodies<f64> | k_synth_bodies<f32> for the resynthesis.  For tests and benchmarks that must
  * know what they measured; the string lives in the plan and is valid until its next call. */
 const char* pvx_plan_last_kernels(const pvx_plan* plan);

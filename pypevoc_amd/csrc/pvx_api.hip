@@ -341,7 +341,7 @@ extern "C" int pvx_plan_set_fft_mode(pvx_plan* plan, int mode) {
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 2 && !pvx_fused_mw_supported(plan->nfft, plan->precision, plan->npks)) {
-        pvx_set_error("the multi-wave fused kernel handles nfft in {2048, 4096, 8192} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
+        pvx_set_error("fft mode 2 (several waves per frame, a witness since the general path took its cases: tests/libpvx_witness.so, not libpvx_hip.so) handles nfft in {2048, 4096, 8192} at precision=32 (this plan: nfft=%d precision=%d)", plan->nfft, plan->precision);
         return PVX_ERR_UNSUPPORTED;
     }
     if (mode == 1 && !pvx_fused_supported(plan->nfft, plan->precision, plan->npks)) {
@@ -484,8 +484,9 @@ extern "C" int pvx_plan_create(pvx_plan** out, double sr, int nfft, int hop, int
         if (hipMemcpy(p->d_twiddle, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { pvx_set_error("hipMemcpy(twiddle) failed"); plan_free(p); return PVX_ERR_HIP; }
         // default: one wave per frame where it exists (nfft <= 2048: independent waves walking their rows downwards
         // over one buffer each, k_fused_rev.hip, while npks leaves them enough LDS), several waves per frame above
-        // (nfft 4096 / 8192: teams of such waves, k_fused_team.hip, while npks <= 128; k_fused_mw.hip beyond)
-        p->fft_mode = can4 ? 4 : can3 ? 3 : can1 ? 1 : can5 ? 5 : 2;
+        // (nfft 4096 / 8192: teams of such waves, k_fused_team.hip, while npks <= 128; the general path beyond -- and wherever
+        // npks asks for more staging than these kernels' LDS holds.  Mode 2, k_fused_mw.hip, is a witness: only when asked for)
+        p->fft_mode = can4 ? 4 : can3 ? 3 : can1 ? 1 : can5 ? 5 : 0;
         if (const char* e = getenv("PVX_FFT_MODE")) {
             const int m = atoi(e);
             if (m == 0 || (m == 1 && can1) || (m == 2 && can2) || (m == 3 && can3) || (m == 4 && can4) || (m == 5 && can5)) p->fft_mode = m;
@@ -699,14 +700,14 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
            : (p->fft_mode == 3) ? pvx_launch_fused_ring(fp, p->nfft, x_dtype, s)
            : (p->fft_mode == 5) ? pvx_launch_fused_team(fp, p->nfft, x_dtype, s) : pvx_launch_fused_rev(fp, p->nfft, x_dtype, s);
         // (what the plan could not know when it chose the team kernel -- a salience radius beyond its fetch, a row count
-        // beyond 32 bits -- goes to the kernel of several waves per frame instead of failing the call)
+        // beyond 32 bits -- goes to the general path below instead of failing the call)
         p->last_analysis = p->fft_mode == 1 ? "k_fused" : p->fft_mode == 2 ? "k_fused_mw" : p->fft_mode == 3 ? "k_fused_ring" : p->fft_mode == 5 ? "k_fused_team" : "k_fused_rev";
-        if (rc == PVX_ERR_UNSUPPORTED && p->fft_mode == 5 && pvx_fused_mw_supported(p->nfft, p->precision, p->npks)) {
-            rc = pvx_launch_fused_mw(fp, p->nfft, x_dtype, s);
-            p->last_analysis = "k_fused_mw";
+        if (rc == PVX_ERR_UNSUPPORTED && p->fft_mode == 5 && !wire_out) {
+            p->fft_mode = 0;                                       // (the plan stays there: what carries a spectrum between calls asks the mode)
+        } else {
+            if (rc != PVX_OK) return rc;
+            return plan_event(p, s, -1);
         }
-        if (rc != PVX_OK) return rc;
-        return plan_event(p, s, -1);
     }
     p->last_from_rev = false;
     const bool take_rev = p->use_stft && p->use_pv_rev && pvx_pv_rev_takes(p->nfft, x_dtype, p->hop) && total_rows < 0x7fffff00LL;

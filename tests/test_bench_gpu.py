@@ -108,7 +108,7 @@ def test_bench_self_launch_c4_gather_matches_oracle():
     assert j["config"]["signals_per_gpu"] == 3 and j["n_gpus"] == 1 and len(j["per_rank_ms_per_step"]) == 1
     # a failing rank fails the launcher: an impossible workload argument inside the child
     rc, j, err = _run(["--gpus", "1", "--workload", "c4", "--shard-signals", "3", "--seconds", "5", "--steps", "1", "--warmup", "0", "--precision", "32",
-                       "--fft-mode", "2"], env=env)       # the multi-wave kernel exists at nfft 2048: fine -> rc 0 (the launcher passes the line through)
+                       "--fft-mode", "0"], env=env)       # the general path exists at every size: fine -> rc 0 (the launcher passes the line through)
     assert rc == 0 and j is not None, err[-2000:]
     rc, j, err = _run(["--gpus", "1", "--workload", "c4", "--shard-signals", "3", "--seconds", "5", "--steps", "1", "--warmup", "0", "--fft-mode", "5"], env=env)
     assert rc != 0 and j is None and "exited with code" in err     # mode 5 does not exist at nfft 2048: the child fails, so does the parent

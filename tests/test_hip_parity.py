@@ -612,14 +612,14 @@ def test_streaming_frame_api(amd, oracle):
 
 
 def test_product_library_carries_no_witness_kernels(amd):
-    """libpvx_hip.so has fft modes 0, 2, 4 and 5; asking it for the witness kernels (modes 1 and 3: tests/libpvx_witness.so) is
-    PVX_ERR_UNSUPPORTED with a message that says where they are, and PVX_FFT_MODE=1 / 3 leave a plan on its default mode."""
+    """libpvx_hip.so has fft modes 0, 4 and 5; asking it for the witness kernels (modes 1, 2 and 3: tests/libpvx_witness.so) is
+    PVX_ERR_UNSUPPORTED with a message that says where they are, and PVX_FFT_MODE=1 / 2 / 3 leave a plan on its default mode."""
     from pypevoc_amd import _lib
     lib = _lib.load()
     assert os.path.basename(_lib.LIB_PATH) == "libpvx_hip.so" or os.environ.get("PVX_LIB")
     p = run_pv(amd, _rand_signal(3, 20000), 22050.0, 2048, 512, 6)
     assert lib.pvx_plan_get_fft_mode(p._plan.handle) == 4
-    for mode in (1, 3):
+    for mode in (1, 2, 3):
         assert lib.pvx_plan_set_fft_mode(p._plan.handle, mode) == -5           # PVX_ERR_UNSUPPORTED
         assert lib.pvx_plan_get_fft_mode(p._plan.handle) == 4
         os.environ["PVX_FFT_MODE"] = str(mode)
@@ -1317,12 +1317,14 @@ def test_team_kernel_against_oracle_and_itself(amd, oracle, monkeypatch, nfft, k
         nv = len(f)
         assert nv == int((full.f[fr] > 0).sum()) and binno == [int(v) for v in full.binno[fr, :nv]]
         assert np.array_equal(np.asarray(f), full.f[fr, :nv]) and np.array_equal(np.asarray(realph), full.realph[fr, :nv])
-    # npks > 128 stays with the multi-wave kernel; up to 128 the teams are the default
+    # npks > 128 goes to the general path (k_fused_mw, which took it until round 6, is a witness kernel); up to 128 the teams are the default
     monkeypatch.delenv("PVX_FFT_MODE")
     if kmode != 5:
         return
-    p = run_pv(amd, harm, sr, nfft, nfft // 4, 129, precision=32)
-    assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 2
+    for xs in (harm, noise):
+        p = run_pv(amd, xs, sr, nfft, nfft // 4, 129, precision=32)
+        assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 0
+        assert_f32(compare_analysis(pv_result(p), oracle.analyze(xs, sr, nfft, nfft // 4, 129), nfft, nfft // 4, sr), absolute=False)
     for K in (64, 65, 100, 128):
         p = run_pv(amd, harm, sr, nfft, nfft // 4, K, precision=32)
         assert _lib.load().pvx_plan_get_fft_mode(p._plan.handle) == 5
