@@ -417,11 +417,10 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
 // partial's points by scanning the staged partial_id rows (a nibble per point in a 64-bit word) and reads the values where
 // they are.  No k_synth_alloc / k_synth_scatter, no second copy of the analysis arrays.
 constexpr int kDirectMaxK = 16, kDirectMaxWL = 16;
-#ifdef PVX_PARAMS_WAVES
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_WAVES, PVX_PARAMS_WAVES))) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
-#else
-__global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
+#ifndef PVX_PARAMS_WAVES
+#define PVX_PARAMS_WAVES 7
 #endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_WAVES, PVX_PARAMS_WAVES))) void k_synth_params_direct(SynthK q, int WB, int rows_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int K = q.K, tid = threadIdx.x;
     const int64_t li0 = (int64_t)blockIdx.x * 256, li = li0 + tid;
@@ -486,11 +485,13 @@ __global__ __launch_bounds__(256) void k_synth_params_direct(SynthK q, int WB, i
     // ---- the wave's records are consecutive in memory (a node's record sits at node - fb0 K): they leave through LDS, half a
     // record at a time, so that a store instruction writes 64 contiguous bytes of 16 records instead of 16 bytes of 64 (one
     // 128-byte line per lane, eight instructions each)
+    // (the staging rows take the place of the staged analysis rows: 20 KB per workgroup instead of 30 -- with the registers held to
+    // seven waves per SIMD every workgroup of BASELINE config 2's 1 615 is resident at once, where five per CU made a second round)
+    __syncthreads();
     {
-        __shared__ __attribute__((aligned(16))) unsigned char stg_all[4][64 * kLaneB];
         const unsigned long long bw = __ballot(has_body);
         if (bw != 0ull) {                                             // wave-uniform
-            unsigned char* stg = stg_all[tid >> 6];
+            unsigned char* stg = dsm + (size_t)(tid >> 6) * (64 * kLaneB);
             const int lane = tid & 63;
             unsigned char* const rec0 = (unsigned char*)(q.body + (li0 + (tid & ~63) + (q.fx0 - q.fb0) * K));
             int4 pc[8];
@@ -1115,7 +1116,7 @@ int pvx_launch_synth(const SynthParams& p, hipStream_t s) {
     const int WB = (int)ceil(q.dfr + 0.5) + 2;                        // points a closed form can need behind its node
     const bool direct = p.K <= kDirectMaxK && WB + 4 <= kDirectMaxWL && getenv("PVX_SYNTH_CSR") == nullptr;
     const int rows_cap = 256 / p.K + 2 + WB + 4;
-    const size_t direct_lds = (size_t)rows_cap * p.K * 28;
+    const size_t direct_lds = (size_t)rows_cap * p.K * 28 > (size_t)4 * 64 * kLaneB ? (size_t)rows_cap * p.K * 28 : (size_t)4 * 64 * kLaneB;   // (the rows, then the records' store staging)
     if (!p.skip_prepare) {
         if (!direct) {
             PVX_HIP_CHECK(hipMemsetAsync(q.cursor, 0, 8, s));
