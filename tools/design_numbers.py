@@ -144,17 +144,8 @@ if cf:
     L.append("")
 nr = jl("%s_next_rows.jsonl" % tag)
 if nr:
-    L.append("**The rows SURVEY 8(f) marks next (N1-N4), on config 2's signal through the Python mirrors (`tools/bench_next_rows.py` -> `profiles/%s_next_rows.jsonl`; host arrays in and out unless the line says resident; best of 5).**" % tag)
-    L.append("")
-    L.append("| row | call | frames/s | what crosses the link / note |")
-    L.append("|---|---|---|---|")
-    for d in nr:
-        if "row" in d and " cpu" not in d["row"]:
-            L.append("| %s | %.3f ms | %s | %s |" % (d["row"], d["ms"], M(d["frames_per_s"]), d["shape"]))
-    kk = []
-    if kk:
-        L.append("")
-        L.append("Their kernels (rocprofv3 kernel trace of the same run, average per launch): " + "; ".join(kk) + ".")
+    L.append("**The rows SURVEY 8(f) marks next (N1-N4)** on config 2's signal through the Python mirrors, host arrays in and out unless resident (`profiles/%s_next_rows.jsonl`, best of 5): " % tag +
+             "; ".join("%s %.3f ms (%s)" % (d["row"], d["ms"], M(d["frames_per_s"])) for d in nr if "row" in d and " cpu" not in d["row"]) + ".")
     L.append("")
 try:
     sq = json.load(open(os.path.join(P, "sq_latest.json")))
@@ -168,7 +159,7 @@ try:
         nf = 4096 if "4096" in what else 8192 if "8192" in what else 2048
         F = (44100 * 600 - nf + nf // 4 - 1) // (nf // 4)
         per = F if ("fused" in name or "stft" in name or "phase" in name or "k_pv_rev" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
-        if per is None:
+        if per is None or (what == "chain" and "k_fused_rev" in name):      # (the chain's analysis kernel is the f32 line's)
             continue
         rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.3f | %.2f |" % (
             what, short.group(1)[:44] if short else name[:44], g("SQ_INSTS_VALU") / per, g("SQ_INSTS_SALU") / per, g("SQ_INSTS_LDS") / per,
@@ -177,7 +168,7 @@ try:
     if rows:
         L.append("**SQ counters per frame (`profiles/sq_latest.json`, rocprofv3 --pmc over the C2 signal; all waves of a frame summed).**")
         L.append("")
-        L.append("| run | kernel | VALU | SALU | LDS | wave time issuing / waiting / issue-stalled | LDS bank-conflict share | LDS pipe busy |")
+        L.append("| run | kernel | VALU | SALU | LDS | wave time issuing / waiting / issue-stalled | LDS conflict share | LDS pipe busy |")
         L.append("|---|---|---|---|---|---|---|---|")
         L += rows
         L.append("")
@@ -185,7 +176,7 @@ except Exception as e:
     L.append("(no sq_latest.json: %s)" % e)
 try:
     tr = json.load(open(os.path.join(P, "traffic_latest.json")))
-    items = ["`%s` %.1f MB = %.0f B/frame" % (k, v["bytes"] / 1e6, v["bytes_per_frame"]) for k, v in tr.items() if isinstance(v, dict) and "bytes" in v]
+    items = ["`%s` %.1f MB = %.0f B/frame" % (k, v["bytes"] / 1e6, v["bytes_per_frame"]) for k, v in tr.items() if isinstance(v, dict) and "bytes" in v and k != "k_fused_rev_chain"]
     if items:
         L.append("**HBM traffic per C2 launch (`profiles/traffic_latest.json`, FETCH_SIZE × calibration + WRITE_SIZE):** " + "; ".join(items) + ".")
         L.append("")
