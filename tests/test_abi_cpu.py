@@ -171,3 +171,14 @@ def test_every_environment_switch_of_the_library_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(v for v in read if v not in doc)
     assert read and not missing, missing
+
+
+def test_design_document_stays_a_design_document():
+    """DESIGN.md is the design as it stands in at most 40 KB (the rounds' narratives live in HISTORY.md and profiles/), and its
+    numbers are the generated block: `tools/design_numbers.py` rewrites what sits between the markers from the committed profiles."""
+    path = os.path.join(ROOT, "DESIGN.md")
+    raw = open(path, "rb").read()
+    assert len(raw) <= 40 * 1024, len(raw)
+    text = raw.decode()
+    assert text.count("<!-- NUMBERS:BEGIN") == 1 and text.count("<!-- NUMBERS:END -->") == 1
+    assert text.index("<!-- NUMBERS:BEGIN") < text.index("<!-- NUMBERS:END -->")
