@@ -288,7 +288,7 @@ def compact_line(full, detail_path):
     if "extras_ok" in full:
         out["extras_ok"] = full["extras_ok"]
     if full.get("gather"):
-        out["gather"] = {k: full["gather"].get(k) for k in ("collective", "rccl_world", "wire_bytes_per_rank", "result_bytes_per_rank", "exposed_ms_per_step", "host_issue_ms_per_step",
+        out["gather"] = {k: full["gather"].get(k) for k in ("collective", "rccl_world", "wire_bytes_per_rank", "wire_bytes_per_slot", "result_bytes_per_rank", "exposed_ms_per_step", "host_issue_ms_per_step",
                                                             "valid_peaks_gathered", "checked_signals", "check_ok") if k in full["gather"]}
     out["detail"] = detail_path
     s = json.dumps(out, separators=(",", ":"))
@@ -413,13 +413,20 @@ def main():
 
     # This rank's results in the reference's layout (five float64 [rows, K] arrays + totalmag + t,
     # PV.py:256-264).  With more than one rank every step ends in ONE gather to rank 0: the rows are
-    # packed to the 18 B/slot wire format (include/pvx.h), gathered asynchronously (RCCL, its own
+    # packed to the wire format (include/pvx.h: 14 B per slot at precision 32), gathered asynchronously (RCCL, its own
     # stream, double-buffered so that the gather of step i overlaps the kernels of step i+1) and
     # unpacked on rank 0 into the full [world, ...] result, bit-identical to what each rank computed.
     if gathered and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    # (precision 32: wire format 2, 14 B per slot -- the float32 a frequency is computed from instead of the float64 frequency, decoded
+    # bit-exactly on the other side; PVX_BENCH_WIRE_FORMAT=1: the 18-byte format, for A/B runs)
+    wire_format = 1
+    if gathered and args.precision == 32 and os.environ.get("PVX_BENCH_WIRE_FORMAT", "2") == "2":
+        for pl in ([plan, plan_b] if plan_b is not None else [plan]):
+            _lib.check(lib.pvx_plan_set_wire_format(pl, 2), "pvx_plan_set_wire_format")
+        wire_format = 2
     wire = ResultWire(plan, FT, K)
     nres = wire.result_numel() + FT
     res2 = [torch.zeros(nres, dtype=torch.float64, device=dev) for _ in range(2)]
@@ -578,7 +585,8 @@ def main():
         n_ok = int((full[:, : FT * K] > 0).sum().item())
         gather_info = dict(collective="one asynchronous RCCL gather per step to rank 0, double-buffered",
                            unpack=("inside the step, on a side stream of rank 0" if args.unpack_in_step else
-                                   "on demand: the gathered blocks stay in the 18 B/slot wire format on rank 0 (decoded after the timed region for the checks)"),
+                                   "on demand: the gathered blocks stay in the wire format on rank 0 (decoded after the timed region for the checks)"),
+                           wire_format=wire_format, wire_bytes_per_slot=(14 if wire_format == 2 else (18 if args.precision == 32 else 26)),
                            rccl_world=int(dist.get_world_size()), wire_bytes_per_rank=int(wire.nbytes),
                            result_bytes_per_rank=int(wire.result_numel() * 8), valid_peaks_gathered=n_ok)
         if args.check_gathered > 0:

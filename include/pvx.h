@@ -384,13 +384,20 @@ int64_t pvx_funcwind_dev(const double* d_x, int x_complex, int64_t n, const doub
  * with the same plan parameters.  `rows` = frames of all signals of the shard; all pointers are
  * device memory; launches are asynchronous on `stream`.
  */
+/* Wire format of a plan: 1 (default) as above; 2, for plans at precision 32: 14 B per slot.  There a peak's frequency is a float64
+ * function of its bin and ONE float32 value (the unwrapped phase offset of PV.py:140-147, or one of twelve cases after a silent
+ * frame): the block carries that value instead of f and the receiver evaluates the kernels' own expression -- the same bits.  Every
+ * function below follows the plan's format; pack of arrays that no precision-32 analysis wrote leaves NaN frequencies in format 2.
+ * PVX_ERR_UNSUPPORTED for format 2 on a precision-64 plan. */
+int pvx_plan_set_wire_format(pvx_plan* plan, int format);
+int pvx_plan_get_wire_format(const pvx_plan* plan);
 int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows);
 int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
                       const double* d_ph, const double* d_binno, const double* d_totalmag,
                       void* d_wire, void* stream);
 /* run_pv of nsig device-resident signals straight into a wire block of pvx_wire_bytes(plan, nsig * F) bytes: what a rank of a
- * multi-GPU job hands to the gather (bench.py).  The fused float32 kernel of nfft 512 / 1024 / 2048 writes the block itself -- 18
- * bytes per slot instead of 40, and no packing pass behind the analysis --; any other plan analyses into a plan-owned block and packs
+ * multi-GPU job hands to the gather (bench.py).  The fused float32 kernel of nfft 512 / 1024 / 2048 writes the block itself -- 18 (14 in
+ * format 2) bytes per slot instead of 40, and no packing pass behind the analysis --; any other plan analyses into a plan-owned block and packs
  * it.  pvx_unpack_rows_dev of the block gives the arrays pvx_analyze_dev would have written, bit for bit.  Returns F. */
 int64_t pvx_analyze_dev_wire(pvx_plan* plan, const void* d_x, int x_dtype, int64_t nsamp, int64_t nsig, int64_t sig_stride,
                              void* d_wire, void* stream);

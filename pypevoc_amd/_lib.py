@@ -105,6 +105,8 @@ SIGNATURES = {
     "pvx_rms_frames_dev": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, c_double_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p, ctypes.c_void_p]),
     "pvx_plan_set_progress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvx_plan_set_wire_format": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pvx_plan_get_wire_format": (ctypes.c_int, [ctypes.c_void_p]),
     "pvx_wire_bytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "pvx_batch_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_double, c_double_p, ctypes.c_int, c_int32_p, ctypes.c_int, ctypes.c_int]),

@@ -54,11 +54,13 @@ constexpr int kDense = 64;               // slots of the dense staging: one per 
 // gather writes 18 bytes per slot instead of 40 and needs no packing pass behind the analysis (which cannot run beside it: twelve
 // waves of 168 registers leave a CU no register for another kernel's wave -- the pass cost a gathered step 23 us of 125).
 typedef const __attribute__((address_space(4))) FusedParams* wire_kargs_t;
+// (wire format 2, FusedParams::wire == 2: the float32 value the frequency is computed from instead of the frequency -- 14 bytes per slot)
 __device__ __forceinline__ void emit_wire(wire_kargs_t q, int64_t i, int nbin, const PeakOut& o) {
     typedef __attribute__((address_space(1))) double gd;
     typedef __attribute__((address_space(1))) float gf;
     typedef __attribute__((address_space(1))) unsigned short gu;
-    ((gd*)q->f)[i] = o.freq;
+    if (q->wire == 2) ((gf*)q->f)[i] = o.wu;
+    else ((gd*)q->f)[i] = o.freq;
     ((gf*)q->mag)[i] = (float)o.mag;                                 // (exact: float32 values widened at precision 32)
     ((gf*)q->ph)[i] = (float)o.thisph;
     ((gu*)q->binno)[i] = (unsigned short)nbin;
@@ -67,7 +69,9 @@ __device__ __forceinline__ void pad_wire(wire_kargs_t q, int64_t i) {
     typedef __attribute__((address_space(1))) double gd;
     typedef __attribute__((address_space(1))) float gf;
     typedef __attribute__((address_space(1))) unsigned short gu;
-    ((gd*)q->f)[i] = 0.0; ((gf*)q->mag)[i] = 0.f; ((gf*)q->ph)[i] = 0.f; ((gu*)q->binno)[i] = 0;
+    if (q->wire == 2) ((gf*)q->f)[i] = 0.f;
+    else ((gd*)q->f)[i] = 0.0;
+    ((gf*)q->mag)[i] = 0.f; ((gf*)q->ph)[i] = 0.f; ((gu*)q->binno)[i] = 0;
 }
 
 template <int R> struct RevGeo {
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             gdouble* ob = (gdouble*)q->binno + orow * K;
             int nbin = 0;
             PeakOut o;
-            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.wu = 0.f; o.valid = false;
             if (valid) {
                 nbin = Lsbin[ent];
                 const float* sv = Lsval + (size_t)ent * 5;
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused_rev(FusedParams p) {
             bool valid = (cnt >= 0) && (e < cnt);
             int nbin = 0;
             PeakOut o;
-            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.valid = false;
+            o.freq = 0.0; o.dfb = 0.0; o.thisph = 0.0; o.mag = 0.0; o.wu = 0.f; o.valid = false;
             if (valid) {
                 nbin = Lsbin[g * kpad + e];
                 const float* sv = Lsval + (size_t)(g * kpad + e) * 5;

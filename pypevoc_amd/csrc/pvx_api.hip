@@ -176,6 +176,7 @@ struct pvx_plan {
     bool last_from_rev = false;  // the last analyze_rows() left its requested spectrum row in d_lastspec
     void* d_pvstage = nullptr;   // k_pv_rev at nfft 2048: the kept peaks' values between the frames (PvRevParams::stage)
     size_t pvstage_cap = 0;
+    int wire_fmt = 1;            // the gather's wire format (k_wire.hip): 1 = f as float64, 2 = the float32 it is computed from (pvx_plan_set_wire_format)
     double* d_wiretmp = nullptr; // pvx_analyze_dev_wire on plans whose kernels do not write the wire format themselves: the result block that is then packed
     size_t wiretmp_cap = 0;
     int64_t rocfft_rows = 0;     // rows of the rocFFT workspace (2 when only pvx_stft_frames uses it)
@@ -682,7 +683,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
         fp.spec_out = spec_row >= 0 ? (p->spec_host ? p->spec_host : p->d_specrow) : nullptr; fp.spec_row = spec_row;
         fp.blocks_override = p->fused_blocks;
         fp.stash = nullptr; fp.stash_bytes = 0;
-        fp.wire = wire_out ? 1 : 0;
+        fp.wire = wire_out ? p->wire_fmt : 0;
         if (p->fft_mode == 4) {
             // k_fused_rev: the block where its waves hand a spectrum to the wave below them (sized once, for a full grid)
             if (!p->d_stash) {
@@ -2158,10 +2159,25 @@ extern "C" int64_t pvx_funcwind(const double* x, int x_complex, int64_t n, const
 }
 
 // ---- result wire format for the multi-GPU gather (k_wire.hip) -------------------------------
+extern "C" int pvx_plan_set_wire_format(pvx_plan* plan, int format) {
+    if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    if (format != 1 && format != 2) { pvx_set_error("unknown wire format %d", format); return PVX_ERR_INVALID; }
+    if (format == 2 && plan->precision != 32) {
+        pvx_set_error("wire format 2 (14 bytes per slot) carries the float32 value a precision-32 analysis computes a frequency from; this plan is at precision %d", plan->precision);
+        return PVX_ERR_UNSUPPORTED;
+    }
+    plan->wire_fmt = format;
+    return PVX_OK;
+}
+extern "C" int pvx_plan_get_wire_format(const pvx_plan* plan) {
+    if (!plan) { pvx_set_error("null plan"); return PVX_ERR_INVALID; }
+    return plan->wire_fmt;
+}
+
 extern "C" int64_t pvx_wire_bytes(const pvx_plan* plan, int64_t rows) {
     if (!plan || rows < 0) { pvx_set_error("bad wire argument"); return PVX_ERR_INVALID; }
     if (plan->nfft / 2 > 65536) { pvx_set_error("wire format holds bin numbers in 16 bits (nfft <= 131072)"); return PVX_ERR_UNSUPPORTED; }
-    return (int64_t)pvx_wire_block_bytes(rows, plan->npks, plan->precision);
+    return (int64_t)pvx_wire_block_bytes(rows, plan->npks, plan->precision, plan->wire_fmt);
 }
 
 extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const double* d_f, const double* d_mag,
@@ -2174,6 +2190,7 @@ extern "C" int pvx_pack_rows_dev(const pvx_plan* plan, int64_t rows, const doubl
     if (!d_f || !d_mag || !d_ph || !d_binno || !d_totalmag || !d_wire) { pvx_set_error("null wire array"); return PVX_ERR_INVALID; }
     WireParams wp = {};
     wp.rows = rows; wp.K = plan->npks; wp.precision = plan->precision; wp.fstep = plan->fstep; wp.wire = d_wire;
+    wp.fmt = plan->wire_fmt; wp.dt = plan->dt; wp.wfbin = plan->d_wfbin;
     wp.f = d_f; wp.mag = d_mag; wp.ph = d_ph; wp.binno = d_binno; wp.totalmag = d_totalmag;
     return pvx_launch_wire(wp, true, (hipStream_t)stream);
 }
@@ -2196,11 +2213,12 @@ extern "C" int64_t pvx_analyze_dev_wire(pvx_plan* p, const void* d_x, int x_dtyp
     unsigned char* w = (unsigned char*)d_wire;
     if (p->fft_mode == 4 && p->precision == 32 && getenv("PVX_NO_WIRE_OUT") == nullptr) {
         // the sections of the block (k_wire.hip) as the kernel's output arrays
+        const size_t fw = p->wire_fmt == 2 ? 4 : 8;                   // (format 2: the float32 the frequency is computed from)
         double* wf = (double*)w;
-        double* wm = (double*)(w + al8(n * 8));
-        double* wp = (double*)(w + al8(n * 8) + al8(n * ts));
-        double* wb = (double*)(w + al8(n * 8) + 2 * al8(n * ts));
-        double* wt = (double*)(w + al8(n * 8) + 2 * al8(n * ts) + al8(n * 2));
+        double* wm = (double*)(w + al8(n * fw));
+        double* wp = (double*)(w + al8(n * fw) + al8(n * ts));
+        double* wb = (double*)(w + al8(n * fw) + 2 * al8(n * ts));
+        double* wt = (double*)(w + al8(n * fw) + 2 * al8(n * ts) + al8(n * 2));
         rc = analyze_rows(p, d_x, x_dtype, nsamp, nsig, sig_stride, F, wf, wm, wp, nullptr, wb, nullptr, wt, nullptr, (hipStream_t)stream, -1, true);
         return rc == PVX_OK ? F : rc;
     }
@@ -2222,6 +2240,7 @@ extern "C" int pvx_unpack_rows_dev(const pvx_plan* plan, int64_t rows, const voi
     if (!d_f || !d_mag || !d_ph || !d_realph || !d_binno || !d_totalmag || !d_wire) { pvx_set_error("null wire array"); return PVX_ERR_INVALID; }
     WireParams wp = {};
     wp.rows = rows; wp.K = plan->npks; wp.precision = plan->precision; wp.fstep = plan->fstep; wp.wire = (void*)d_wire;
+    wp.fmt = plan->wire_fmt; wp.dt = plan->dt; wp.wfbin = plan->d_wfbin;
     wp.of = d_f; wp.omag = d_mag; wp.oph = d_ph; wp.orealph = d_realph; wp.obinno = d_binno; wp.ototalmag = d_totalmag;
     return pvx_launch_wire(wp, false, (hipStream_t)stream);
 }

@@ -272,12 +272,15 @@ int pvx_launch_funcwind(const ReduceParams& p, int func, bool cpx, hipStream_t s
 struct WireParams {
     int64_t rows;                     // frames (all signals of the shard)
     int K, precision;
+    int fmt = 1;                      // 1: f as float64 (18 / 26 B per slot); 2 (precision 32): the float32 it is computed from (14 B)
     double fstep;
+    double dt = 0.0;                  // fmt 2: hop / sr and the plan's wfbin table (what peak_math computes a frequency from)
+    const double* wfbin = nullptr;
     void* wire;
     const double *f, *mag, *ph, *binno, *totalmag;                    // pack: inputs
     double *of, *omag, *oph, *orealph, *obinno, *ototalmag;           // unpack: outputs
 };
-size_t pvx_wire_block_bytes(int64_t rows, int K, int precision);
+size_t pvx_wire_block_bytes(int64_t rows, int K, int precision, int fmt = 1);
 int pvx_launch_wire(const WireParams& p, bool pack, hipStream_t s);
 
 // frame descriptors and helpers on the result arrays (k_desc.hip)

@@ -889,6 +889,8 @@ struct PeakConst {
 
 struct PeakOut {
     double freq, dfb, thisph, mag;
+    float wu;         // precision 32: the float32 value freq is computed from (wire format 2, k_wire.hip): the unwrapped offset `best` of
+                      // the ordinary case, or 8 + 3 quadrant + (m + 1) of a frame that follows a zero spectrum
     bool valid;
     bool nanph;       // the phase difference is NaN (x/0 with a zero real or imaginary part)
 };
@@ -918,17 +920,20 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
             // arithmetic literally here (rare frames, cost irrelevant).
             nanph = (re == 0.f || im == 0.f || re != re || im != im);
             const double dphd = (re > 0.f) ? (im > 0.f ? kPi / 4 : -kPi / 4) : (im > 0.f ? 3 * kPi / 4 : -3 * kPi / 4);
+            const int qi = (re > 0.f) ? (im > 0.f ? 0 : 1) : (im > 0.f ? 2 : 3);
             const double fb = (double)nbin * c.fstep;
             const double w0 = dphd + wfb;
             double bestabs = 0.0;
+            int mi = -1;
             o.freq = 0.0; o.dfb = 0.0;
 #pragma unroll
             for (int m = -1; m <= 1; m++) {
                 const double fq = (w0 + kPi2 * (double)m) / c.dt / kPi2;
                 const double df = fb - fq;
                 const double a = fabs(df);
-                if (m == -1 || a < bestabs) { o.freq = fq; o.dfb = df; bestabs = a; }
+                if (m == -1 || a < bestabs) { o.freq = fq; o.dfb = df; bestabs = a; mi = m; }
             }
+            o.wu = 8.f + (float)(qi * 3 + (mi + 1));
         } else {
             const float dph = atan2f(im * pr - re * pi, re * pr + im * pi);   // angle(fx * conj(old))
             nanph = dph != dph;
@@ -942,6 +947,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
             if (fabsf(u - 1.f) < ab) { best = u - 1.f; }                 // m = +1
             const double fb = (double)nbin * c.fstep;
             o.freq = fb - (double)best / c.dt;
+            o.wu = best;
             o.dfb = fb - o.freq;                                         // df = fbin - freq (PV.py:146), in the
                                                                          // reference's order: realph is then a
                                                                          // function of (nbin, freq, ph) alone,
@@ -951,6 +957,7 @@ __device__ __forceinline__ PeakOut peak_math(int nbin, T re, T im, T pr, T pi, T
         o.mag = (double)sqrtf(s3);
     } else {
         const double dre = re, dim = im, dpr = pr, dpi = pi;
+        o.wu = 0.f;
         o.thisph = atan2(dim, dre);                                  // PV.py:188
         double dph;
         if (dpr == 0.0 && dpi == 0.0) {

@@ -1766,7 +1766,7 @@ def test_first_frame_unwrapping_ties_follow_reference(amd, oracle, mode, monkeyp
 
 
 # ------------------------------------------------------------------ multi-GPU result wire format
-@pytest.mark.parametrize("precision,nfft,mode", [(32, 2048, 4), (32, 4096, 2), (32, 1000, 0), (64, 1024, 0)])
+@pytest.mark.parametrize("precision,nfft,mode", [(32, 2048, 4), (32, 4096, 5), (32, 1000, 0), (64, 1024, 0)])
 def test_result_wire_round_trip_is_bit_exact(amd, precision, nfft, mode, monkeypatch):
     """pvx_pack_rows_dev -> pvx_unpack_rows_dev (include/pvx.h: the gather's 18 / 26 B per slot format)
     gives back f, mag, ph, realph, binno, totalmag bit for bit, for every analysis kernel, including
@@ -1861,6 +1861,85 @@ def test_analysis_straight_into_the_wire_block(amd, monkeypatch, nfft, precision
         assert (res[: n] > 0).sum().item() > rows
     finally:
         lib.pvx_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("nfft,mode,K", [(2048, 4, 8), (2048, 4, 100), (1024, 4, 20), (512, 4, 3), (4096, 5, 100), (1000, 0, 12)])
+def test_wire_format_2_carries_the_float32_a_frequency_is_computed_from(amd, monkeypatch, nfft, mode, K):
+    """pvx_plan_set_wire_format(plan, 2), precision 32: 14 bytes per slot -- the float32 value peak_math computes a frequency from
+    (the unwrapped phase offset, or one of twelve cases in a frame that follows a zero spectrum) instead of the float64 frequency.
+    pack -> unpack of pvx_analyze_dev's arrays, and unpack of the block pvx_analyze_dev_wire writes (k_fused_rev itself at fft mode
+    4, analyse + pack elsewhere and under PVX_NO_WIRE_OUT=1), give f, mag, ph, realph, binno, totalmag back bit for bit: a batch of
+    signals with silent stretches (zero rows, x/0 frames), tones exactly on bin centres (an offset of zero), noise.  Frequencies
+    that no precision-32 analysis computed come back as NaN, not as something near; a precision-64 plan refuses the format."""
+    import ctypes
+    import torch
+    from pypevoc_amd import _lib
+    from pypevoc_amd.batch import ResultWire
+    lib = _lib.load()
+    monkeypatch.setenv("PVX_FFT_MODE", str(mode))
+    rng = np.random.default_rng(79)
+    sr, hop = 44100.0, nfft // 4
+    nsamp, nsig = nfft + hop * 150 + 9, 4
+    t = np.arange(nsamp) / sr
+    xb = np.stack([0.2 * np.sin(2 * np.pi * 440 * (b + 1) * t) + 0.01 * rng.standard_normal(nsamp) for b in range(nsig)]).astype(np.float32)
+    xb[1, hop * 40: hop * 40 + 3 * nfft] = 0.0
+    xb[2] = (0.3 * np.cos(2 * np.pi * (sr / nfft * 16) * t) + 0.2 * np.cos(2 * np.pi * (sr / nfft * 40) * t)).astype(np.float32)   # bin centres
+    xb[2, : 2 * nfft] = 0.0
+    xb[3] = (0.1 * rng.standard_normal(nsamp)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx = torch.from_numpy(xb).to(dev)
+    plan = ctypes.c_void_p()
+    _lib.check(lib.pvx_plan_create(ctypes.byref(plan), sr, nfft, hop, K, 0.005, _lib.dptr(np.hanning(nfft)), 32, 0), "pvx_plan_create")
+    try:
+        assert lib.pvx_plan_get_fft_mode(plan) == mode and lib.pvx_plan_get_wire_format(plan) == 1
+        F = int(lib.pvx_nframes(nsamp, nfft, hop))
+        rows = nsig * F
+        n18 = int(lib.pvx_wire_bytes(plan, rows))
+        _lib.check(lib.pvx_plan_set_wire_format(plan, 2), "pvx_plan_set_wire_format")
+        assert lib.pvx_plan_get_wire_format(plan) == 2
+        wire = ResultWire(plan, rows, K)
+        assert wire.nbytes <= 14 * rows * K + 8 * rows + 64 and wire.nbytes < n18
+        res = torch.zeros(wire.result_numel() + rows, dtype=torch.float64, device=dev)
+        rp = wire.result_ptrs(res.data_ptr())
+        _lib.check(lib.pvx_analyze_dev(plan, dx.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, rp[0], rp[1], rp[2], rp[3], rp[4],
+                                       res.data_ptr() + wire.result_numel() * 8, rp[5], None, None), "pvx_analyze_dev")
+        want = res[: wire.result_numel()].cpu().numpy().view(np.int64)
+        assert (res[: rows * K] > 0).sum().item() > rows
+
+        def decoded(block):
+            out = torch.full((wire.result_numel(),), np.nan, dtype=torch.float64, device=dev)
+            wire.unpack(block.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            return out.cpu().numpy()
+
+        w_pack = torch.full((wire.nbytes,), 0xAB, dtype=torch.uint8, device=dev)
+        wire.pack(res.data_ptr(), w_pack.data_ptr())
+        assert np.array_equal(decoded(w_pack).view(np.int64), want)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("PVX_NO_WIRE_OUT", env)
+            w = torch.full((wire.nbytes,), 0xAB, dtype=torch.uint8, device=dev)
+            r = lib.pvx_analyze_dev_wire(plan, dx.data_ptr(), _lib.PVX_F32, nsamp, nsig, nsamp, w.data_ptr(), None)
+            if env:
+                monkeypatch.delenv("PVX_NO_WIRE_OUT")
+            assert r == F, (r, lib.pvx_last_error())
+            assert np.array_equal(decoded(w).view(np.int64), want), env
+        # a frequency nobody computed: NaN on the other side
+        bad = res.clone()
+        idx = int(torch.nonzero(bad[: rows * K] > 0)[5].item())
+        bad[idx] = bad[idx] * (1.0 + 1e-9)
+        wire.pack(bad.data_ptr(), w_pack.data_ptr())
+        got = decoded(w_pack)
+        assert np.isnan(got[idx]) and np.isnan(got[: rows * K]).sum() == 1
+    finally:
+        lib.pvx_plan_destroy(plan)
+    p64 = ctypes.c_void_p()
+    _lib.check(lib.pvx_plan_create(ctypes.byref(p64), sr, 1024, 256, 8, 0.005, _lib.dptr(np.hanning(1024)), 64, 0), "pvx_plan_create")
+    try:
+        assert lib.pvx_plan_set_wire_format(p64, 2) == -5 and lib.pvx_plan_get_wire_format(p64) == 1      # PVX_ERR_UNSUPPORTED
+        assert lib.pvx_plan_set_wire_format(p64, 3) < 0
+    finally:
+        lib.pvx_plan_destroy(p64)
 
 
 # ------------------------------------------------------------------ PVHarmonic (SURVEY 8f, N3)
