@@ -695,7 +695,7 @@ constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_s
 // stated precision-32 tolerance of 1e-4 max|w|, at half the vector-ALU cycles of the float64 loop and half the
 // registers for the sums (four waves per SIMD instead of three).
 #ifndef PVX_SYNTH_WAVES_F32
-#define PVX_SYNTH_WAVES_F32(R) ((R) <= 8 ? 6 : ((R) <= 16 ? 5 : 4))
+#define PVX_SYNTH_WAVES_F32(R) ((R) <= 8 ? 5 : 4)
 #endif
 template <int R, typename S = double>
 __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((sizeof(S) == 4 ? PVX_SYNTH_WAVES_F32(R) : PVX_SYNTH_WAVES(R)), (sizeof(S) == 4 ? PVX_SYNTH_WAVES_F32(R) : PVX_SYNTH_WAVES(R))))) void k_synth_bodies(SampK q) {
@@ -801,48 +801,98 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
             __builtin_amdgcn_wave_barrier();
             const int a0 = m0 > tile ? m0 : tile, a1 = m1 < tile + cnt ? m1 : tile + cnt;
             if (mine && a1 > a0) {
-                for_bits_pre(q.bbits, a0, a1, wdA, wA, wdB, wB, [&](const int li) {
-                    const BodyRec* c = (const BodyRec*)lds + (li - tile);
-                    // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
-                    const bool fa = s < c->fmb, ma = s < c->mmb;
-                    if constexpr (sizeof(S) == 4) {
-                        PVX_BODY_PHASE(c, s, ds, ts, fa)
-                        float zr, zi, wr, wi;
+                {
+                    // float32: TWO bodies side by side -- two independent recurrences for the scheduler to interleave (a wave's dependent
+                    // instructions are ~8 cycles apart, and four waves per SIMD do not fill that: 0.127 -> 0.115 ms at BASELINE config 2) --,
+                    // each sample's sum taking body A's term, then body B's: the additions and their order are the one-body loop's, bit for
+                    // bit.  float64: one body at a time (a second body's state does not fit the three-wave register budget: 218 spilled).
+                    constexpr bool PAIR = sizeof(S) == 4;
+                    // Seeds of a body at sample s: the float64 closed form (float32 loop: float32 polynomials, then float32 state)
+                    auto seed = [&](const BodyRec* c, S (&sd)[8]) {
+                        // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
+                        const bool fa = s < c->fmb, ma = s < c->mmb;
+                        if constexpr (sizeof(S) == 4) {
+                            PVX_BODY_PHASE(c, s, ds, ts, fa)
 #ifdef PVX_AB_SYNTH_NOSEED      // tools/ab: timing-only builds (wrong waveform)
-                        zr = (float)ph_; zi = 0.f; wr = (float)dl_; wi = 0.f;
+                            sd[0] = (float)ph_; sd[1] = 0.f; sd[2] = (float)dl_; sd[3] = 0.f;
 #else
-                        fsincos_f(ph_, zi, zr);
-                        fsincos_f(dl_, wi, wr);
+                            fsincos_f(ph_, sd[1], sd[0]);
+                            fsincos_f(dl_, sd[3], sd[2]);
 #endif
-                        const float dr = (float)(fa ? c->dar : c->dbr), di = (float)(fa ? c->dai : c->dbi);
-                        const float dms = (float)(ma ? c->msa : c->msb);
-                        float ms = (float)__builtin_fma(ma ? c->msa : c->msb, ds, ma ? c->ma0 : c->mb0);
+                            sd[4] = (float)(fa ? c->dar : c->dbr); sd[5] = (float)(fa ? c->dai : c->dbi);
+                            sd[7] = (float)(ma ? c->msa : c->msb);
+                            sd[6] = (float)__builtin_fma(ma ? c->msa : c->msb, ds, ma ? c->ma0 : c->mb0);
+                        } else {
+                            PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
+                            sd[0] = zr; sd[1] = zi; sd[2] = wr; sd[3] = wi; sd[4] = dr; sd[5] = di; sd[6] = ms; sd[7] = dms;
+                        }
+                    };
+                    auto fm = [](const S x, const S y, const S z) -> S {
+                        if constexpr (sizeof(S) == 4) return __builtin_fmaf(x, y, z); else return __builtin_fma(x, y, z);
+                    };
+                    // the set bits [a0, a1) of the body bits, two at a time
+                    int wd = a0 >> 6;
+                    const int wlast = (a1 - 1) >> 6;
+                    auto word = [&](const int w) {
+                        unsigned long long m = w == wdA ? wA : (w == wdB ? wB : q.bbits[w]);
+                        if (w == (a0 >> 6)) m &= ~0ull << (a0 & 63);
+                        if (w == wlast && (a1 & 63)) m &= (1ull << (a1 & 63)) - 1ull;
+                        return m;
+                    };
+                    unsigned long long mb = word(wd);
+                    auto next = [&]() -> int {
+                        for (;;) {
+                            if (mb) { const int b = __builtin_ctzll(mb); mb &= mb - 1ull; return (wd << 6) + b; }
+                            if (wd >= wlast) return -1;
+                            wd++;
+                            mb = word(wd);
+                        }
+                    };
+                    for (;;) {
+                        const int liA = next();
+                        if (liA < 0) break;
+                        const int liB = PAIR ? next() : -1;
+                        S sa[8], sb[8] = {(S)0, (S)0, (S)0, (S)0, (S)0, (S)0, (S)0, (S)0};       // (no partner: a body of amplitude zero -- its terms are +0)
+                        seed((const BodyRec*)lds + (liA - tile), sa);
+                        if (liB >= 0) seed((const BodyRec*)lds + (liB - tile), sb);
+                        S zrA = sa[0], ziA = sa[1], wrA = sa[2], wiA = sa[3], msA = sa[6];
+                        S zrB = sb[0], ziB = sb[1], wrB = sb[2], wiB = sb[3], msB = sb[6];
+                        const S drA = sa[4], diA = sa[5], dmsA = sa[7], drB = sb[4], diB = sb[5], dmsB = sb[7];
 #ifdef PVX_AB_SYNTH_NOLOOP
-                        a[0] += ms * zr + wr * dr + wi * di + dms;
+                        a[0] += msA * zrA + wrA * drA + wiA * diA + dmsA + msB * zrB + wrB * drB + wiB * diB + dmsB;
 #else
+                        if (!PAIR || __ballot(liB >= 0) == 0ull) {
+                            // (no lane of the wave has a second body -- segments with one partial left, noise: the one-body loop)
+#pragma unroll
+                            for (int k = 0; k < R; k++) {
+                                a[k] = fm(msA, zrA, a[k]);
+                                const S tA = fm(zrA, wrA, -(ziA * wiA));
+                                ziA = fm(zrA, wiA, ziA * wrA);
+                                zrA = tA;
+                                const S uA = fm(wrA, drA, fm(-wiA, diA, wrA));
+                                wiA = fm(wrA, diA, fm(wiA, drA, wiA));
+                                wrA = uA;
+                                msA += dmsA;
+                            }
+                            continue;
+                        }
+                        if constexpr (PAIR) {
 #pragma unroll
                         for (int k = 0; k < R; k++) {
-                            a[k] = __builtin_fmaf(ms, zr, a[k]);                 // PVAnalysis.py:734-736
-                            const float t_ = __builtin_fmaf(zr, wr, -(zi * wi));
-                            zi = __builtin_fmaf(zr, wi, zi * wr);
-                            zr = t_;
-                            const float u_ = __builtin_fmaf(wr, dr, __builtin_fmaf(-wi, di, wr));
-                            wi = __builtin_fmaf(wr, di, __builtin_fmaf(wi, dr, wi));
-                            wr = u_;
-                            ms += dms;
+                            a[k] = fm(msA, zrA, a[k]);                           // PVAnalysis.py:734-736
+                            a[k] = fm(msB, zrB, a[k]);
+                            const S tA = fm(zrA, wrA, -(ziA * wiA)), tB = fm(zrB, wrB, -(ziB * wiB));            // z *= w
+                            ziA = fm(zrA, wiA, ziA * wrA); ziB = fm(zrB, wiB, ziB * wrB);
+                            zrA = tA; zrB = tB;
+                            const S uA = fm(wrA, drA, fm(-wiA, diA, wrA)), uB = fm(wrB, drB, fm(-wiB, diB, wrB));  // w += w d
+                            wiA = fm(wrA, diA, fm(wiA, drA, wiA)); wiB = fm(wrB, diB, fm(wiB, drB, wiB));
+                            wrA = uA; wrB = uB;
+                            msA += dmsA; msB += dmsB;
+                        }
                         }
 #endif
-                    } else {
-                    PVX_BODY_SEEDS(c, s, ds, ts, fa, ma)
-#pragma unroll
-                    for (int k = 0; k < R; k++) {
-                        a[k] = __builtin_fma(ms, zr, a[k]);                      // PVAnalysis.py:734-736
-                        PVX_CMUL(zr, zi, wr, wi);
-                        PVX_CROT(wr, wi, dr, di);
-                        ms += dms;
                     }
-                    }
-                });
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -6,7 +6,7 @@ src = os.path.abspath(sys.argv[1]); flt = sys.argv[2] if len(sys.argv) > 2 else 
 inc = os.path.join(os.path.dirname(src), "..", "..", "include")
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + inc, "-I/opt/rocm/include",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off"] + (["-fno-slp-vectorize"] if os.path.basename(src) == "k_synth.hip" else []) + ["-I" + inc, "-I/opt/rocm/include",
                            "-I" + os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
     txt = open(out).read()
 pat = re.compile(r'\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)', re.S)
