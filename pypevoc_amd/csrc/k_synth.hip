@@ -37,6 +37,8 @@
 #include <map>
 #include <mutex>
 
+#include <type_traits>
+
 #include "pvx_internal.h"
 
 namespace {
@@ -694,6 +696,9 @@ constexpr int kBodiesTB = PVX_BODIES_TB;         // threads per workgroup of k_s
 // ramp and the R sums in float32: the recurrence's rounding grows like R^2 / 2 x 6e-8 = 3e-5 rad over a run of 32, inside the
 // stated precision-32 tolerance of 1e-4 max|w|, at half the vector-ALU cycles of the float64 loop and half the
 // registers for the sums (four waves per SIMD instead of three).
+#ifndef PVX_SYNTH_NB
+#define PVX_SYNTH_NB 2                         // bodies whose recurrences the float32 loop runs side by side
+#endif
 #ifndef PVX_SYNTH_WAVES_F32
 #define PVX_SYNTH_WAVES_F32(R) ((R) <= 8 ? 5 : 4)
 #endif
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
                     // instructions are ~8 cycles apart, and four waves per SIMD do not fill that: 0.127 -> 0.115 ms at BASELINE config 2) --,
                     // each sample's sum taking body A's term, then body B's: the additions and their order are the one-body loop's, bit for
                     // bit.  float64: one body at a time (a second body's state does not fit the three-wave register budget: 218 spilled).
-                    constexpr bool PAIR = sizeof(S) == 4;
+                    constexpr int NB = sizeof(S) == 4 ? PVX_SYNTH_NB : 1;
                     // Seeds of a body at sample s: the float64 closed form (float32 loop: float32 polynomials, then float32 state)
                     auto seed = [&](const BodyRec* c, S (&sd)[8]) {
                         // a run lies on one piece of fsig and one of msig (sample fmb itself sits on both)
@@ -848,49 +853,51 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
                             mb = word(wd);
                         }
                     };
-                    for (;;) {
-                        const int liA = next();
-                        if (liA < 0) break;
-                        const int liB = PAIR ? next() : -1;
-                        S sa[8], sb[8] = {(S)0, (S)0, (S)0, (S)0, (S)0, (S)0, (S)0, (S)0};       // (no partner: a body of amplitude zero -- its terms are +0)
-                        seed((const BodyRec*)lds + (liA - tile), sa);
-                        if (liB >= 0) seed((const BodyRec*)lds + (liB - tile), sb);
-                        S zrA = sa[0], ziA = sa[1], wrA = sa[2], wiA = sa[3], msA = sa[6];
-                        S zrB = sb[0], ziB = sb[1], wrB = sb[2], wiB = sb[3], msB = sb[6];
-                        const S drA = sa[4], diA = sa[5], dmsA = sa[7], drB = sb[4], diB = sb[5], dmsB = sb[7];
-#ifdef PVX_AB_SYNTH_NOLOOP
-                        a[0] += msA * zrA + wrA * drA + wiA * diA + dmsA + msB * zrB + wrB * drB + wiB * diB + dmsB;
-#else
-                        if (!PAIR || __ballot(liB >= 0) == 0ull) {
-                            // (no lane of the wave has a second body -- segments with one partial left, noise: the one-body loop)
+                    // NBX bodies' recurrences through a run, sample by sample: body 0's term, then body 1's, ... into each sum
+                    auto run = [&](auto nbc, S (&st)[NB][8]) {
+                        constexpr int NBX = decltype(nbc)::value;
+                        S zr[NBX], zi[NBX], wr[NBX], wi[NBX], ms[NBX];
 #pragma unroll
-                            for (int k = 0; k < R; k++) {
-                                a[k] = fm(msA, zrA, a[k]);
-                                const S tA = fm(zrA, wrA, -(ziA * wiA));
-                                ziA = fm(zrA, wiA, ziA * wrA);
-                                zrA = tA;
-                                const S uA = fm(wrA, drA, fm(-wiA, diA, wrA));
-                                wiA = fm(wrA, diA, fm(wiA, drA, wiA));
-                                wrA = uA;
-                                msA += dmsA;
-                            }
-                            continue;
-                        }
-                        if constexpr (PAIR) {
+                        for (int b = 0; b < NBX; b++) { zr[b] = st[b][0]; zi[b] = st[b][1]; wr[b] = st[b][2]; wi[b] = st[b][3]; ms[b] = st[b][6]; }
+#ifdef PVX_AB_SYNTH_NOLOOP
+#pragma unroll
+                        for (int b = 0; b < NBX; b++) a[0] += ms[b] * zr[b] + wr[b] * st[b][4] + wi[b] * st[b][5] + st[b][7];
+#else
 #pragma unroll
                         for (int k = 0; k < R; k++) {
-                            a[k] = fm(msA, zrA, a[k]);                           // PVAnalysis.py:734-736
-                            a[k] = fm(msB, zrB, a[k]);
-                            const S tA = fm(zrA, wrA, -(ziA * wiA)), tB = fm(zrB, wrB, -(ziB * wiB));            // z *= w
-                            ziA = fm(zrA, wiA, ziA * wrA); ziB = fm(zrB, wiB, ziB * wrB);
-                            zrA = tA; zrB = tB;
-                            const S uA = fm(wrA, drA, fm(-wiA, diA, wrA)), uB = fm(wrB, drB, fm(-wiB, diB, wrB));  // w += w d
-                            wiA = fm(wrA, diA, fm(wiA, drA, wiA)); wiB = fm(wrB, diB, fm(wiB, drB, wiB));
-                            wrA = uA; wrB = uB;
-                            msA += dmsA; msB += dmsB;
-                        }
+#pragma unroll
+                            for (int b = 0; b < NBX; b++) a[k] = fm(ms[b], zr[b], a[k]);                          // PVAnalysis.py:734-736
+#pragma unroll
+                            for (int b = 0; b < NBX; b++) {
+                                const S t_ = fm(zr[b], wr[b], -(zi[b] * wi[b]));                                 // z *= w
+                                zi[b] = fm(zr[b], wi[b], zi[b] * wr[b]);
+                                zr[b] = t_;
+                                const S u_ = fm(wr[b], st[b][4], fm(-wi[b], st[b][5], wr[b]));                   // w += w d
+                                wi[b] = fm(wr[b], st[b][5], fm(wi[b], st[b][4], wi[b]));
+                                wr[b] = u_;
+                                ms[b] += st[b][7];
+                            }
                         }
 #endif
+                    };
+                    for (;;) {
+                        int li[NB];
+                        li[0] = next();
+                        if (li[0] < 0) break;
+#pragma unroll
+                        for (int b = 1; b < NB; b++) li[b] = next();
+                        S st[NB][8];
+                        int nmax = 1;                                             // bodies of the wave's busiest lane (the same for all lanes)
+#pragma unroll
+                        for (int b = 0; b < NB; b++) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) st[b][j] = (S)0;          // (no body: amplitude zero -- its terms are +0)
+                            if (li[b] >= 0) seed((const BodyRec*)lds + (li[b] - tile), st[b]);
+                            if (b > 0 && __ballot(li[b] >= 0) != 0ull) nmax = b + 1;
+                        }
+                        if (nmax == 1) run(std::integral_constant<int, 1>{}, st);
+                        else if (NB == 2 || nmax == 2) { if constexpr (NB >= 2) run(std::integral_constant<int, 2>{}, st); }
+                        else run(std::integral_constant<int, NB>{}, st);
                     }
                 }
             }
