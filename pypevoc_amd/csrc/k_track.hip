@@ -664,7 +664,7 @@ template <int CL>
 __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
     __shared__ int R[CL * KL];
     __shared__ int Lnn[CL];                                              // per frame of the chunk: new partials | kAmbBit | kHasBit
-    __shared__ __attribute__((aligned(16))) double Lrow[G8F][3 * KL];     // per frame of a pass: magnitudes' keys now | before; new frequencies by rank
+    __shared__ __attribute__((aligned(16))) double Lrow[CL / G8F][G8F][3 * KL];   // per pass and frame: magnitudes' keys now | before; new frequencies by rank
     __shared__ int wtot[CL / 64], wamb[CL / 64], wlast[CL / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, K = p.K;
     const int l = tid & 7, g = tid >> 3, sh = lane & ~7;
@@ -682,101 +682,133 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
             return;
         }
     }
-    // (the rows of both passes are asked for before the first pass starts)
-    double cf_[CL / G8F], cm_[CL / G8F], pf_[CL / G8F], pm_[CL / G8F];
+    // The chunk's NP = CL / 128 passes run SIDE BY SIDE: pass p is frame p * 128 + g of the chunk, and every step of the assignment
+    // loop is written without a branch, so that the passes' dependent chains (quotient -> distance -> three DPP minima -> ballots)
+    // interleave in one basic block -- a wave alone is a chain of ~60 dependent instructions per step, ~8 cycles apart, and four waves
+    // per SIMD do not fill that.
+    constexpr int NP = CL / G8F;
+    double cf[NP], cm[NP], pf[NP], pm[NP];
 #pragma unroll
-    for (int ps = 0; ps < CL / G8F; ps++) {
+    for (int ps = 0; ps < NP; ps++) {
         const int64_t fr = fb + ps * G8F + g;
-        cf_[ps] = cm_[ps] = pf_[ps] = pm_[ps] = 0.0;
+        cf[ps] = cm[ps] = pf[ps] = pm[ps] = 0.0;
         if (fr < p.F && l < K) {
-            cf_[ps] = p.f[fr * K + l]; cm_[ps] = p.mag[fr * K + l];
-            if (fr > 0) { pf_[ps] = p.f[(fr - 1) * K + l]; pm_[ps] = p.mag[(fr - 1) * K + l]; }
+            cf[ps] = p.f[fr * K + l]; cm[ps] = p.mag[fr * K + l];
+            if (fr > 0) { pf[ps] = p.f[(fr - 1) * K + l]; pm[ps] = p.mag[(fr - 1) * K + l]; }
         }
     }
+    // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first (see the header)
+    bool vc[NP], vp[NP];
+    double kc[NP], kpv[NP];
 #pragma unroll
-    for (int ps = 0; ps < CL / G8F; ps++) {
-        const int fl = ps * G8F + g;                                      // frame of the chunk
-        const int64_t fr = fb + fl;
-        const bool live = fr < p.F;
-        const double cf = cf_[ps], cm = cm_[ps], pf = pf_[ps], pm = pm_[ps];
-        // valid entries (PVAnalysis.py:874-876, 887) and their descending-magnitude ranks, ties: higher slot first (see the header)
-        const bool vc = cf > 0.0 && cm > 0.0, vp = pf > 0.0 && pm > 0.0;
-        const double kc = vc ? cm : -1.0, kpv = vp ? pm : -1.0;          // invalid entries rank below every valid one
-        double* row = &Lrow[g][0];
-        row[l] = kc; row[KL + l] = kpv;
-        pvxw::wave_sync();
+    for (int ps = 0; ps < NP; ps++) {
+        vc[ps] = cf[ps] > 0.0 && cm[ps] > 0.0; vp[ps] = pf[ps] > 0.0 && pm[ps] > 0.0;
+        kc[ps] = vc[ps] ? cm[ps] : -1.0; kpv[ps] = vp[ps] ? pm[ps] : -1.0;     // invalid entries rank below every valid one
+        double* row = &Lrow[ps][g][0];
+        row[l] = kc[ps]; row[KL + l] = kpv[ps];
+    }
+    pvxw::wave_sync();
+    int rc[NP], rp[NP], nc[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const double* row = &Lrow[ps][g][0];
         int ra = 0, rb = 0;
 #pragma unroll
         for (int j = 0; j < KL; j++) {
             const double cj = row[j], pj = row[KL + j];
-            ra += (cj > kc) | ((cj == kc) & (j > l));
-            rb += (pj > kpv) | ((pj == kpv) & (j > l));
+            ra += (cj > kc[ps]) | ((cj == kc[ps]) & (j > l));
+            rb += (pj > kpv[ps]) | ((pj == kpv[ps]) & (j > l));
         }
-        const int rc = vc ? ra : KL, rp = vp ? rb : KL;
-        const int nc = __popc((unsigned)(__ballot(vc) >> sh) & 0xffu);
-        if (vc) row[2 * KL + rc] = cf;                                    // the new peaks' frequencies by rank
-        pvxw::wave_sync();
-        double cfs[KL];
+        rc[ps] = vc[ps] ? ra : KL; rp[ps] = vp[ps] ? rb : KL;
+        nc[ps] = __popc((unsigned)(__ballot(vc[ps]) >> sh) & 0xffu);
+    }
 #pragma unroll
-        for (int c = 0; c < KL; c++) cfs[c] = row[2 * KL + c];           // (entries from nc on: not used)
-        const double pfc = vp ? pf : 1.0;
-        const double rpf = 1.0 / pfc;
+    for (int ps = 0; ps < NP; ps++)
+        if (vc[ps]) Lrow[ps][g][2 * KL + rc[ps]] = cf[ps];                // the new peaks' frequencies by rank
+    pvxw::wave_sync();
+    double cfs[NP][KL], rpf[NP];
+    bool amb[NP], used[NP];
+    int link[NP], nrk[NP], nnew[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+        for (int c = 0; c < KL; c++) cfs[ps][c] = Lrow[ps][g][2 * KL + c];   // (entries from nc on: not used)
+        const double pfc = vp[ps] ? pf[ps] : 1.0;
+        rpf[ps] = 1.0 / pfc;
         // (a frequency whose reciprocal or quotients could leave the normal range: let the exact loop build the table)
-        bool amb = vp && !(pfc > 1e-290 && pfc < 1e290);
-        // the assignment loop (PVAnalysis.py:903-957): this lane is previous peak l, and the new peak of rank rc
-        int link = -2, nrk = -1, nnew = 0;
-        bool used = false;
+        amb[ps] = vp[ps] && !(pfc > 1e-290 && pfc < 1e290);
+        link[ps] = -2; nrk[ps] = -1; nnew[ps] = 0; used[ps] = false;
+    }
+    // the assignment loop (PVAnalysis.py:903-957): this lane is previous peak l, and the new peak of rank rc
 #pragma unroll
-        for (int c = 0; c < KL; c++) {
-            if (c < nc) {                                                 // (the same for the eight lanes of a frame)
-                const double fcur = cfs[c];
-                // fcur / pf through the previous peak's reciprocal, then dpitch2st: k_track_links_lane's expressions
-                const double q0 = fcur * rpf;
-                const double q = __builtin_fma(__builtin_fma(-q0, pf, fcur), rpf, q0);
-                const bool avail = vp && !used;
-                const double st = avail ? fabs(17.312 * (q - 1.0)) : INFINITY;
-                double best = st;
-                best = min_nn(best, pvxw::dpp_d<0xB1>(best));
-                best = min_nn(best, pvxw::dpp_d<0x4E>(best));
-                best = min_nn(best, pvxw::dpp_d<0x141>(best));
-                // the first minimum in the order of the previous partials (np.argmin over the sorted list, PVAnalysis.py:893, 920)
-                const bool cand = avail && st == best;
-                int wr = cand ? rp : KL;
-                wr = min(wr, dpp_i<0xB1>(wr));
-                wr = min(wr, dpp_i<0x4E>(wr));
-                wr = min(wr, dpp_i<0x141>(wr));
-                const bool win = cand && rp == wr;
-                const unsigned gw = (unsigned)(__ballot(win) >> sh) & 0xffu;
-                const bool some = gw != 0u;                               // an unused previous peak exists (best is finite)
-                const bool hit = some && best < p.maxjmp;                 // PVAnalysis.py:923
-                // where the threshold test or the choice of the nearest partial hangs on less than the quotients' rounding: see
-                // k_track_links_lane
-                const double eps = 0x1p-46 * (1.0 + best);
-                const bool n2 = hit && !win && (st - best <= eps);        // (unavailable ones are at infinity)
-                const bool near = some && (fabs(best - p.maxjmp) <= eps || ((unsigned)(__ballot(n2) >> sh) & 0xffu) != 0u);
-                amb = amb || near;
-                if (hit) {
-                    const unsigned ge = (unsigned)(__ballot(st == best) >> sh) & 0xffu;
-                    if (__popc(ge) > 1) {
-                        // another unused previous partial exactly as near: if it is also exactly as strong as the winner the
-                        // reference would let the partial index decide (see the header)
-                        const double wm = row[KL + (__ffs((int)gw) - 1)];   // (the winner is a valid peak: its key is its magnitude)
-                        const unsigned gs = (unsigned)(__ballot(st == best && pm == wm) >> sh) & 0xffu;
-                        amb = amb || __popc(gs) > 1;
-                    }
-                    used = used || win;
-                    if (rc == c) link = __ffs((int)gw) - 1;
-                } else {
-                    if (rc == c) { link = -1; nrk = nnew; }               // add_empty_partial
-                    nnew++;
-                }
+    for (int c = 0; c < KL; c++) {
+        bool tie[NP], hit_[NP];
+        unsigned gw_[NP];
+        double st_[NP], best_[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ps++) {
+            const bool act = c < nc[ps];                                  // (the same for the eight lanes of a frame)
+            const double fcur = cfs[ps][c];
+            // fcur / pf through the previous peak's reciprocal, then dpitch2st: k_track_links_lane's expressions
+            const double q0 = fcur * rpf[ps];
+            const double q = __builtin_fma(__builtin_fma(-q0, pf[ps], fcur), rpf[ps], q0);
+            const bool avail = vp[ps] && !used[ps];
+            const double st = avail ? fabs(17.312 * (q - 1.0)) : INFINITY;
+            double best = st;
+            best = min_nn(best, pvxw::dpp_d<0xB1>(best));
+            best = min_nn(best, pvxw::dpp_d<0x4E>(best));
+            best = min_nn(best, pvxw::dpp_d<0x141>(best));
+            // the first minimum in the order of the previous partials (np.argmin over the sorted list, PVAnalysis.py:893, 920)
+            const bool cand = avail && st == best;
+            int wr = cand ? rp[ps] : KL;
+            wr = min(wr, dpp_i<0xB1>(wr));
+            wr = min(wr, dpp_i<0x4E>(wr));
+            wr = min(wr, dpp_i<0x141>(wr));
+            const bool win = cand && rp[ps] == wr;
+            const unsigned gw = (unsigned)(__ballot(win) >> sh) & 0xffu;
+            const bool some = gw != 0u;                                   // an unused previous peak exists (best is finite)
+            const bool hit = some && best < p.maxjmp;                     // PVAnalysis.py:923
+            // where the threshold test or the choice of the nearest partial hangs on less than the quotients' rounding: see
+            // k_track_links_lane
+            const double eps = 0x1p-46 * (1.0 + best);
+            const bool n2 = hit && !win && (st - best <= eps);            // (unavailable ones are at infinity)
+            const bool near = some && (fabs(best - p.maxjmp) <= eps || ((unsigned)(__ballot(n2) >> sh) & 0xffu) != 0u);
+            amb[ps] = amb[ps] || (act && near);
+            const unsigned ge = (unsigned)(__ballot(st == best) >> sh) & 0xffu;
+            tie[ps] = act && hit && __popc(ge) > 1;
+            hit_[ps] = hit; gw_[ps] = gw; st_[ps] = st; best_[ps] = best;
+            used[ps] = used[ps] || (act && hit && win);
+            const bool turn = act && rc[ps] == c;
+            link[ps] = turn ? (hit ? __ffs((int)gw) - 1 : -1) : link[ps];
+            nrk[ps] = (turn && !hit) ? nnew[ps] : nrk[ps];                // add_empty_partial
+            nnew[ps] += (act && !hit) ? 1 : 0;
+        }
+        bool anytie = false;
+#pragma unroll
+        for (int ps = 0; ps < NP; ps++) anytie = anytie || tie[ps];
+        if (__ballot(anytie) != 0ull) {
+            // another unused previous partial exactly as near as the winner: if it is also exactly as strong the reference would
+            // let the partial index decide (see the header)
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+                const int wl = gw_[ps] ? __ffs((int)gw_[ps]) - 1 : 0;
+                const double wm = Lrow[ps][g][KL + wl];                   // (the winner is a valid peak: its key is its magnitude)
+                const unsigned gs = (unsigned)(__ballot(tie[ps] && st_[ps] == best_[ps] && pm[ps] == wm) >> sh) & 0xffu;
+                amb[ps] = amb[ps] || (tie[ps] && __popc(gs) > 1);
             }
         }
+        (void)hit_;
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const int fl = ps * G8F + g;                                      // frame of the chunk
+        const int64_t fr = fb + fl;
+        const bool live = fr < p.F;
         // ---- the frame's rows of the table's workspace
         if (live) {
             if (l < K) {
-                p.link[fr * K + l] = link >= 0 ? link : (link == -2 ? -1 : -(nrk + 2));   // the table's code (pvx_internal.h)
-                if (fr > 0) p.succ[(fr - 1) * K + l] = (unsigned char)used;          // by slot of frame fr-1: continued
+                p.link[fr * K + l] = link[ps] >= 0 ? link[ps] : (link[ps] == -2 ? -1 : -(nrk[ps] + 2));   // the table's code (pvx_internal.h)
+                if (fr > 0) p.succ[(fr - 1) * K + l] = (unsigned char)used[ps];      // by slot of frame fr-1: continued
                 if (fr == p.F - 1) p.succ[fr * K + l] = 0;
             }
             for (int s2 = KL + l; s2 < K; s2 += 8) {                      // (empty slots of a wide row)
@@ -786,14 +818,14 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
                 p.root[fr * K + s2] = -1;
             }
         }
-        const bool amb_any = ((unsigned)(__ballot(amb) >> sh) & 0xffu) != 0u;
+        const bool amb_any = ((unsigned)(__ballot(amb[ps]) >> sh) & 0xffu) != 0u;
         if (l == 0) {
-            const int v = live ? (nnew | (amb_any ? kAmbBit : 0) | (nc > 0 ? kHasBit : 0)) : 0;
+            const int v = live ? (nnew[ps] | (amb_any ? kAmbBit : 0) | (nc[ps] > 0 ? kHasBit : 0)) : 0;
             Lnn[fl] = v;
             if (live) p.newcount[fr] = v;
         }
         // roots: a new partial's root is its own node, a continued peak starts at its predecessor's node (k_track_links_lane)
-        R[fl * KL + l] = (!live || l >= K || link == -2) ? -1 : (link == -1 ? fl * KL + l : (fl == 0 ? kOut + link : (fl - 1) * KL + link));
+        R[fl * KL + l] = (!live || l >= K || link[ps] == -2) ? -1 : (link[ps] == -1 ? fl * KL + l : (fl == 0 ? kOut + link[ps] : (fl - 1) * KL + link[ps]));
     }
     __syncthreads();
     // ---- creation ranks inside the chunk, the chunk's totals: thread t < CL is frame t
