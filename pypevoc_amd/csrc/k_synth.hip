@@ -619,37 +619,76 @@ template <int R, typename S> __device__ __forceinline__ void add_edges(const Sam
             mb = masked(kind == 1 ? q.abits : q.rbits, wd);
         }
     };
-    auto process = [&](const int knd, const EdgeRec& er) {
+    // float32 sums: the edge's two rotations in float32 as well, seeded per run from the float64 closed forms like a body's (an edge is
+    // 2 h samples of every partial that starts or stops: on noise five times the bodies' work; 0.088 -> 0.074 ms there).  NE edges side
+    // by side, as k_synth_bodies' float32 loop takes its bodies: measured at NE = 2, 7 registers spilled and 0.079 ms -- one at a time.
+#ifndef PVX_SYNTH_NE
+#define PVX_SYNTH_NE 1
+#endif
+    constexpr int NE = sizeof(S) == 4 ? PVX_SYNTH_NE : 1;
+    struct Edge { S zr, zi, ur, ui, ah, ahs, ewr, ewi; unsigned ulo, un; };
+    auto fm = [](const S x_, const S y_, const S z_) -> S {
+        if constexpr (sizeof(S) == 4) return __builtin_fmaf(x_, y_, z_); else return __builtin_fma(x_, y_, z_);
+    };
+    auto setup = [&](const int knd, const EdgeRec& er, Edge& E) {
         const EdgeRec* e = &er;
+        E.zr = E.zi = E.ur = E.ui = E.ah = E.ahs = E.ewr = E.ewi = (S)0; E.ulo = 0u; E.un = 0u;     // (un = 0: no sample of the run sounds)
         const long long j0l = (long long)seg * h + s - e->o0;
         if (j0l + R <= 0 || j0l >= q.edgsam) return;
         const int j0 = (int)j0l;
         const double cfr = e->cfr;
         const double x = (knd == 1) ? e->ph0 - kPi2 * ((double)(q.edgsam - j0) * cfr)
                                     : e->ph0 + kPi2 * ((double)(j0 + 1) * cfr);
-        double zr, zi, ur, ui;
-        fsincos(x, zi, zr);
-        fsincos(kPi * (double)j0 / (double)q.edgsam, ui, ur);
-        const double ah = e->ah, ahs = (knd == 1) ? -ah : ah;
-        const double ewr = e->wr, ewi = e->wi;
-        const unsigned ulo = (unsigned)(-j0), un = (unsigned)q.edgsam;       // sample k sounds when 0 <= j0 + k < edgsam
+        if constexpr (sizeof(S) == 4) {
+            fsincos_f(x, E.zi, E.zr);
+            fsincos_f(kPi * (double)j0 / (double)q.edgsam, E.ui, E.ur);
+        } else {
+            fsincos(x, E.zi, E.zr);
+            fsincos(kPi * (double)j0 / (double)q.edgsam, E.ui, E.ur);
+        }
+        E.ah = (S)e->ah; E.ahs = (knd == 1) ? -E.ah : E.ah;
+        E.ewr = (S)e->wr; E.ewi = (S)e->wi;
+        E.ulo = (unsigned)(-j0); E.un = (unsigned)q.edgsam;                 // sample k sounds when 0 <= j0 + k < edgsam
+    };
+    const S evr = (S)q.vr, evi = (S)q.vi;
+    auto run = [&](auto nec, Edge (&E)[NE]) {
+        constexpr int NX = decltype(nec)::value;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const double v = __builtin_fma(__builtin_fma(ahs, ur, ah), zr, (double)a[k]);
-            a[k] = ((unsigned)k - ulo < un) ? (S)v : a[k];
-            PVX_CMUL(zr, zi, ewr, ewi);
-            PVX_CMUL(ur, ui, q.vr, q.vi);
+#pragma unroll
+            for (int b = 0; b < NX; b++) {
+                const S v = fm(fm(E[b].ahs, E[b].ur, E[b].ah), E[b].zr, a[k]);
+                a[k] = ((unsigned)k - E[b].ulo < E[b].un) ? v : a[k];
+            }
+#pragma unroll
+            for (int b = 0; b < NX; b++) {
+                const S t_ = fm(E[b].zr, E[b].ewr, -(E[b].zi * E[b].ewi));    // z *= exp(i 2 pi cfr)
+                E[b].zi = fm(E[b].zr, E[b].ewi, E[b].zi * E[b].ewr);
+                E[b].zr = t_;
+                const S u_ = fm(E[b].ur, evr, -(E[b].ui * evi));              // u *= exp(i pi / edgsam)
+                E[b].ui = fm(E[b].ur, evi, E[b].ui * evr);
+                E[b].ur = u_;
+            }
         }
     };
-    int li = advance(), ck = kind;
-    EdgeRec rec;
-    if (li >= 0) rec = (ck == 1 ? q.att : q.rel)[li];
-    while (li >= 0) {
-        const int lj = advance(), nk = kind;
-        EdgeRec nxt;
-        if (lj >= 0) nxt = (nk == 1 ? q.att : q.rel)[lj];
-        process(ck, rec);
-        rec = nxt; li = lj; ck = nk;
+    for (;;) {
+        int li[NE], kd[NE];
+        li[0] = advance(); kd[0] = kind;
+        if (li[0] < 0) break;
+#pragma unroll
+        for (int b = 1; b < NE; b++) { li[b] = advance(); kd[b] = kind; }
+        Edge E[NE];
+        bool any = false, second = false;
+#pragma unroll
+        for (int b = 0; b < NE; b++) {
+            E[b].zr = E[b].zi = E[b].ur = E[b].ui = E[b].ah = E[b].ahs = E[b].ewr = E[b].ewi = (S)0; E[b].ulo = 0u; E[b].un = 0u;
+            if (li[b] >= 0) setup(kd[b], (kd[b] == 1 ? q.att : q.rel)[li[b]], E[b]);
+            any = any || E[b].un != 0u;
+            if (b > 0) second = second || E[b].un != 0u;
+        }
+        if (__ballot(any) == 0ull) continue;                                // (no lane's run is touched by these edges)
+        if (NE == 1 || __ballot(second) == 0ull) run(std::integral_constant<int, 1>{}, E);
+        else run(std::integral_constant<int, NE>{}, E);
     }
 }
 
