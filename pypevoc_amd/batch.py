@@ -373,12 +373,17 @@ class PipelinedGather(object):
 
 class ResultWire(object):
     """Device-side packing of a shard's result rows into the compact wire format of include/pvx.h
-    (pvx_pack_rows_dev / pvx_unpack_rows_dev): 18 B per peak slot instead of 40 B at precision 32,
-    bit-exact round trip.  `plan` is a pvx plan handle, `rows` the frames of all signals of a shard."""
+    (pvx_pack_rows_dev / pvx_unpack_rows_dev): 18 B per peak slot instead of 40 B at precision 32 --
+    14 B in the plan's wire format 2 (`wire_format=2`: pvx_plan_set_wire_format, precision-32 plans) --,
+    bit-exact round trip.  `plan` is a pvx plan handle, `rows` the frames of all signals of a shard;
+    every rank of a gather must use the same format."""
 
-    def __init__(self, plan, rows, npks):
+    def __init__(self, plan, rows, npks, wire_format=None):
         self.lib = _lib.load()
         self.plan = plan
+        if wire_format is not None:
+            _lib.check(self.lib.pvx_plan_set_wire_format(plan, int(wire_format)), "pvx_plan_set_wire_format")
+        self.wire_format = int(self.lib.pvx_plan_get_wire_format(plan))
         self.rows = int(rows)
         self.npks = int(npks)
         self.nbytes = int(self.lib.pvx_wire_bytes(plan, self.rows))
