@@ -573,7 +573,9 @@ __global__ __launch_bounds__(CLL) void k_track_links_lane(TrackParams p) {
 // The scan over the chunks' totals and the roots of the chunks' LAST frames, as k_track_boundaries does for k_track_links:
 // one workgroup; chunkbase[c] = new partials before chunk c.
 // (a workgroup of 1 024 threads; rb: NCH K ints of LDS)
-__device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32_t* rb) {
+// cb: where the scan of the chunks' totals goes ([NCH + 1]: p.chunkbase, or LDS); to_global: the result words and the resolved
+// rows leave for memory (k_track_boundaries_lane; k_assign_bounds' first workgroup writes the words only).  false: TrackParams::wide
+__device__ __forceinline__ bool boundaries_lane_body(const TrackParams& p, int32_t* rb, int64_t* cb, bool words, bool store_roots) {
     // (one workgroup alone on the chip: every dependent round trip to memory is 2 us of the launch, so the word that says whether
     // k_track_links_lane has given up (TrackParams::wide), the chunks' totals and their last rows are all asked for at once)
     const unsigned widev = p.wide != nullptr ? *(volatile unsigned*)p.wide_dev : 0u;
@@ -589,7 +591,7 @@ __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32
     auto last_frame = [&](int c) { const int64_t e = ((int64_t)(c + 1)) * CL; return (e < F ? e : F) - 1; };
     const int raw0 = tid < NCH ? p.chunktot[tid] : 0, last0 = tid < NCH ? p.chunklast[tid] : -1;
     for (int w = tid; w < items; w += 1024) { const int c = (int)((unsigned)w / (unsigned)K); rb[w] = p.root[last_frame(c) * K + (w - c * K)]; }
-    if (p.wide != nullptr && widev == p.gen) return;              // (the same for every thread)
+    if (p.wide != nullptr && widev == p.gen) return false;        // (the same for every thread)
     if (tid == 0) { carry_s = 0; amb_s = 0; last_s = -1; }
     __syncthreads();
     bool amb = false;
@@ -610,7 +612,7 @@ __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32
         __syncthreads();
         long long run = carry_s + inc - v;
         for (int w = 0; w < wid; w++) run += wsum[w];
-        if (c < NCH) p.chunkbase[c] = run;
+        if (c < NCH) cb[c] = run;
         __syncthreads();
         if (tid == 1023) carry_s = run + v;
         __syncthreads();
@@ -618,7 +620,10 @@ __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32
     if (amb) amb_s = 1;
     if (last >= 0) atomicMax(&last_s, last);
     __syncthreads();
-    if (tid == 0) { p.chunkbase[NCH] = carry_s; *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
+    if (tid == 0) {
+        cb[NCH] = carry_s;
+        if (words) { *p.npartials = carry_s; *p.ambiguous = amb_s; *p.maxend = last_s; }
+    }
     // pointer doubling over the chunks' last frames.  An item is -1 (empty slot), a root that is final (>= 0: a node inside the
     // item's own chunk, or one that is not on a chunk's last frame), or -2 - j: "whatever item j says" (j: the last-frame node of an
     // earlier chunk the root so far names) -- the divisions that find j happen once, the rounds are two LDS reads and a write
@@ -639,12 +644,62 @@ __device__ __forceinline__ void boundaries_lane_body(const TrackParams& p, int32
         }
         if (!__syncthreads_or(moved)) break;
     }
-    for (int w = tid; w < items; w += 1024) { const int c = (int)((unsigned)w / (unsigned)K); p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+    if (store_roots)
+        for (int w = tid; w < items; w += 1024) { const int c = (int)((unsigned)w / (unsigned)K); p.root[last_frame(c) * K + (w - c * K)] = rb[w]; }
+    return true;
 }
 
 __global__ __launch_bounds__(1024) void k_track_boundaries_lane(TrackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    boundaries_lane_body(p, (int32_t*)smem);                      // [NCH][K]
+    (void)boundaries_lane_body(p, (int32_t*)smem, p.chunkbase, true, true);     // [NCH][K]
+}
+
+// The boundary step and k_assign_chunked in ONE launch: every workgroup works the boundary step out for itself, in LDS -- a few
+// thousand items, the same few microseconds for all of them side by side -- and then assigns its 1 024 nodes from what it holds:
+// no launch of one workgroup that the whole chip waits for (13 us at BASELINE config 2), no dependent launch behind it.  While the
+// chunks' last-frame rows are few (PVX_TRACK_NO_FUSE_ASSIGN=1: the two launches).
+__global__ __launch_bounds__(1024) void k_assign_bounds(TrackParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = p.K, CL = p.chunk;
+    const int NCH = (int)((p.F + CL - 1) / CL);
+    int32_t* rb = (int32_t*)smem;                                 // [NCH][K]: the chunks' last-frame roots, resolved
+    int64_t* cb = (int64_t*)(smem + (((size_t)NCH * K * 4 + 15) & ~(size_t)15));   // [NCH + 1]: new partials before each chunk
+    // (what the first of a thread's nodes needs from memory is asked for before the boundary step, not after it: its root, and --
+    // when that root lies in the node's own chunk, the usual case -- the root's creation rank and frame count)
+    const int64_t n = p.F * (int64_t)K;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int32_t r0 = -1, lk0 = 0;
+    int64_t nb0 = 0;
+    unsigned char sc0 = 0;
+    bool pre = false;
+    if (i0 < n) {
+        r0 = p.root[i0];
+        sc0 = p.succ[i0];
+        // (r0 < n: when k_track_links_g8 gave a wide table up -- TrackParams::wide, known only inside the boundary step -- the roots are whatever the workspace held)
+        if (r0 >= 0 && (int64_t)r0 < n && (int64_t)r0 >= ((i0 / K) / CL) * CL * K) { nb0 = p.newbase[r0 / K]; lk0 = p.link[r0]; pre = true; }
+    }
+    if (!boundaries_lane_body(p, rb, cb, blockIdx.x == 0, false)) return;
+    __syncthreads();
+    // (at most a workgroup per CU, each taking its share of the nodes: the boundary step is worked out once per CU, not once per
+    // 1 024 nodes -- 404 workgroups doing it, two to a CU, took 27 us where 202 take 10)
+    for (int64_t i = i0; i < n; i += (int64_t)gridDim.x * 1024) {
+        const bool first = i == i0;
+        int32_t r = first ? r0 : p.root[i];
+        if (r < 0) { p.partial_id[i] = -1; continue; }
+        const int64_t ifr = i / K;
+        const int64_t c = ifr / CL;
+        if ((int64_t)r < c * CL * K) r = rb[(c - 1) * K + (r - (int32_t)((c * CL - 1) * K))];   // a node of the frame before the chunk: that chunk's last row
+        const int64_t rfr = r / K;
+        const int64_t nbv = (first && pre) ? nb0 : p.newbase[rfr];
+        const int32_t lkv = (first && pre) ? lk0 : p.link[r];
+        const int64_t pid = nbv + cb[rfr / CL] + (-(lkv + 2));                                  // creation order, PVAnalysis.py:826
+        p.partial_id[i] = (int32_t)pid;
+        if (pid < p.cap) {
+            if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
+            // the last point of a partial (no peak of the next frame continues it) knows the length
+            if (!(first ? sc0 : p.succ[i])) p.part_len[pid] = (int32_t)(ifr - rfr + 1);
+        }
+    }
 }
 
 // ---- npks <= 8: EIGHT LANES per frame ---------------------------------------------------------------------------
@@ -1167,6 +1222,15 @@ int pvx_launch_track(const TrackParams& p_in, hipStream_t s) {
             if (!g8) hipLaunchKernelGGL(k_track_links_lane, dim3((unsigned)nchl), dim3(CLL), 0, s, p);
             else if (c128) hipLaunchKernelGGL(k_track_links_g8<128>, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
             else hipLaunchKernelGGL(k_track_links_g8<256>, dim3((unsigned)nchl), dim3(G8T), 0, s, p);
+            if (nchl * p.K <= 4096 && !getenv("PVX_TRACK_NO_FUSE_ASSIGN")) {
+                const size_t flds = (((size_t)nchl * p.K * 4 + 15) & ~(size_t)15) + (size_t)(nchl + 1) * 8;
+                int64_t ab = (n + 1023) / 1024;
+                if (const char* e = getenv("PVX_TRACK_ASSIGN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < ab) ab = v; }   // tests, A/B
+                else if (ab > 256) ab = 256;
+                hipLaunchKernelGGL(k_assign_bounds, dim3((unsigned)ab), dim3(1024), flds, s, p);
+                PVX_HIP_CHECK(hipGetLastError());
+                return PVX_OK;
+            }
             if (blds > 48 * 1024)
                 PVX_HIP_CHECK(hipFuncSetAttribute((const void*)k_track_boundaries_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
             hipLaunchKernelGGL(k_track_boundaries_lane, dim3(1), dim3(1024), blds, s, p);

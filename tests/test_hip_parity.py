@@ -191,7 +191,8 @@ def test_tracker_short_rows_eight_lanes_per_frame(amd, oracle, monkeypatch):
             mag[30:33] = 0.0                                                            # empty frames
             mag[35, :kk] = 0.5                                                          # equal magnitudes: the tie order of the ranks
         tables = []
-        for env in ({}, {"PVX_TRACK_LANE_FRAME": "1"}, {"PVX_TRACK_CHUNK256": "1"}):     # (chunks of 128 frames | a frame per lane | chunks of 256)
+        for env in ({}, {"PVX_TRACK_LANE_FRAME": "1"}, {"PVX_TRACK_CHUNK256": "1"}, {"PVX_TRACK_NO_FUSE_ASSIGN": "1"},
+                    {"PVX_TRACK_NO_FUSE_ASSIGN": "1", "PVX_TRACK_CHUNK256": "1"}):   # (chunks of 128 frames | a frame per lane | chunks of 256 | boundary step + assignment as two launches)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             ss = amd.SinSum(44100.0, nfft=2048, hop=512)
