@@ -121,7 +121,7 @@ if sw:
 s64 = jl("%s_config5_sweep_f64.jsonl" % tag)
 if s64:
     p64 = {(d["nfft"], d["hop"]): d for d in jl("%s_config5_sweep_f64.jsonl" % prev)}
-    L.append("**Config 5 at float64** (`profiles/%s_config5_sweep_f64.jsonl`, M frames/s, the round before in brackets): " % tag +
+    L.append("**Config 5 at float64** (`profiles/%s_config5_sweep_f64.jsonl`, M frames/s; round 5 in brackets): " % tag +
              ", ".join("%d/%d %s%s" % (d["nfft"], d["hop"], M(d["frames_per_s"]).replace(" M", ""), (" (%s)" % M(p64[(d["nfft"], d["hop"])]["frames_per_s"]).replace(" M", "")) if (d["nfft"], d["hop"]) in p64 else "") for d in s64) + ".")
     L.append("")
 hn = []       # (`profiles/<tag>_nfft_harmonic_vs_noise.jsonl`: the nfft sweep on three kinds of material; the bench table above carries the noise / recording lines)
@@ -161,24 +161,24 @@ try:
         per = F if ("fused" in name or "stft" in name or "phase" in name or "k_pv_rev" in name or (what == "chain" and ("k_track" in name or "k_synth" in name or "k_assign" in name))) else None
         if per is None or (what == "chain" and "k_fused_rev" in name):      # (the chain's analysis kernel is the f32 line's)
             continue
-        rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.3f | %.2f |" % (
+        rows.append("| %s | `%s` | %.0f | %.0f | %.0f | %.2f / %.2f / %.2f | %.2f |" % (
             what, short.group(1)[:44] if short else name[:44], g("SQ_INSTS_VALU") / per, g("SQ_INSTS_SALU") / per, g("SQ_INSTS_LDS") / per,
             g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
-            g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), g("SQ_LDS_IDX_ACTIVE") / max(g("SQ_BUSY_CU_CYCLES"), 1)))
+            g("SQ_LDS_IDX_ACTIVE") / max(g("SQ_BUSY_CU_CYCLES"), 1)))
     if rows:
         L.append("**SQ counters per frame (`profiles/sq_latest.json`, rocprofv3 --pmc over the C2 signal; all waves of a frame summed).**")
         L.append("")
-        L.append("| run | kernel | VALU | SALU | LDS | wave time issuing / waiting / issue-stalled | LDS conflict share | LDS pipe busy |")
-        L.append("|---|---|---|---|---|---|---|---|")
+        L.append("| run | kernel | VALU | SALU | LDS | wave time issuing / waiting / issue-stalled | LDS pipe busy |")
+        L.append("|---|---|---|---|---|---|---|")
         L += rows
         L.append("")
 except Exception as e:
     L.append("(no sq_latest.json: %s)" % e)
 try:
     tr = json.load(open(os.path.join(P, "traffic_latest.json")))
-    items = ["`%s` %.1f MB = %.0f B/frame" % (k, v["bytes"] / 1e6, v["bytes_per_frame"]) for k, v in tr.items() if isinstance(v, dict) and "bytes" in v and k != "k_fused_rev_chain"]
+    items = ["`%s` %.1f MB = %.0f B/frame" % (k.replace("_chain", ""), v["bytes"] / 1e6, v["bytes_per_frame"]) for k, v in tr.items() if isinstance(v, dict) and "bytes" in v and k != "k_fused_rev_chain"]
     if items:
-        L.append("**HBM traffic per C2 launch (`profiles/traffic_latest.json`, FETCH_SIZE × calibration + WRITE_SIZE):** " + "; ".join(items) + ".")
+        L.append("**HBM traffic per C2 launch (`traffic_latest.json`: FETCH_SIZE × calibration + WRITE_SIZE):** " + "; ".join(items) + ".")
         L.append("")
 except Exception:
     pass
