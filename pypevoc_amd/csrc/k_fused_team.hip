@@ -29,7 +29,8 @@
 // them behind those of the waves below them -- rows stay left-packed in ascending bin order (PV.py:226-239).
 // npks <= 64: one candidate per lane (PPL = 1).  64 < npks <= 128 (BASELINE config 3: npks = 100): TWO per lane (PPL = 2) --
 // lane l owns entries l and l + 64 of its wave's list, everything a candidate carries through B3 exists twice, the key rows
-// are 128 long, the per-peak pass takes a wave's staged peaks in two rounds.  Larger npks stay with k_fused_mw.hip.
+// are 128 long, the per-peak pass takes a wave's staged peaks in two rounds.  Larger npks: the general path (k_fused_mw.hip,
+// which took them until round 6, is a witness kernel).
 #include <stdlib.h>
 
 #include "pvx_fft4.h"

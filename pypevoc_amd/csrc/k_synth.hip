@@ -11,26 +11,33 @@
 //   - the releases of partials that ended within the previous ceil(E/h) frames.
 // No atomics; the order of the additions is fixed (kind, then node index), so the output is reproducible.
 //
-// Four kernels:
+// The kernels:
 //   k_synth_alloc    one thread per partial: where the points of a partial that will sound live in the
 //                    partial-major copy of the analysis arrays (wave prefix sum + one atomic per wave)
 //   k_synth_scatter  one thread per (frame, slot) node: f / mag / realph of every partial, contiguous
-//   k_synth_params   one thread per node: the closed form of that node's contribution(s) -- fsig and msig
+//                    (rows of more than 16 peaks only: k_synth_params_direct reads the analysis rows where they are)
+//   k_synth_params[_direct]
+//                    one thread per node: the closed form of that node's contribution(s) -- fsig and msig
 //                    (np.interp of the partial's f / mag, PVAnalysis.py:701-702) are piecewise linear with
 //                    breakpoints one hop apart, so inside a segment each is two linear pieces and the cumulative
 //                    phase (PVAnalysis.py:705-708) is a quadratic in the sample index; attack / release are pure
 //                    sinusoids under a raised cosine.  One 128-byte record per body, 64 bytes per edge, and one bit
 //                    per node and kind (the wave's ballot) saying which records exist.
-//   k_synth_samples  one thread per RUN of R consecutive output samples: walks the set bits of its segment,
+//   k_synth_bodies<R, S>
+//                    one thread per RUN of R consecutive output samples: walks the set bits of its segment,
 //                    and for each contribution seeds exp(i phase) and exp(i phase increment) exactly (two sincos)
 //                    at the run's first sample, then advances both by complex rotations -- the phase is
-//                    quadratic, so its increment is linear and ITS increment constant: z *= w, w *= r, ten
-//                    float64 instructions per sample instead of a forty-instruction cosine.  The recurrence is
-//                    re-seeded every run, so its error stays below R^2 * 1e-16.  R sums live in registers across
-//                    all contributions and are stored once.
-// Bound: float64 VALU issue (sample loop).  HBM: 8*h bytes written per segment, 128 B per body record
-// written and read once (cache-resident between the two launches).
-// All arithmetic is float64 (phase arguments reach 1e3..1e4 rad).
+//                    quadratic, so its increment is linear and ITS increment constant: z *= w, w += w d, ten
+//                    instructions per sample instead of a forty-instruction cosine.  The recurrence is re-seeded
+//                    every run, so its error stays below R^2 * 1e-16 (S = double; S = float, plans at precision
+//                    32: R^2 / 2 * 6e-8, two bodies' recurrences side by side).  R sums live in registers across all
+//                    contributions and are stored once.  A segment's attacks and releases are added here as well.
+//   k_synth_extras<R, XB>
+//                    bodies whose pieces change inside a run (float rounding of a non-dyadic nfft / hop), and the
+//                    attacks / releases as a launch of their own when those exist.
+// Bound: VALU issue (sample loop).  HBM: 8*h bytes written per segment, 128 B per body record written and read
+// once (cache-resident between the two launches).
+// The closed forms and the seeds are float64 (phase arguments reach 1e3..1e4 rad).
 #include <math.h>
 #include <stdlib.h>
 

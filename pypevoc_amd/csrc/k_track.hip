@@ -15,8 +15,9 @@
 //   k_assign_chunked    every peak: at most one more hop to its root, then partial_id / part_start / part_len
 //                       (length written by the partial's last point)
 // Three launches whatever F is (the first version chained 3 + log2 F launches; for a 240-frame signal their launch
-// gaps were most of the tracker's time).  k_scan_counts / k_root_* / k_assign_ids remain for tables whose chunk
-// boundaries do not fit one workgroup's LDS.
+// gaps were most of the tracker's time) -- two for rows of at most 8 peaks: k_track_links_g8 (eight lanes per frame), then
+// k_assign_bounds, whose every workgroup works the boundary step out for itself in LDS before it assigns its nodes.
+// k_scan_counts / k_root_* / k_assign_ids remain for tables whose chunk boundaries do not fit one workgroup's LDS.
 // Tiny, latency-bound integer work (<= K^2 compares per frame); no roofline claim.
 //
 // Exact ties.

@@ -663,7 +663,7 @@ static int analyze_rows(pvx_plan* p, const void* d_x, int x_dtype, int64_t nsamp
     // that write it themselves take such a call
     if (wire_out && !(p->fft_mode == 4 && p->precision == 32)) return PVX_ERR_UNSUPPORTED;
     if (p->fft_mode >= 1 && p->fft_mode <= 5) {
-        // one launch: window + FFT + peaks, no intermediate arrays (k_fused.hip / k_fused_mw.hip)
+        // one launch: window + FFT + peaks, no intermediate arrays (k_fused_rev.hip / k_fused_team.hip; the witnesses' modes 1 - 3)
         if (x_dtype == PVX_F64) {
             // float64 samples already in HBM (the host entry points narrow while they stage): the fused kernels' first step
             // is (float) x[n] -- done here in one pass, so that they exist for float32 and int16 samples only (a float64
