@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_
         Lp[i] = q.pid[g]; Lf[i] = q.f[g]; Lm[i] = q.mag[g]; Lr[i] = q.realph[g];
     }
     __syncthreads();
+#ifdef PVX_AB_PARAMS_EXIT0     // tools/ab: the launch and the staging of the rows alone
+    if (q.F >= 0) return;
+#endif
     NodeKinds kd;
     kd.isb = kd.isx = kd.isa = kd.isr = false;
     BodyRec crec;                                                     // this node's body record, if it has one
@@ -498,7 +501,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_
     // seven waves per SIMD every workgroup of BASELINE config 2's 1 615 is resident at once, where five per CU made a second round)
     __syncthreads();
     {
+#ifdef PVX_AB_PARAMS_NOSTORE   // tools/ab: without the records' way out
+        const unsigned long long bw = __ballot(has_body && crec.ph0 == 12345.0);
+#else
         const unsigned long long bw = __ballot(has_body);
+#endif
         if (bw != 0ull) {                                             // wave-uniform
             unsigned char* stg = dsm + (size_t)(tid >> 6) * (64 * kLaneB);
             const int lane = tid & 63;
