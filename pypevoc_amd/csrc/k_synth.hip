@@ -379,7 +379,7 @@ __device__ __forceinline__ NodeKinds node_params(const SynthK& q, int64_t li, in
             auto on_edge = [&](int x) {
                 if (x <= 0 || x >= h || x == q.c1 || x == q.c2) return true;
                 const int base = x > q.c2 ? q.c2 : (x > q.c1 ? q.c1 : 0);
-                return (x - base) % q.R == 0;
+                return ((x - base) & (q.R - 1)) == 0;                 // (R: 8, 16 or 32)
             };
             isb = on_edge(c.fmb) && on_edge(c.mmb);
             isx = !isb;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_synth_params(SynthK q) {
     kd.isb = kd.isx = kd.isa = kd.isr = false;
     if (li < nloc) {
         const int64_t node = q.fx0 * q.K + li;
-        const int64_t fr = node / q.K;
+        const int64_t fr = q.fx0 + (int64_t)((unsigned)li / (unsigned)q.K);     // (a slice holds about a million nodes)
         const int pid = q.pid[node];
         if (pid >= 0 && pid < q.P) {
             const long long off = q.off[pid];
@@ -435,8 +435,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_
     const int64_t li0 = (int64_t)blockIdx.x * 256, li = li0 + tid;
     const int64_t nloc = (q.fx1 - q.fx0) * K;
     // frames of this workgroup's nodes and the rows staged around them
-    const int64_t nodeA = q.fx0 * K + li0, nodeB = q.fx0 * K + (li0 + 255 < nloc - 1 ? li0 + 255 : nloc - 1);
-    int64_t frow0 = nodeA / K - WB, frow1 = nodeB / K + 3 + 1;
+    const int64_t liB = li0 + 255 < nloc - 1 ? li0 + 255 : nloc - 1;          // the workgroup's last node (slice-local)
+    // (a slice holds about a million nodes: 32-bit quotients -- a 64-bit division by a run-time K is ~100 instructions)
+    int64_t frow0 = q.fx0 + (int64_t)((unsigned)li0 / (unsigned)K) - WB, frow1 = q.fx0 + (int64_t)((unsigned)liB / (unsigned)K) + 3 + 1;
     if (frow0 < 0) frow0 = 0;
     if (frow1 > q.F) frow1 = q.F;
     const int nrows = (int)(frow1 - frow0);                          // <= rows_cap (host)
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVX_PARAMS_
     bool has_body = false;
     if (li < nloc) {
         const int64_t node = q.fx0 * K + li;
-        const int64_t fr = node / K;
+        const int64_t fr = q.fx0 + (int64_t)((unsigned)li / (unsigned)K);
         const int pid = Lp[(int)(node - frow0 * K)];
         if (pid >= 0 && pid < q.P) {
             const int st = q.pst[pid], nfr = q.pln[pid];
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
     if (q.wlen >= 0) return;
 #endif
     const int64_t g = live ? gid : q.nthreads - 1;
-    const int64_t segl = g / q.rps;
+    const bool small = q.nthreads < ((int64_t)1 << 31);              // (32-bit quotients then: a 64-bit division is ~100 instructions)
+    const int64_t segl = small ? (int64_t)((unsigned)g / (unsigned)q.rps) : g / q.rps;
     const int run = (int)(g - segl * q.rps);
     const int seg = (int)(q.seg0 + segl);
     const int h = q.h, K = q.K;
@@ -844,7 +846,8 @@ __global__ __launch_bounds__(kBodiesTB) __attribute__((amdgpu_waves_per_eu((size
     // the wave's segments and their body nodes (slice-local indices; wave-uniform)
     {
         const int64_t gfirst = gid0 + wbase, glast = gfirst + 63 < q.nthreads - 1 ? gfirst + 63 : q.nthreads - 1;
-        int seg_lo = (int)(q.seg0 + gfirst / q.rps), seg_hi = (int)(q.seg0 + glast / q.rps) + 1;
+        int seg_lo = (int)(q.seg0 + (small ? (int64_t)((unsigned)gfirst / (unsigned)q.rps) : gfirst / q.rps));
+        int seg_hi = (int)(q.seg0 + (small ? (int64_t)((unsigned)glast / (unsigned)q.rps) : glast / q.rps)) + 1;
         if (gfirst >= q.nthreads) seg_hi = seg_lo;
         if (seg_lo < q.fb0) seg_lo = q.fb0;
         if (seg_hi > q.fb1) seg_hi = q.fb1;

@@ -667,7 +667,10 @@ __global__ __launch_bounds__(1024) void k_assign_bounds(TrackParams p) {
     int64_t* cb = (int64_t*)(smem + (((size_t)NCH * K * 4 + 15) & ~(size_t)15));   // [NCH + 1]: new partials before each chunk
     // (what the first of a thread's nodes needs from memory is asked for before the boundary step, not after it: its root, and --
     // when that root lies in the node's own chunk, the usual case -- the root's creation rank and frame count)
+    // (n < 2^31, pvx_launch_track: 32-bit quotients and a shift for the chunk -- four 64-bit divisions per node were most of this loop)
     const int64_t n = p.F * (int64_t)K;
+    const int cls = 31 - __builtin_clz((unsigned)CL);               // CL = 1 << cls
+    const unsigned uK = (unsigned)K;
     const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     int32_t r0 = -1, lk0 = 0;
     int64_t nb0 = 0;
@@ -677,7 +680,8 @@ __global__ __launch_bounds__(1024) void k_assign_bounds(TrackParams p) {
         r0 = p.root[i0];
         sc0 = p.succ[i0];
         // (r0 < n: when k_track_links_g8 gave a wide table up -- TrackParams::wide, known only inside the boundary step -- the roots are whatever the workspace held)
-        if (r0 >= 0 && (int64_t)r0 < n && (int64_t)r0 >= ((i0 / K) / CL) * CL * K) { nb0 = p.newbase[r0 / K]; lk0 = p.link[r0]; pre = true; }
+        const unsigned c0 = ((unsigned)i0 / uK) >> cls;
+        if (r0 >= 0 && (int64_t)r0 < n && (unsigned)r0 >= (c0 << cls) * uK) { nb0 = p.newbase[(unsigned)r0 / uK]; lk0 = p.link[r0]; pre = true; }
     }
     if (!boundaries_lane_body(p, rb, cb, blockIdx.x == 0, false)) return;
     __syncthreads();
@@ -687,18 +691,17 @@ __global__ __launch_bounds__(1024) void k_assign_bounds(TrackParams p) {
         const bool first = i == i0;
         int32_t r = first ? r0 : p.root[i];
         if (r < 0) { p.partial_id[i] = -1; continue; }
-        const int64_t ifr = i / K;
-        const int64_t c = ifr / CL;
-        if ((int64_t)r < c * CL * K) r = rb[(c - 1) * K + (r - (int32_t)((c * CL - 1) * K))];   // a node of the frame before the chunk: that chunk's last row
-        const int64_t rfr = r / K;
+        const unsigned ifr = (unsigned)i / uK, c = ifr >> cls;
+        if ((unsigned)r < (c << cls) * uK) r = rb[(c - 1u) * uK + ((unsigned)r - ((c << cls) - 1u) * uK)];   // a node of the frame before the chunk: that chunk's last row
+        const unsigned rfr = (unsigned)r / uK;
         const int64_t nbv = (first && pre) ? nb0 : p.newbase[rfr];
         const int32_t lkv = (first && pre) ? lk0 : p.link[r];
-        const int64_t pid = nbv + cb[rfr / CL] + (-(lkv + 2));                                  // creation order, PVAnalysis.py:826
+        const int64_t pid = nbv + cb[rfr >> cls] + (-(lkv + 2));                                // creation order, PVAnalysis.py:826
         p.partial_id[i] = (int32_t)pid;
         if (pid < p.cap) {
             if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
             // the last point of a partial (no peak of the next frame continues it) knows the length
-            if (!(first ? sc0 : p.succ[i])) p.part_len[pid] = (int32_t)(ifr - rfr + 1);
+            if (!(first ? sc0 : p.succ[i])) p.part_len[pid] = (int32_t)(ifr - rfr + 1u);
         }
     }
 }
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
     // the assignment loop (PVAnalysis.py:903-957): this lane is previous peak l, and the new peak of rank rc
 #pragma unroll
     for (int c = 0; c < KL; c++) {
-        bool tie[NP], hit_[NP];
+        bool tie[NP];
         unsigned gw_[NP];
         double st_[NP], best_[NP];
 #pragma unroll
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
             amb[ps] = amb[ps] || (act && near);
             const unsigned ge = (unsigned)(__ballot(st == best) >> sh) & 0xffu;
             tie[ps] = act && hit && __popc(ge) > 1;
-            hit_[ps] = hit; gw_[ps] = gw; st_[ps] = st; best_[ps] = best;
+            gw_[ps] = gw; st_[ps] = st; best_[ps] = best;
             used[ps] = used[ps] || (act && hit && win);
             const bool turn = act && rc[ps] == c;
             link[ps] = turn ? (hit ? __ffs((int)gw) - 1 : -1) : link[ps];
@@ -853,7 +856,6 @@ __global__ __launch_bounds__(G8T) void k_track_links_g8(TrackParams p) {
                 amb[ps] = amb[ps] || (tie[ps] && __popc(gs) > 1);
             }
         }
-        (void)hit_;
     }
 #pragma unroll
     for (int ps = 0; ps < NP; ps++) {
@@ -1126,17 +1128,20 @@ __global__ __launch_bounds__(256) void k_assign_chunked(TrackParams p) {
     if (i >= n) return;
     int32_t r = p.root[i];
     if (r < 0) { p.partial_id[i] = -1; return; }
-    const int64_t ifr = i / p.K;
-    if ((int64_t)r < (ifr / p.chunk) * p.chunk * p.K) r = p.root[r];     // before the chunk: a last-frame node, final by now
-    const int64_t rfr = r / p.K;
-    const int64_t pid = p.newbase[rfr] + (p.chunkbase ? p.chunkbase[rfr / p.chunk] : 0) + (-(p.link[r] + 2));   // creation order, PVAnalysis.py:826
+    // (n < 2^31: 32-bit quotients; the chunk length is a power of two)
+    const unsigned uK = (unsigned)p.K;
+    const int cls = 31 - __builtin_clz((unsigned)p.chunk);
+    const unsigned ifr = (unsigned)i / uK;
+    if ((unsigned)r < ((ifr >> cls) << cls) * uK) r = p.root[r];         // before the chunk: a last-frame node, final by now
+    const unsigned rfr = (unsigned)r / uK;
+    const int64_t pid = p.newbase[rfr] + (p.chunkbase ? p.chunkbase[rfr >> cls] : 0) + (-(p.link[r] + 2));   // creation order, PVAnalysis.py:826
     p.partial_id[i] = (int32_t)pid;
     const bool last = !p.succ[i];
     if (pid < p.cap) {
         if (r == (int32_t)i) p.part_start[pid] = (int32_t)rfr;
         // the last point of a partial (no peak of the next frame continues it) knows the length:
         // one plain store per partial instead of one contended atomic per point
-        if (last) p.part_len[pid] = (int32_t)(ifr - rfr + 1);
+        if (last) p.part_len[pid] = (int32_t)(ifr - rfr + 1u);
     }
 }
 
